@@ -1,0 +1,212 @@
+/*
+ * lighthand_hip.h -- C ABI of liblighthand_hip.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for the heatmap-regression hot path of leejeongho3214/LightHand.
+ * The reference has no FFI of its own: all arithmetic on this
+ * path is done by PyTorch/cuDNN underneath plain Python callables.  Each entry point
+ * below therefore cites the reference call site whose device work it replaces
+ * (paths relative to the reference root); the Python mirror of those callables lives
+ * in lighthand_amd/ and reaches this library through ctypes (lighthand_amd/_lib.py).
+ *
+ * Conventions
+ *  - the caller owns every buffer (device pointers unless stated); the library never
+ *    allocates, frees or retains device memory;
+ *  - all work is enqueued asynchronously on `stream` (a hipStream_t passed as void*);
+ *    no entry point synchronises, so every call is legal inside hipGraph capture;
+ *  - return 0 on success, a negative lh_status otherwise; lh_last_error() gives text;
+ *  - activations are NHWC, `dtype` selects their element type (weights packs use the
+ *    same type; BatchNorm vectors, loss, gradients of weights and Adam state are fp32);
+ *  - weight tensors at the boundary keep the reference/PyTorch layouts (OIHW for
+ *    Conv2d, [C_in, C_out, kH, kW] for ConvTranspose2d); the pack functions build the
+ *    device-side K-major images the MFMA kernels consume.
+ */
+#ifndef LIGHTHAND_HIP_H
+#define LIGHTHAND_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { LH_F32 = 0, LH_BF16 = 1, LH_F16 = 2 } lh_dtype;
+
+typedef enum {
+    LH_OK = 0,
+    LH_ERR_ARG = -1,      /* bad shape / dtype / alignment */
+    LH_ERR_HIP = -2,      /* a HIP runtime call failed     */
+    LH_ERR_UNSUPPORTED = -3
+} lh_status;
+
+int lh_version(void);
+const char* lh_last_error(void);
+/* number of bytes of one activation element for `dtype` */
+int lh_dtype_size(int dtype);
+
+/* ------------------------------------------------------------------ layout transforms
+ * images.cuda() -> model(images): src/utils/method.py:165-167.  NCHW fp32 image batch ->
+ * zero-padded NHWC4 image in the run dtype ([N][H+2*pad][Wp][4], channel 3 = 0), the
+ * input format of the stem convolution kernel. */
+int lh_image_to_nhwc4(const float* nchw, void* out, int n, int h, int w, int pad, int wp,
+                      int dtype, void* stream);
+/* NHWC (run dtype) -> NCHW fp32 heatmaps (what model(images) returns, pose_resnet.py:246)
+ * and the inverse for the incoming gradient. c_stride = channel stride of the NHWC side. */
+int lh_nhwc_to_nchw_f32(const void* nhwc, float* nchw, int n, int h, int w, int c, int c_stride,
+                        int dtype, void* stream);
+int lh_nchw_f32_to_nhwc(const float* nchw, void* nhwc, int n, int h, int w, int c, int c_stride,
+                        int dtype, void* stream);
+
+/* ------------------------------------------------------------------ weight packs
+ * Build the K-major device image [Cout_pad128][ntaps][Kpad] of one tap subset of a
+ * weight tensor.  Logical weight element (o, i, r, s) is read from
+ * w[o*so + i*si + r*sr + s*ss] (fp32, reference layout via strides), taps are listed as
+ * (r, s) pairs; rows o >= n_out and columns i >= n_in are zero.  Returns packed bytes
+ * through *bytes when out == NULL (size query). */
+int lh_pack_weight(const float* w, void* out, size_t* bytes, int n_out, int n_in,
+                   long so, long si, long sr, long ss, int ntaps, const int* taps_rs,
+                   int dtype, void* stream);
+
+/* ------------------------------------------------------------------ convolutions
+ * nn.Conv2d(..., bias=False) + the head conv with bias: pose_resnet.py:23-26,66-72,152,
+ * 169-175,181-182; pose_hrnet.py:22-25,65-71,145-149,200-204,218-222,230-234,282-286,
+ * 323-329,344-348,363-365,378-381.  nn.ConvTranspose2d(k=4,s=2,p=1): pose_resnet.py:219-227.
+ *
+ * One descriptor covers forward, data-gradient and transposed forms: an output pixel
+ * grid (ho, wo) per image, a list of taps (dh, dw) that select the input pixel
+ * (a*sh + dh, b*sw + dw) and the weight-pack slice, and an affine placement of the
+ * output pixel (a*osh + ooh, b*osw + oow) inside an [OH][OW] image (used by the four
+ * sub-pixel phases of stride-2 transposed convolutions). */
+typedef struct {
+    int n, hi, wi;            /* input batch / image size in pixels                  */
+    int in_pix_stride;        /* elements between adjacent input pixels              */
+    int k_run;                /* valid contiguous elements per tap                   */
+    int ho, wo;               /* output pixel grid of this launch                    */
+    int sh, sw;               /* input sampling stride                               */
+    int cout;                 /* valid output channels                               */
+    int OH, OW;               /* full output image size                              */
+    int osh, osw, ooh, oow;   /* output pixel = (a*osh + ooh, b*osw + oow)           */
+    int out_pix_stride;       /* elements between adjacent output pixels             */
+    int ntaps;
+    int relu;                 /* apply max(.,0) before the store                     */
+    signed char dh[64];
+    signed char dw[64];
+} lh_igemm_desc;
+
+/* out[pixel][co] = sum_taps sum_k in[pix(tap)][k] * wpack[co][tap][k] (+bias[co]) (+addend).
+ * stats (optional): fp32 [gridM][2][cout_stats_stride] per-block column sums / sums of
+ * squares of the stored values, consumed by lh_bn_finalize.  addend may alias out. */
+int lh_igemm(const lh_igemm_desc* d, const void* in, const void* wpack, void* out,
+             const void* addend, const float* bias, float* stats, int dtype, void* stream);
+/* rows of the stats slab lh_igemm writes for this descriptor (= number of pixel tiles) */
+int lh_igemm_stats_rows(const lh_igemm_desc* d, int dtype);
+
+/* Weight gradient (loss.backward(), src/utils/method.py:182):
+ *   dW[tap][o][i] = sum_pixels dy[pixel][o] * x[pix(tap)][i]
+ * with the same tap/gather description (x is the gathered operand, dy is dense
+ * [n*ho*wo][dy_pix_stride]).  Partial sums go to `slab` (fp32, lh_wgrad_slab_bytes), then
+ * lh_wgrad_reduce folds the split-K slabs into the reference-layout gradient
+ * grad[o*so + i*si + r*sr + s*ss] (accumulate != 0 adds to what is there). */
+size_t lh_wgrad_slab_bytes(const lh_igemm_desc* d, int n_out, int n_in, int dtype);
+int lh_wgrad(const lh_igemm_desc* d, const void* x, const void* dy, int dy_pix_stride,
+             int n_out, int n_in, float* slab, int dtype, void* stream);
+int lh_wgrad_reduce(const lh_igemm_desc* d, const float* slab, float* grad, int n_out, int n_in,
+                    long so, long si, long sr, long ss, const int* taps_rs, int accumulate,
+                    int dtype, void* stream);
+
+/* ------------------------------------------------------------------ BatchNorm / fused elementwise
+ * nn.BatchNorm2d(C, momentum=0.1): pose_resnet.py:19,35,... ; nn.ReLU / residual add:
+ * pose_resnet.py:55-56,96-97; nn.Upsample(nearest): pose_hrnet.py:207. */
+
+/* Column sums / sums of squares of a dense [m][c] activation -> stats slab [rows][2][c]. */
+int lh_bn_stats(const void* y, int m, int c, float* stats, int* rows_out, int dtype, void* stream);
+int lh_bn_stats_rows(int m, int c);
+/* Bytes a stats slab of `rows` rows and `c` channels must have (slab + fp64 fold scratch). */
+size_t lh_bn_stats_slab_bytes(int rows, int c);
+/* Fold a stats slab: batch mean / biased var -> scale = gamma*rsqrt(var+eps),
+ * shift = beta - mean*scale, saved mean / invstd; running stats updated with momentum and
+ * the unbiased variance, num_batches_tracked (int64) += 1 (all device pointers). */
+int lh_bn_finalize(const float* stats, int rows, int count, int c, const float* gamma,
+                   const float* beta, float* running_mean, float* running_var,
+                   long long* num_batches_tracked, float momentum, float eps, float* scale,
+                   float* shift, float* save_mean, float* save_invstd, void* stream);
+/* Eval mode: scale/shift from running statistics. */
+int lh_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
+                      const float* running_var, float eps, int c, float* scale, float* shift,
+                      void* stream);
+
+/* out = relu?( sum_t term_t ),  term_t = up_t( x_t * scale_t + shift_t )   (scale_t NULL = identity).
+ * Up to 4 terms; up_t is nearest-neighbour upsampling by 2^log2up of a [n][h>>l][w>>l][c] map. */
+typedef struct {
+    const void* x[4];
+    const float* scale[4];
+    const float* shift[4];
+    int log2up[4];
+    int nterms;
+    int relu;
+} lh_fuse_desc;
+int lh_fuse_fwd(const lh_fuse_desc* d, void* out, int n, int h, int w, int c, int dtype, void* stream);
+
+/* Backward of lh_fuse_fwd, two launches per BN term:
+ *  reduce: sums[t] = { sum g_t, sum g_t * xhat_t } with g = dout * (out > 0), g_t = g summed over
+ *          each upsampling cell;  apply: dx_t = scale_t * (g_t - mean(g_t) - xhat_t * mean(g_t xhat_t));
+ *          identity terms get dx_t = g_t.  dgamma = sum g xhat, dbeta = sum g are written to
+ *          dgamma/dbeta (fp32 [c]).  accumulate[t] != 0 adds into dx[t]. */
+typedef struct {
+    const void* dout;
+    const void* out;            /* forward result (ReLU mask); NULL when relu == 0 */
+    const void* x[4];           /* raw BN inputs (NULL for identity terms)          */
+    const float* scale[4];
+    const float* save_mean[4];
+    const float* save_invstd[4];
+    void* dx[4];
+    float* dgamma[4];
+    float* dbeta[4];
+    int log2up[4];
+    int accumulate[4];
+    int nterms;
+    int relu;
+} lh_fuse_bwd_desc;
+size_t lh_fuse_bwd_workspace_bytes(int n, int h, int w, int c);
+int lh_fuse_bwd(const lh_fuse_bwd_desc* d, int n, int h, int w, int c, void* workspace,
+                int dtype, void* stream);
+
+/* nn.MaxPool2d(3, 2, 1): pose_resnet.py:156.  idx (uint8 [n][ho][wo][c]) keeps the window
+ * position (first maximum in scan order, NaN propagates) for the backward pass. */
+int lh_maxpool3x3s2_fwd(const void* x, void* out, unsigned char* idx, int n, int h, int w, int c,
+                        int dtype, void* stream);
+int lh_maxpool3x3s2_bwd(const void* dout, const unsigned char* idx, void* dx, int n, int h, int w,
+                        int c, int dtype, void* stream);
+
+/* ------------------------------------------------------------------ heatmap target / loss / decode */
+/* CustomDataset.generate_target: src/tools/dataset.py:165-212.  joints fp32 [b][j][jstride]
+ * (x, y in input pixels) -> fp32 [b][j][size][size].  `patch` is the (2*radius+1)^2 fp32
+ * Gaussian the host evaluates exactly as the reference does (numpy float32 exp), so that the
+ * placed values are bit-identical to the reference's on the same host. */
+int lh_gaussian_target(const float* joints, int jstride, const float* patch, int radius,
+                       float* target, int b, int j, int size, void* stream);
+/* JointsMSELoss(use_target_weight=False): src/utils/loss.py:306-325.  loss (fp32 scalar on
+ * device) = 0.5*mean((p-g)^2); grad (optional) = (p-g) * grad_scale/(numel). workspace >=
+ * lh_mse_workspace_bytes(numel). */
+size_t lh_mse_workspace_bytes(long numel);
+int lh_mse_heatmap(const float* pred, const float* target, long numel, float* loss, float* grad,
+                   const float* grad_scale, void* workspace, void* stream);
+/* get_max_preds: src/utils/loss.py:327-355 (+ the x4 of src/utils/method.py:157,176-178 via
+ * `scale`).  heatmaps fp32 NCHW [b*j][h*w] -> preds fp32 [b*j][2], maxvals fp32 [b*j],
+ * idx int32 [b*j] (first-occurrence arg-max, NaN counts as maximum). */
+int lh_heatmap_argmax(const float* heatmaps, int bj, int h, int w, float scale, float* preds,
+                      float* maxvals, int* idx, void* stream);
+
+/* ------------------------------------------------------------------ optimiser
+ * torch.optim.Adam(lr, betas, eps, weight_decay=0).step(): src/tools/train.py:45-48,
+ * src/utils/method.py:183.  One launch over a flat fp32 arena (plus a one-thread
+ * tick kernel).  hyper (device, fp64[4]) = { lr, beta1, beta2, eps }; step (device int32) is
+ * incremented on the device, so a captured hipGraph replays correctly; derived (device fp32[8])
+ * is scratch for the bias-corrected step size evaluated in fp64 like the reference's Python. */
+int lh_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long numel,
+                 const double* hyper, int* step, float* derived, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIGHTHAND_HIP_H */

@@ -1,0 +1,103 @@
+"""ctypes binding of liblighthand_hip.so (the C ABI declared in include/lighthand_hip.h).
+
+The library is the only compute backend of this package: if it cannot be loaded the
+import of any compute module fails loudly -- there is no CPU / eager fallback.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblighthand_hip.so")
+
+LH_F32, LH_BF16, LH_F16 = 0, 1, 2
+
+
+class LightHandError(RuntimeError):
+    pass
+
+
+class IgemmDesc(C.Structure):
+    _fields_ = [("n", C.c_int), ("hi", C.c_int), ("wi", C.c_int), ("in_pix_stride", C.c_int),
+                ("k_run", C.c_int), ("ho", C.c_int), ("wo", C.c_int), ("sh", C.c_int), ("sw", C.c_int),
+                ("cout", C.c_int), ("OH", C.c_int), ("OW", C.c_int), ("osh", C.c_int), ("osw", C.c_int),
+                ("ooh", C.c_int), ("oow", C.c_int), ("out_pix_stride", C.c_int), ("ntaps", C.c_int),
+                ("relu", C.c_int), ("dh", C.c_byte * 64), ("dw", C.c_byte * 64)]
+
+
+class FuseDesc(C.Structure):
+    _fields_ = [("x", C.c_void_p * 4), ("scale", C.c_void_p * 4), ("shift", C.c_void_p * 4),
+                ("log2up", C.c_int * 4), ("nterms", C.c_int), ("relu", C.c_int)]
+
+
+class FuseBwdDesc(C.Structure):
+    _fields_ = [("dout", C.c_void_p), ("out", C.c_void_p), ("x", C.c_void_p * 4), ("scale", C.c_void_p * 4),
+                ("save_mean", C.c_void_p * 4), ("save_invstd", C.c_void_p * 4), ("dx", C.c_void_p * 4),
+                ("dgamma", C.c_void_p * 4), ("dbeta", C.c_void_p * 4), ("log2up", C.c_int * 4),
+                ("accumulate", C.c_int * 4), ("nterms", C.c_int), ("relu", C.c_int)]
+
+
+_P, _I, _L, _F, _SZ = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); every symbol include/lighthand_hip.h declares
+SIGNATURES = {
+    "lh_version": (_I, []),
+    "lh_last_error": (C.c_char_p, []),
+    "lh_dtype_size": (_I, [_I]),
+    "lh_image_to_nhwc4": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "lh_nhwc_to_nchw_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "lh_nchw_f32_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "lh_pack_weight": (_I, [_P, _P, C.POINTER(_SZ), _I, _I, _L, _L, _L, _L, _I, C.POINTER(_I), _I, _P]),
+    "lh_igemm": (_I, [C.POINTER(IgemmDesc), _P, _P, _P, _P, _P, _P, _I, _P]),
+    "lh_igemm_stats_rows": (_I, [C.POINTER(IgemmDesc), _I]),
+    "lh_wgrad_slab_bytes": (_SZ, [C.POINTER(IgemmDesc), _I, _I, _I]),
+    "lh_wgrad": (_I, [C.POINTER(IgemmDesc), _P, _P, _I, _I, _I, _P, _I, _P]),
+    "lh_wgrad_reduce": (_I, [C.POINTER(IgemmDesc), _P, _P, _I, _I, _L, _L, _L, _L, C.POINTER(_I), _I, _I, _P]),
+    "lh_bn_stats": (_I, [_P, _I, _I, _P, C.POINTER(_I), _I, _P]),
+    "lh_bn_stats_rows": (_I, [_I, _I]),
+    "lh_bn_stats_slab_bytes": (_SZ, [_I, _I]),
+    "lh_bn_finalize": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
+    "lh_bn_eval_affine": (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),
+    "lh_fuse_fwd": (_I, [C.POINTER(FuseDesc), _P, _I, _I, _I, _I, _I, _P]),
+    "lh_fuse_bwd_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
+    "lh_fuse_bwd": (_I, [C.POINTER(FuseBwdDesc), _I, _I, _I, _I, _P, _I, _P]),
+    "lh_maxpool3x3s2_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "lh_maxpool3x3s2_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "lh_gaussian_target": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _P]),
+    "lh_mse_workspace_bytes": (_SZ, [_L]),
+    "lh_mse_heatmap": (_I, [_P, _P, _L, _P, _P, _P, _P, _P]),
+    "lh_heatmap_argmax": (_I, [_P, _I, _I, _I, _F, _P, _P, _P, _P]),
+    "lh_adam_step": (_I, [_P, _P, _P, _P, _L, _P, _P, _P, _F, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once) and set every prototype.  Raises LightHandError when
+    the library is missing: build it with ``python -c 'import __graft_entry__ as g; g.build()'``
+    or ``make -C lighthand_amd/csrc``."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LightHandError(
+            f"{LIB_PATH} not found: the HIP extension is the only backend of lighthand_amd "
+            "(no CPU fallback). Build it with `make -C lighthand_amd/csrc`.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header / library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().lh_last_error().decode("utf-8", "replace")
+        raise LightHandError(f"{what or 'liblighthand_hip'} failed (status {rc}): {msg}")
+
+
+def dtype_code(torch_dtype):
+    import torch
+    return {torch.float32: LH_F32, torch.bfloat16: LH_BF16, torch.float16: LH_F16}[torch_dtype]

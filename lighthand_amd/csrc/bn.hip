@@ -1,0 +1,516 @@
+// BatchNorm statistics / finalize, the fused "sum of affine terms (+nearest upsample) + ReLU"
+// elementwise op with its backward, and the 3x3/s2 max-pool -- all HBM-bound NHWC kernels:
+// one 16-byte chunk (8 x 16-bit or 4 x fp32 channels) per lane, per-channel vectors in fp32.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// Column sums of a [rows][ncol] slab in double: block = 16 columns x 16 row lanes.
+template <typename TI>
+__global__ __launch_bounds__(256) void colsum_kernel(const TI* src, int rows, int ncol, int rows_per_block,
+                                                     double* dst) {
+    __shared__ double red[16][17];
+    const int col = blockIdx.x * 16 + (threadIdx.x & 15), rl = threadIdx.x >> 4;
+    const int r0 = blockIdx.y * rows_per_block;
+    int r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    double a = 0.0;
+    if (col < ncol)
+        for (int r = r0 + rl; r < r1; r += 16) a += (double)src[(long)r * ncol + col];
+    red[rl][threadIdx.x & 15] = a;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += red[i][threadIdx.x];
+        if (col < ncol) dst[(long)blockIdx.y * ncol + col] = s;
+    }
+}
+
+// Sum `rows` rows of `ncol` floats into totals[ncol] (double).  scratch: >= ceil(rows/256)*ncol doubles.
+static int column_totals(const float* slab, int rows, int ncol, double* scratch, double* totals, hipStream_t s) {
+    const int gx = ceil_div(ncol, 16);
+    if (rows <= 512) {
+        hipLaunchKernelGGL((colsum_kernel<float>), dim3(gx, 1), dim3(256), 0, s, slab, rows, ncol, rows, totals);
+    } else {
+        const int gy = ceil_div(rows, 256);
+        hipLaunchKernelGGL((colsum_kernel<float>), dim3(gx, gy), dim3(256), 0, s, slab, rows, ncol, 256, scratch);
+        hipLaunchKernelGGL((colsum_kernel<double>), dim3(gx, 1), dim3(256), 0, s, (const double*)scratch, gy, ncol, gy, totals);
+    }
+    LH_LAUNCH_CHECK("colsum launch");
+    return LH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Generic stats of a dense [m][c] activation (the conv kernels normally produce these slabs
+// in their epilogue; this kernel serves tensors that did not come out of lh_igemm).
+constexpr int STAT_ROWS = 128;
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* y, int m, int c, float* stats) {
+    constexpr int EPC = 16 / sizeof(T);
+    const int nchunk = c / EPC;
+    const long r0 = (long)blockIdx.x * STAT_ROWS;
+    float* out = stats + (long)blockIdx.x * 2 * c;
+    for (int ch = threadIdx.x; ch < nchunk; ch += 256) {
+        float s1[EPC], s2[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) s1[e] = s2[e] = 0.f;
+        for (int r = 0; r < STAT_ROWS && r0 + r < m; ++r) {
+            float v[EPC];
+            unpack16<T>(*reinterpret_cast<const uint4*>(y + (r0 + r) * c + ch * EPC), v);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) { s1[e] += v[e]; s2[e] += v[e] * v[e]; }
+        }
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) { out[ch * EPC + e] = s1[e]; out[c + ch * EPC + e] = s2[e]; }
+    }
+}
+
+extern "C" int lh_bn_stats_rows(int m, int c) { (void)c; return ceil_div(m, STAT_ROWS); }
+
+extern "C" int lh_bn_stats(const void* y, int m, int c, float* stats, int* rows_out, int dtype, void* stream) {
+    LH_REQUIRE(y && stats && m > 0 && c > 0, "lh_bn_stats: bad arguments");
+    const int es = lh_dtype_size(dtype);
+    LH_REQUIRE(es > 0 && c % (16 / es) == 0, "lh_bn_stats: c %d not a multiple of %d", c, 16 / (es > 0 ? es : 1));
+    const int rows = ceil_div(m, STAT_ROWS);
+    if (rows_out) *rows_out = rows;
+    LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_stats_kernel<T>), dim3(rows), dim3(256), 0, (hipStream_t)stream,
+                                                   (const T*)y, m, c, stats));
+    LH_LAUNCH_CHECK("bn_stats launch");
+    return LH_OK;
+}
+
+__global__ void bn_finalize_kernel(const double* tot, int count, int c, const float* gamma, const float* beta,
+                                   float* rmean, float* rvar, long long* nbt, float momentum, float eps,
+                                   float* scale, float* shift, float* smean, float* sinv) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch == 0 && nbt) *nbt += 1;
+    if (ch >= c) return;
+    const double mean = tot[ch] / count;
+    double var = tot[c + ch] / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma ? gamma[ch] : 1.f, b = beta ? beta[ch] : 0.f;
+    const float sc = g * invstd;
+    scale[ch] = sc;
+    shift[ch] = b - (float)mean * sc;
+    if (smean) smean[ch] = (float)mean;
+    if (sinv) sinv[ch] = invstd;
+    if (rmean) rmean[ch] = (1.f - momentum) * rmean[ch] + momentum * (float)mean;
+    if (rvar) {
+        const double unb = count > 1 ? var * ((double)count / (count - 1)) : var;
+        rvar[ch] = (1.f - momentum) * rvar[ch] + momentum * (float)unb;
+    }
+}
+
+extern "C" size_t lh_bn_stats_slab_bytes(int rows, int c) {
+    return ((size_t)rows * 2 * c + 2) * 4 + (size_t)(ceil_div(rows, 256) + 1) * 2 * c * 8;
+}
+
+// stats: [rows][2][c] floats followed by scratch for (ceil(rows/256) + 1) * 2c doubles.
+extern "C" int lh_bn_finalize(const float* stats, int rows, int count, int c, const float* gamma,
+                              const float* beta, float* running_mean, float* running_var,
+                              long long* num_batches_tracked, float momentum, float eps, float* scale,
+                              float* shift, float* save_mean, float* save_invstd, void* stream) {
+    LH_REQUIRE(stats && scale && shift && rows > 0 && count > 0 && c > 0, "lh_bn_finalize: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const long slab_floats = (long)rows * 2 * c;
+    double* scratch = (double*)(stats + ((slab_floats + 1) & ~1L));
+    double* totals = scratch + (long)ceil_div(rows, 256) * 2 * c;
+    int rc = column_totals(stats, rows, 2 * c, scratch, totals, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(c, 128)), dim3(128), 0, s, (const double*)totals, count, c,
+                       gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, scale, shift,
+                       save_mean, save_invstd);
+    LH_LAUNCH_CHECK("bn_finalize launch");
+    return LH_OK;
+}
+
+__global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, const float* rm, const float* rv,
+                                      float eps, int c, float* scale, float* shift) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    const float sc = gamma[ch] / sqrtf(rv[ch] + eps);
+    scale[ch] = sc;
+    shift[ch] = beta[ch] - rm[ch] * sc;
+}
+
+extern "C" int lh_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
+                                 const float* running_var, float eps, int c, float* scale, float* shift,
+                                 void* stream) {
+    LH_REQUIRE(gamma && beta && running_mean && running_var && scale && shift && c > 0, "lh_bn_eval_affine: bad arguments");
+    hipLaunchKernelGGL(bn_eval_affine_kernel, dim3(ceil_div(c, 128)), dim3(128), 0, (hipStream_t)stream, gamma, beta,
+                       running_mean, running_var, eps, c, scale, shift);
+    LH_LAUNCH_CHECK("bn_eval_affine launch");
+    return LH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+struct FuseArgs {
+    const unsigned char* x[4];
+    const float* scale[4];
+    const float* shift[4];
+    int log2up[4];
+    int nterms, relu;
+    unsigned char* out;
+    int n, h, w, c;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void fuse_fwd_kernel(const FuseArgs p) {
+    constexpr int EPC = 16 / sizeof(T);
+    const int nchunk = p.c / EPC;
+    const long total = (long)p.n * p.h * p.w * nchunk;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int ch = (int)(idx % nchunk);
+        const long pix = idx / nchunk;
+        const int x = (int)(pix % p.w);
+        const long t2 = pix / p.w;
+        const int y = (int)(t2 % p.h), n = (int)(t2 / p.h);
+        float acc[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+        for (int t = 0; t < p.nterms; ++t) {
+            const int l = p.log2up[t];
+            const long sp = ((long)n * (p.h >> l) + (y >> l)) * (p.w >> l) + (x >> l);
+            float v[EPC];
+            unpack16<T>(*reinterpret_cast<const uint4*>(p.x[t] + (sp * p.c + ch * EPC) * sizeof(T)), v);
+            if (p.scale[t]) {
+                const float* sc = p.scale[t] + ch * EPC;
+                const float* sh = p.shift[t] + ch * EPC;
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) v[e] = v[e] * sc[e] + sh[e];
+                if (p.nterms > 1) {
+                    // each BN output is a stored tensor in the reference: round it like one
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) v[e] = to_f<T>(from_f<T>(v[e]));
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) acc[e] += v[e];
+        }
+        if (p.relu) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) acc[e] = fmaxf(acc[e], 0.f);
+        }
+        *reinterpret_cast<uint4*>(p.out + idx * 16) = pack16<T>(acc);
+    }
+}
+
+extern "C" int lh_fuse_fwd(const lh_fuse_desc* d, void* out, int n, int h, int w, int c, int dtype, void* stream) {
+    LH_REQUIRE(d && out && d->nterms >= 1 && d->nterms <= 4, "lh_fuse_fwd: bad descriptor");
+    const int es = lh_dtype_size(dtype);
+    LH_REQUIRE(es > 0 && c % (16 / es) == 0, "lh_fuse_fwd: c %d not a multiple of the 16-byte chunk", c);
+    FuseArgs a;
+    for (int t = 0; t < 4; ++t) {
+        a.x[t] = t < d->nterms ? (const unsigned char*)d->x[t] : nullptr;
+        a.scale[t] = t < d->nterms ? d->scale[t] : nullptr;
+        a.shift[t] = t < d->nterms ? d->shift[t] : nullptr;
+        a.log2up[t] = t < d->nterms ? d->log2up[t] : 0;
+        if (t < d->nterms) {
+            LH_REQUIRE(a.x[t], "lh_fuse_fwd: term %d has no input", t);
+            LH_REQUIRE(a.log2up[t] >= 0 && (h >> a.log2up[t]) << a.log2up[t] == h && (w >> a.log2up[t]) << a.log2up[t] == w,
+                       "lh_fuse_fwd: %dx%d not divisible by 2^%d", h, w, a.log2up[t]);
+            LH_REQUIRE((a.scale[t] == nullptr) == (a.shift[t] == nullptr), "lh_fuse_fwd: scale/shift must come together");
+        }
+    }
+    a.nterms = d->nterms; a.relu = d->relu; a.out = (unsigned char*)out; a.n = n; a.h = h; a.w = w; a.c = c;
+    const long total = (long)n * h * w * (c / (16 / es));
+    const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((fuse_fwd_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a));
+    LH_LAUNCH_CHECK("fuse_fwd launch");
+    return LH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward of one term.  g = dout * (out > 0) summed over the term's 2^l x 2^l upsampling cell.
+struct FuseBwdArgs {
+    const unsigned char* dout;
+    const unsigned char* out;
+    const unsigned char* x;      // raw BN input of this term (null: identity)
+    const float* scale;
+    const float* mean;
+    const float* invstd;
+    unsigned char* dx;
+    float* partial;              // [strips][2][c]
+    const double* totals;        // [2][c]
+    float* coef;                 // [2][c]: mean(g), mean(g*xhat)
+    float* dgamma;
+    float* dbeta;
+    int n, h, w, c;              // OUTPUT resolution
+    int l, relu, accumulate;
+    int rows_per_strip;
+    long count;                  // n * (h>>l) * (w>>l)
+};
+
+template <typename T, int EPC>
+__device__ __forceinline__ void cell_grad(const FuseBwdArgs& p, int n, int ys, int xs, int chunk, float* g) {
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) g[e] = 0.f;
+    const int f = 1 << p.l;
+    for (int dy = 0; dy < f; ++dy)
+        for (int dx = 0; dx < f; ++dx) {
+            const long pix = ((long)n * p.h + (ys << p.l) + dy) * p.w + (xs << p.l) + dx;
+            const long off = (pix * p.c + chunk * EPC) * sizeof(T);
+            float d[EPC];
+            unpack16<T>(*reinterpret_cast<const uint4*>(p.dout + off), d);
+            if (p.relu) {
+                float o[EPC];
+                unpack16<T>(*reinterpret_cast<const uint4*>(p.out + off), o);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) d[e] = o[e] > 0.f ? d[e] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) g[e] += d[e];
+        }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void fuse_bwd_reduce_kernel(const FuseBwdArgs p) {
+    constexpr int EPC = 16 / sizeof(T);
+    __shared__ float red[256 * EPC * 2];
+    const int nchunk = p.c / EPC;
+    const int hs = p.h >> p.l, ws = p.w >> p.l;
+    const long r0 = (long)blockIdx.x * p.rows_per_strip;
+    long r1 = r0 + p.rows_per_strip;
+    if (r1 > p.count) r1 = p.count;
+    float* out = p.partial + (long)blockIdx.x * 2 * p.c;
+    // active threads: a whole number of row lanes over the chunks (chunk fixed per thread)
+    for (int cb = 0; cb < nchunk; cb += 256) {
+        const int nc = nchunk - cb < 256 ? nchunk - cb : 256;
+        const int lanes = 256 / nc;
+        const int chunk = cb + (int)(threadIdx.x % nc), rl = threadIdx.x / nc;
+        float s1[EPC], s2[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) s1[e] = s2[e] = 0.f;
+        if (rl < lanes) {
+            float mean[EPC], inv[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) { mean[e] = p.mean[chunk * EPC + e]; inv[e] = p.invstd[chunk * EPC + e]; }
+            for (long r = r0 + rl; r < r1; r += lanes) {
+                const int xs = (int)(r % ws);
+                const long t2 = r / ws;
+                const int ys = (int)(t2 % hs), n = (int)(t2 / hs);
+                float g[EPC], xv[EPC];
+                cell_grad<T, EPC>(p, n, ys, xs, chunk, g);
+                unpack16<T>(*reinterpret_cast<const uint4*>(p.x + (r * p.c + chunk * EPC) * sizeof(T)), xv);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) { s1[e] += g[e]; s2[e] += g[e] * (xv[e] - mean[e]) * inv[e]; }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) { red[(threadIdx.x * EPC + e) * 2] = s1[e]; red[(threadIdx.x * EPC + e) * 2 + 1] = s2[e]; }
+        __syncthreads();
+        for (int t = threadIdx.x; t < nc * EPC; t += 256) {
+            const int cl = t / EPC, e = t % EPC;
+            float a = 0.f, b = 0.f;
+            for (int k = 0; k < lanes; ++k) { a += red[((k * nc + cl) * EPC + e) * 2]; b += red[((k * nc + cl) * EPC + e) * 2 + 1]; }
+            out[(cb + cl) * EPC + e] = a;
+            out[p.c + (cb + cl) * EPC + e] = b;
+        }
+        __syncthreads();
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void fuse_bwd_apply_kernel(const FuseBwdArgs p) {
+    constexpr int EPC = 16 / sizeof(T);
+    const int nchunk = p.c / EPC;
+    const int hs = p.h >> p.l, ws = p.w >> p.l;
+    const long total = p.count * nchunk;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int chunk = (int)(idx % nchunk);
+        const long r = idx / nchunk;
+        const int xs = (int)(r % ws);
+        const long t2 = r / ws;
+        const int ys = (int)(t2 % hs), n = (int)(t2 / hs);
+        float g[EPC];
+        cell_grad<T, EPC>(p, n, ys, xs, chunk, g);
+        if (p.x) {
+            float xv[EPC];
+            unpack16<T>(*reinterpret_cast<const uint4*>(p.x + idx * 16), xv);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const int ch = chunk * EPC + e;
+                const float xh = (xv[e] - p.mean[ch]) * p.invstd[ch];
+                g[e] = p.scale[ch] * (g[e] - p.coef[ch] - xh * p.coef[p.c + ch]);
+            }
+        }
+        uint4* dst = reinterpret_cast<uint4*>(p.dx + idx * 16);
+        if (p.accumulate) {
+            float o[EPC];
+            unpack16<T>(*dst, o);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) g[e] += o[e];
+        }
+        *dst = pack16<T>(g);
+    }
+}
+
+__global__ void fuse_bwd_coef_kernel(const double* totals, long count, int c, float* coef, float* dgamma, float* dbeta) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    coef[ch] = (float)(totals[ch] / (double)count);
+    coef[c + ch] = (float)(totals[c + ch] / (double)count);
+    if (dbeta) dbeta[ch] = (float)totals[ch];
+    if (dgamma) dgamma[ch] = (float)totals[c + ch];
+}
+
+static long fuse_bwd_strips(long count, int* rows_per_strip) {
+    long rps = (count + 1023) / 1024;
+    if (rps < 32) rps = 32;
+    *rows_per_strip = (int)rps;
+    return (count + rps - 1) / rps;
+}
+
+extern "C" size_t lh_fuse_bwd_workspace_bytes(int n, int h, int w, int c) {
+    int rps;
+    const long strips = fuse_bwd_strips((long)n * h * w, &rps);
+    // partial slab + colsum scratch + totals (doubles)
+    return (size_t)strips * 2 * c * 4 + 16 + (size_t)(ceil_div(strips, 256) + 1) * 2 * c * 8 + (size_t)2 * c * 4;
+}
+
+extern "C" int lh_fuse_bwd(const lh_fuse_bwd_desc* d, int n, int h, int w, int c, void* workspace, int dtype,
+                           void* stream) {
+    LH_REQUIRE(d && d->dout && d->nterms >= 1 && d->nterms <= 4, "lh_fuse_bwd: bad descriptor");
+    LH_REQUIRE(!d->relu || d->out, "lh_fuse_bwd: relu needs the forward output");
+    const int es = lh_dtype_size(dtype);
+    LH_REQUIRE(es > 0 && c % (16 / es) == 0, "lh_fuse_bwd: c %d not a multiple of the 16-byte chunk", c);
+    hipStream_t s = (hipStream_t)stream;
+    for (int t = 0; t < d->nterms; ++t) {
+        if (!d->dx[t]) continue;
+        FuseBwdArgs a;
+        a.dout = (const unsigned char*)d->dout; a.out = (const unsigned char*)d->out;
+        a.x = (const unsigned char*)d->x[t]; a.scale = d->scale[t]; a.mean = d->save_mean[t]; a.invstd = d->save_invstd[t];
+        a.dx = (unsigned char*)d->dx[t]; a.dgamma = d->dgamma[t]; a.dbeta = d->dbeta[t];
+        a.n = n; a.h = h; a.w = w; a.c = c; a.l = d->log2up[t]; a.relu = d->relu; a.accumulate = d->accumulate[t];
+        LH_REQUIRE(a.l >= 0 && (h >> a.l) << a.l == h && (w >> a.l) << a.l == w, "lh_fuse_bwd: bad upsampling factor");
+        a.count = (long)n * (h >> a.l) * (w >> a.l);
+        a.partial = nullptr; a.totals = nullptr; a.coef = nullptr; a.rows_per_strip = 0;
+        if (a.x) {
+            LH_REQUIRE(workspace && a.scale && a.mean && a.invstd, "lh_fuse_bwd: BN term %d lacks workspace/statistics", t);
+            const long strips = fuse_bwd_strips(a.count, &a.rows_per_strip);
+            a.partial = (float*)workspace;
+            const long slab_floats = strips * 2 * c;
+            double* scratch = (double*)((float*)workspace + ((slab_floats + 3) & ~3L));
+            double* totals = scratch + (long)ceil_div(strips, 256) * 2 * c;
+            a.totals = totals;
+            LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((fuse_bwd_reduce_kernel<T>), dim3((int)strips), dim3(256), 0, s, a));
+            LH_LAUNCH_CHECK("fuse_bwd_reduce launch");
+            int rc = column_totals(a.partial, (int)strips, 2 * c, scratch, totals, s);
+            if (rc) return rc;
+            a.coef = (float*)(totals + 2 * c);
+            hipLaunchKernelGGL(fuse_bwd_coef_kernel, dim3(ceil_div(c, 128)), dim3(128), 0, s, (const double*)totals, a.count, c,
+                               a.coef, a.dgamma, a.dbeta);
+            LH_LAUNCH_CHECK("fuse_bwd_coef launch");
+        }
+        const long total = a.count * (c / (16 / es));
+        const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+        LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((fuse_bwd_apply_kernel<T>), dim3(grid), dim3(256), 0, s, a));
+        LH_LAUNCH_CHECK("fuse_bwd_apply launch");
+    }
+    return LH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* x, T* out, unsigned char* idx, int n, int h, int w,
+                                                          int c, int ho, int wo) {
+    constexpr int EPC = 16 / sizeof(T);
+    const int nchunk = c / EPC;
+    const long total = (long)n * ho * wo * nchunk;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int ch = (int)(i % nchunk);
+        const long pix = i / nchunk;
+        const int ow = (int)(pix % wo);
+        const long t2 = pix / wo;
+        const int oh = (int)(t2 % ho), b = (int)(t2 / ho);
+        float best[EPC];
+        unsigned char bi[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) { best[e] = -INFINITY; bi[e] = 255; }
+        for (int r = 0; r < 3; ++r) {
+            const int ih = oh * 2 - 1 + r;
+            if ((unsigned)ih >= (unsigned)h) continue;
+            for (int s = 0; s < 3; ++s) {
+                const int iw = ow * 2 - 1 + s;
+                if ((unsigned)iw >= (unsigned)w) continue;
+                float v[EPC];
+                unpack16<T>(*reinterpret_cast<const uint4*>(x + (((long)b * h + ih) * w + iw) * c + ch * EPC), v);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    // same rule as the framework's CPU kernel: strictly greater or NaN replaces
+                    if (v[e] > best[e] || v[e] != v[e] || bi[e] == 255) { best[e] = v[e]; bi[e] = (unsigned char)(r * 3 + s); }
+                }
+            }
+        }
+        *reinterpret_cast<uint4*>(out + i * EPC) = pack16<T>(best);
+        unsigned char* ip = idx + i * EPC;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) ip[e] = bi[e];
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* dout, const unsigned char* idx, T* dx, int n, int h,
+                                                          int w, int c, int ho, int wo) {
+    constexpr int EPC = 16 / sizeof(T);
+    const int nchunk = c / EPC;
+    const long total = (long)n * h * w * nchunk;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int ch = (int)(i % nchunk);
+        const long pix = i / nchunk;
+        const int iw = (int)(pix % w);
+        const long t2 = pix / w;
+        const int ih = (int)(t2 % h), b = (int)(t2 / h);
+        float g[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) g[e] = 0.f;
+        for (int oh = (ih >> 1); oh <= ((ih + 1) >> 1); ++oh) {
+            if (oh >= ho) continue;
+            const int r = ih + 1 - 2 * oh;
+            if (r < 0 || r > 2) continue;
+            for (int ow = (iw >> 1); ow <= ((iw + 1) >> 1); ++ow) {
+                if (ow >= wo) continue;
+                const int s = iw + 1 - 2 * ow;
+                if (s < 0 || s > 2) continue;
+                const long o = (((long)b * ho + oh) * wo + ow) * c + ch * EPC;
+                float d[EPC];
+                unpack16<T>(*reinterpret_cast<const uint4*>(dout + o), d);
+                const unsigned char* ip = idx + o;
+#pragma unroll
+                for (int e = 0; e < EPC; ++e)
+                    if (ip[e] == r * 3 + s) g[e] += d[e];
+            }
+        }
+        *reinterpret_cast<uint4*>(dx + i * EPC) = pack16<T>(g);
+    }
+}
+
+extern "C" int lh_maxpool3x3s2_fwd(const void* x, void* out, unsigned char* idx, int n, int h, int w, int c,
+                                   int dtype, void* stream) {
+    LH_REQUIRE(x && out && idx && n > 0 && h > 0 && w > 0, "lh_maxpool3x3s2_fwd: bad arguments");
+    const int es = lh_dtype_size(dtype);
+    LH_REQUIRE(es > 0 && c % (16 / es) == 0, "lh_maxpool3x3s2_fwd: c %d not a multiple of the 16-byte chunk", c);
+    const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
+    const long total = (long)n * ho * wo * (c / (16 / es));
+    const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((maxpool_fwd_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                                                   (const T*)x, (T*)out, idx, n, h, w, c, ho, wo));
+    LH_LAUNCH_CHECK("maxpool_fwd launch");
+    return LH_OK;
+}
+
+extern "C" int lh_maxpool3x3s2_bwd(const void* dout, const unsigned char* idx, void* dx, int n, int h, int w,
+                                   int c, int dtype, void* stream) {
+    LH_REQUIRE(dout && dx && idx && n > 0 && h > 0 && w > 0, "lh_maxpool3x3s2_bwd: bad arguments");
+    const int es = lh_dtype_size(dtype);
+    LH_REQUIRE(es > 0 && c % (16 / es) == 0, "lh_maxpool3x3s2_bwd: c %d not a multiple of the 16-byte chunk", c);
+    const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
+    const long total = (long)n * h * w * (c / (16 / es));
+    const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                                                   (const T*)dout, idx, (T*)dx, n, h, w, c, ho, wo));
+    LH_LAUNCH_CHECK("maxpool_bwd launch");
+    return LH_OK;
+}

@@ -1,0 +1,335 @@
+// Implicit-GEMM gather convolution for gfx950 (MI355X): forward conv, data-gradient,
+// and the sub-pixel phases of stride-2 transposed convolutions, all through one kernel.
+//
+//   out[pixel][co] = sum_{tap} sum_{k < k_run} in[pix(pixel, tap)][k] * wpack[co][tap][k]
+//
+// GEMM view: D[co][pixel] (MFMA "A" = weights, "B" = gathered pixels, both K-major in LDS),
+// so each lane ends up with 4 consecutive output channels of one pixel (NHWC-friendly).
+//  * 256 threads = 4 waves, tile BM (channels) x BP (pixels), K step = 64 bytes per row
+//    (32 bf16 / 16 fp32): one v_mfma_f32_16x16x32_bf16 (or 4 v_mfma_f32_16x16x4_f32) per
+//    16x16 sub-tile and step.
+//  * global -> registers -> LDS staging, double buffered, ONE barrier per K step; next
+//    step's global loads are in flight while the MFMAs of the current step run.
+//  * LDS image: [16-row group][16-B chunk c][row ^ 2c] x 16 B  -- lane-linear for the
+//    fragment reads (conflict free) and conflict free for the staging writes.
+//  * epilogue through LDS: bias, then full-line NHWC stores with optional addend / ReLU,
+//    and per-block column sums / sums of squares of the STORED values for BatchNorm.
+#include "common.h"
+
+struct IgemmArgs {
+    const unsigned char* in;
+    const unsigned char* w;
+    unsigned char* out;
+    const unsigned char* addend;
+    const float* bias;
+    float* stats;
+    int n, hi, wi, in_pix_stride, k_run, kspt;
+    int ho, wo, M, sh, sw, cout;
+    int OH, OW, osh, osw, ooh, oow, out_pix_stride;
+    int ntaps, relu;
+    signed char dh[64];
+    signed char dw[64];
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16> {
+    static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                   __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma<f16> {
+    static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a),
+                                                  __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    // lane group g = lane>>4 holds k = 4g..4g+3 of the 16-float step; instruction kk consumes
+    // element kk of every group, so A and B agree on the k each slot stands for.
+    static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4& c) {
+        const f32x4 fa = __builtin_bit_cast(f32x4, a), fb = __builtin_bit_cast(f32x4, b);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0], fb[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1], fb[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[2], fb[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[3], fb[3], c, 0, 0, 0);
+    }
+};
+
+__device__ __forceinline__ int stage_off(int row, int c) {
+    return ((row >> 4) << 10) + (c << 8) + ((((row & 15) ^ (c << 1)) & 15) << 4);
+}
+
+template <typename T, int BM, int BP, int WC, int WP>
+__global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int ES = sizeof(T);
+    constexpr int EPC = 16 / ES;          // elements per 16-byte chunk
+    constexpr int KSTEP = 64 / ES;        // elements per K step
+    constexpr int TC = BM / WC, TP = BP / WP;
+    constexpr int CT = TC / 16, PT = TP / 16;
+    constexpr int RW = BM / 64, RX = BP / 64;
+    constexpr int STAGE = (BM + BP) * 64;
+    static_assert(WC * WP == 4 && CT >= 1 && PT >= 1, "bad tile");
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wc = wave / WP, wp = wave % WP;
+    const int pblk = blockIdx.x, cblk = blockIdx.y;
+    const int c4 = tid & 3, r4 = tid >> 2;
+
+    // ---- per-thread gather state for the pixel rows it stages
+    int xbase[RX], xh[RX], xw[RX];
+    bool xok[RX];
+    const int hw = p.ho * p.wo;
+#pragma unroll
+    for (int i = 0; i < RX; ++i) {
+        const int m = pblk * BP + r4 + 64 * i;
+        xok[i] = m < p.M;
+        const int mm = xok[i] ? m : 0;
+        const int n = mm / hw, rem = mm - n * hw;
+        const int a = rem / p.wo, b = rem - a * p.wo;
+        xbase[i] = n * p.hi * p.wi;
+        xh[i] = a * p.sh;
+        xw[i] = b * p.sw;
+    }
+    const long kpad = (long)p.kspt * KSTEP;
+    const unsigned char* wrow[RW];
+#pragma unroll
+    for (int i = 0; i < RW; ++i)
+        wrow[i] = p.w + ((long)(cblk * BM + r4 + 64 * i) * p.ntaps * kpad + c4 * EPC) * ES;
+
+    f32x4 acc[CT][PT];
+#pragma unroll
+    for (int i = 0; i < CT; ++i)
+#pragma unroll
+        for (int j = 0; j < PT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    uint4 xr[RX], wr[RW];
+    auto gload = [&](int tap, int kc) {
+        const int koff = kc * KSTEP + c4 * EPC;
+        const int dh = p.dh[tap], dw = p.dw[tap];
+#pragma unroll
+        for (int i = 0; i < RX; ++i) {
+            const int ih = xh[i] + dh, iw = xw[i] + dw;
+            const bool ok = xok[i] && (unsigned)ih < (unsigned)p.hi && (unsigned)iw < (unsigned)p.wi &&
+                            koff < p.k_run;
+            if (ok) {
+                const long e = (long)(xbase[i] + ih * p.wi + iw) * p.in_pix_stride + koff;
+                xr[i] = *reinterpret_cast<const uint4*>(p.in + e * ES);
+            } else {
+                xr[i] = uint4{0u, 0u, 0u, 0u};
+            }
+        }
+        const long wo = ((long)tap * kpad + (long)kc * KSTEP) * ES;
+#pragma unroll
+        for (int i = 0; i < RW; ++i) wr[i] = *reinterpret_cast<const uint4*>(wrow[i] + wo);
+    };
+
+    const int S = p.ntaps * p.kspt;
+    int tap = 0, kc = 0;
+    if (S > 0) gload(0, 0);
+    const int lane_off = ((lane >> 4) << 8) + ((((lane & 15) ^ ((lane >> 4) << 1)) & 15) << 4);
+
+    for (int s = 0; s < S; ++s) {
+        unsigned char* st = smem + (s & 1) * STAGE;
+#pragma unroll
+        for (int i = 0; i < RW; ++i)
+            *reinterpret_cast<uint4*>(st + stage_off(r4 + 64 * i, c4)) = wr[i];
+#pragma unroll
+        for (int i = 0; i < RX; ++i)
+            *reinterpret_cast<uint4*>(st + BM * 64 + stage_off(r4 + 64 * i, c4)) = xr[i];
+        __syncthreads();
+        if (++kc == p.kspt) { kc = 0; ++tap; }
+        if (s + 1 < S) gload(tap, kc);
+
+        uint4 fa[CT], fb[PT];
+#pragma unroll
+        for (int i = 0; i < CT; ++i)
+            fa[i] = *reinterpret_cast<const uint4*>(st + ((wc * CT + i) << 10) + lane_off);
+#pragma unroll
+        for (int j = 0; j < PT; ++j)
+            fb[j] = *reinterpret_cast<const uint4*>(st + BM * 64 + ((wp * PT + j) << 10) + lane_off);
+#pragma unroll
+        for (int i = 0; i < CT; ++i)
+#pragma unroll
+            for (int j = 0; j < PT; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
+    }
+
+    // ---- epilogue: D -> LDS tile [BP][BM] (row stride RS), then full-line stores
+    constexpr int RS = BM * ES + 8;
+    __syncthreads();
+    {
+        const int q = lane >> 4, pl = lane & 15;
+#pragma unroll
+        for (int i = 0; i < CT; ++i) {
+            const int col = wc * TC + i * 16 + q * 4;
+            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int gc = cblk * BM + col + r;
+                    bv[r] = gc < p.cout ? p.bias[gc] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < PT; ++j) {
+                const int pr = wp * TP + j * 16 + pl;
+                T* dst = reinterpret_cast<T*>(smem + pr * RS + col * ES);
+                if constexpr (ES == 4) {
+                    float2 lo = {acc[i][j][0] + bv[0], acc[i][j][1] + bv[1]};
+                    float2 hi = {acc[i][j][2] + bv[2], acc[i][j][3] + bv[3]};
+                    reinterpret_cast<float2*>(dst)[0] = lo;
+                    reinterpret_cast<float2*>(dst)[1] = hi;
+                } else {
+                    union { uint2 u; T e[4]; } pk;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pk.e[r] = from_f<T>(acc[i][j][r] + bv[r]);
+                    *reinterpret_cast<uint2*>(dst) = pk.u;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    constexpr int CH = BM * ES / 16;        // 16-byte chunks per pixel row
+    constexpr int RPP = 256 / CH;           // pixel rows per pass
+    const int chunk = tid % CH, r0 = tid / CH;
+    const int col0 = cblk * BM + chunk * EPC;
+    const bool col_ok = col0 < p.cout;      // cout % EPC == 0 is required by the host
+    float s1[EPC], s2[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) s1[e] = s2[e] = 0.f;
+
+    for (int pr = r0; pr < BP; pr += RPP) {
+        const int m = pblk * BP + pr;
+        if (m >= p.M || !col_ok) continue;
+        const int n = m / hw, rem = m - n * hw;
+        const int a = rem / p.wo, b = rem - a * p.wo;
+        const long opix = ((long)n * p.OH + a * p.osh + p.ooh) * p.OW + b * p.osw + p.oow;
+        const long eoff = opix * p.out_pix_stride + col0;
+        const unsigned char* src = smem + pr * RS + chunk * 16;
+        uint4 u;
+        {
+            const uint2 lo = *reinterpret_cast<const uint2*>(src);
+            const uint2 hi = *reinterpret_cast<const uint2*>(src + 8);
+            u = uint4{lo.x, lo.y, hi.x, hi.y};
+        }
+        float v[EPC];
+        unpack16<T>(u, v);
+        if (p.addend) {
+            float av[EPC];
+            unpack16<T>(*reinterpret_cast<const uint4*>(p.addend + eoff * ES), av);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) v[e] += av[e];
+        }
+        if (p.relu) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (p.addend || p.relu) u = pack16<T>(v);
+        if (p.stats) {
+            float sv[EPC];
+            unpack16<T>(u, sv);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) { s1[e] += sv[e]; s2[e] += sv[e] * sv[e]; }
+        }
+        *reinterpret_cast<uint4*>(p.out + eoff * ES) = u;
+    }
+
+    if (p.stats) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);      // [RPP][2][BM]
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            red[(r0 * 2 + 0) * BM + chunk * EPC + e] = s1[e];
+            red[(r0 * 2 + 1) * BM + chunk * EPC + e] = s2[e];
+        }
+        __syncthreads();
+        for (int t = tid; t < 2 * BM; t += 256) {
+            const int which = t / BM, col = t - which * BM;
+            float a = 0.f;
+#pragma unroll 4
+            for (int r = 0; r < RPP; ++r) a += red[(r * 2 + which) * BM + col];
+            const int gc = cblk * BM + col;
+            if (gc < p.cout) p.stats[((long)pblk * 2 + which) * p.cout + gc] = a;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <typename T, int BM, int BP, int WC, int WP>
+static int launch_tile(const IgemmArgs& a, hipStream_t s) {
+    constexpr int ES = sizeof(T);
+    constexpr int stage = 2 * (BM + BP) * 64;
+    constexpr int epi = BP * (BM * ES + 8);
+    constexpr int red = (256 / (BM * ES / 16)) * 2 * BM * 4;
+    constexpr int lds = stage > epi ? (stage > red ? stage : red) : (epi > red ? epi : red);
+    static_assert(lds <= 65536, "LDS budget");
+    dim3 grid(ceil_div(a.M, BP), ceil_div(a.cout, BM));
+    hipLaunchKernelGGL((igemm_kernel<T, BM, BP, WC, WP>), grid, dim3(256), lds, s, a);
+    LH_LAUNCH_CHECK("igemm launch");
+    return LH_OK;
+}
+
+static void pick_tile(const lh_igemm_desc* d, int dtype, int* bm, int* bp) {
+    const long M = (long)d->n * d->ho * d->wo;
+    int BM = d->cout > 64 ? 128 : 64;
+    int BP = 128;
+    if (dtype == LH_F32 && BM == 128) BP = 64;          // LDS budget of the fp32 epilogue tile
+    const long blocks = ((M + BP - 1) / BP) * ((d->cout + BM - 1) / BM);
+    if (BP == 128 && blocks < 384) BP = 64;
+    *bm = BM;
+    *bp = BP;
+}
+
+extern "C" int lh_igemm_stats_rows(const lh_igemm_desc* d, int dtype) {
+    int bm, bp;
+    pick_tile(d, dtype, &bm, &bp);
+    const long M = (long)d->n * d->ho * d->wo;
+    return (int)((M + bp - 1) / bp);
+}
+
+extern "C" int lh_igemm(const lh_igemm_desc* d, const void* in, const void* wpack, void* out,
+                        const void* addend, const float* bias, float* stats, int dtype, void* stream) {
+    LH_REQUIRE(d && in && wpack && out, "lh_igemm: null pointer");
+    const int es = lh_dtype_size(dtype);
+    LH_REQUIRE(es > 0, "lh_igemm: bad dtype %d", dtype);
+    const int epc = 16 / es;
+    LH_REQUIRE(d->ntaps >= 0 && d->ntaps <= 64, "lh_igemm: ntaps %d out of range", d->ntaps);
+    LH_REQUIRE(d->k_run > 0 && d->k_run % epc == 0, "lh_igemm: k_run %d must be a multiple of %d", d->k_run, epc);
+    LH_REQUIRE(d->cout > 0 && d->cout % epc == 0, "lh_igemm: cout %d must be a multiple of %d", d->cout, epc);
+    LH_REQUIRE(d->out_pix_stride % epc == 0 && d->out_pix_stride >= d->cout, "lh_igemm: bad out_pix_stride %d", d->out_pix_stride);
+    LH_REQUIRE(d->in_pix_stride > 0 && (d->in_pix_stride * es) % 4 == 0, "lh_igemm: bad in_pix_stride");
+    LH_REQUIRE(d->n > 0 && d->ho > 0 && d->wo > 0 && d->hi > 0 && d->wi > 0, "lh_igemm: bad sizes");
+    LH_REQUIRE((d->ho - 1) * d->osh + d->ooh < d->OH && (d->wo - 1) * d->osw + d->oow < d->OW && d->ooh >= 0 && d->oow >= 0,
+               "lh_igemm: output placement exceeds the %dx%d image", d->OH, d->OW);
+    IgemmArgs a;
+    a.in = (const unsigned char*)in; a.w = (const unsigned char*)wpack; a.out = (unsigned char*)out;
+    a.addend = (const unsigned char*)addend; a.bias = bias; a.stats = stats;
+    a.n = d->n; a.hi = d->hi; a.wi = d->wi; a.in_pix_stride = d->in_pix_stride; a.k_run = d->k_run;
+    a.kspt = (d->k_run * es + 63) / 64;
+    a.ho = d->ho; a.wo = d->wo; a.M = d->n * d->ho * d->wo; a.sh = d->sh; a.sw = d->sw; a.cout = d->cout;
+    a.OH = d->OH; a.OW = d->OW; a.osh = d->osh; a.osw = d->osw; a.ooh = d->ooh; a.oow = d->oow;
+    a.out_pix_stride = d->out_pix_stride; a.ntaps = d->ntaps; a.relu = d->relu;
+    for (int i = 0; i < 64; ++i) { a.dh[i] = d->dh[i]; a.dw[i] = d->dw[i]; }
+    int bm, bp;
+    pick_tile(d, dtype, &bm, &bp);
+    hipStream_t s = (hipStream_t)stream;
+#define LH_TILE(T)                                                               \
+    if (bm == 128 && bp == 128) return launch_tile<T, 128, 128, 2, 2>(a, s);     \
+    if (bm == 128 && bp == 64) return launch_tile<T, 128, 64, 4, 1>(a, s);       \
+    if (bm == 64 && bp == 128) return launch_tile<T, 64, 128, 1, 4>(a, s);       \
+    return launch_tile<T, 64, 64, 2, 2>(a, s);
+    switch (dtype) {
+        case LH_BF16: { LH_TILE(bf16) }
+        case LH_F16: { LH_TILE(f16) }
+        case LH_F32: {
+            if (bm == 128) return launch_tile<float, 128, 64, 4, 1>(a, s);
+            if (bp == 128) return launch_tile<float, 64, 128, 1, 4>(a, s);
+            return launch_tile<float, 64, 64, 2, 2>(a, s);
+        }
+    }
+#undef LH_TILE
+    lh_set_error("lh_igemm: unsupported dtype %d", dtype);
+    return LH_ERR_ARG;
+}

@@ -1,0 +1,340 @@
+// Layout transforms, weight packs, heatmap target / loss / arg-max decode, fused Adam.
+#include "common.h"
+#include <stdarg.h>
+#include <stdio.h>
+
+// ------------------------------------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+void lh_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* lh_last_error(void) { return g_err; }
+extern "C" int lh_version(void) { return 100; }
+extern "C" int lh_dtype_size(int dtype) {
+    switch (dtype) {
+        case LH_F32: return 4;
+        case LH_BF16: return 2;
+        case LH_F16: return 2;
+        default: return 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ transforms
+template <typename T>
+__global__ void image_to_nhwc4_kernel(const float* src, T* dst, int n, int h, int w, int pad, int hp, int wp) {
+    const long total = (long)n * hp * wp;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % wp);
+        const long t = i / wp;
+        const int y = (int)(t % hp), b = (int)(t / hp);
+        const int sy = y - pad, sx = x - pad;
+        float v[3] = {0.f, 0.f, 0.f};
+        if ((unsigned)sy < (unsigned)h && (unsigned)sx < (unsigned)w) {
+            const long base = ((long)b * 3 * h + sy) * w + sx;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[c] = src[base + (long)c * h * w];
+        }
+        T* o = dst + i * 4;
+        o[0] = from_f<T>(v[0]); o[1] = from_f<T>(v[1]); o[2] = from_f<T>(v[2]); o[3] = from_f<T>(0.f);
+    }
+}
+
+extern "C" int lh_image_to_nhwc4(const float* nchw, void* out, int n, int h, int w, int pad, int wp, int dtype,
+                                 void* stream) {
+    LH_REQUIRE(nchw && out && n > 0 && h > 0 && w > 0 && pad >= 0 && wp >= w + 2 * pad, "lh_image_to_nhwc4: bad arguments");
+    const int hp = h + 2 * pad;
+    const long total = (long)n * hp * wp;
+    const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((image_to_nhwc4_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                                                   nchw, (T*)out, n, h, w, pad, hp, wp));
+    LH_LAUNCH_CHECK("image_to_nhwc4 launch");
+    return LH_OK;
+}
+
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* src, float* dst, int n, int hw, int c, int cs) {
+    const long total = (long)n * hw;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / hw), p = (int)(i % hw);
+        const T* s = src + i * cs;
+        for (int ch = 0; ch < c; ++ch) dst[((long)b * c + ch) * hw + p] = to_f<T>(s[ch]);
+    }
+}
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* src, T* dst, int n, int hw, int c, int cs) {
+    const long total = (long)n * hw;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / hw), p = (int)(i % hw);
+        T* d = dst + i * cs;
+        for (int ch = 0; ch < cs; ++ch) d[ch] = from_f<T>(ch < c ? src[((long)b * c + ch) * hw + p] : 0.f);
+    }
+}
+
+extern "C" int lh_nhwc_to_nchw_f32(const void* nhwc, float* nchw, int n, int h, int w, int c, int c_stride, int dtype,
+                                   void* stream) {
+    LH_REQUIRE(nhwc && nchw && n > 0 && h > 0 && w > 0 && c > 0 && c_stride >= c, "lh_nhwc_to_nchw_f32: bad arguments");
+    const long total = (long)n * h * w;
+    const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((nhwc_to_nchw_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                                                   (const T*)nhwc, nchw, n, h * w, c, c_stride));
+    LH_LAUNCH_CHECK("nhwc_to_nchw launch");
+    return LH_OK;
+}
+extern "C" int lh_nchw_f32_to_nhwc(const float* nchw, void* nhwc, int n, int h, int w, int c, int c_stride, int dtype,
+                                   void* stream) {
+    LH_REQUIRE(nhwc && nchw && n > 0 && h > 0 && w > 0 && c > 0 && c_stride >= c, "lh_nchw_f32_to_nhwc: bad arguments");
+    const long total = (long)n * h * w;
+    const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                                                   nchw, (T*)nhwc, n, h * w, c, c_stride));
+    LH_LAUNCH_CHECK("nchw_to_nhwc launch");
+    return LH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ weight pack
+struct PackArgs {
+    const float* w;
+    void* out;
+    int n_out, n_in, ntaps, kpad, rows;
+    long so, si, sr, ss;
+    signed char r[64];
+    signed char s[64];
+};
+
+template <typename T>
+__global__ void pack_weight_kernel(const PackArgs p) {
+    const long total = (long)p.rows * p.ntaps * p.kpad;
+    T* out = (T*)p.out;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % p.kpad);
+        const long t2 = i / p.kpad;
+        const int t = (int)(t2 % p.ntaps), o = (int)(t2 / p.ntaps);
+        float v = 0.f;
+        if (o < p.n_out && k < p.n_in) v = p.w[o * p.so + k * p.si + p.r[t] * p.sr + p.s[t] * p.ss];
+        out[i] = from_f<T>(v);
+    }
+}
+
+extern "C" int lh_pack_weight(const float* w, void* out, size_t* bytes, int n_out, int n_in, long so, long si,
+                              long sr, long ss, int ntaps, const int* taps_rs, int dtype, void* stream) {
+    const int es = lh_dtype_size(dtype);
+    LH_REQUIRE(es > 0, "lh_pack_weight: bad dtype %d", dtype);
+    LH_REQUIRE(n_out > 0 && n_in > 0 && ntaps >= 0 && ntaps <= 64, "lh_pack_weight: bad sizes");
+    const int kstep = 64 / es;
+    const int kpad = (n_in + kstep - 1) / kstep * kstep;
+    const int rows = (n_out + 127) / 128 * 128;
+    const size_t need = (size_t)rows * (ntaps > 0 ? ntaps : 1) * kpad * es;
+    if (bytes) *bytes = need;
+    if (!out) return LH_OK;
+    if (ntaps == 0) return LH_OK;
+    LH_REQUIRE(w && taps_rs, "lh_pack_weight: null pointer");
+    PackArgs a;
+    a.w = w; a.out = out; a.n_out = n_out; a.n_in = n_in; a.ntaps = ntaps; a.kpad = kpad; a.rows = rows;
+    a.so = so; a.si = si; a.sr = sr; a.ss = ss;
+    for (int t = 0; t < 64; ++t) {
+        a.r[t] = t < ntaps ? (signed char)taps_rs[2 * t] : 0;
+        a.s[t] = t < ntaps ? (signed char)taps_rs[2 * t + 1] : 0;
+    }
+    const long total = (long)rows * ntaps * kpad;
+    const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((pack_weight_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a));
+    LH_LAUNCH_CHECK("pack_weight launch");
+    return LH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ Gaussian target
+__global__ void gaussian_target_kernel(const float* joints, int jstride, const float* patch, int radius, float* target,
+                                       int bj, int size) {
+    const long total = (long)bj * size * size;
+    const int pw = 2 * radius + 1;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % size);
+        const long t = i / size;
+        const int y = (int)(t % size);
+        const long j = t / size;
+        const float jx = joints[j * jstride], jy = joints[j * jstride + 1];
+        // int(v / 4 + 0.5): truncation toward zero, like Python's int()
+        const int mx = (int)(jx * 0.25f + 0.5f), my = (int)(jy * 0.25f + 0.5f);
+        const int x0 = mx - radius, y0 = my - radius, x1 = mx + radius + 1, y1 = my + radius + 1;
+        float v = 0.f;
+        const bool skip = x0 >= size || y0 >= size || x1 < 0 || y1 < 0;
+        if (!skip && x >= x0 && x < x1 && y >= y0 && y < y1) v = patch[(y - y0) * pw + (x - x0)];
+        target[i] = v;
+    }
+}
+
+extern "C" int lh_gaussian_target(const float* joints, int jstride, const float* patch, int radius, float* target,
+                                  int b, int j, int size, void* stream) {
+    LH_REQUIRE(joints && patch && target && jstride >= 2 && b > 0 && j > 0 && size > 0 && radius >= 0,
+               "lh_gaussian_target: bad arguments");
+    const long total = (long)b * j * size * size;
+    const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(gaussian_target_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, joints, jstride, patch, radius,
+                       target, b * j, size);
+    LH_LAUNCH_CHECK("gaussian_target launch");
+    return LH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ MSE loss
+constexpr int MSE_BLOCKS = 512;
+
+__global__ __launch_bounds__(256) void mse_partial_kernel(const float* pred, const float* target, long numel, float* grad,
+                                                         const float* grad_scale, double* partial) {
+    __shared__ double red[4];
+    const float gs = (grad_scale ? *grad_scale : 1.f) / (float)numel;
+    double acc = 0.0;
+    const long nvec = numel / 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+        const float4 p = reinterpret_cast<const float4*>(pred)[i];
+        const float4 t = reinterpret_cast<const float4*>(target)[i];
+        const float4 d = {p.x - t.x, p.y - t.y, p.z - t.z, p.w - t.w};
+        acc += (double)(d.x * d.x) + (double)(d.y * d.y) + (double)(d.z * d.z) + (double)(d.w * d.w);
+        if (grad) reinterpret_cast<float4*>(grad)[i] = float4{d.x * gs, d.y * gs, d.z * gs, d.w * gs};
+    }
+    if (blockIdx.x == 0)
+        for (long i = nvec * 4 + threadIdx.x; i < numel; i += 256) {
+            const float d = pred[i] - target[i];
+            acc += (double)(d * d);
+            if (grad) grad[i] = d * gs;
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ void mse_final_kernel(const double* partial, int nblocks, long numel, float* loss) {
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) acc += partial[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) *loss = (float)(0.5 * (red[0] + red[1] + red[2] + red[3]) / (double)numel);
+}
+
+extern "C" size_t lh_mse_workspace_bytes(long numel) { (void)numel; return MSE_BLOCKS * sizeof(double); }
+
+extern "C" int lh_mse_heatmap(const float* pred, const float* target, long numel, float* loss, float* grad,
+                              const float* grad_scale, void* workspace, void* stream) {
+    LH_REQUIRE(pred && target && loss && workspace && numel > 0, "lh_mse_heatmap: bad arguments");
+    LH_REQUIRE(((uintptr_t)pred % 16 == 0) && ((uintptr_t)target % 16 == 0) && (!grad || (uintptr_t)grad % 16 == 0),
+               "lh_mse_heatmap: buffers must be 16-byte aligned");
+    int blocks = (int)((numel / 4 + 255) / 256);
+    if (blocks > MSE_BLOCKS) blocks = MSE_BLOCKS;
+    if (blocks < 1) blocks = 1;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(mse_partial_kernel, dim3(blocks), dim3(256), 0, s, pred, target, numel, grad, grad_scale,
+                       (double*)workspace);
+    hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(256), 0, s, (const double*)workspace, blocks, numel, loss);
+    LH_LAUNCH_CHECK("mse launch");
+    return LH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ arg-max decode
+struct Cand { float v; int i; };
+// true when a precedes b under numpy.argmax's rule: NaN beats everything, then larger value,
+// ties (and NaN vs NaN) broken by the lower flat index.
+__device__ __forceinline__ bool cand_before(const Cand& a, const Cand& b) {
+    const bool an = a.v != a.v, bn = b.v != b.v;
+    if (an || bn) return an && (!bn || a.i < b.i);
+    return a.v > b.v || (a.v == b.v && a.i < b.i);
+}
+
+__global__ __launch_bounds__(256) void heatmap_argmax_kernel(const float* hm, int hw, int w, float scale, float* preds,
+                                                            float* maxvals, int* idx) {
+    __shared__ Cand red[4];
+    const float* m = hm + (long)blockIdx.x * hw;
+    Cand best = {0.f, 0x7fffffff};
+    bool have = false;
+    for (int i = threadIdx.x; i < hw; i += 256) {
+        const Cand c = {m[i], i};
+        if (!have || cand_before(c, best)) { best = c; have = true; }
+    }
+    if (!have) best = Cand{-INFINITY, 0x7fffffff};
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        Cand other = {__shfl_xor(best.v, o), __shfl_xor(best.i, o)};
+        if (other.i != 0x7fffffff && (best.i == 0x7fffffff || cand_before(other, best))) best = other;
+    }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        Cand b = red[0];
+        for (int k = 1; k < 4; ++k)
+            if (red[k].i != 0x7fffffff && (b.i == 0x7fffffff || cand_before(red[k], b))) b = red[k];
+        const float keep = b.v > 0.f ? 1.f : 0.f;
+        preds[blockIdx.x * 2 + 0] = (float)(b.i % w) * keep * scale;
+        preds[blockIdx.x * 2 + 1] = (float)(b.i / w) * keep * scale;
+        maxvals[blockIdx.x] = b.v;
+        if (idx) idx[blockIdx.x] = b.i;
+    }
+}
+
+extern "C" int lh_heatmap_argmax(const float* heatmaps, int bj, int h, int w, float scale, float* preds, float* maxvals,
+                                 int* idx, void* stream) {
+    LH_REQUIRE(heatmaps && preds && maxvals && bj > 0 && h > 0 && w > 0, "lh_heatmap_argmax: bad arguments");
+    hipLaunchKernelGGL(heatmap_argmax_kernel, dim3(bj), dim3(256), 0, (hipStream_t)stream, heatmaps, h * w, w, scale, preds,
+                       maxvals, idx);
+    LH_LAUNCH_CHECK("heatmap_argmax launch");
+    return LH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ Adam
+__global__ void adam_tick_kernel(const double* hyper, int* step, float* derived) {
+    const int t = *step + 1;
+    *step = t;
+    const double lr = hyper[0], b1 = hyper[1], b2 = hyper[2];
+    derived[0] = (float)(lr / (1.0 - pow(b1, (double)t)));      // step size
+    derived[1] = (float)sqrt(1.0 - pow(b2, (double)t));         // sqrt of bias correction 2
+    derived[2] = (float)b1;
+    derived[3] = (float)b2;
+    derived[4] = (float)hyper[3];
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, long numel,
+                                                   const float* derived, float gscale) {
+    const float step_size = derived[0], bc2 = derived[1], b1 = derived[2], b2 = derived[3], eps = derived[4];
+    const long nvec = numel / 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+        float4 pp = reinterpret_cast<float4*>(p)[i];
+        const float4 gg = reinterpret_cast<const float4*>(g)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+        float* P = &pp.x; const float* G = &gg.x; float* M = &mm.x; float* V = &vv.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gk = G[k] * gscale;
+            M[k] = M[k] * b1 + gk * (1.f - b1);
+            V[k] = V[k] * b2 + gk * gk * (1.f - b2);
+            P[k] -= step_size * (M[k] / (sqrtf(V[k]) / bc2 + eps));
+        }
+        reinterpret_cast<float4*>(p)[i] = pp;
+        reinterpret_cast<float4*>(m)[i] = mm;
+        reinterpret_cast<float4*>(v)[i] = vv;
+    }
+    if (blockIdx.x == 0)
+        for (long i = nvec * 4 + threadIdx.x; i < numel; i += 256) {
+            const float gk = g[i] * gscale;
+            m[i] = m[i] * b1 + gk * (1.f - b1);
+            v[i] = v[i] * b2 + gk * gk * (1.f - b2);
+            p[i] -= step_size * (m[i] / (sqrtf(v[i]) / bc2 + eps));
+        }
+}
+
+extern "C" int lh_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long numel,
+                            const double* hyper, int* step, float* derived, float grad_scale, void* stream) {
+    LH_REQUIRE(param && grad && exp_avg && exp_avg_sq && hyper && step && derived && numel > 0, "lh_adam_step: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, s, hyper, step, derived);
+    const long nvec = numel / 4;
+    const int grid = (int)((nvec + 255) / 256 > 2048 ? 2048 : ((nvec + 255) / 256 < 1 ? 1 : (nvec + 255) / 256));
+    hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq, numel,
+                       (const float*)derived, grad_scale);
+    LH_LAUNCH_CHECK("adam launch");
+    return LH_OK;
+}

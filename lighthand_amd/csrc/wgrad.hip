@@ -1,0 +1,285 @@
+// Weight-gradient GEMM for gfx950:  dW[tap][o][i] = sum_pixels dy[pixel][o] * x[pix(pixel,tap)][i]
+//
+// The contraction index (pixels) is the SLOW index of both NHWC operands, so the MFMA
+// fragments (8 consecutive k per lane) are formed with the CDNA4 transposing LDS read
+// ds_read_b64_tr_b16 from row-major [pixel][channel] LDS images (16-bit types); the fp32
+// path reads its one-k-per-lane fragments with plain ds_read_b32.
+//  * tile BO x BI output, K step = 32 pixels (16-bit) / 16 pixels (fp32), 4 waves,
+//    double-buffered register staging with one barrier per step (as igemm.hip);
+//  * LDS rows are padded so that the 8 pixel rows a half-wave touches per transposed read
+//    land on distinct bank groups; the k order inside a step is {4g..4g+3, 16+4g..16+4g+3}
+//    for lane group g -- the same permutation for both operands, so the sum is unchanged;
+//  * split-K over pixels -> fp32 slabs [split][tap][o][i], folded (deterministically, in
+//    split order) into the reference-layout gradient by wgrad_reduce_kernel.
+#include "common.h"
+
+struct WgradArgs {
+    const unsigned char* x;
+    const unsigned char* dy;
+    float* slab;
+    int n, hi, wi, in_pix_stride, k_run;
+    int ho, wo, M, sh, sw;
+    int dy_pix_stride, n_out, n_in;
+    int ntaps, nsplit, steps_per_split, i_tiles;
+    signed char dh[64];
+    signed char dw[64];
+};
+
+template <typename T> struct WFrag;
+
+// 16-bit types: two transposed reads give the lane 8 k-values of one channel.
+template <typename T> struct WFrag {
+    static constexpr int KP = 32;
+    static constexpr int PAD = 32;
+    static __device__ __forceinline__ uint4 load(const unsigned char* tile, int rs, int ctile, int lane) {
+        const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+        const unsigned char* a0 = tile + (4 * g + q) * rs + (ctile * 16 + 4 * pp) * 2;
+        const unsigned char* a1 = a0 + 16 * rs;
+        typedef s16x4 __attribute__((address_space(3))) * lds_p;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a1));
+        union { struct { s16x4 l, h; } s; uint4 u; } r;
+        r.s.l = lo; r.s.h = hi;
+        return r.u;
+    }
+    static __device__ __forceinline__ void mma(const uint4& a, const uint4& b, f32x4& c);
+};
+template <> __device__ __forceinline__ void WFrag<bf16>::mma(const uint4& a, const uint4& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ void WFrag<f16>::mma(const uint4& a, const uint4& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// fp32: 16 pixels per step, instruction kk uses pixel 4*kk + (lane>>4).
+template <> struct WFrag<float> {
+    static constexpr int KP = 16;
+    static constexpr int PAD = 64;
+    static __device__ __forceinline__ uint4 load(const unsigned char* tile, int rs, int ctile, int lane) {
+        const int g = lane >> 4, c = lane & 15;
+        const unsigned char* a = tile + g * rs + (ctile * 16 + c) * 4;
+        uint4 r;
+        r.x = *reinterpret_cast<const unsigned*>(a);
+        r.y = *reinterpret_cast<const unsigned*>(a + 4 * rs);
+        r.z = *reinterpret_cast<const unsigned*>(a + 8 * rs);
+        r.w = *reinterpret_cast<const unsigned*>(a + 12 * rs);
+        return r;
+    }
+    static __device__ __forceinline__ void mma(const uint4& a, const uint4& b, f32x4& c) {
+        const f32x4 fa = __builtin_bit_cast(f32x4, a), fb = __builtin_bit_cast(f32x4, b);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0], fb[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1], fb[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[2], fb[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[3], fb[3], c, 0, 0, 0);
+    }
+};
+
+template <typename T, int BO, int BI, int WO, int WI>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int ES = sizeof(T);
+    constexpr int EPC = 16 / ES;
+    constexpr int KP = WFrag<T>::KP;
+    constexpr int RSO = BO * ES + WFrag<T>::PAD, RSI = BI * ES + WFrag<T>::PAD;
+    constexpr int CPO = BO * ES / 16, CPI = BI * ES / 16;     // chunks per pixel row
+    constexpr int NO = KP * CPO / 256, NI = KP * CPI / 256;   // chunks per thread and step
+    constexpr int STAGE = KP * (RSO + RSI);
+    constexpr int TO = BO / WO, TI = BI / WI, OT = TO / 16, IT = TI / 16;
+    static_assert(WO * WI == 4 && NO >= 1 && NI >= 1, "bad tile");
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wo_ = wave / WI, wi_ = wave % WI;
+    const int otile = blockIdx.x / p.i_tiles, itile = blockIdx.x % p.i_tiles;
+    const int tap = blockIdx.y, split = blockIdx.z;
+    const int dh = p.dh[tap], dw = p.dw[tap];
+    const int hw = p.ho * p.wo;
+    const long m_begin = (long)split * p.steps_per_split * KP;
+    long m_end = m_begin + (long)p.steps_per_split * KP;
+    if (m_end > p.M) m_end = p.M;
+    const int S = m_begin < m_end ? (int)((m_end - m_begin + KP - 1) / KP) : 0;
+
+    f32x4 acc[OT][IT];
+#pragma unroll
+    for (int i = 0; i < OT; ++i)
+#pragma unroll
+        for (int j = 0; j < IT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int orow = tid / CPO, ochunk = tid % CPO;
+    const int irow = tid / CPI, ichunk = tid % CPI;
+    const int ocol = otile * BO + ochunk * EPC, icol = itile * BI + ichunk * EPC;
+    uint4 ro[NO], ri[NI];
+
+    auto gload = [&](int s) {
+        const long mb = m_begin + (long)s * KP;
+#pragma unroll
+        for (int i = 0; i < NO; ++i) {
+            const long m = mb + orow + i * (256 / CPO);
+            if (m < m_end && ocol < p.n_out)
+                ro[i] = *reinterpret_cast<const uint4*>(p.dy + (m * p.dy_pix_stride + ocol) * ES);
+            else
+                ro[i] = uint4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const long m = mb + irow + i * (256 / CPI);
+            bool ok = m < m_end && icol < p.k_run;
+            long e = 0;
+            if (ok) {
+                const int mi = (int)m;
+                const int n = mi / hw, rem = mi - n * hw;
+                const int a = rem / p.wo, b = rem - a * p.wo;
+                const int ih = a * p.sh + dh, iw = b * p.sw + dw;
+                ok = (unsigned)ih < (unsigned)p.hi && (unsigned)iw < (unsigned)p.wi;
+                e = ((long)(n * p.hi + ih) * p.wi + iw) * p.in_pix_stride + icol;
+            }
+            ri[i] = ok ? *reinterpret_cast<const uint4*>(p.x + e * ES) : uint4{0u, 0u, 0u, 0u};
+        }
+    };
+
+    if (S > 0) gload(0);
+    for (int s = 0; s < S; ++s) {
+        unsigned char* so = smem + (s & 1) * STAGE;
+        unsigned char* si = so + KP * RSO;
+#pragma unroll
+        for (int i = 0; i < NO; ++i)
+            *reinterpret_cast<uint4*>(so + (orow + i * (256 / CPO)) * RSO + ochunk * 16) = ro[i];
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            *reinterpret_cast<uint4*>(si + (irow + i * (256 / CPI)) * RSI + ichunk * 16) = ri[i];
+        __syncthreads();
+        if (s + 1 < S) gload(s + 1);
+        uint4 fo[OT], fi[IT];
+#pragma unroll
+        for (int i = 0; i < OT; ++i) fo[i] = WFrag<T>::load(so, RSO, wo_ * OT + i, lane);
+#pragma unroll
+        for (int j = 0; j < IT; ++j) fi[j] = WFrag<T>::load(si, RSI, wi_ * IT + j, lane);
+#pragma unroll
+        for (int i = 0; i < OT; ++i)
+#pragma unroll
+            for (int j = 0; j < IT; ++j) WFrag<T>::mma(fo[i], fi[j], acc[i][j]);
+    }
+
+    float* slab = p.slab + ((long)split * p.ntaps + tap) * p.n_out * p.n_in;
+    const int q = lane >> 4, c = lane & 15;
+#pragma unroll
+    for (int i = 0; i < OT; ++i)
+#pragma unroll
+        for (int j = 0; j < IT; ++j) {
+            const int ci = itile * BI + wi_ * TI + j * 16 + c;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = otile * BO + wo_ * TO + i * 16 + q * 4 + r;
+                if (o < p.n_out && ci < p.n_in) slab[(long)o * p.n_in + ci] = acc[i][j][r];
+            }
+        }
+}
+
+struct WreduceArgs {
+    const float* slab;
+    float* grad;
+    int n_out, n_in, ntaps, nsplit, accumulate;
+    long so, si, sr, ss;
+    signed char r[64];
+    signed char s[64];
+};
+
+__global__ void wgrad_reduce_kernel(const WreduceArgs p) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long per = (long)p.n_out * p.n_in;
+    if (idx >= per) return;
+    const int o = (int)(idx / p.n_in), i = (int)(idx - (long)o * p.n_in);
+    for (int t = 0; t < p.ntaps; ++t) {
+        float a = 0.f;
+        for (int sp = 0; sp < p.nsplit; ++sp) a += p.slab[((long)sp * p.ntaps + t) * per + idx];
+        float* g = p.grad + o * p.so + i * p.si + p.r[t] * p.sr + p.s[t] * p.ss;
+        *g = p.accumulate ? *g + a : a;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+static void wgrad_plan(const lh_igemm_desc* d, int n_out, int n_in, int dtype, int* bo, int* bi,
+                       int* nsplit, int* steps_per_split) {
+    const int kp = dtype == LH_F32 ? 16 : 32;
+    *bo = n_out > 64 ? 128 : 64;
+    *bi = n_in > 64 ? 128 : 64;
+    const long M = (long)d->n * d->ho * d->wo;
+    const long steps = (M + kp - 1) / kp;
+    const long tiles = (long)((n_out + *bo - 1) / *bo) * ((n_in + *bi - 1) / *bi) * d->ntaps;
+    long want = (1024 + tiles - 1) / tiles;          // aim at >= ~1024 blocks in flight
+    const long max_split = (steps + 7) / 8;          // at least 8 K steps per block
+    if (want > max_split) want = max_split;
+    if (want < 1) want = 1;
+    const long sps = (steps + want - 1) / want;
+    *steps_per_split = (int)sps;
+    *nsplit = (int)((steps + sps - 1) / sps);
+}
+
+extern "C" size_t lh_wgrad_slab_bytes(const lh_igemm_desc* d, int n_out, int n_in, int dtype) {
+    int bo, bi, ns, sps;
+    wgrad_plan(d, n_out, n_in, dtype, &bo, &bi, &ns, &sps);
+    return (size_t)ns * d->ntaps * n_out * n_in * sizeof(float);
+}
+
+template <typename T, int BO, int BI, int WO, int WI>
+static int launch_wgrad(const WgradArgs& a, hipStream_t s) {
+    constexpr int ES = sizeof(T);
+    constexpr int lds = 2 * WFrag<T>::KP * (BO * ES + BI * ES + 2 * WFrag<T>::PAD);
+    dim3 grid(ceil_div(a.n_out, BO) * a.i_tiles, a.ntaps, a.nsplit);
+    hipLaunchKernelGGL((wgrad_kernel<T, BO, BI, WO, WI>), grid, dim3(256), lds, s, a);
+    LH_LAUNCH_CHECK("wgrad launch");
+    return LH_OK;
+}
+
+extern "C" int lh_wgrad(const lh_igemm_desc* d, const void* x, const void* dy, int dy_pix_stride,
+                        int n_out, int n_in, float* slab, int dtype, void* stream) {
+    LH_REQUIRE(d && x && dy && slab, "lh_wgrad: null pointer");
+    const int es = lh_dtype_size(dtype);
+    LH_REQUIRE(es > 0, "lh_wgrad: bad dtype %d", dtype);
+    const int epc = 16 / es;
+    LH_REQUIRE(d->ntaps > 0 && d->ntaps <= 64, "lh_wgrad: ntaps %d out of range", d->ntaps);
+    LH_REQUIRE(n_in == d->k_run && n_in % epc == 0, "lh_wgrad: n_in %d must equal k_run %d and be a multiple of %d", n_in, d->k_run, epc);
+    LH_REQUIRE(n_out % epc == 0 && dy_pix_stride % epc == 0 && dy_pix_stride >= n_out, "lh_wgrad: n_out %d / stride %d", n_out, dy_pix_stride);
+    WgradArgs a;
+    a.x = (const unsigned char*)x; a.dy = (const unsigned char*)dy; a.slab = slab;
+    a.n = d->n; a.hi = d->hi; a.wi = d->wi; a.in_pix_stride = d->in_pix_stride; a.k_run = d->k_run;
+    a.ho = d->ho; a.wo = d->wo; a.M = d->n * d->ho * d->wo; a.sh = d->sh; a.sw = d->sw;
+    a.dy_pix_stride = dy_pix_stride; a.n_out = n_out; a.n_in = n_in; a.ntaps = d->ntaps;
+    for (int i = 0; i < 64; ++i) { a.dh[i] = d->dh[i]; a.dw[i] = d->dw[i]; }
+    int bo, bi;
+    wgrad_plan(d, n_out, n_in, dtype, &bo, &bi, &a.nsplit, &a.steps_per_split);
+    a.i_tiles = ceil_div(n_in, bi);
+    hipStream_t s = (hipStream_t)stream;
+#define LH_WT(T)                                                             \
+    if (bo == 128 && bi == 128) return launch_wgrad<T, 128, 128, 2, 2>(a, s); \
+    if (bo == 128 && bi == 64) return launch_wgrad<T, 128, 64, 4, 1>(a, s);   \
+    if (bo == 64 && bi == 128) return launch_wgrad<T, 64, 128, 1, 4>(a, s);   \
+    return launch_wgrad<T, 64, 64, 2, 2>(a, s);
+    switch (dtype) {
+        case LH_BF16: { LH_WT(bf16) }
+        case LH_F16: { LH_WT(f16) }
+        case LH_F32: { LH_WT(float) }
+    }
+#undef LH_WT
+    lh_set_error("lh_wgrad: unsupported dtype %d", dtype);
+    return LH_ERR_ARG;
+}
+
+extern "C" int lh_wgrad_reduce(const lh_igemm_desc* d, const float* slab, float* grad, int n_out,
+                               int n_in, long so, long si, long sr, long ss, const int* taps_rs,
+                               int accumulate, int dtype, void* stream) {
+    LH_REQUIRE(d && slab && grad && taps_rs, "lh_wgrad_reduce: null pointer");
+    LH_REQUIRE(d->ntaps > 0 && d->ntaps <= 64, "lh_wgrad_reduce: ntaps %d out of range", d->ntaps);
+    WreduceArgs a;
+    int bo, bi, sps;
+    wgrad_plan(d, n_out, n_in, dtype, &bo, &bi, &a.nsplit, &sps);
+    a.slab = slab; a.grad = grad; a.n_out = n_out; a.n_in = n_in; a.ntaps = d->ntaps;
+    a.accumulate = accumulate; a.so = so; a.si = si; a.sr = sr; a.ss = ss;
+    for (int t = 0; t < 64; ++t) {
+        a.r[t] = t < d->ntaps ? (signed char)taps_rs[2 * t] : 0;
+        a.s[t] = t < d->ntaps ? (signed char)taps_rs[2 * t + 1] : 0;
+    }
+    const long per = (long)n_out * n_in;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(per, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    LH_LAUNCH_CHECK("wgrad_reduce launch");
+    return LH_OK;
+}

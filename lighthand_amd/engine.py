@@ -1,0 +1,588 @@
+"""Static-shape execution engine: turns a model's layer description into two flat lists
+of pre-bound HIP launches (forward, backward) over pre-allocated NHWC buffers.
+
+There is no tracing compiler and no per-op autograd: a model describes itself once through
+``GraphBuilder`` (conv / deconv / fuse / maxpool nodes that name their parameters by the
+reference's state_dict keys), ``Plan`` allocates every activation, gradient, weight pack
+and workspace for one (batch, H, W, precision, mode), and running the network is a loop
+of ctypes calls on the caller's HIP stream -- which is exactly what a hipGraph captures
+(``lighthand_amd.runtime.TrainStep``).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import FuseBwdDesc, FuseDesc, IgemmDesc, check
+
+PRECISIONS = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}
+BN_MOMENTUM = 0.1   # src/modeling/simplebaseline/pose_resnet.py:19, src/modeling/hrnet/pose_hrnet.py:18
+BN_EPS = 1e-5
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+class Act:
+    """One NHWC activation (and, in training plans, its gradient)."""
+    __slots__ = ("n", "h", "w", "c", "c_valid", "buf", "grad", "needs_grad", "stats", "stats_rows",
+                 "is_image", "name")
+
+    def __init__(self, n, h, w, c, c_valid=None, name=""):
+        self.n, self.h, self.w, self.c = n, h, w, c
+        self.c_valid = c if c_valid is None else c_valid
+        self.buf = self.grad = self.stats = None
+        self.stats_rows = 0
+        self.needs_grad = True
+        self.is_image = False
+        self.name = name
+
+    @property
+    def pixels(self):
+        return self.n * self.h * self.w
+
+
+# --------------------------------------------------------------------------------------- graph
+class GraphBuilder:
+    """Collects the nodes a model emits from ``describe``.  Parameter names are state_dict keys."""
+
+    def __init__(self, n, h, w, params):
+        self.n, self.h, self.w = n, h, w
+        self.params = params
+        self.nodes = []
+        self.out = None
+
+    def input(self):
+        a = Act(self.n, self.h, self.w, 3, name="input")
+        a.is_image = True
+        a.needs_grad = False
+        self.nodes.append(("input", a))
+        return a
+
+    def input_act(self, c, h=None, w=None):
+        """A dense NHWC activation fed directly (kernel tests, sub-networks); it takes gradients."""
+        a = Act(self.n, h or self.h, w or self.w, c, name="input_act")
+        self.nodes.append(("input_act", a))
+        return a
+
+    def conv(self, x, wname, k, stride, pad, bias=None):
+        w = self.params[wname + ".weight"]
+        cout, cin = w.shape[0], w.shape[1]
+        assert w.shape[2] == k and w.shape[3] == k, wname
+        assert x.is_image or cin == x.c_valid, (wname, cin, x.c_valid)
+        ho = (x.h + 2 * pad - k) // stride + 1
+        wo = (x.w + 2 * pad - k) // stride + 1
+        y = Act(x.n, ho, wo, (cout + 31) // 32 * 32 if cout % 8 else cout, cout, name=wname)
+        self.nodes.append(("conv", dict(x=x, y=y, w=wname, k=k, s=stride, p=pad, bias=bias)))
+        return y
+
+    def deconv(self, x, wname, k, bias=None):
+        w = self.params[wname + ".weight"]          # [C_in, C_out, k, k]
+        assert w.shape[0] == x.c_valid and w.shape[2] == k
+        pad, opad = {4: (1, 0), 3: (1, 1), 2: (0, 0)}[k]     # pose_resnet.py:194-205
+        ho = (x.h - 1) * 2 - 2 * pad + k + opad
+        wo = (x.w - 1) * 2 - 2 * pad + k + opad
+        y = Act(x.n, ho, wo, w.shape[1], name=wname)
+        self.nodes.append(("deconv", dict(x=x, y=y, w=wname, k=k, p=pad, bias=bias)))
+        return y
+
+    def fuse(self, terms, relu=True):
+        """terms: Act (identity) | (Act, bn_prefix) | (Act, bn_prefix, log2_upsample)."""
+        norm = []
+        for t in terms:
+            if isinstance(t, Act):
+                norm.append((t, None, 0))
+            elif len(t) == 2:
+                norm.append((t[0], t[1], 0))
+            else:
+                norm.append(tuple(t))
+        base = max(norm, key=lambda t: t[0].h << t[2])
+        h, w = base[0].h << base[2], base[0].w << base[2]
+        for a, _, l in norm:
+            assert (a.h << l, a.w << l) == (h, w) and a.c == norm[0][0].c
+        out = Act(norm[0][0].n, h, w, norm[0][0].c, name="fuse")
+        self.nodes.append(("fuse", dict(terms=norm, out=out, relu=relu)))
+        return out
+
+    def maxpool(self, x):
+        y = Act(x.n, (x.h + 2 - 3) // 2 + 1, (x.w + 2 - 3) // 2 + 1, x.c, name="maxpool")
+        self.nodes.append(("maxpool", dict(x=x, y=y)))
+        return y
+
+    def output(self, y):
+        self.out = y
+        self.nodes.append(("output", dict(y=y)))
+
+
+def _desc(n, hi, wi, pix_stride, k_run, ho, wo, sh, sw, cout, OH, OW, osh, osw, ooh, oow, out_stride, taps):
+    d = IgemmDesc()
+    d.n, d.hi, d.wi, d.in_pix_stride, d.k_run = n, hi, wi, pix_stride, k_run
+    d.ho, d.wo, d.sh, d.sw, d.cout = ho, wo, sh, sw, cout
+    d.OH, d.OW, d.osh, d.osw, d.ooh, d.oow, d.out_pix_stride = OH, OW, osh, osw, ooh, oow, out_stride
+    d.ntaps, d.relu = len(taps), 0
+    assert len(taps) <= 64
+    for i, (dh, dw) in enumerate(taps):
+        assert -128 <= dh < 128 and -128 <= dw < 128
+        d.dh[i], d.dw[i] = dh, dw
+    return d
+
+
+def _taps_array(rs):
+    flat = [v for t in rs for v in t] or [0, 0]
+    return (C.c_int * len(flat))(*flat)
+
+
+class _Call:
+    """A pre-bound C-ABI call; the stream is appended at run time."""
+    __slots__ = ("fn", "args", "what", "keep")
+
+    def __init__(self, fn, args, what, keep=None):
+        self.fn, self.args, self.what, self.keep = fn, args, what, keep
+
+    def __call__(self, stream):
+        rc = self.fn(*self.args, stream)
+        if rc:
+            check(rc, self.what)
+
+
+class _TorchCall:
+    """Host-side glue expressed with torch ops on tiny tensors (layout shuffles of <10k values)."""
+    __slots__ = ("fn", "what")
+
+    def __init__(self, fn, what):
+        self.fn, self.what = fn, what
+
+    def __call__(self, stream):
+        self.fn()
+
+
+# --------------------------------------------------------------------------------------- plan
+class Plan:
+    """Everything needed to run one model at one static shape."""
+
+    def __init__(self, model, n, h, w, precision="fp32", training=True, backward=None, device=None):
+        self.lib = _lib.load()
+        self.precision = precision
+        self.tdtype = PRECISIONS[precision]
+        self.dt = _lib.dtype_code(self.tdtype)
+        self.es = self.tdtype.itemsize if hasattr(self.tdtype, "itemsize") else torch.tensor([], dtype=self.tdtype).element_size()
+        self.epc = 16 // self.es
+        self.training = training                 # BatchNorm mode: batch statistics + running update
+        self.with_bwd = training if backward is None else backward
+        self.n, self.h, self.w = n, h, w
+        self.params = dict(model.state_dict(keep_vars=True))
+        self.device = device or next(iter(self.params.values())).device
+        if self.device.type != "cuda":
+            raise _lib.LightHandError("lighthand_amd runs on a HIP device only; move the model with .to('cuda')")
+        self.grads = {}
+        if self.with_bwd:
+            arena = getattr(model, "_lh_arena", None)
+            for k, p in self.params.items():
+                if isinstance(p, torch.nn.Parameter):
+                    self.grads[k] = arena.grad_view(k) if arena is not None else torch.zeros_like(p)
+        gb = GraphBuilder(n, h, w, self.params)
+        model.describe(gb)
+        self.nodes = gb.nodes
+        self.out_act = gb.out
+        self.fwd, self.bwd, self.packs = [], [], []
+        self.keep = []                     # ctypes objects / tensors referenced by raw pointer
+        self._ws_wgrad = 0
+        self._ws_fuse = 0
+        self._ws_users = []
+        self._written = set()
+        self.profile_meta = []             # (list name, index, kernel family, flops, bytes)
+        self._compile()
+
+    # ------------------------------------------------------------------ helpers
+    def _alloc(self, *shape, dtype=None, zero=False):
+        f = torch.zeros if zero else torch.empty
+        t = f(*shape, dtype=dtype or self.tdtype, device=self.device)
+        self.keep.append(t)
+        return t
+
+    def _act_buf(self, a):
+        if a.buf is None:
+            a.buf = self._alloc(a.n, a.h, a.w, a.c, zero=a.c != a.c_valid)
+        return a.buf
+
+    def _act_grad(self, a):
+        if a.grad is None:
+            a.grad = self._alloc(a.n, a.h, a.w, a.c, zero=True)
+        return a.grad
+
+    def _pack(self, wt, n_out, n_in, strides, taps_rs, what):
+        """Allocate a pack image and register the launch that (re)builds it from ``wt``."""
+        nbytes = C.c_size_t(0)
+        arr = _taps_array(taps_rs)
+        check(self.lib.lh_pack_weight(None, None, C.byref(nbytes), n_out, n_in, *strides, len(taps_rs), arr, self.dt, None), what)
+        buf = self._alloc(max(nbytes.value, 16), dtype=torch.uint8)
+        if taps_rs:
+            self.packs.append(_Call(self.lib.lh_pack_weight,
+                                    (wt.data_ptr(), buf.data_ptr(), None, n_out, n_in, *strides, len(taps_rs), arr, self.dt),
+                                    what, keep=(arr, wt)))
+        return buf
+
+    def _igemm(self, lst, d, src, pack, dst, addend, bias, stats, what, flops=0):
+        self.keep.append(d)
+        lst.append(_Call(self.lib.lh_igemm, (C.byref(d), _ptr(src), _ptr(pack), _ptr(dst), _ptr(addend), _ptr(bias), _ptr(stats), self.dt), what))
+        return lst[-1]
+
+    def _first_write(self, a):
+        """True the first time a gradient buffer is produced in the backward list."""
+        if id(a) in self._written:
+            return False
+        self._written.add(id(a))
+        return True
+
+    def _stats_for(self, y, descs):
+        rows = [self.lib.lh_igemm_stats_rows(C.byref(d), self.dt) for d in descs]
+        total = sum(rows)
+        nbytes = self.lib.lh_bn_stats_slab_bytes(total, y.c)
+        y.stats = self._alloc((nbytes + 3) // 4, dtype=torch.float32)
+        y.stats_rows = total
+        offs, o = [], 0
+        for r in rows:
+            offs.append(o)
+            o += r * 2 * y.c * 4
+        return offs
+
+    # ------------------------------------------------------------------ compile
+    def _compile(self):
+        consumers_bn = set()
+        for kind, nd in self.nodes:
+            if kind == "fuse":
+                for a, bn, _ in nd["terms"]:
+                    if bn is not None:
+                        consumers_bn.add(id(a))
+        self._bn_inputs = consumers_bn
+        bwd_blocks = []
+        for kind, nd in self.nodes:
+            blk = []
+            getattr(self, "_c_" + kind)(nd, blk)
+            bwd_blocks.append(blk)
+        # backward list: node blocks in reverse order; accumulate flags resolved in that order
+        if self.with_bwd:
+            for blk in reversed(bwd_blocks):
+                for emit in blk:
+                    emit()
+            ws = self._alloc(max(self._ws_wgrad, self._ws_fuse, 256), dtype=torch.uint8)
+            for setter in self._ws_users:
+                setter(ws.data_ptr())
+
+    def _c_input(self, a, blk):
+        pass        # the consumer (stem conv) owns the image transform
+
+    def _c_input_act(self, a, blk):
+        self.in_act = a
+        self._act_buf(a)
+        if self.with_bwd:
+            self._act_grad(a)
+
+    def _c_output(self, nd, blk):
+        y = nd["y"]
+        self.out_nchw = self._alloc(y.n, y.c_valid, y.h, y.w, dtype=torch.float32)
+        self.fwd.append(_Call(self.lib.lh_nhwc_to_nchw_f32, (y.buf.data_ptr(), self.out_nchw.data_ptr(), y.n, y.h, y.w, y.c_valid, y.c, self.dt), "output transform"))
+        if self.with_bwd:
+            self.dout_nchw = self._alloc(y.n, y.c_valid, y.h, y.w, dtype=torch.float32, zero=True)
+
+            def emit():
+                g = self._act_grad(y)
+                self._first_write(y)
+                self.bwd.append(_Call(self.lib.lh_nchw_f32_to_nhwc, (self.dout_nchw.data_ptr(), g.data_ptr(), y.n, y.h, y.w, y.c_valid, y.c, self.dt), "dheat transform"))
+            blk.append(emit)
+
+    # ---- convolution ---------------------------------------------------------------------------
+    def _c_conv(self, nd, blk):
+        x, y, k, s, p = nd["x"], nd["y"], nd["k"], nd["s"], nd["p"]
+        wt = self.params[nd["w"] + ".weight"]
+        cout, cin = wt.shape[0], wt.shape[1]
+        ybuf = self._act_buf(y)
+        bias = None
+        if nd["bias"]:
+            bias = self._alloc(y.c, dtype=torch.float32, zero=True)
+            bsrc = self.params[nd["bias"]]
+            self.packs.append(_TorchCall(lambda: bias[:cout].copy_(bsrc.detach()), "bias pad"))
+        all_rs = [(r, q) for r in range(k) for q in range(k)]
+        if x.is_image:
+            self._c_stem(nd, blk, bias)
+            return
+        xbuf = self._act_buf(x)
+        taps = [(r - p, q - p) for r, q in all_rs]
+        d = _desc(x.n, x.h, x.w, x.c, cin, y.h, y.w, s, s, y.c, y.h, y.w, 1, 1, 0, 0, y.c, taps)
+        pack = self._pack(wt, cout, cin, (cin * k * k, k * k, k, 1), all_rs, nd["w"] + " fwd pack")
+        stats_ptr = None
+        if id(y) in self._bn_inputs and self.training:
+            self._stats_for(y, [d])
+            stats_ptr = y.stats
+        flops = 2.0 * y.pixels * cout * cin * k * k
+        self._igemm(self.fwd, d, xbuf, pack, ybuf, None, bias, stats_ptr, nd["w"] + " fwd")
+        self.profile_meta.append(("fwd", len(self.fwd) - 1, "igemm", flops, (x.pixels * x.c + y.pixels * y.c) * self.es))
+        if not self.with_bwd:
+            return
+        # --- backward: weight gradient, then data gradient
+        slab_bytes = self.lib.lh_wgrad_slab_bytes(C.byref(d), y.c, cin, self.dt)
+        self._ws_wgrad = max(self._ws_wgrad, slab_bytes)
+        rs_arr = _taps_array(all_rs)
+        gw = self.grads[nd["w"] + ".weight"]
+        pad_out = y.c != cout
+        gtmp = self._alloc(y.c, cin, k, k, dtype=torch.float32) if pad_out else gw
+        dpacks, ddescs = [], []
+        if x.needs_grad:
+            for ph in range(s):
+                for pw in range(s):
+                    sub = [(r, q) for r, q in all_rs if (ph + p - r) % s == 0 and (pw + p - q) % s == 0]
+                    tp = [((ph + p - r) // s, (pw + p - q) // s) for r, q in sub]
+                    gh, gw_ = (x.h - ph + s - 1) // s, (x.w - pw + s - 1) // s
+                    dd = _desc(y.n, y.h, y.w, y.c, y.c if pad_out else cout, gh, gw_, 1, 1, x.c, x.h, x.w, s, s, ph, pw, x.c, tp)
+                    ddescs.append(dd)
+                    dpacks.append(self._pack(wt, cin, cout, (k * k, cin * k * k, k, 1), sub, nd["w"] + " dgrad pack"))
+
+        def emit():
+            dy = self._act_grad(y)
+            call_w = [self.lib.lh_wgrad, [C.byref(d), xbuf.data_ptr(), dy.data_ptr(), y.c, y.c, cin, 0, self.dt], nd["w"] + " wgrad"]
+            call_r = [self.lib.lh_wgrad_reduce, [C.byref(d), 0, gtmp.data_ptr(), y.c if pad_out else cout, cin, cin * k * k, k * k, k, 1, rs_arr, 0, self.dt], nd["w"] + " wgrad reduce"]
+            cw, cr = _Call(call_w[0], None, call_w[2]), _Call(call_r[0], None, call_r[2], keep=rs_arr)
+
+            def set_ws(ptr, cw=cw, cr=cr, a=call_w[1], b=call_r[1]):
+                a[6] = ptr
+                b[1] = ptr
+                cw.args, cr.args = tuple(a), tuple(b)
+            self._ws_users.append(set_ws)
+            self.bwd.append(cw)
+            self.profile_meta.append(("bwd", len(self.bwd) - 1, "wgrad", flops, (x.pixels * x.c + y.pixels * y.c) * self.es))
+            self.bwd.append(cr)
+            if pad_out:
+                self.bwd.append(_TorchCall(lambda: gw.copy_(gtmp[:cout]), "head grad crop"))
+            if nd["bias"]:
+                gb_ = self.grads[nd["bias"]]
+                self.bwd.append(_TorchCall(lambda: gb_.copy_(dy.view(-1, y.c)[:, :cout].sum(0, dtype=torch.float32)), "bias grad"))
+            if x.needs_grad:
+                dx = self._act_grad(x)
+                first = self._first_write(x)
+                for dd, pk in zip(ddescs, dpacks):
+                    self._igemm(self.bwd, dd, dy, pk, dx, None if first else dx, None, None, nd["w"] + " dgrad")
+                    self.profile_meta.append(("bwd", len(self.bwd) - 1, "igemm", 2.0 * dd.n * dd.ho * dd.wo * cin * cout * dd.ntaps,
+                                              (dd.n * dd.ho * dd.wo * x.c + y.pixels * y.c / (s * s)) * self.es))
+        blk.append(emit)
+
+    def _c_stem(self, nd, blk, bias):
+        """C_in = 3 convolution: the image is stored as zero-padded NHWC4 and every kernel ROW is
+        one tap whose K run covers the k pixels x 4 channels that are contiguous in memory."""
+        x, y, k, s, p = nd["x"], nd["y"], nd["k"], nd["s"], nd["p"]
+        wt = self.params[nd["w"] + ".weight"]
+        cout = wt.shape[0]
+        kr = (k * 4 + 7) // 8 * 8
+        hp, wp = x.h + 2 * p, x.w + 2 * p + 2
+        assert (y.w - 1) * s * 4 + kr <= wp * 4
+        self.img_nchw = self._alloc(x.n, 3, x.h, x.w, dtype=torch.float32)
+        img = self._alloc(x.n, hp, wp, 4)
+        self.fwd.append(_Call(self.lib.lh_image_to_nhwc4, (self.img_nchw.data_ptr(), img.data_ptr(), x.n, x.h, x.w, p, wp, self.dt), "image transform"))
+        stage = self._alloc(cout, k, kr // 4, 4, dtype=torch.float32, zero=True)
+        self.packs.append(_TorchCall(lambda: stage[:, :, :k, :3].copy_(wt.detach().permute(0, 2, 3, 1)), "stem weight staging"))
+        rows = [(r, 0) for r in range(k)]
+        pack = self._pack(stage, cout, kr, (k * kr, 1, kr, 0), rows, nd["w"] + " stem pack")
+        d = _desc(x.n, hp, wp, 4, kr, y.h, y.w, s, s, y.c, y.h, y.w, 1, 1, 0, 0, y.c, rows)
+        ybuf = self._act_buf(y)
+        stats_ptr = None
+        if id(y) in self._bn_inputs and self.training:
+            self._stats_for(y, [d])
+            stats_ptr = y.stats
+        flops = 2.0 * y.pixels * cout * 3 * k * k
+        self._igemm(self.fwd, d, img, pack, ybuf, None, bias, stats_ptr, nd["w"] + " stem fwd")
+        self.profile_meta.append(("fwd", len(self.fwd) - 1, "igemm", flops, (x.pixels * 4 + y.pixels * y.c) * self.es))
+        if not self.with_bwd:
+            return
+        self._ws_wgrad = max(self._ws_wgrad, self.lib.lh_wgrad_slab_bytes(C.byref(d), y.c, kr, self.dt))
+        rs_arr = _taps_array(rows)
+        gstage = self._alloc(cout, k, kr // 4, 4, dtype=torch.float32)
+        gw = self.grads[nd["w"] + ".weight"]
+
+        def emit():
+            dy = self._act_grad(y)
+            a = [C.byref(d), img.data_ptr(), dy.data_ptr(), y.c, y.c, kr, 0, self.dt]
+            b = [C.byref(d), 0, gstage.data_ptr(), cout, kr, k * kr, 1, kr, 0, rs_arr, 0, self.dt]
+            cw, cr = _Call(self.lib.lh_wgrad, None, "stem wgrad"), _Call(self.lib.lh_wgrad_reduce, None, "stem wgrad reduce", keep=rs_arr)
+
+            def set_ws(ptr):
+                a[6] = ptr
+                b[1] = ptr
+                cw.args, cr.args = tuple(a), tuple(b)
+            self._ws_users.append(set_ws)
+            self.bwd.append(cw)
+            self.profile_meta.append(("bwd", len(self.bwd) - 1, "wgrad", flops, (x.pixels * 4 + y.pixels * y.c) * self.es))
+            self.bwd.append(cr)
+            self.bwd.append(_TorchCall(lambda: gw.copy_(gstage[:, :, :k, :3].permute(0, 3, 1, 2)), "stem grad unstage"))
+        blk.append(emit)
+
+    # ---- transposed convolution ------------------------------------------------------------------
+    def _c_deconv(self, nd, blk):
+        x, y, k, p = nd["x"], nd["y"], nd["k"], nd["p"]
+        wt = self.params[nd["w"] + ".weight"]          # [cin, cout, k, k]
+        cin, cout = wt.shape[0], wt.shape[1]
+        xbuf, ybuf = self._act_buf(x), self._act_buf(y)
+        all_rs = [(r, q) for r in range(k) for q in range(k)]
+        bias = None
+        if nd["bias"]:
+            bias = self._alloc(y.c, dtype=torch.float32, zero=True)
+            bsrc = self.params[nd["bias"]]
+            self.packs.append(_TorchCall(lambda: bias[:cout].copy_(bsrc.detach()), "bias pad"))
+        descs, packs = [], []
+        for ph in range(2):
+            for pw in range(2):
+                sub = [(r, q) for r, q in all_rs if (ph + p - r) % 2 == 0 and (pw + p - q) % 2 == 0]
+                tp = [((ph + p - r) // 2, (pw + p - q) // 2) for r, q in sub]
+                gh, gw_ = (y.h - ph + 1) // 2, (y.w - pw + 1) // 2
+                descs.append(_desc(x.n, x.h, x.w, x.c, cin, gh, gw_, 1, 1, cout, y.h, y.w, 2, 2, ph, pw, y.c, tp))
+                packs.append(self._pack(wt, cout, cin, (k * k, cout * k * k, k, 1), sub, nd["w"] + " deconv pack"))
+        offs = [None] * 4
+        if id(y) in self._bn_inputs and self.training:
+            offs = self._stats_for(y, descs)
+        for d, pk, off in zip(descs, packs, offs):
+            self.keep.append(d)
+            st = 0 if off is None else y.stats.data_ptr() + off
+            self.fwd.append(_Call(self.lib.lh_igemm, (C.byref(d), xbuf.data_ptr(), pk.data_ptr(), ybuf.data_ptr(), 0, _ptr(bias), st, self.dt), nd["w"] + " deconv fwd"))
+            self.profile_meta.append(("fwd", len(self.fwd) - 1, "igemm", 2.0 * d.n * d.ho * d.wo * cin * cout * d.ntaps,
+                                      (x.pixels * x.c + y.pixels * y.c / 4) * self.es))
+        if not self.with_bwd:
+            return
+        # data gradient = stride-2 convolution of dy; weight gradient gathers dy, dense operand is x
+        taps = [(r - p, q - p) for r, q in all_rs]
+        dg = _desc(y.n, y.h, y.w, y.c, cout, x.h, x.w, 2, 2, x.c, x.h, x.w, 1, 1, 0, 0, x.c, taps)
+        self.keep.append(dg)
+        gpack = self._pack(wt, cin, cout, (cout * k * k, k * k, k, 1), all_rs, nd["w"] + " deconv dgrad pack")
+        self._ws_wgrad = max(self._ws_wgrad, self.lib.lh_wgrad_slab_bytes(C.byref(dg), cin, cout, self.dt))
+        rs_arr = _taps_array(all_rs)
+        gw = self.grads[nd["w"] + ".weight"]
+        flops = 2.0 * x.pixels * cin * cout * k * k
+
+        def emit():
+            dy = self._act_grad(y)
+            a = [C.byref(dg), dy.data_ptr(), xbuf.data_ptr(), x.c, cin, cout, 0, self.dt]
+            b = [C.byref(dg), 0, gw.data_ptr(), cin, cout, cout * k * k, k * k, k, 1, rs_arr, 0, self.dt]
+            cw, cr = _Call(self.lib.lh_wgrad, None, nd["w"] + " wgrad"), _Call(self.lib.lh_wgrad_reduce, None, nd["w"] + " wgrad reduce", keep=rs_arr)
+
+            def set_ws(ptr):
+                a[6] = ptr
+                b[1] = ptr
+                cw.args, cr.args = tuple(a), tuple(b)
+            self._ws_users.append(set_ws)
+            self.bwd.append(cw)
+            self.profile_meta.append(("bwd", len(self.bwd) - 1, "wgrad", flops, (x.pixels * x.c + y.pixels * y.c) * self.es))
+            self.bwd.append(cr)
+            if nd["bias"]:
+                gb_ = self.grads[nd["bias"]]
+                self.bwd.append(_TorchCall(lambda: gb_.copy_(dy.view(-1, y.c)[:, :cout].sum(0, dtype=torch.float32)), "bias grad"))
+            if x.needs_grad:
+                dx = self._act_grad(x)
+                first = self._first_write(x)
+                self._igemm(self.bwd, dg, dy, gpack, dx, None if first else dx, None, None, nd["w"] + " deconv dgrad")
+                self.profile_meta.append(("bwd", len(self.bwd) - 1, "igemm", flops, (x.pixels * x.c + y.pixels * y.c) * self.es))
+        blk.append(emit)
+
+    # ---- BatchNorm + sum + ReLU ------------------------------------------------------------------
+    def _c_fuse(self, nd, blk):
+        terms, out, relu = nd["terms"], nd["out"], nd["relu"]
+        obuf = self._act_buf(out)
+        c = out.c
+        fd = FuseDesc()
+        fd.nterms, fd.relu = len(terms), int(relu)
+        bn_state = []
+        for i, (a, bn, l) in enumerate(terms):
+            fd.x[i] = self._act_buf(a).data_ptr()
+            fd.log2up[i] = l
+            if bn is None:
+                bn_state.append(None)
+                continue
+            st = {k: self._alloc(c, dtype=torch.float32) for k in ("scale", "shift", "mean", "invstd")}
+            bn_state.append(st)
+            fd.scale[i], fd.shift[i] = st["scale"].data_ptr(), st["shift"].data_ptr()
+            P = self.params
+            if self.training:
+                assert a.stats is not None, f"BN {bn} input has no statistics slab"
+                self.fwd.append(_Call(self.lib.lh_bn_finalize, (
+                    a.stats.data_ptr(), a.stats_rows, a.pixels, c, P[bn + ".weight"].data_ptr(), P[bn + ".bias"].data_ptr(),
+                    P[bn + ".running_mean"].data_ptr(), P[bn + ".running_var"].data_ptr(),
+                    _ptr(P.get(bn + ".num_batches_tracked")), BN_MOMENTUM, BN_EPS,
+                    st["scale"].data_ptr(), st["shift"].data_ptr(), st["mean"].data_ptr(), st["invstd"].data_ptr()), bn + " finalize"))
+            else:
+                self.fwd.append(_Call(self.lib.lh_bn_eval_affine, (
+                    P[bn + ".weight"].data_ptr(), P[bn + ".bias"].data_ptr(), P[bn + ".running_mean"].data_ptr(),
+                    P[bn + ".running_var"].data_ptr(), BN_EPS, c, st["scale"].data_ptr(), st["shift"].data_ptr()), bn + " eval affine"))
+        self.keep.append(fd)
+        self.fwd.append(_Call(self.lib.lh_fuse_fwd, (C.byref(fd), obuf.data_ptr(), out.n, out.h, out.w, c, self.dt), "fuse fwd"))
+        self.profile_meta.append(("fwd", len(self.fwd) - 1, "fuse", 0.0, (sum(a.pixels for a, _, _ in terms) + out.pixels) * c * self.es))
+        if not self.with_bwd:
+            return
+        self._ws_fuse = max(self._ws_fuse, self.lib.lh_fuse_bwd_workspace_bytes(out.n, out.h, out.w, c))
+
+        def emit():
+            bd = FuseBwdDesc()
+            bd.dout = self._act_grad(out).data_ptr()
+            bd.out = obuf.data_ptr() if relu else None
+            bd.nterms, bd.relu = len(terms), int(relu)
+            for i, (a, bn, l) in enumerate(terms):
+                bd.log2up[i] = l
+                if not a.needs_grad:
+                    continue
+                bd.dx[i] = self._act_grad(a).data_ptr()
+                bd.accumulate[i] = 0 if self._first_write(a) else 1
+                if bn is not None:
+                    st = bn_state[i]
+                    bd.x[i] = a.buf.data_ptr()
+                    bd.scale[i], bd.save_mean[i], bd.save_invstd[i] = st["scale"].data_ptr(), st["mean"].data_ptr(), st["invstd"].data_ptr()
+                    bd.dgamma[i] = self.grads[bn + ".weight"].data_ptr()
+                    bd.dbeta[i] = self.grads[bn + ".bias"].data_ptr()
+            self.keep.append(bd)
+            args = [C.byref(bd), out.n, out.h, out.w, c, 0, self.dt]
+            call = _Call(self.lib.lh_fuse_bwd, None, "fuse bwd")
+
+            def set_ws(ptr):
+                args[5] = ptr
+                call.args = tuple(args)
+            self._ws_users.append(set_ws)
+            self.bwd.append(call)
+            self.profile_meta.append(("bwd", len(self.bwd) - 1, "fuse_bwd", 0.0, 0.0))
+        blk.append(emit)
+
+    def _c_maxpool(self, nd, blk):
+        x, y = nd["x"], nd["y"]
+        xbuf, ybuf = self._act_buf(x), self._act_buf(y)
+        idx = self._alloc(y.n, y.h, y.w, y.c, dtype=torch.uint8)
+        self.fwd.append(_Call(self.lib.lh_maxpool3x3s2_fwd, (xbuf.data_ptr(), ybuf.data_ptr(), idx.data_ptr(), x.n, x.h, x.w, x.c, self.dt), "maxpool fwd"))
+        if not self.with_bwd:
+            return
+
+        def emit():
+            dy, dx = self._act_grad(y), self._act_grad(x)
+            assert self._first_write(x), "maxpool input gradient must be produced by the pool alone"
+            self.bwd.append(_Call(self.lib.lh_maxpool3x3s2_bwd, (dy.data_ptr(), idx.data_ptr(), dx.data_ptr(), x.n, x.h, x.w, x.c, self.dt), "maxpool bwd"))
+        blk.append(emit)
+
+    # ------------------------------------------------------------------ run
+    def refresh_packs(self, stream):
+        for c in self.packs:
+            c(stream)
+
+    def run_forward(self, stream):
+        for c in self.fwd:
+            c(stream)
+
+    def run_backward(self, stream):
+        for c in self.bwd:
+            c(stream)
+
+    def forward(self, images, repack=True):
+        """images: fp32 NCHW on the device.  Returns the plan's fp32 NCHW heatmap buffer."""
+        if tuple(images.shape) != (self.n, 3, self.h, self.w):
+            raise _lib.LightHandError(f"plan was built for {(self.n, 3, self.h, self.w)}, got {tuple(images.shape)}")
+        self.img_nchw.copy_(images)
+        stream = torch.cuda.current_stream().cuda_stream
+        if repack:
+            self.refresh_packs(stream)
+        self.run_forward(stream)
+        return self.out_nchw
+
+    def backward(self, dheat):
+        self.dout_nchw.copy_(dheat)
+        self.run_backward(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,80 @@
+"""Fused Adam on the HIP device (torch.optim.Adam semantics: src/tools/train.py:45-48).
+
+A ``torch.optim.Optimizer`` subclass, so ``CosineAnnealingLR`` and ``param_groups['lr']``
+work as in the reference loop.  When every parameter lives in one ``ParamArena`` the whole
+model is updated by ONE launch over the flat fp32 arena; otherwise one launch per tensor.
+Step count and bias corrections live on the device, so a captured hipGraph replays correctly.
+"""
+import torch
+
+from . import _lib
+from ._lib import check
+
+
+class Adam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0):
+        if weight_decay != 0:
+            raise ValueError("weight_decay is not used on this path (reference: train.py:45-48 passes none)")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=0))
+        self._flat = None        # (param_flat, grad_flat) when bound to an arena
+        self._dev = {}
+
+    def bind_arena(self, arena):
+        """Use the model's flat arena: one launch per step for all parameters."""
+        self._flat = arena
+        return self
+
+    def _group_state(self, gi, device, numel):
+        st = self._dev.get(gi)
+        if st is None:
+            st = dict(hyper=torch.zeros(4, dtype=torch.float64, device=device),
+                      step=torch.zeros(1, dtype=torch.int32, device=device),
+                      derived=torch.zeros(8, dtype=torch.float32, device=device),
+                      host=None)
+            self._dev[gi] = st
+        return st
+
+    def _sync_hyper(self, st, group):
+        host = (group["lr"], group["betas"][0], group["betas"][1], group["eps"])
+        if st["host"] != host:
+            st["hyper"].copy_(torch.tensor(host, dtype=torch.float64))
+            st["host"] = host
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale=1.0):
+        loss = closure() if closure is not None else None
+        lib = _lib.load()
+        stream = torch.cuda.current_stream().cuda_stream
+        for gi, group in enumerate(self.param_groups):
+            params = [p for p in group["params"] if p.grad is not None]
+            if not params:
+                continue
+            dev = params[0].device
+            if dev.type != "cuda":
+                raise _lib.LightHandError("lighthand_amd.optim.Adam runs on the HIP device only")
+            st = self._group_state(gi, dev, 0)
+            self._sync_hyper(st, group)
+            arena = self._flat
+            if arena is not None and gi == 0 and len(self.param_groups) == 1:
+                s = self.state.setdefault("flat", {})
+                if "exp_avg" not in s:
+                    s["exp_avg"] = torch.zeros_like(arena.flat)
+                    s["exp_avg_sq"] = torch.zeros_like(arena.flat)
+                check(lib.lh_adam_step(arena.flat.data_ptr(), arena.flat_grad.data_ptr(), s["exp_avg"].data_ptr(),
+                                       s["exp_avg_sq"].data_ptr(), arena.numel, st["hyper"].data_ptr(), st["step"].data_ptr(),
+                                       st["derived"].data_ptr(), float(grad_scale), stream), "lh_adam_step")
+                continue
+            # generic path: per-tensor launches sharing one device step counter per group.
+            first = True
+            for p in params:
+                s = self.state[p]
+                if "exp_avg" not in s:
+                    s["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    s["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    s["step_t"] = torch.zeros(1, dtype=torch.int32, device=dev)
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                check(lib.lh_adam_step(p.data_ptr(), g.data_ptr(), s["exp_avg"].data_ptr(), s["exp_avg_sq"].data_ptr(),
+                                       p.numel(), st["hyper"].data_ptr(), s["step_t"].data_ptr(), st["derived"].data_ptr(),
+                                       float(grad_scale), stream), "lh_adam_step")
+                first = False
+        return loss

@@ -1,0 +1,324 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures G1..G7 from the reference.
+
+Runs ONLY in the build container, where the read-only reference tree is mounted
+at /root/reference.  It imports the reference's own Python (with inert stand-ins
+for third-party modules that are absent from this image and are never touched by
+the hot-path functions), feeds it small seeded synthetic inputs and stores the
+inputs + outputs as data under tests/golden/.  Nothing from the reference's
+source text is stored; the GPU box never sees the reference.
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz|json
+"""
+import hashlib
+import json
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+import yaml
+
+REF = os.environ.get("LIGHTHAND_REFERENCE", "/root/reference")
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+# --------------------------------------------------------------------------- stand-ins
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def install_standins():
+    class _AttrDict(dict):
+        def __getattr__(self, k):
+            try:
+                return self[k]
+            except KeyError:
+                raise AttributeError(k)
+
+        def __setattr__(self, k, v):
+            self[k] = v
+
+    _stub("cv2")
+    tv = _stub("torchvision")
+    tv.transforms = _stub("torchvision.transforms")
+    pc = _stub("pycocotools")
+    pc.coco = _stub("pycocotools.coco", COCO=object)
+    _stub("easydict", EasyDict=_AttrDict)
+    y = _stub("yacs")
+    y.config = _stub("yacs.config", CfgNode=dict)
+    import torch.utils
+
+    tb = _stub("torch.utils.tensorboard", SummaryWriter=object)
+    torch.utils.tensorboard = tb
+
+
+def sha(t):
+    return hashlib.sha256(t.detach().cpu().contiguous().numpy().tobytes()).hexdigest()[:16]
+
+
+def resnet_cfg(num_layers, style="pytorch"):
+    ns = types.SimpleNamespace
+    extra = ns(NUM_LAYERS=num_layers, DECONV_WITH_BIAS=False, NUM_DECONV_LAYERS=3,
+               NUM_DECONV_FILTERS=[256, 256, 256], NUM_DECONV_KERNELS=[4, 4, 4],
+               FINAL_CONV_KERNEL=1)
+    return ns(MODEL=ns(EXTRA=extra, STYLE=style))
+
+
+def hrnet_cfg(width):
+    with open(os.path.join(REF, "src/modeling/hrnet/config/cfg.yaml")) as f:
+        cfg = yaml.safe_load(f)
+    for s, n in (("STAGE2", 2), ("STAGE3", 3), ("STAGE4", 4)):
+        cfg["MODEL"]["EXTRA"][s]["NUM_CHANNELS"] = [width * (2 ** i) for i in range(n)]
+    return cfg
+
+
+# --------------------------------------------------------------------------- generators
+def g1_targets():
+    from src.tools.dataset import CustomDataset
+    from src.utils.dataset_loader import GenerateHeatmap
+
+    rng = np.random.RandomState(9001)
+    sets = []
+    probe = np.zeros((21, 2), np.float32)
+    probe[0] = (128, 128)
+    probe[1] = (0, 0)
+    probe[2] = (255, 255)
+    probe[3] = (-30, 10)
+    probe[4] = (300, 300)
+    probe[5] = (2.3, 251.9)
+    probe[6] = (-1.9, -1.9)        # int() truncates toward zero
+    probe[7] = (279.9, 100.0)      # ul = 64 -> skipped
+    probe[8] = (277.9, 100.0)      # ul = 63 -> one column written
+    probe[9] = (-26.1, 40.0)       # br = 0 -> empty slice
+    probe[10] = (-30.1, 40.0)      # br < 0 -> skipped
+    for i in range(11, 21):
+        probe[i] = (10 * i, 5 * i)
+    sets.append(probe)
+    for _ in range(5):
+        sets.append(rng.uniform(-40, 296, size=(21, 2)).astype(np.float32))
+    sets.append(rng.uniform(20, 236, size=(21, 3)).astype(np.float32)[:, :2].copy())
+    joints = np.stack(sets)
+    tgt = np.stack([CustomDataset.generate_target(None, j).numpy() for j in joints])
+    alt = np.stack([GenerateHeatmap(64, 21)(j / 4) for j in joints])
+    np.savez_compressed(os.path.join(OUT, "g1_target.npz"), joints=joints, target=tgt, alt=alt)
+    print("G1 sum(probe) =", float(tgt[0].sum()))
+
+
+def g2_loss():
+    from src.utils.loss import JointsMSELoss
+
+    out = {}
+    for tag, b in (("b4", 4), ("b1", 1)):
+        torch.manual_seed(0)
+        pred = torch.randn(b, 21, 64, 64, requires_grad=True)
+        tgt = torch.rand(b, 21, 64, 64)
+        loss = JointsMSELoss(use_target_weight=False)(pred, tgt, None)
+        loss.backward()
+        out[f"pred_{tag}"] = pred.detach().numpy()
+        out[f"tgt_{tag}"] = tgt.numpy()
+        out[f"loss_{tag}"] = np.float32(loss.item())
+        out[f"grad_{tag}"] = pred.grad.numpy()
+        print("G2", tag, loss.item())
+    np.savez_compressed(os.path.join(OUT, "g2_loss.npz"), **out)
+
+
+def g3_decode():
+    from src.utils.loss import get_max_preds
+
+    rng = np.random.RandomState(3)
+    hm = rng.randn(3, 21, 64, 64).astype(np.float32)
+    # crafted cases in batch 0
+    hm[0, 0] = -1.0                                   # all negative -> (0,0)
+    hm[0, 1] = 0.0                                    # all zero -> mask 0
+    hm[0, 2] = -5.0; hm[0, 2, 10, 20] = 3.0; hm[0, 2, 40, 5] = 3.0      # tie -> lowest flat idx
+    hm[0, 3] = 0.0; hm[0, 3, 0, 0] = 1.0             # corner peaks
+    hm[0, 4] = 0.0; hm[0, 4, 0, 63] = 1.0
+    hm[0, 5] = 0.0; hm[0, 5, 63, 0] = 1.0
+    hm[0, 6] = 0.0; hm[0, 6, 63, 63] = 1.0
+    hm[0, 7] = 0.5; hm[0, 7, 30, 31] = np.nan        # NaN counts as max
+    hm[0, 8] = 0.25                                   # constant positive -> idx 0, mask 1
+    hm[0, 9] = -0.0
+    hm[0, 10] = 1e-30; hm[0, 10, 7, 9] = 2e-30
+    hm[0, 11] = -np.inf; hm[0, 11, 5, 5] = -1.0
+    hm[0, 12] = 0.0; hm[0, 12, 33, 17] = np.inf
+    preds, maxvals = get_max_preds(hm)
+    # non-square map
+    hm2 = rng.randn(2, 5, 48, 96).astype(np.float32)
+    p2, m2 = get_max_preds(hm2)
+    np.savez_compressed(os.path.join(OUT, "g3_decode.npz"), hm=hm, preds=preds, maxvals=maxvals,
+                        hm2=hm2, preds2=p2, maxvals2=m2)
+
+
+def _fwd_record(model, x, rec, tag):
+    model.train()
+    y_tr = model(x)
+    model.eval()
+    with torch.no_grad():
+        y_ev = model(x)
+    rec[f"{tag}_train"] = y_tr.detach().numpy()
+    rec[f"{tag}_eval"] = y_ev.numpy()
+
+
+def g5_models():
+    from src.modeling.simplebaseline.pose_resnet import get_pose_net
+    from src.modeling.hrnet.pose_hrnet import get_hrnet
+
+    rec, meta = {}, {}
+
+    def do(tag, build, seed):
+        torch.manual_seed(seed)
+        model = build()
+        sd = model.state_dict()
+        meta[tag] = {
+            "seed": seed,
+            "n_entries": len(sd),
+            "n_params": int(sum(p.numel() for p in model.parameters())),
+            "keys_sha": hashlib.sha256("\n".join(sd.keys()).encode()).hexdigest()[:16],
+            "sha": {k: sha(v) for k, v in list(sd.items())[:4] + list(sd.items())[-6:]},
+            "all_sha": hashlib.sha256("".join(sha(v) for v in sd.values()).encode()).hexdigest()[:16],
+        }
+        torch.manual_seed(seed + 1)
+        x = torch.randn(2, 3, 64, 64)
+        rec[f"{tag}_x"] = x.numpy()
+        _fwd_record(model, x, rec, tag)
+        sd2 = model.state_dict()
+        bn_keys = [k for k in sd2 if k.endswith("running_mean") or k.endswith("running_var")]
+        meta[tag]["bn_after_train_fwd"] = {k: float(sd2[k].double().sum()) for k in bn_keys[:3] + bn_keys[-3:]}
+        print("G5", tag, meta[tag]["n_params"], float(np.abs(rec[f"{tag}_train"]).mean()))
+
+    do("r18", lambda: get_pose_net(resnet_cfg(18), True), 0)
+    do("r34", lambda: get_pose_net(resnet_cfg(34), True), 0)
+    do("r50", lambda: get_pose_net(resnet_cfg(50), True), 0)
+    do("r50caffe", lambda: get_pose_net(resnet_cfg(50, "caffe"), True), 0)
+    do("hrnet_w32", lambda: get_hrnet(hrnet_cfg(32), True), 0)
+    do("hrnet_w48", lambda: get_hrnet(hrnet_cfg(48), True), 0)
+
+    # 256x256 mean-abs for R18 / R50 (output too big to keep, only a scalar)
+    for tag, nl in (("r18", 18), ("r50", 50)):
+        torch.manual_seed(0)
+        m = get_pose_net(resnet_cfg(nl), True)
+        torch.manual_seed(1)
+        x = torch.randn(1, 3, 256, 256)
+        m.train()
+        meta[tag]["meanabs_256_train"] = float(m(x).abs().mean())
+    np.savez_compressed(os.path.join(OUT, "g5_models.npz"), **rec)
+    with open(os.path.join(OUT, "g5_models.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+
+
+def g6_trajectory():
+    from src.modeling.simplebaseline.pose_resnet import get_pose_net
+    from src.modeling.hrnet.pose_hrnet import get_hrnet
+    from src.tools.dataset import CustomDataset
+    from src.utils.loss import JointsMSELoss
+
+    rec, meta = {}, {}
+
+    def run(tag, build, hm_size):
+        torch.manual_seed(9001)
+        model = build()
+        model.train()
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.999))
+        crit = JointsMSELoss(use_target_weight=False)
+        rng = np.random.RandomState(9001)
+        x = torch.from_numpy(rng.randn(2, 3, 64, 64).astype(np.float32))
+        joints = rng.uniform(20, 236, size=(2, 21, 2)).astype(np.float32)
+        tgt64 = torch.stack([CustomDataset.generate_target(None, j) for j in joints])
+        tgt = tgt64[:, :, :hm_size, :hm_size].contiguous()   # model output is 16x16 for a 64x64 input
+        losses = []
+        for _ in range(3):
+            pred = model(x)
+            loss = crit(pred, tgt, None)
+            losses.append(float(loss.item()))
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+        sd = model.state_dict()
+        keys = list(sd.keys())
+        pick = [keys[0], keys[1], keys[3], keys[4], keys[5], keys[-1], keys[-2]]
+        pick += [k for k in keys if k.endswith("running_var")][-1:]
+        pick += [k for k in keys if "deconv_layers.6" in k or "stage2.0.fuse_layers.1.0.0.0" in k][:1]
+        meta[tag] = {"losses": losses,
+                     "sums": {k: float(sd[k].double().sum()) for k in pick},
+                     "abs_sums": {k: float(sd[k].double().abs().sum()) for k in pick}}
+        rec[f"{tag}_x"] = x.numpy()
+        rec[f"{tag}_joints"] = joints
+        rec[f"{tag}_final_pred"] = model(x).detach().numpy()
+        print("G6", tag, losses)
+
+    run("r18", lambda: get_pose_net(resnet_cfg(18), True), 16)
+    run("r50", lambda: get_pose_net(resnet_cfg(50), True), 16)
+    run("hrnet_w32", lambda: get_hrnet(hrnet_cfg(32), True), 16)
+    np.savez_compressed(os.path.join(OUT, "g6_traj.npz"), **rec)
+    with open(os.path.join(OUT, "g6_traj.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+
+
+def g7_metrics():
+    from src.utils.loss import PCK_2d_loss, EPE_train
+    from src.utils import argparser as ref_ap
+
+    rng = np.random.RandomState(7)
+    cats = {}
+    for name, n in (("palm_occ", 13), ("finger_occ", 9), ("no_occ", 17), ("both", 5)):
+        gt = rng.uniform(20, 236, size=(n, 21, 2))
+        vis = (rng.rand(n, 21, 1) > 0.3).astype(np.float64)
+        pred = gt + rng.randn(n, 21, 2) * rng.choice([2.0, 8.0, 30.0], size=(n, 1, 1))
+        bb = np.sqrt((gt[..., 0].max(1) - gt[..., 0].min(1)) ** 2 + (gt[..., 1].max(1) - gt[..., 1].min(1)) ** 2)
+        cats[name] = {"bb": bb.tolist(), "pred": pred.tolist(), "gt": np.concatenate([gt, vis], -1).tolist()}
+    meta = [cats]
+
+    class _Bar:
+        def update(self, n):
+            pass
+
+    out = {}
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as d:
+        os.makedirs(os.path.join(d, "output", "fx"))
+        with open(os.path.join(d, "output", "fx", "evaluation.json"), "w") as f:
+            json.dump(meta, f)
+        os.chdir(d)
+        try:
+            args = types.SimpleNamespace(name="fx")
+            for key, T, method in (("pckb", [0.1, 0.3], "pckb"), ("mm30", [0, 30], "mm"), ("mm50", [0, 50], "mm")):
+                res, _ = ref_ap.pred_eval(args, T, _Bar(), method)
+                out[key] = {k: [float(v[0]), float(v[1]), np.asarray(v[2]).tolist()] for k, v in res.items()}
+        finally:
+            os.chdir(cwd)
+
+    pred = torch.tensor(rng.uniform(0, 256, size=(4, 21, 2)).astype(np.float32))
+    gt = torch.tensor(rng.uniform(20, 236, size=(4, 21, 2)).astype(np.float32))
+    pred[:2] = gt[:2] + torch.tensor(rng.randn(2, 21, 2).astype(np.float32)) * 6
+    pck = PCK_2d_loss(pred, gt, T=0.2, threshold="proportion")
+    pck_mm = PCK_2d_loss(pred, gt, T=5.0, threshold="mm")
+    (esum, ecnt), _ = EPE_train(pred, gt)
+    with open(os.path.join(OUT, "g7_metrics.json"), "w") as f:
+        json.dump({"evaluation": meta, "pred_eval": out,
+                   "val_pred": pred.numpy().tolist(), "val_gt": gt.numpy().tolist(),
+                   "pck02": float(pck), "pck_mm5": float(pck_mm),
+                   "epe_sum": float(esum), "epe_cnt": float(ecnt)}, f)
+    print("G7", pck, float(esum), float(ecnt), out["pckb"]["mean_auc"][:2])
+
+
+def main():
+    install_standins()
+    sys.path.insert(0, REF)
+    sys.path.insert(0, os.path.join(REF, "src", "tools"))
+    torch.set_num_threads(8)
+    g1_targets()
+    g2_loss()
+    g3_decode()
+    g5_models()
+    g6_trajectory()
+    g7_metrics()
+
+
+if __name__ == "__main__":
+    main()

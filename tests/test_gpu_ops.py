@@ -1,0 +1,276 @@
+"""Per-kernel parity on the GPU: every HIP op vs the same op in plain PyTorch fp32 on the CPU
+(golden set G4 of SURVEY.md section 8c is regenerated on the fly -- it needs no reference)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"fp32": 2e-5, "bf16": 3e-2, "fp16": 4e-3}
+
+
+def rel_err(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def _mods():
+    from lighthand_amd.module import HipModule
+
+    class ConvNet(HipModule):
+        def __init__(self, cin, cout, k, s, p, bias=False, transposed=False):
+            super().__init__()
+            self.transposed, self.k, self.s, self.p, self.cin = transposed, k, s, p, cin
+            if transposed:
+                self.conv = nn.ConvTranspose2d(cin, cout, k, 2, {4: 1, 3: 1, 2: 0}[k], {4: 0, 3: 1, 2: 0}[k], bias=bias)
+            else:
+                self.conv = nn.Conv2d(cin, cout, k, s, p, bias=bias)
+
+        def describe(self, gb):
+            x = gb.input_act(self.cin)
+            b = "conv.bias" if self.conv.bias is not None else None
+            y = gb.deconv(x, "conv", self.k, bias=b) if self.transposed else gb.conv(x, "conv", self.k, self.s, self.p, bias=b)
+            gb.output(y)
+
+    class BnNet(HipModule):
+        """conv -> BN (+ residual / second BN branch / upsampled branch) -> ReLU"""
+
+        def __init__(self, c, mode):
+            super().__init__()
+            self.c, self.mode = c, mode
+            self.conv = nn.Conv2d(c, c, 3, 1, 1, bias=False)
+            self.bn = nn.BatchNorm2d(c, momentum=0.1)
+            if mode in ("two_bn", "up"):
+                self.conv2 = nn.Conv2d(c, c, 1, 2 if mode == "up" else 1, 0, bias=False)
+                self.bn2 = nn.BatchNorm2d(c, momentum=0.1)
+            self.out = nn.Conv2d(c, 8, 1, bias=False)
+
+        def describe(self, gb):
+            x = gb.input_act(self.c)
+            y = gb.conv(x, "conv", 3, 1, 1)
+            if self.mode == "plain":
+                z = gb.fuse([(y, "bn")])
+            elif self.mode == "residual":
+                z = gb.fuse([(y, "bn"), x])
+            elif self.mode == "two_bn":
+                z = gb.fuse([(y, "bn"), (gb.conv(x, "conv2", 1, 1, 0), "bn2")])
+            elif self.mode == "up":
+                z = gb.fuse([(y, "bn"), (gb.conv(x, "conv2", 1, 2, 0), "bn2", 1)], relu=True)
+            elif self.mode == "pool":
+                z = gb.maxpool(gb.fuse([(y, "bn")]))
+            gb.output(gb.conv(z, "out", 1, 1, 0))
+
+        def torch_forward(self, x):
+            y = self.bn(self.conv(x))
+            if self.mode == "residual":
+                y = y + x
+            elif self.mode == "two_bn":
+                y = y + self.bn2(self.conv2(x))
+            elif self.mode == "up":
+                y = y + F.interpolate(self.bn2(self.conv2(x)), scale_factor=2, mode="nearest")
+            y = F.relu(y)
+            if self.mode == "pool":
+                y = F.max_pool2d(y, 3, 2, 1)
+            return self.out(y)
+
+    return ConvNet, BnNet
+
+
+def _run_plan(model, x_nchw, dy_fn, precision):
+    """Run fwd+bwd of a test net through the engine; returns (out, dx_nchw, {param grads})."""
+    m = model.cuda().set_precision(precision)
+    m.train()
+    n, c, h, w = x_nchw.shape
+    plan = m.plan(n, h, w, training=True, backward=True)
+    plan.in_act.buf.copy_(x_nchw.permute(0, 2, 3, 1).to(plan.tdtype))
+    s = torch.cuda.current_stream().cuda_stream
+    plan.refresh_packs(s)
+    plan.run_forward(s)
+    out = plan.out_nchw.clone().cpu()
+    dy = dy_fn(out)
+    plan.dout_nchw.copy_(dy)
+    plan.run_backward(s)
+    torch.cuda.synchronize()
+    dx = plan.in_act.grad.float().permute(0, 3, 1, 2).cpu()
+    grads = {k: plan.grads[k].clone().cpu() for k in plan.grads}
+    return out, dx, grads
+
+
+CONV_CASES = [
+    # cin, cout, k, s, p, n, h, w
+    (64, 64, 1, 1, 0, 2, 16, 16),
+    (64, 128, 3, 1, 1, 2, 16, 16),
+    (128, 64, 3, 2, 1, 2, 16, 16),
+    (64, 256, 1, 2, 0, 2, 16, 16),
+    (32, 32, 3, 1, 1, 3, 12, 20),          # HRNet-W32 branch width, ragged pixel count
+    (48, 96, 3, 2, 1, 1, 8, 8),            # HRNet-W48 widths (partial K step)
+    (256, 21, 1, 1, 0, 1, 8, 8),           # padded output channels + bias path below
+    (16, 16, 3, 1, 1, 1, 4, 4),
+]
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_bwd(case, precision):
+    ConvNet, _ = _mods()
+    cin, cout, k, s, p, n, h, w = case
+    torch.manual_seed(1)
+    m = ConvNet(cin, cout, k, s, p, bias=(cout == 21))
+    x = torch.randn(n, cin, h, w)
+    xq = x.to(torch.bfloat16).float() if precision == "bf16" else x
+    ref_m = nn.Conv2d(cin, cout, k, s, p, bias=(cout == 21))
+    ref_m.load_state_dict(m.conv.state_dict())
+    if precision == "bf16":
+        with torch.no_grad():
+            ref_m.weight.copy_(ref_m.weight.to(torch.bfloat16).float())
+    xr = xq.clone().requires_grad_(True)
+    ref = ref_m(xr)
+    torch.manual_seed(2)
+    dy = torch.randn_like(ref)
+    dyq = dy.to(torch.bfloat16).float() if precision == "bf16" else dy
+    ref.backward(dyq)
+    out, dx, grads = _run_plan(m, xq, lambda o: dy, precision)
+    tol = TOL[precision]
+    assert rel_err(out, ref.detach()) < tol
+    assert rel_err(dx, xr.grad) < tol
+    assert rel_err(grads["conv.weight"], ref_m.weight.grad) < tol
+    if cout == 21:
+        assert rel_err(grads["conv.bias"], ref_m.bias.grad) < tol
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", [(64, 32, 4, 2, 8, 8), (128, 64, 4, 1, 6, 10), (32, 32, 3, 1, 4, 4), (32, 16, 2, 1, 4, 4)])
+def test_deconv_fwd_bwd(case, precision):
+    ConvNet, _ = _mods()
+    cin, cout, k, n, h, w = case
+    torch.manual_seed(3)
+    m = ConvNet(cin, cout, k, 2, 1, transposed=True)
+    x = torch.randn(n, cin, h, w)
+    xq = x.to(torch.bfloat16).float() if precision == "bf16" else x
+    wt = m.conv.weight.detach().clone()
+    if precision == "bf16":
+        wt = wt.to(torch.bfloat16).float()
+    wt.requires_grad_(True)
+    xr = xq.clone().requires_grad_(True)
+    pad, opad = {4: (1, 0), 3: (1, 1), 2: (0, 0)}[k]
+    ref = F.conv_transpose2d(xr, wt, None, 2, pad, opad)
+    torch.manual_seed(4)
+    dy = torch.randn_like(ref)
+    dyq = dy.to(torch.bfloat16).float() if precision == "bf16" else dy
+    ref.backward(dyq)
+    out, dx, grads = _run_plan(m, xq, lambda o: dy, precision)
+    tol = TOL[precision]
+    assert out.shape == ref.shape
+    assert rel_err(out, ref.detach()) < tol
+    assert rel_err(dx, xr.grad) < tol
+    assert rel_err(grads["conv.weight"], wt.grad) < tol
+
+
+@pytest.mark.parametrize("mode", ["plain", "residual", "two_bn", "up", "pool"])
+def test_bn_fuse_fwd_bwd_fp32(mode):
+    _, BnNet = _mods()
+    torch.manual_seed(5)
+    m = BnNet(32, mode)
+    with torch.no_grad():
+        m.bn.weight.uniform_(0.5, 1.5)
+        m.bn.bias.uniform_(-0.5, 0.5)
+    import copy
+    ref = copy.deepcopy(m)
+    x = torch.randn(3, 32, 8, 12)
+    xr = x.clone().requires_grad_(True)
+    ref.train()
+    y = ref.torch_forward(xr)
+    torch.manual_seed(6)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    out, dx, grads = _run_plan(m, x, lambda o: dy, "fp32")
+    assert rel_err(out, y.detach()) < 5e-5
+    assert rel_err(dx, xr.grad) < 2e-4
+    rp = dict(ref.named_parameters())
+    for k, g in grads.items():
+        assert rel_err(g, rp[k].grad) < 3e-4, k
+    # running statistics and the batch counter follow nn.BatchNorm2d(momentum=0.1)
+    msd = {k: v.cpu() for k, v in m.state_dict().items()}
+    for k, v in ref.state_dict().items():
+        if "running" in k:
+            assert rel_err(msd[k], v) < 1e-5, k
+        if "num_batches" in k:
+            assert int(msd[k]) == int(v) == 1
+
+
+def test_maxpool_ties_route_to_first():
+    """All-equal windows (post-ReLU zeros): gradient goes to the first element in scan order."""
+    from lighthand_amd import _lib
+    lib = _lib.load()
+    x = torch.zeros(1, 6, 6, 8, device="cuda")
+    x[0, 2, 3, :] = 2.0
+    out = torch.empty(1, 3, 3, 8, device="cuda")
+    idx = torch.empty(1, 3, 3, 8, dtype=torch.uint8, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.lh_maxpool3x3s2_fwd(x.data_ptr(), out.data_ptr(), idx.data_ptr(), 1, 6, 6, 8, _lib.LH_F32, s))
+    dy = torch.ones_like(out)
+    dx = torch.empty_like(x)
+    _lib.check(lib.lh_maxpool3x3s2_bwd(dy.data_ptr(), idx.data_ptr(), dx.data_ptr(), 1, 6, 6, 8, _lib.LH_F32, s))
+    xr = x.permute(0, 3, 1, 2).cpu().clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, 3, 2, 1)
+    yr.backward(torch.ones_like(yr))
+    assert torch.equal(out.permute(0, 3, 1, 2).cpu(), yr.detach())
+    assert torch.equal(dx.permute(0, 3, 1, 2).cpu(), xr.grad)
+
+
+def test_gaussian_target_matches_oracle_and_golden(golden_dir):
+    from lighthand_amd.heatmap import render_targets, generate_target
+    from oracle.heatmap import generate_target as oracle_target
+    import os
+    g = np.load(os.path.join(golden_dir, "g1_target.npz"))
+    joints = torch.from_numpy(g["joints"]).cuda()
+    got = render_targets(joints).cpu().numpy()
+    want = np.stack([oracle_target(j) for j in g["joints"]])
+    assert np.array_equal(got, want)                       # bit-exact vs the oracle on this host
+    assert np.abs(got - g["target"]).max() <= 6e-8         # golden: equal up to the host's expf ulp
+    assert np.array_equal(got != 0, g["target"] != 0)      # identical support
+    assert np.array_equal(generate_target(g["joints"][0]).numpy(), want[0])
+
+
+def test_mse_loss_golden(golden_dir):
+    import os
+    from lighthand_amd.heatmap import JointsMSELoss
+    g = np.load(os.path.join(golden_dir, "g2_loss.npz"))
+    for tag in ("b4", "b1"):
+        pred = torch.from_numpy(g[f"pred_{tag}"]).cuda().requires_grad_(True)
+        tgt = torch.from_numpy(g[f"tgt_{tag}"]).cuda()
+        loss = JointsMSELoss(False)(pred, tgt, None)
+        loss.backward()
+        assert abs(float(loss) - float(g[f"loss_{tag}"])) < 1e-6 * float(g[f"loss_{tag}"])
+        assert rel_err(pred.grad.cpu(), torch.from_numpy(g[f"grad_{tag}"])) < 1e-6
+
+
+def test_argmax_decode_golden_bit_exact(golden_dir):
+    import os
+    from lighthand_amd.heatmap import get_max_preds, max_preds_device
+    g = np.load(os.path.join(golden_dir, "g3_decode.npz"))
+    for hm, p, m in ((g["hm"], g["preds"], g["maxvals"]), (g["hm2"], g["preds2"], g["maxvals2"])):
+        preds, maxvals = get_max_preds(hm)
+        assert np.array_equal(preds, p)
+        assert np.array_equal(maxvals, m, equal_nan=True)
+        pd, md, idx = max_preds_device(torch.from_numpy(hm).cuda(), scale=4.0)
+        assert np.array_equal(pd.cpu().numpy(), p * 4)
+
+
+def test_adam_matches_torch():
+    from lighthand_amd.optim import Adam
+    torch.manual_seed(7)
+    p0 = torch.randn(1000 + 3)
+    pr = p0.clone().requires_grad_(True)
+    pg = p0.clone().cuda().requires_grad_(True)
+    o_ref = torch.optim.Adam([pr], lr=1e-3)
+    o_hip = Adam([pg], lr=1e-3)
+    for i in range(5):
+        g = torch.randn(1003) * (10.0 ** (i - 2))
+        pr.grad = g.clone()
+        pg.grad = g.clone().cuda()
+        o_ref.step()
+        o_hip.step()
+    assert rel_err(pg.detach().cpu(), pr.detach()) < 1e-6

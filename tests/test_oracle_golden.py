@@ -1,0 +1,123 @@
+"""CPU: the oracle (oracle/) against the golden vectors generated from the reference
+(tests/golden/make_golden.py).  This is what pins the oracle; the GPU parity tests then
+compare the HIP path with the oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import resnet_cfg
+from oracle import heatmap as oh
+from oracle import metrics as om
+from oracle import models as omod
+
+
+def test_g1_generate_target(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g1_target.npz"))
+    for j, t in zip(g["joints"], g["target"]):
+        got = oh.generate_target(j)
+        assert got.dtype == np.float32 and got.shape == (21, 64, 64)
+        assert np.array_equal(got != 0, t != 0)
+        assert np.abs(got - t).max() <= 6e-8          # numpy float32 exp: <= 1 ulp across hosts
+    probe = g["target"][0]
+    assert probe[3].sum() == 0 and probe[4].sum() == 0 and probe[7].sum() == 0 and probe[10].sum() == 0
+    assert abs(probe[0].max() - 1.0) < 1e-7 and probe[8].sum() > 0 and probe[9].sum() > 0
+    for j, t in zip(g["joints"], g["alt"]):
+        assert np.allclose(oh.generate_heatmap_alt(j / 4), t, atol=1e-7)
+
+
+def test_g2_joints_mse(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g2_loss.npz"))
+    for tag in ("b4", "b1"):
+        loss, grad = oh.joints_mse_loss(g[f"pred_{tag}"], g[f"tgt_{tag}"])
+        assert abs(loss - g[f"loss_{tag}"]) < 2e-7
+        assert np.allclose(grad, g[f"grad_{tag}"], rtol=1e-6, atol=1e-12)
+
+
+def test_g3_get_max_preds(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g3_decode.npz"))
+    for hm, p, m in ((g["hm"], g["preds"], g["maxvals"]), (g["hm2"], g["preds2"], g["maxvals2"])):
+        preds, maxvals = oh.get_max_preds(hm)
+        assert np.array_equal(preds, p)
+        assert np.array_equal(maxvals, m, equal_nan=True)
+    with pytest.raises(AssertionError):
+        oh.get_max_preds(np.zeros((4, 4), np.float32))
+
+
+def _build(tag):
+    from lighthand_amd.modeling.simplebaseline.pose_resnet import get_pose_net
+    from lighthand_amd.modeling.hrnet.pose_hrnet import get_hrnet, hrnet_cfg
+    if tag.startswith("hrnet"):
+        return get_hrnet(hrnet_cfg(int(tag.split("w")[1])), True), lambda sd, x, tr: omod.hrnet_forward(sd, x, training=tr)
+    depth = {"r18": 18, "r34": 34, "r50": 50, "r50caffe": 50}[tag]
+    style = "caffe" if tag.endswith("caffe") else "pytorch"
+    return (get_pose_net(resnet_cfg(depth, style), True),
+            lambda sd, x, tr: omod.pose_resnet_forward(sd, x, depth, style, training=tr))
+
+
+@pytest.mark.parametrize("tag", ["r18", "r34", "r50", "r50caffe", "hrnet_w32", "hrnet_w48"])
+def test_g5_whole_model_forward(golden_dir, tag):
+    """Same seed -> same state_dict as the reference (keys, shapes, values); oracle forward in
+    train mode then eval mode reproduces the reference's outputs and BN running statistics."""
+    import hashlib
+    meta = json.load(open(os.path.join(golden_dir, "g5_models.json")))[tag]
+    g = np.load(os.path.join(golden_dir, "g5_models.npz"))
+    torch.manual_seed(meta["seed"])
+    model, fwd = _build(tag)
+    sd = model.state_dict()
+    sha = lambda t: hashlib.sha256(t.detach().cpu().contiguous().numpy().tobytes()).hexdigest()[:16]
+    assert len(sd) == meta["n_entries"]
+    assert sum(p.numel() for p in model.parameters()) == meta["n_params"]
+    assert hashlib.sha256("\n".join(sd.keys()).encode()).hexdigest()[:16] == meta["keys_sha"]
+    assert hashlib.sha256("".join(sha(v) for v in sd.values()).encode()).hexdigest()[:16] == meta["all_sha"]
+    sd = omod.clone_state(sd)
+    x = torch.from_numpy(g[f"{tag}_x"])
+    with torch.no_grad():
+        y_tr = fwd(sd, x, True)
+        y_ev = fwd(sd, x, False)
+    assert np.allclose(y_tr.numpy(), g[f"{tag}_train"], rtol=1e-4, atol=1e-5)
+    assert np.allclose(y_ev.numpy(), g[f"{tag}_eval"], rtol=1e-4, atol=1e-5)
+    for k, v in meta["bn_after_train_fwd"].items():
+        assert abs(float(sd[k].double().sum()) - v) <= 1e-5 * max(1.0, abs(v)), k
+
+
+@pytest.mark.parametrize("tag", ["r18", "r50", "hrnet_w32"])
+def test_g6_adam_trajectory(golden_dir, tag):
+    meta = json.load(open(os.path.join(golden_dir, "g6_traj.json")))[tag]
+    g = np.load(os.path.join(golden_dir, "g6_traj.npz"))
+    torch.manual_seed(9001)
+    model, fwd = _build(tag)
+    sd = omod.clone_state(model.state_dict())
+    x = torch.from_numpy(g[f"{tag}_x"])
+    tgt = torch.from_numpy(np.stack([oh.generate_target(j) for j in g[f"{tag}_joints"]]))[:, :, :16, :16].contiguous()
+    adam = omod.AdamState(lr=1e-3)
+    losses = []
+    for _ in range(3):
+        loss, _, grads = omod.loss_and_grads(sd, lambda s, xx: fwd(s, xx, True), x, tgt)
+        losses.append(loss)
+        adam.step(sd, grads)
+    assert np.allclose(losses, meta["losses"], rtol=2e-3), (losses, meta["losses"])
+    for k, v in meta["abs_sums"].items():
+        got = float(sd[k].double().abs().sum())
+        assert abs(got - v) <= 2e-3 * max(1e-6, abs(v)), (k, got, v)
+
+
+def test_g7_metrics(golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "g7_metrics.json")))
+    cats = g["evaluation"][0]
+    for key, T, method in (("pckb", [0.1, 0.3], "pckb"), ("mm30", [0, 30], "mm"), ("mm50", [0, 50], "mm")):
+        got = om.pred_eval(cats, T, method)
+        for cat, (auc, epe, curve) in g["pred_eval"][key].items():
+            assert abs(got[cat][0] - auc) < 1e-9 * max(1, abs(auc)), (key, cat)
+            assert abs(got[cat][1] - epe) < 1e-9 * max(1, abs(epe)), (key, cat)
+            assert np.allclose(got[cat][2], curve)
+    # the diluted mean_auc EPE quirk is reproduced (971 zero rows)
+    assert got["mean_auc"][1] < 0.5 * min(v[1] for k, v in got.items() if k != "mean_auc")
+    pred, gt = np.array(g["val_pred"], np.float32), np.array(g["val_gt"], np.float32)
+    assert abs(om.pck_2d(pred, gt, 0.2) - g["pck02"]) < 1e-12
+    assert abs(om.pck_2d(pred, gt, 5.0, "mm") - g["pck_mm5"]) < 1e-12
+    s, c = om.epe_train(pred, gt)
+    assert c == g["epe_cnt"] == 19 * 4
+    assert abs(s - g["epe_sum"]) < 1e-4 * g["epe_sum"]
