@@ -55,10 +55,11 @@ def _bottleneck(sd, p, x, stride, training, caffe=False):
     return F.relu(out + res)
 
 
-def pose_resnet_forward(sd, x, num_layers=50, style="pytorch", training=True):
+def pose_resnet_forward(sd, x, num_layers=50, style="pytorch", training=True, spec=None):
     """PoseResNet.forward (pose_resnet.py:234-248) evaluated from ``sd``.  BN running
-    statistics inside ``sd`` are updated in place when ``training``."""
-    kind, blocks = RESNET_SPEC[num_layers]
+    statistics inside ``sd`` are updated in place when ``training``.  ``spec`` overrides the
+    (kind, units-per-stage) lookup for truncated test networks."""
+    kind, blocks = spec or RESNET_SPEC[num_layers]
     x = F.relu(_bn(sd, "bn1", _conv(sd, "conv1", x, 2, 3), training))
     x = F.max_pool2d(x, 3, 2, 1)
     for li, n in enumerate(blocks):
