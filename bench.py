@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of the SimpleBaseline-ResNet50 training step (256x256, bs=64 per
+GPU, bf16 activations/weights with fp32 accumulation) on the HIP engine -- BASELINE.json configs[1].
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" = one full training iteration on a synthetic batch already resident in HBM: weight packs,
+forward, Gaussian target render from joints, MSE loss + gradient, arg-max decode, backward,
+[gradient all-reduce], fused Adam -- one hipGraph replay.  Rank 0 prints ONE JSON line with
+throughput, the roofline of the dominant kernel (per-launch HIP-event timing, measured live) and
+a CPU baseline (the oracle's plain-PyTorch restatement on the host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+METRIC = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+# conv/deconv FLOPs per image (x2 per MAC), R50 @ 256x256
+TRAIN_GFLOP_PER_IMG = 43.128
+FWD_GFLOP_PER_IMG = 14.479
+PEAK_BF16_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA
+PEAK_HBM_GBS = 8000.0
+
+
+def build_model(depth=50, precision="bf16"):
+    import types
+    from lighthand_amd.modeling.simplebaseline.pose_resnet import get_pose_net
+    ns = types.SimpleNamespace
+    extra = ns(NUM_LAYERS=depth, DECONV_WITH_BIAS=False, NUM_DECONV_LAYERS=3, NUM_DECONV_FILTERS=[256] * 3,
+               NUM_DECONV_KERNELS=[4] * 3, FINAL_CONV_KERNEL=1)
+    torch.manual_seed(9001)                                  # src/tools/train.py:15
+    return get_pose_net(ns(MODEL=ns(EXTRA=extra, STYLE="pytorch")), True).cuda().set_precision(precision)
+
+
+def synthetic_batch(batch, size, device, seed=9001):
+    rng = np.random.RandomState(seed)
+    images = torch.from_numpy(rng.randn(batch, 3, size, size).astype(np.float32)).to(device)
+    joints = torch.from_numpy(rng.uniform(20, size - 20, size=(batch, 21, 2)).astype(np.float32)).to(device)
+    return images, joints
+
+
+def profile_kernels(step, iters=3):
+    """Per-launch HIP-event timing of every conv-family launch of the (eager) step, on the stream the
+    kernels are launched on.  Returns {kernel name: dict(ms, launches, flops, bytes)} per step."""
+    plan = step.plan
+    meta = {}
+    for which, idx, name, flops, nbytes in plan.profile_meta:
+        meta[(which, idx)] = (name, flops, nbytes)
+    agg = {}
+    stream = torch.cuda.current_stream()
+    s = stream.cuda_stream
+    for it in range(iters + 1):
+        evs = []
+        plan.refresh_packs(s)
+        for which, lst in (("fwd", plan.fwd), ("bwd", plan.bwd)):
+            if which == "bwd":
+                step._fwd_loss_tail(s)
+            for i, call in enumerate(lst):
+                m = meta.get((which, i))
+                if m is None:
+                    call(s)
+                    continue
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(stream)
+                call(s)
+                b.record(stream)
+                evs.append((m, a, b))
+        torch.cuda.synchronize()
+        if it == 0:
+            continue                                             # first pass = warm-up
+        for (name, flops, nbytes), a, b in evs:
+            d = agg.setdefault(name, dict(ms=0.0, launches=0, flops=0.0, bytes=0.0))
+            d["ms"] += a.elapsed_time(b)
+            d["launches"] += 1
+            d["flops"] += flops
+            d["bytes"] += nbytes
+    for d in agg.values():
+        for k in ("ms", "flops", "bytes"):
+            d[k] /= iters
+        d["launches"] //= iters
+    return agg
+
+
+def cpu_baseline(depth, size, batch, seconds_budget=25.0):
+    """The oracle (plain PyTorch fp32 on the host cores) running the same training step on a
+    bounded sample of the workload."""
+    from oracle import heatmap as oh
+    from oracle import models as omod
+    import types
+    from lighthand_amd.modeling.simplebaseline.pose_resnet import get_pose_net
+    ns = types.SimpleNamespace
+    extra = ns(NUM_LAYERS=depth, DECONV_WITH_BIAS=False, NUM_DECONV_LAYERS=3, NUM_DECONV_FILTERS=[256] * 3,
+               NUM_DECONV_KERNELS=[4] * 3, FINAL_CONV_KERNEL=1)
+    torch.manual_seed(9001)
+    sd = omod.clone_state(get_pose_net(ns(MODEL=ns(EXTRA=extra, STYLE="pytorch")), True).state_dict())
+    cores = torch.get_num_threads()
+    rng = np.random.RandomState(9001)
+    x = torch.from_numpy(rng.randn(batch, 3, size, size).astype(np.float32))
+    joints = rng.uniform(20, size - 20, size=(batch, 21, 2)).astype(np.float32)
+    adam = omod.AdamState(lr=1e-3)
+    fwd = lambda s, xx: omod.pose_resnet_forward(s, xx, depth, "pytorch", training=True)
+
+    def one():
+        tgt = torch.from_numpy(np.stack([oh.generate_target(j) for j in joints]))[:, :, :size // 4, :size // 4]
+        loss, pred, grads = omod.loss_and_grads(sd, fwd, x, tgt)
+        oh.get_max_preds(pred.numpy())
+        adam.step(sd, grads)
+
+    one()                                                       # warm-up
+    t0, n = time.time(), 0
+    while True:
+        one()
+        n += 1
+        if time.time() - t0 > seconds_budget * 0.6 or n >= 3:
+            break
+    dt = (time.time() - t0) / n
+    return dict(value=round(batch / dt, 2), unit="images/s", cores=cores, kind="port",
+                sample=f"oracle (plain PyTorch fp32 CPU) R{depth} {size}x{size} train step, batch {batch}, {n} timed step(s) of {dt:.2f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--depth", type=int, default=50)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    from lighthand_amd import parallel
+    from lighthand_amd.runtime import InferStep, TrainStep
+
+    rank, world, local = parallel.init_distributed()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    model = build_model(args.depth, args.precision)
+    sync = parallel.GradSync(world) if world > 1 else None
+    step = TrainStep(model, args.batch, args.size, args.size, lr=1e-3, use_graph=not args.no_graph, grad_sync=sync)
+    images, joints = synthetic_batch(args.batch, args.size, dev, seed=9001 + rank)
+    step.images.copy_(images)
+    step.joints.copy_(joints)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t)
+    loss_val = float(step.loss)
+    ms = elapsed / args.steps * 1e3
+    value = world * args.batch * args.steps / elapsed
+
+    out = {
+        "metric": METRIC, "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+        "config": {"workload": f"SimpleBaseline-ResNet{args.depth} {args.size}x{args.size} training step "
+                               f"(fwd + JointsMSELoss + argmax decode + bwd + Adam), batch {args.batch}/GPU, 21 joints, "
+                               f"random init (seed 9001), hipGraph replay" + (f", dp{world} RCCL all-reduce" if world > 1 else ""),
+                   "global_batch": world * args.batch, "parallelism": f"dp{world}"},
+        "loss_after": round(loss_val, 6),
+        "train_tflops": round(value * (TRAIN_GFLOP_PER_IMG if (args.depth, args.size) == (50, 256) else 0) / 1e3, 1),
+    }
+
+    if rank == 0 and world == 1:
+        # eval-mode forward + decode throughput (the "infer" half of the metric)
+        torch.cuda.synchronize()
+        inf = InferStep(model, args.batch, args.size, args.size)
+        inf.images.copy_(images)
+        for _ in range(3):
+            inf()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            inf()
+        torch.cuda.synchronize()
+        out["infer_images_per_s"] = round(args.batch * args.steps / (time.perf_counter() - t1), 1)
+
+        if not args.no_roofline:
+            agg = profile_kernels(step)
+            name, d = max(agg.items(), key=lambda kv: kv[1]["ms"])
+            tot = sum(v["ms"] for v in agg.values())
+            avg_ms = d["ms"] / d["launches"]
+            flops_per_launch = d["flops"] / d["launches"]
+            if flops_per_launch > 0:
+                ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
+                out["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS if args.precision != "fp32" else 157.3,
+                                   "unit": "TFLOP/s", "frac": round(ach / (PEAK_BF16_TFLOPS if args.precision != "fp32" else 157.3), 4), "traffic": None}
+            else:
+                ach = d["bytes"] / d["launches"] / (avg_ms * 1e-3) / 1e9
+                out["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                   "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None}
+            out["roofline"].update({"kernel": name, "launches_per_step": d["launches"], "avg_launch_ms": round(avg_ms, 4),
+                                    "share_of_profiled_ms": round(d["ms"] / tot, 3)})
+            out["kernel_breakdown_ms"] = {k: [round(v["ms"], 3), v["launches"],
+                                              round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] else None]
+                                          for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.depth, args.size, batch=16)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -67,6 +67,17 @@ int lh_pack_weight(const float* w, void* out, size_t* bytes, int n_out, int n_in
                    long so, long si, long sr, long ss, int ntaps, const int* taps_rs,
                    int dtype, void* stream);
 
+/* The same for every pack of a model in one launch: `items` is a DEVICE array of descriptors. */
+typedef struct {
+    const float* w;
+    void* out;
+    int n_out, n_in, ntaps, pad_;
+    long so, si, sr, ss;
+    signed char r[64];
+    signed char s[64];
+} lh_pack_item;
+int lh_pack_weights_multi(const lh_pack_item* items_dev, int n_items, int dtype, void* stream);
+
 /* ------------------------------------------------------------------ convolutions
  * nn.Conv2d(..., bias=False) + the head conv with bias: pose_resnet.py:23-26,66-72,152,
  * 169-175,181-182; pose_hrnet.py:22-25,65-71,145-149,200-204,218-222,230-234,282-286,
@@ -98,6 +109,11 @@ typedef struct {
  * squares of the stored values, consumed by lh_bn_finalize.  addend may alias out. */
 int lh_igemm(const lh_igemm_desc* d, const void* in, const void* wpack, void* out,
              const void* addend, const float* bias, float* stats, int dtype, void* stream);
+/* tile (output channels x pixels) the dispatcher picks for this descriptor: names the kernel
+ * instantiation a launch uses -- igemm_ring_kernel<T, bm, bp, .., 4> when *ring (LDS-DMA ring path,
+ * 16-byte aligned pixel rows) else igemm_kernel<T, bm, bp, ..> (profiling / roofline attribution). */
+int lh_igemm_tile(const lh_igemm_desc* d, int dtype, int* bm, int* bp, int* ring);
+int lh_wgrad_tile(const lh_igemm_desc* d, int n_out, int n_in, int dtype, int* bo, int* bi, int* nsplit);
 /* rows of the stats slab lh_igemm writes for this descriptor (= number of pixel tiles) */
 int lh_igemm_stats_rows(const lh_igemm_desc* d, int dtype);
 

@@ -36,6 +36,12 @@ class FuseBwdDesc(C.Structure):
                 ("accumulate", C.c_int * 4), ("nterms", C.c_int), ("relu", C.c_int)]
 
 
+class PackItem(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("out", C.c_void_p), ("n_out", C.c_int), ("n_in", C.c_int), ("ntaps", C.c_int),
+                ("pad_", C.c_int), ("so", C.c_long), ("si", C.c_long), ("sr", C.c_long), ("ss", C.c_long),
+                ("r", C.c_byte * 64), ("s", C.c_byte * 64)]
+
+
 _P, _I, _L, _F, _SZ = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
 
 # name -> (restype, argtypes); every symbol include/lighthand_hip.h declares
@@ -47,7 +53,10 @@ SIGNATURES = {
     "lh_nhwc_to_nchw_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "lh_nchw_f32_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "lh_pack_weight": (_I, [_P, _P, C.POINTER(_SZ), _I, _I, _L, _L, _L, _L, _I, C.POINTER(_I), _I, _P]),
+    "lh_pack_weights_multi": (_I, [_P, _I, _I, _P]),
     "lh_igemm": (_I, [C.POINTER(IgemmDesc), _P, _P, _P, _P, _P, _P, _I, _P]),
+    "lh_igemm_tile": (_I, [C.POINTER(IgemmDesc), _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
+    "lh_wgrad_tile": (_I, [C.POINTER(IgemmDesc), _I, _I, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "lh_igemm_stats_rows": (_I, [C.POINTER(IgemmDesc), _I]),
     "lh_wgrad_slab_bytes": (_SZ, [C.POINTER(IgemmDesc), _I, _I, _I]),
     "lh_wgrad": (_I, [C.POINTER(IgemmDesc), _P, _P, _I, _I, _I, _P, _I, _P]),
@@ -79,6 +88,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch must come first: the library has to bind to the HIP runtime torch itself loaded
+    # (PyTorch owns device memory and streams); loading ours first would start a second runtime.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise LightHandError(
             f"{LIB_PATH} not found: the HIP extension is the only backend of lighthand_amd "

@@ -26,6 +26,29 @@ __global__ __launch_bounds__(256) void colsum_kernel(const TI* src, int rows, in
     }
 }
 
+// One workgroup = 16 channels x 16 row lanes: totals of the sum / sum-of-squares (or g / g*xhat) columns of a
+// [rows][2][c] slab, handed to a per-channel functor by the first 16 threads (no second launch).
+template <typename TI, typename F>
+__device__ __forceinline__ void slab_totals_then(const TI* slab, int rows, int c, F&& fin) {
+    __shared__ double red[2][16][17];
+    const int ch = blockIdx.x * 16 + (threadIdx.x & 15), rl = threadIdx.x >> 4;
+    double a = 0.0, b = 0.0;
+    if (ch < c)
+        for (int r = rl; r < rows; r += 16) {
+            a += (double)slab[((long)r * 2) * c + ch];
+            b += (double)slab[((long)r * 2 + 1) * c + ch];
+        }
+    red[0][rl][threadIdx.x & 15] = a;
+    red[1][rl][threadIdx.x & 15] = b;
+    __syncthreads();
+    if (threadIdx.x < 16 && ch < c) {
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { s0 += red[0][i][threadIdx.x]; s1 += red[1][i][threadIdx.x]; }
+        fin(ch, s0, s1);
+    }
+}
+
 // Sum `rows` rows of `ncol` floats into totals[ncol] (double).  scratch: >= ceil(rows/256)*ncol doubles.
 static int column_totals(const float* slab, int rows, int ncol, double* scratch, double* totals, hipStream_t s) {
     const int gx = ceil_div(ncol, 16);
@@ -107,6 +130,31 @@ extern "C" size_t lh_bn_stats_slab_bytes(int rows, int c) {
     return ((size_t)rows * 2 * c + 2) * 4 + (size_t)(ceil_div(rows, 256) + 1) * 2 * c * 8;
 }
 
+template <typename TI>
+__global__ __launch_bounds__(256) void bn_finalize_fused_kernel(const TI* slab, int rows, int count, int c, const float* gamma,
+                                                                const float* beta, float* rmean, float* rvar, long long* nbt,
+                                                                float momentum, float eps, float* scale, float* shift,
+                                                                float* smean, float* sinv) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
+    slab_totals_then(slab, rows, c, [&](int ch, double s0, double s1) {
+        const double mean = s0 / count;
+        double var = s1 / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float g = gamma ? gamma[ch] : 1.f, b = beta ? beta[ch] : 0.f;
+        const float sc = g * invstd;
+        scale[ch] = sc;
+        shift[ch] = b - (float)mean * sc;
+        if (smean) smean[ch] = (float)mean;
+        if (sinv) sinv[ch] = invstd;
+        if (rmean) rmean[ch] = (1.f - momentum) * rmean[ch] + momentum * (float)mean;
+        if (rvar) {
+            const double unb = count > 1 ? var * ((double)count / (count - 1)) : var;
+            rvar[ch] = (1.f - momentum) * rvar[ch] + momentum * (float)unb;
+        }
+    });
+}
+
 // stats: [rows][2][c] floats followed by scratch for (ceil(rows/256) + 1) * 2c doubles.
 extern "C" int lh_bn_finalize(const float* stats, int rows, int count, int c, const float* gamma,
                               const float* beta, float* running_mean, float* running_var,
@@ -117,6 +165,21 @@ extern "C" int lh_bn_finalize(const float* stats, int rows, int count, int c, co
     const long slab_floats = (long)rows * 2 * c;
     double* scratch = (double*)(stats + ((slab_floats + 1) & ~1L));
     double* totals = scratch + (long)ceil_div(rows, 256) * 2 * c;
+    if (rows <= 1024) {      // one launch: fold the slab and finalize
+        hipLaunchKernelGGL((bn_finalize_fused_kernel<float>), dim3(ceil_div(c, 16)), dim3(256), 0, s, stats, rows, count, c, gamma, beta,
+                           running_mean, running_var, num_batches_tracked, momentum, eps, scale, shift, save_mean, save_invstd);
+        LH_LAUNCH_CHECK("bn_finalize launch");
+        return LH_OK;
+    }
+    {                        // two launches: 256-row partial folds (fp64), then fold + finalize
+        const int gy = ceil_div(rows, 256);
+        hipLaunchKernelGGL((colsum_kernel<float>), dim3(ceil_div(2 * c, 16), gy), dim3(256), 0, s, stats, rows, 2 * c, 256, scratch);
+        hipLaunchKernelGGL((bn_finalize_fused_kernel<double>), dim3(ceil_div(c, 16)), dim3(256), 0, s, (const double*)scratch, gy, count, c,
+                           gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, scale, shift, save_mean,
+                           save_invstd);
+        LH_LAUNCH_CHECK("bn_finalize launch");
+        return LH_OK;
+    }
     int rc = column_totals(stats, rows, 2 * c, scratch, totals, s);
     if (rc) return rc;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(c, 128)), dim3(128), 0, s, (const double*)totals, count, c,
@@ -356,6 +419,17 @@ __global__ void fuse_bwd_coef_kernel(const double* totals, long count, int c, fl
     if (dgamma) dgamma[ch] = (float)totals[c + ch];
 }
 
+template <typename TI>
+__global__ __launch_bounds__(256) void fuse_bwd_coef_fused_kernel(const TI* slab, int rows, long count, int c, float* coef,
+                                                                  float* dgamma, float* dbeta) {
+    slab_totals_then(slab, rows, c, [&](int ch, double s0, double s1) {
+        coef[ch] = (float)(s0 / (double)count);
+        coef[c + ch] = (float)(s1 / (double)count);
+        if (dbeta) dbeta[ch] = (float)s0;
+        if (dgamma) dgamma[ch] = (float)s1;
+    });
+}
+
 static long fuse_bwd_strips(long count, int* rows_per_strip) {
     long rps = (count + 1023) / 1024;
     if (rps < 32) rps = 32;
@@ -397,11 +471,9 @@ extern "C" int lh_fuse_bwd(const lh_fuse_bwd_desc* d, int n, int h, int w, int c
             a.totals = totals;
             LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((fuse_bwd_reduce_kernel<T>), dim3((int)strips), dim3(256), 0, s, a));
             LH_LAUNCH_CHECK("fuse_bwd_reduce launch");
-            int rc = column_totals(a.partial, (int)strips, 2 * c, scratch, totals, s);
-            if (rc) return rc;
             a.coef = (float*)(totals + 2 * c);
-            hipLaunchKernelGGL(fuse_bwd_coef_kernel, dim3(ceil_div(c, 128)), dim3(128), 0, s, (const double*)totals, a.count, c,
-                               a.coef, a.dgamma, a.dbeta);
+            hipLaunchKernelGGL((fuse_bwd_coef_fused_kernel<float>), dim3(ceil_div(c, 16)), dim3(256), 0, s, (const float*)a.partial,
+                               (int)strips, a.count, c, a.coef, a.dgamma, a.dbeta);
             LH_LAUNCH_CHECK("fuse_bwd_coef launch");
         }
         const long total = a.count * (c / (16 / es));

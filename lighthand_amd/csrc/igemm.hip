@@ -16,20 +16,7 @@
 //    and per-block column sums / sums of squares of the STORED values for BatchNorm.
 #include "common.h"
 
-struct IgemmArgs {
-    const unsigned char* in;
-    const unsigned char* w;
-    unsigned char* out;
-    const unsigned char* addend;
-    const float* bias;
-    float* stats;
-    int n, hi, wi, in_pix_stride, k_run, kspt;
-    int ho, wo, M, sh, sw, cout;
-    int OH, OW, osh, osw, ooh, oow, out_pix_stride;
-    int ntaps, relu;
-    signed char dh[64];
-    signed char dw[64];
-};
+#include "igemm_args.h"
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16> {
@@ -92,7 +79,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
         xh[i] = a * p.sh;
         xw[i] = b * p.sw;
     }
-    const long kpad = (long)p.kspt * KSTEP;
+    const long kpad = p.kpad;
     const unsigned char* wrow[RW];
 #pragma unroll
     for (int i = 0; i < RW; ++i)
@@ -272,6 +259,10 @@ static int launch_tile(const IgemmArgs& a, hipStream_t s) {
 }
 
 static void pick_tile(const lh_igemm_desc* d, int dtype, int* bm, int* bp) {
+    if (lh_ring_supported(d, dtype)) {
+        lh_ring_pick_tile(d, dtype, bm, bp);
+        return;
+    }
     const long M = (long)d->n * d->ho * d->wo;
     int BM = d->cout > 64 ? 128 : 64;
     int BP = 128;
@@ -280,6 +271,13 @@ static void pick_tile(const lh_igemm_desc* d, int dtype, int* bm, int* bp) {
     if (BP == 128 && blocks < 384) BP = 64;
     *bm = BM;
     *bp = BP;
+}
+
+extern "C" int lh_igemm_tile(const lh_igemm_desc* d, int dtype, int* bm, int* bp, int* ring) {
+    LH_REQUIRE(d && bm && bp && ring, "lh_igemm_tile: null pointer");
+    pick_tile(d, dtype, bm, bp);
+    *ring = lh_ring_supported(d, dtype) ? lh_ring_kb() : 0;
+    return LH_OK;
 }
 
 extern "C" int lh_igemm_stats_rows(const lh_igemm_desc* d, int dtype) {
@@ -308,6 +306,7 @@ extern "C" int lh_igemm(const lh_igemm_desc* d, const void* in, const void* wpac
     a.addend = (const unsigned char*)addend; a.bias = bias; a.stats = stats;
     a.n = d->n; a.hi = d->hi; a.wi = d->wi; a.in_pix_stride = d->in_pix_stride; a.k_run = d->k_run;
     a.kspt = (d->k_run * es + 63) / 64;
+    a.kpad = (d->k_run * es + 127) / 128 * (128 / es);
     a.ho = d->ho; a.wo = d->wo; a.M = d->n * d->ho * d->wo; a.sh = d->sh; a.sw = d->sw; a.cout = d->cout;
     a.OH = d->OH; a.OW = d->OW; a.osh = d->osh; a.osw = d->osw; a.ooh = d->ooh; a.oow = d->oow;
     a.out_pix_stride = d->out_pix_stride; a.ntaps = d->ntaps; a.relu = d->relu;
@@ -315,6 +314,12 @@ extern "C" int lh_igemm(const lh_igemm_desc* d, const void* in, const void* wpac
     int bm, bp;
     pick_tile(d, dtype, &bm, &bp);
     hipStream_t s = (hipStream_t)stream;
+    a.tw = 1; a.dh0 = a.dhs = a.dw0 = a.dws = 0;
+    if (lh_ring_supported(d, dtype)) {
+        lh_tap_grid(d, &a.tw, &a.dh0, &a.dhs, &a.dw0, &a.dws);
+        a.kspt = (d->k_run * es + lh_ring_kb() - 1) / lh_ring_kb();
+        return lh_igemm_ring_launch(a, bm, bp, dtype, s);
+    }
 #define LH_TILE(T)                                                               \
     if (bm == 128 && bp == 128) return launch_tile<T, 128, 128, 2, 2>(a, s);     \
     if (bm == 128 && bp == 64) return launch_tile<T, 128, 64, 4, 1>(a, s);       \

@@ -1,0 +1,26 @@
+// Kernel-argument block shared by the two implicit-GEMM kernels (igemm.hip, igemm_ring.hip).
+#pragma once
+#include "common.h"
+
+struct IgemmArgs {
+    const unsigned char* in;
+    const unsigned char* w;
+    unsigned char* out;
+    const unsigned char* addend;
+    const float* bias;
+    float* stats;
+    int n, hi, wi, in_pix_stride, k_run, kspt, kpad;   // kpad: elements per (row, tap) of the weight pack
+    int ho, wo, M, sh, sw, cout;
+    int OH, OW, osh, osw, ooh, oow, out_pix_stride;
+    int ntaps, relu;
+    int tw, dh0, dhs, dw0, dws;      // regular tap grid (ring kernel): tap t = (t / tw, t % tw)
+    signed char dh[64];
+    signed char dw[64];
+};
+
+// igemm_ring.hip
+bool lh_ring_supported(const lh_igemm_desc* d, int dtype);
+bool lh_tap_grid(const lh_igemm_desc* d, int* tw, int* dh0, int* dhs, int* dw0, int* dws);
+void lh_ring_pick_tile(const lh_igemm_desc* d, int dtype, int* bm, int* bp);
+int lh_ring_kb();
+int lh_igemm_ring_launch(const IgemmArgs& a, int bm, int bp, int dtype, hipStream_t s);

@@ -1,0 +1,389 @@
+// Implicit-GEMM gather convolution, LDS-DMA ring version (the production path on gfx950).
+//
+// Same contract as igemm.hip (see there for the GEMM view, LDS image and epilogue) but the K loop
+// is fed by direct-to-LDS loads (global_load_lds_dwordx4): no staging registers, a ring of D
+// stages of (BM + BP) rows x 128 bytes of K, ONE raw s_barrier per K step and a COUNTED
+// s_waitcnt vmcnt(N) that leaves D-2 later stages in flight across the barrier, so HBM/L2 latency
+// is covered by the ring and not by occupancy (one or two workgroups per CU).
+//  * the LDS destination of an LDS-DMA is lane-linear (wave base + lane*16), so the image's
+//    XOR swizzle is applied to the per-lane SOURCE: lane L of the instruction that fills 16-byte
+//    chunk c = 4*half + (L>>4) of a 16-row group fetches row (L&15) ^ 2c of that group;
+//  * rows that fall into the zero padding (or past k_run / past the last pixel) read a 16-byte
+//    zero page instead, so every lane issues every load and the vmcnt bookkeeping is exact;
+//  * the pixel operand needs 16-byte aligned pixel rows (in_pix_stride * sizeof(T) % 16 == 0); the
+//    C_in = 3 stem keeps the register-staged kernel of igemm.hip.
+#include "common.h"
+
+#include "igemm_args.h"
+#include <stdlib.h>
+
+__device__ __attribute__((aligned(16))) unsigned int lh_zero_page[4] = {0u, 0u, 0u, 0u};
+
+template <typename T> struct MmaR;
+template <> struct MmaR<bf16> {
+    static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct MmaR<f16> {
+    static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct MmaR<float> {
+    static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4& c) {
+        const f32x4 fa = __builtin_bit_cast(f32x4, a), fb = __builtin_bit_cast(f32x4, b);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0], fb[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1], fb[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[2], fb[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[3], fb[3], c, 0, 0, 0);
+    }
+};
+
+typedef __attribute__((address_space(3))) void* lds_void_p;
+typedef const __attribute__((address_space(1))) void* gbl_void_p;
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <typename T, int BM, int BP, int WC, int WP, int D, int KB>
+__global__ __launch_bounds__(256) void igemm_ring_kernel(const IgemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int ES = sizeof(T);
+    constexpr int EPC = 16 / ES;
+    constexpr int KSTEP = KB / ES;                    // elements per K step (KB bytes per row)
+    constexpr int TC = BM / WC, TP = BP / WP;
+    constexpr int CT = TC / 16, PT = TP / 16;
+    constexpr int STAGE = (BM + BP) * KB;
+    constexpr int H = KB / 64;                        // LDS-DMA instructions per 16-row group (1 KiB each)
+    constexpr int GB = 16 * KB;                       // bytes of one 16-row group
+    constexpr int NW = BM / 16 * H / 4, NX = BP / 16 * H / 4;   // instructions per wave and stage
+    constexpr int L = NW + NX;
+    constexpr int KSUB = KB / 64;                     // MFMA K sub-steps per stage
+    static_assert(WC * WP == 4 && D >= 2 && D <= 4 && (KB == 64 || KB == 128) && NW >= 1 && NX >= 1, "bad configuration");
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wave / WP, wp = wave % WP;
+    const int pblk = blockIdx.x, cblk = blockIdx.y;
+    const int hw = p.ho * p.wo;
+
+    // ---- per-lane source bookkeeping.  Instruction q = 4*j + wave of a stage fills (16-row group,
+    //      half) = (q / H, q % H); this lane supplies chunk c = 4*half + (lane>>4) of row (lane&15)^2c.
+    int xbase[NX], xh[NX], xw[NX], xc[NX];
+    bool xok[NX];
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+        const int q = 4 * j + wave;
+        const int g = q / H, c = 4 * (q % H) + (lane >> 4);
+        const int row = g * 16 + ((lane & 15) ^ ((2 * c) & 15));
+        const int m = pblk * BP + row;
+        xok[j] = m < p.M;
+        const int mm = xok[j] ? m : 0;
+        const int n = mm / hw, rem = mm - n * hw;
+        const int a = rem / p.wo, b = rem - a * p.wo;
+        xbase[j] = n * p.hi * p.wi;
+        xh[j] = a * p.sh;
+        xw[j] = b * p.sw;
+        xc[j] = c * EPC;
+    }
+    const long kpad = p.kpad;
+    const unsigned char* wsrc[NW];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+        const int q = 4 * j + wave;
+        const int g = q / H, c = 4 * (q % H) + (lane >> 4);
+        const int row = g * 16 + ((lane & 15) ^ ((2 * c) & 15));
+        wsrc[j] = p.w + ((long)(cblk * BM + row) * p.ntaps * kpad + c * EPC) * ES;
+    }
+    const unsigned char* zero = reinterpret_cast<const unsigned char*>(lh_zero_page);
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+
+    auto issue = [&](int tap, int kc, int slot, int dh, int dw) {
+        unsigned char* st = smem + slot * STAGE;
+        const long woff = ((long)tap * kpad + (long)kc * KSTEP) * ES;
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            const int q = 4 * j + wave;
+            unsigned char* dst = st + (q / H) * GB + (q % H) * 1024;
+            __builtin_amdgcn_global_load_lds((gbl_void_p)(wsrc[j] + woff), (lds_void_p)dst, 16, 0, 0);
+        }
+        const int kbase = kc * KSTEP;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const int q = 4 * j + wave;
+            unsigned char* dst = st + BM * KB + (q / H) * GB + (q % H) * 1024;
+            const int ih = xh[j] + dh, iw = xw[j] + dw, koff = kbase + xc[j];
+            const bool ok = (int)xok[j] & (int)((unsigned)ih < (unsigned)p.hi) & (int)((unsigned)iw < (unsigned)p.wi) & (int)(koff < p.k_run);
+            const unsigned char* src = p.in + ((long)(xbase[j] + ih * p.wi + iw) * p.in_pix_stride + koff) * ES;
+            src = ok ? src : zero;                      // select, not a branch: every lane issues the load
+            __builtin_amdgcn_global_load_lds((gbl_void_p)src, (lds_void_p)dst, 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[CT][PT];
+#pragma unroll
+    for (int i = 0; i < CT; ++i)
+#pragma unroll
+        for (int j = 0; j < PT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int S = p.ntaps * p.kspt;
+    int itap = 0, ikc = 0;                       // (tap, kc) of the next stage to issue
+    int tj = 0, cdh = p.dh0, cdw = p.dw0;        // the tap's (dh, dw), advanced without memory loads
+    int issued = 0;
+    auto advance = [&]() {
+        ++issued;
+        if (++ikc == p.kspt) {
+            ikc = 0; ++itap;
+            cdw += p.dws;
+            if (++tj == p.tw) { tj = 0; cdw = p.dw0; cdh += p.dhs; }
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < D - 1; ++s) {
+        if (issued < S) {
+            issue(itap, ikc, issued % D, cdh, cdw);
+            advance();
+        }
+    }
+    // fragment read offsets: chunk c = 4*kk + (lane>>4), row = lane&15
+    int foff[KSUB];
+#pragma unroll
+    for (int kk = 0; kk < KSUB; ++kk) {
+        const int c = 4 * kk + (lane >> 4);
+        foff[kk] = c * 256 + (((lane & 15) ^ ((2 * c) & 15)) << 4);
+    }
+
+    for (int s = 0; s < S; ++s) {
+        // stage s must have landed; stages s+1 .. issued-1 may stay in flight
+        const int ahead = issued - 1 - s;
+        if (ahead >= 2) wait_vmcnt<2 * L>();
+        else if (ahead == 1) wait_vmcnt<L>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (issued < S) {
+            issue(itap, ikc, issued % D, cdh, cdw);
+            advance();
+        }
+        // Fragment reads are inline asm: the compiler cannot tell LDS-DMA writes from these reads
+        // and would otherwise drain the whole ring (s_waitcnt vmcnt(0)) in front of every ds_read.
+        const unsigned st = lds_base + (s % D) * STAGE;
+        uint4 fa[KSUB][CT], fb[KSUB][PT];
+#pragma unroll
+        for (int kk = 0; kk < KSUB; ++kk) {
+#pragma unroll
+            for (int i = 0; i < CT; ++i)
+                asm volatile("ds_read_b128 %0, %1" : "=v"(fa[kk][i]) : "v"(st + (wc * CT + i) * GB + foff[kk]));
+#pragma unroll
+            for (int j = 0; j < PT; ++j)
+                asm volatile("ds_read_b128 %0, %1" : "=v"(fb[kk][j]) : "v"(st + BM * KB + (wp * PT + j) * GB + foff[kk]));
+        }
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"((KSUB - 1) * (CT + PT)) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < CT; ++i)
+#pragma unroll
+            for (int j = 0; j < PT; ++j) MmaR<T>::run(fa[0][i], fb[0][j], acc[i][j]);
+        if constexpr (KSUB == 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < CT; ++i)
+#pragma unroll
+                for (int j = 0; j < PT; ++j) MmaR<T>::run(fa[KSUB - 1][i], fb[KSUB - 1][j], acc[i][j]);
+        }
+    }
+
+    // ---- epilogue (identical to igemm.hip): D -> LDS tile [BP][BM], full-line stores, BN partial sums
+    constexpr int RS = BM * ES + 8;
+    __syncthreads();
+    {
+        const int q = lane >> 4, pl = lane & 15;
+#pragma unroll
+        for (int i = 0; i < CT; ++i) {
+            const int col = wc * TC + i * 16 + q * 4;
+            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int gc = cblk * BM + col + r;
+                    bv[r] = gc < p.cout ? p.bias[gc] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < PT; ++j) {
+                const int pr = wp * TP + j * 16 + pl;
+                T* dst = reinterpret_cast<T*>(smem + pr * RS + col * ES);
+                if constexpr (ES == 4) {
+                    reinterpret_cast<float2*>(dst)[0] = float2{acc[i][j][0] + bv[0], acc[i][j][1] + bv[1]};
+                    reinterpret_cast<float2*>(dst)[1] = float2{acc[i][j][2] + bv[2], acc[i][j][3] + bv[3]};
+                } else {
+                    union { uint2 u; T e[4]; } pk;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pk.e[r] = from_f<T>(acc[i][j][r] + bv[r]);
+                    *reinterpret_cast<uint2*>(dst) = pk.u;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    constexpr int CH = BM * ES / 16;
+    constexpr int RPP = 256 / CH;
+    const int chunk = tid % CH, r0 = tid / CH;
+    const int col0 = cblk * BM + chunk * EPC;
+    const bool col_ok = col0 < p.cout;
+    float s1[EPC], s2[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) s1[e] = s2[e] = 0.f;
+
+    for (int pr = r0; pr < BP; pr += RPP) {
+        const int m = pblk * BP + pr;
+        if (m >= p.M || !col_ok) continue;
+        const int n = m / hw, rem = m - n * hw;
+        const int a = rem / p.wo, b = rem - a * p.wo;
+        const long opix = ((long)n * p.OH + a * p.osh + p.ooh) * p.OW + b * p.osw + p.oow;
+        const long eoff = opix * p.out_pix_stride + col0;
+        const unsigned char* src = smem + pr * RS + chunk * 16;
+        const uint2 lo = *reinterpret_cast<const uint2*>(src);
+        const uint2 hi = *reinterpret_cast<const uint2*>(src + 8);
+        uint4 u = uint4{lo.x, lo.y, hi.x, hi.y};
+        if (p.addend || p.relu) {
+            float v[EPC];
+            unpack16<T>(u, v);
+            if (p.addend) {
+                float av[EPC];
+                unpack16<T>(*reinterpret_cast<const uint4*>(p.addend + eoff * ES), av);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) v[e] += av[e];
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            u = pack16<T>(v);
+        }
+        if (p.stats) {
+            float sv[EPC];
+            unpack16<T>(u, sv);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) { s1[e] += sv[e]; s2[e] += sv[e] * sv[e]; }
+        }
+        *reinterpret_cast<uint4*>(p.out + eoff * ES) = u;
+    }
+
+    if (p.stats) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            red[(r0 * 2 + 0) * BM + chunk * EPC + e] = s1[e];
+            red[(r0 * 2 + 1) * BM + chunk * EPC + e] = s2[e];
+        }
+        __syncthreads();
+        for (int t = tid; t < 2 * BM; t += 256) {
+            const int which = t / BM, col = t - which * BM;
+            float a = 0.f;
+#pragma unroll 4
+            for (int r = 0; r < RPP; ++r) a += red[(r * 2 + which) * BM + col];
+            const int gc = cblk * BM + col;
+            if (gc < p.cout) p.stats[((long)pblk * 2 + which) * p.cout + gc] = a;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <typename T, int BM, int BP, int WC, int WP, int D, int KB>
+static int launch_ring(const IgemmArgs& a, hipStream_t s) {
+    constexpr int ES = sizeof(T);
+    constexpr int ring = D * (BM + BP) * KB;
+    constexpr int epi = BP * (BM * ES + 8);
+    constexpr int lds = ring > epi ? ring : epi;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_ring_kernel<T, BM, BP, WC, WP, D, KB>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e != hipSuccess) {
+                lh_set_error("igemm_ring: cannot raise dynamic LDS to %d bytes: %s", lds, hipGetErrorString(e));
+                return LH_ERR_HIP;
+            }
+        }
+        attr_done = true;
+    }
+    dim3 grid(ceil_div(a.M, BP), ceil_div(a.cout, BM));
+    hipLaunchKernelGGL((igemm_ring_kernel<T, BM, BP, WC, WP, D, KB>), grid, dim3(256), lds, s, a);
+    LH_LAUNCH_CHECK("igemm_ring launch");
+    return LH_OK;
+}
+
+// Tile choice: the largest tile that still gives >= 2 workgroups per CU, else the smallest.
+void lh_ring_pick_tile(const lh_igemm_desc* d, int dtype, int* bm, int* bp) {
+    const long M = (long)d->n * d->ho * d->wo;
+    const int cands[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
+    const bool f32 = dtype == LH_F32;
+    for (int i = 0; i < 4; ++i) {
+        const int BM = cands[i][0], BP = cands[i][1];
+        if (BM == 128 && d->cout <= 64) continue;
+        if (f32 && BM == 128 && BP == 128) continue;            // fp32 epilogue tile would not fit 64 KiB well
+        const long blocks = ((M + BP - 1) / BP) * ((d->cout + BM - 1) / BM);
+        if (blocks >= 512 || i == 3) { *bm = BM; *bp = BP; return; }
+    }
+    *bm = 64; *bp = 64;
+}
+
+// Taps of every convolution form on this path are a regular grid: tap t = (t / tw, t % tw) with
+// dh = dh0 + (t / tw) * dhs, dw = dw0 + (t % tw) * dws.  Returns false for an irregular list.
+bool lh_tap_grid(const lh_igemm_desc* d, int* tw, int* dh0, int* dhs, int* dw0, int* dws) {
+    const int n = d->ntaps;
+    if (n <= 0) return false;
+    int w = 1;
+    while (w < n && d->dh[w] == d->dh[0]) ++w;
+    if (n % w) return false;
+    *tw = w; *dh0 = d->dh[0]; *dw0 = d->dw[0];
+    *dws = w > 1 ? d->dw[1] - d->dw[0] : 0;
+    *dhs = n > w ? d->dh[w] - d->dh[0] : 0;
+    for (int t = 0; t < n; ++t)
+        if (d->dh[t] != *dh0 + (t / w) * *dhs || d->dw[t] != *dw0 + (t % w) * *dws) return false;
+    return true;
+}
+
+bool lh_ring_supported(const lh_igemm_desc* d, int dtype) {
+    const int es = lh_dtype_size(dtype);
+    int a, b, c, e, f;
+    return (d->in_pix_stride * es) % 16 == 0 && d->ntaps > 0 && lh_tap_grid(d, &a, &b, &c, &e, &f);
+}
+
+int lh_ring_kb() {
+    static int kb = 0;
+    if (!kb) {
+        const char* e = getenv("LH_RING_KB");
+        kb = (e && atoi(e) == 128) ? 128 : 64;
+    }
+    return kb;
+}
+
+template <typename T, int KB>
+static int ring_dispatch(const IgemmArgs& a, int bm, int bp, hipStream_t s) {
+    if (bm == 128 && bp == 128) {
+        if constexpr (sizeof(T) == 4) return launch_ring<T, 128, 64, 4, 1, 4, KB>(a, s);
+        else return launch_ring<T, 128, 128, 2, 2, 4, KB>(a, s);
+    }
+    if (bm == 128 && bp == 64) return launch_ring<T, 128, 64, 4, 1, 4, KB>(a, s);
+    if (bm == 64 && bp == 128) return launch_ring<T, 64, 128, 1, 4, 4, KB>(a, s);
+    return launch_ring<T, 64, 64, 2, 2, 4, KB>(a, s);
+}
+
+int lh_igemm_ring_launch(const IgemmArgs& a, int bm, int bp, int dtype, hipStream_t s) {
+    const int kb = lh_ring_kb();
+    switch (dtype) {
+        case LH_BF16: return kb == 128 ? ring_dispatch<bf16, 128>(a, bm, bp, s) : ring_dispatch<bf16, 64>(a, bm, bp, s);
+        case LH_F16: return kb == 128 ? ring_dispatch<f16, 128>(a, bm, bp, s) : ring_dispatch<f16, 64>(a, bm, bp, s);
+        case LH_F32: return kb == 128 ? ring_dispatch<float, 128>(a, bm, bp, s) : ring_dispatch<float, 64>(a, bm, bp, s);
+    }
+    lh_set_error("igemm_ring: unsupported dtype %d", dtype);
+    return LH_ERR_ARG;
+}

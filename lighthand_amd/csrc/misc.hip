@@ -123,7 +123,7 @@ extern "C" int lh_pack_weight(const float* w, void* out, size_t* bytes, int n_ou
     const int es = lh_dtype_size(dtype);
     LH_REQUIRE(es > 0, "lh_pack_weight: bad dtype %d", dtype);
     LH_REQUIRE(n_out > 0 && n_in > 0 && ntaps >= 0 && ntaps <= 64, "lh_pack_weight: bad sizes");
-    const int kstep = 64 / es;
+    const int kstep = 128 / es;          // K is padded to the 128-byte step of the ring kernel
     const int kpad = (n_in + kstep - 1) / kstep * kstep;
     const int rows = (n_out + 127) / 128 * 128;
     const size_t need = (size_t)rows * (ntaps > 0 ? ntaps : 1) * kpad * es;
@@ -142,6 +142,34 @@ extern "C" int lh_pack_weight(const float* w, void* out, size_t* bytes, int n_ou
     const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((pack_weight_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a));
     LH_LAUNCH_CHECK("pack_weight launch");
+    return LH_OK;
+}
+
+// All packs of a model in ONE launch: blockIdx.y selects the pack descriptor (device table).
+template <typename T>
+__global__ void pack_weight_multi_kernel(const lh_pack_item* items) {
+    const lh_pack_item& p = items[blockIdx.y];
+    const int es = sizeof(T);
+    const int kstep = 128 / es;
+    const int kpad = (p.n_in + kstep - 1) / kstep * kstep;
+    const int rows = (p.n_out + 127) / 128 * 128;
+    const long total = (long)rows * p.ntaps * kpad;
+    T* out = (T*)p.out;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % kpad);
+        const long t2 = i / kpad;
+        const int t = (int)(t2 % p.ntaps), o = (int)(t2 / p.ntaps);
+        float v = 0.f;
+        if (o < p.n_out && k < p.n_in) v = p.w[o * p.so + k * p.si + p.r[t] * p.sr + p.s[t] * p.ss];
+        out[i] = from_f<T>(v);
+    }
+}
+
+extern "C" int lh_pack_weights_multi(const lh_pack_item* items_dev, int n_items, int dtype, void* stream) {
+    LH_REQUIRE(items_dev && n_items > 0, "lh_pack_weights_multi: bad arguments");
+    LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((pack_weight_multi_kernel<T>), dim3(48, n_items), dim3(256), 0, (hipStream_t)stream,
+                                                   items_dev));
+    LH_LAUNCH_CHECK("pack_weights_multi launch");
     return LH_OK;
 }
 

@@ -183,17 +183,54 @@ struct WreduceArgs {
     signed char s[64];
 };
 
+// Fast path for the plain layout grad[(o*n_in + i)*ntaps + t]: a workgroup folds 256 consecutive (o, i)
+// pairs (coalesced slab reads per tap), transposes through LDS and writes 256*ntaps contiguous floats.
+__global__ __launch_bounds__(256) void wgrad_reduce_contig_kernel(const WreduceArgs p) {
+    extern __shared__ float tile[];                       // [256][ntaps + 1]
+    const long per = (long)p.n_out * p.n_in;
+    const long base = (long)blockIdx.x * 256;
+    const long idx = base + threadIdx.x;
+    const int ld = p.ntaps + 1;
+    if (idx < per) {
+        for (int t = 0; t < p.ntaps; ++t) {
+            float a = 0.f;
+            for (int sp = 0; sp < p.nsplit; ++sp) a += p.slab[((long)sp * p.ntaps + t) * per + idx];
+            tile[threadIdx.x * ld + t] = a;
+        }
+    }
+    __syncthreads();
+    const long n_here = per - base < 256 ? per - base : 256;
+    const long total = n_here * p.ntaps;
+    float* g = p.grad + base * p.ntaps;
+    for (long e = threadIdx.x; e < total; e += 256) {
+        const int pair = (int)(e / p.ntaps), t = (int)(e - (long)pair * p.ntaps);
+        const float v = tile[pair * ld + t];
+        g[e] = p.accumulate ? g[e] + v : v;
+    }
+}
+
+// Generic layout / small tensors: one thread per (tap, o, i) -- coalesced slab reads, strided writes.
 __global__ void wgrad_reduce_kernel(const WreduceArgs p) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long per = (long)p.n_out * p.n_in;
-    if (idx >= per) return;
-    const int o = (int)(idx / p.n_in), i = (int)(idx - (long)o * p.n_in);
-    for (int t = 0; t < p.ntaps; ++t) {
-        float a = 0.f;
-        for (int sp = 0; sp < p.nsplit; ++sp) a += p.slab[((long)sp * p.ntaps + t) * per + idx];
-        float* g = p.grad + o * p.so + i * p.si + p.r[t] * p.sr + p.s[t] * p.ss;
-        *g = p.accumulate ? *g + a : a;
+    if (idx >= per * p.ntaps) return;
+    const int t = (int)(idx / per);
+    const long pair = idx - (long)t * per;
+    const int o = (int)(pair / p.n_in), i = (int)(pair - (long)o * p.n_in);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    const float* src = p.slab + (long)t * per + pair;
+    const long stride = (long)p.ntaps * per;
+    int sp = 0;
+    for (; sp + 4 <= p.nsplit; sp += 4) {
+        a0 += src[(long)sp * stride];
+        a1 += src[(long)(sp + 1) * stride];
+        a2 += src[(long)(sp + 2) * stride];
+        a3 += src[(long)(sp + 3) * stride];
     }
+    for (; sp < p.nsplit; ++sp) a0 += src[(long)sp * stride];
+    const float a = (a0 + a1) + (a2 + a3);
+    float* g = p.grad + o * p.so + i * p.si + p.r[t] * p.sr + p.s[t] * p.ss;
+    *g = p.accumulate ? *g + a : a;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -205,13 +242,21 @@ static void wgrad_plan(const lh_igemm_desc* d, int n_out, int n_in, int dtype, i
     const long M = (long)d->n * d->ho * d->wo;
     const long steps = (M + kp - 1) / kp;
     const long tiles = (long)((n_out + *bo - 1) / *bo) * ((n_in + *bi - 1) / *bi) * d->ntaps;
-    long want = (1024 + tiles - 1) / tiles;          // aim at >= ~1024 blocks in flight
-    const long max_split = (steps + 7) / 8;          // at least 8 K steps per block
+    long want = (1024 + tiles - 1) / tiles;          // aim at >= ~3 workgroups per CU
+    long max_split = (steps + 7) / 8;                // at least 8 K steps per block
+    if (max_split > 128) max_split = 128;            // bound the slab traffic of the fold
     if (want > max_split) want = max_split;
     if (want < 1) want = 1;
     const long sps = (steps + want - 1) / want;
     *steps_per_split = (int)sps;
     *nsplit = (int)((steps + sps - 1) / sps);
+}
+
+extern "C" int lh_wgrad_tile(const lh_igemm_desc* d, int n_out, int n_in, int dtype, int* bo, int* bi, int* nsplit) {
+    LH_REQUIRE(d && bo && bi && nsplit, "lh_wgrad_tile: null pointer");
+    int sps;
+    wgrad_plan(d, n_out, n_in, dtype, bo, bi, nsplit, &sps);
+    return LH_OK;
 }
 
 extern "C" size_t lh_wgrad_slab_bytes(const lh_igemm_desc* d, int n_out, int n_in, int dtype) {
@@ -279,7 +324,15 @@ extern "C" int lh_wgrad_reduce(const lh_igemm_desc* d, const float* slab, float*
         a.s[t] = t < d->ntaps ? (signed char)taps_rs[2 * t + 1] : 0;
     }
     const long per = (long)n_out * n_in;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(per, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    bool contig = so == (long)n_in * d->ntaps && si == d->ntaps && ss == 1;
+    for (int t = 0; t < d->ntaps && contig; ++t) contig = (a.r[t] * sr + a.s[t] * ss) == t;
+    if (contig && per * d->ntaps > (2L << 20)) {
+        hipLaunchKernelGGL(wgrad_reduce_contig_kernel, dim3(ceil_div(per, 256)), dim3(256), 256 * (d->ntaps + 1) * sizeof(float),
+                           (hipStream_t)stream, a);
+        LH_LAUNCH_CHECK("wgrad_reduce launch");
+        return LH_OK;
+    }
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(per * d->ntaps, 256)), dim3(256), 0, (hipStream_t)stream, a);
     LH_LAUNCH_CHECK("wgrad_reduce launch");
     return LH_OK;
 }

@@ -176,6 +176,9 @@ class Plan:
         if self.device.type != "cuda":
             raise _lib.LightHandError("lighthand_amd runs on a HIP device only; move the model with .to('cuda')")
         self.grads = {}
+        arena0 = getattr(model, "_lh_arena", None)
+        self.arena_offsets = arena0.offsets if arena0 is not None else {}
+        self.arena_numel = arena0.numel if arena0 is not None else 0
         if self.with_bwd:
             arena = getattr(model, "_lh_arena", None)
             for k, p in self.params.items():
@@ -186,6 +189,7 @@ class Plan:
         self.nodes = gb.nodes
         self.out_act = gb.out
         self.fwd, self.bwd, self.packs = [], [], []
+        self._pack_items = []
         self.keep = []                     # ctypes objects / tensors referenced by raw pointer
         self._ws_wgrad = 0
         self._ws_fuse = 0
@@ -218,15 +222,33 @@ class Plan:
         check(self.lib.lh_pack_weight(None, None, C.byref(nbytes), n_out, n_in, *strides, len(taps_rs), arr, self.dt, None), what)
         buf = self._alloc(max(nbytes.value, 16), dtype=torch.uint8)
         if taps_rs:
-            self.packs.append(_Call(self.lib.lh_pack_weight,
-                                    (wt.data_ptr(), buf.data_ptr(), None, n_out, n_in, *strides, len(taps_rs), arr, self.dt),
-                                    what, keep=(arr, wt)))
+            it = _lib.PackItem()
+            it.w, it.out, it.n_out, it.n_in, it.ntaps = wt.data_ptr(), buf.data_ptr(), n_out, n_in, len(taps_rs)
+            it.so, it.si, it.sr, it.ss = strides
+            for i, (r, q) in enumerate(taps_rs):
+                it.r[i], it.s[i] = r, q
+            self._pack_items.append(it)
+            self.keep.append(wt)
         return buf
 
     def _igemm(self, lst, d, src, pack, dst, addend, bias, stats, what, flops=0):
         self.keep.append(d)
         lst.append(_Call(self.lib.lh_igemm, (C.byref(d), _ptr(src), _ptr(pack), _ptr(dst), _ptr(addend), _ptr(bias), _ptr(stats), self.dt), what))
         return lst[-1]
+
+    def _kname(self, d, wgrad=None):
+        """Kernel instantiation name as rocprofv3 prints it (for roofline attribution)."""
+        t = {"fp32": "float", "bf16": "__bf16", "fp16": "_Float16"}[self.precision]
+        a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
+        if wgrad is None:
+            self.lib.lh_igemm_tile(C.byref(d), self.dt, C.byref(a), C.byref(b), C.byref(c))
+            wc, wp = {(128, 128): (2, 2), (128, 64): (4, 1), (64, 128): (1, 4), (64, 64): (2, 2)}[(a.value, b.value)]
+            if c.value:
+                return f"igemm_ring_kernel<{t}, {a.value}, {b.value}, {wc}, {wp}, 4, {c.value}>"
+            return f"igemm_kernel<{t}, {a.value}, {b.value}, {wc}, {wp}>"
+        self.lib.lh_wgrad_tile(C.byref(d), wgrad[0], wgrad[1], self.dt, C.byref(a), C.byref(b), C.byref(c))
+        wo, wi = {(128, 128): (2, 2), (128, 64): (4, 1), (64, 128): (1, 4), (64, 64): (2, 2)}[(a.value, b.value)]
+        return f"wgrad_kernel<{t}, {a.value}, {b.value}, {wo}, {wi}>"
 
     def _first_write(self, a):
         """True the first time a gradient buffer is produced in the backward list."""
@@ -262,10 +284,27 @@ class Plan:
             getattr(self, "_c_" + kind)(nd, blk)
             bwd_blocks.append(blk)
         # backward list: node blocks in reverse order; accumulate flags resolved in that order
+        if self._pack_items:       # every weight pack of the model is rebuilt by ONE launch
+            arr = (_lib.PackItem * len(self._pack_items))(*self._pack_items)
+            table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+            self.keep.append(table)
+            self.packs.append(_Call(self.lib.lh_pack_weights_multi, (table.data_ptr(), len(self._pack_items), self.dt), "weight packs"))
+        self.bwd_marks = []        # (end index in self.bwd, parameter names whose gradient is final there)
         if self.with_bwd:
-            for blk in reversed(bwd_blocks):
+            for (kind, nd), blk in zip(reversed(self.nodes), reversed(bwd_blocks)):
                 for emit in blk:
                     emit()
+                names = []
+                if kind in ("conv", "deconv"):
+                    names.append(nd["w"] + ".weight")
+                    if nd["bias"]:
+                        names.append(nd["bias"])
+                elif kind == "fuse":
+                    for _, bn, _ in nd["terms"]:
+                        if bn is not None:
+                            names += [bn + ".weight", bn + ".bias"]
+                if names:
+                    self.bwd_marks.append((len(self.bwd), names))
             ws = self._alloc(max(self._ws_wgrad, self._ws_fuse, 256), dtype=torch.uint8)
             for setter in self._ws_users:
                 setter(ws.data_ptr())
@@ -317,7 +356,7 @@ class Plan:
             stats_ptr = y.stats
         flops = 2.0 * y.pixels * cout * cin * k * k
         self._igemm(self.fwd, d, xbuf, pack, ybuf, None, bias, stats_ptr, nd["w"] + " fwd")
-        self.profile_meta.append(("fwd", len(self.fwd) - 1, "igemm", flops, (x.pixels * x.c + y.pixels * y.c) * self.es))
+        self.profile_meta.append(("fwd", len(self.fwd) - 1, self._kname(d), flops, (x.pixels * x.c + y.pixels * y.c) * self.es))
         if not self.with_bwd:
             return
         # --- backward: weight gradient, then data gradient
@@ -350,19 +389,22 @@ class Plan:
                 cw.args, cr.args = tuple(a), tuple(b)
             self._ws_users.append(set_ws)
             self.bwd.append(cw)
-            self.profile_meta.append(("bwd", len(self.bwd) - 1, "wgrad", flops, (x.pixels * x.c + y.pixels * y.c) * self.es))
+            self.profile_meta.append(("bwd", len(self.bwd) - 1, self._kname(d, (y.c, cin)), flops, (x.pixels * x.c + y.pixels * y.c) * self.es))
             self.bwd.append(cr)
             if pad_out:
                 self.bwd.append(_TorchCall(lambda: gw.copy_(gtmp[:cout]), "head grad crop"))
             if nd["bias"]:
                 gb_ = self.grads[nd["bias"]]
-                self.bwd.append(_TorchCall(lambda: gb_.copy_(dy.view(-1, y.c)[:, :cout].sum(0, dtype=torch.float32)), "bias grad"))
+                if y is self.out_act:      # the head: reduce the contiguous fp32 NCHW gradient instead of strided bf16
+                    self.bwd.append(_TorchCall(lambda: torch.sum(self.dout_nchw, dim=(0, 2, 3), out=gb_), "head bias grad"))
+                else:
+                    self.bwd.append(_TorchCall(lambda: gb_.copy_(dy.view(-1, y.c)[:, :cout].sum(0, dtype=torch.float32)), "bias grad"))
             if x.needs_grad:
                 dx = self._act_grad(x)
                 first = self._first_write(x)
                 for dd, pk in zip(ddescs, dpacks):
                     self._igemm(self.bwd, dd, dy, pk, dx, None if first else dx, None, None, nd["w"] + " dgrad")
-                    self.profile_meta.append(("bwd", len(self.bwd) - 1, "igemm", 2.0 * dd.n * dd.ho * dd.wo * cin * cout * dd.ntaps,
+                    self.profile_meta.append(("bwd", len(self.bwd) - 1, self._kname(dd), 2.0 * dd.n * dd.ho * dd.wo * cin * cout * dd.ntaps,
                                               (dd.n * dd.ho * dd.wo * x.c + y.pixels * y.c / (s * s)) * self.es))
         blk.append(emit)
 
@@ -390,7 +432,7 @@ class Plan:
             stats_ptr = y.stats
         flops = 2.0 * y.pixels * cout * 3 * k * k
         self._igemm(self.fwd, d, img, pack, ybuf, None, bias, stats_ptr, nd["w"] + " stem fwd")
-        self.profile_meta.append(("fwd", len(self.fwd) - 1, "igemm", flops, (x.pixels * 4 + y.pixels * y.c) * self.es))
+        self.profile_meta.append(("fwd", len(self.fwd) - 1, self._kname(d), flops, (x.pixels * 4 + y.pixels * y.c) * self.es))
         if not self.with_bwd:
             return
         self._ws_wgrad = max(self._ws_wgrad, self.lib.lh_wgrad_slab_bytes(C.byref(d), y.c, kr, self.dt))
@@ -410,7 +452,7 @@ class Plan:
                 cw.args, cr.args = tuple(a), tuple(b)
             self._ws_users.append(set_ws)
             self.bwd.append(cw)
-            self.profile_meta.append(("bwd", len(self.bwd) - 1, "wgrad", flops, (x.pixels * 4 + y.pixels * y.c) * self.es))
+            self.profile_meta.append(("bwd", len(self.bwd) - 1, self._kname(d, (y.c, kr)), flops, (x.pixels * 4 + y.pixels * y.c) * self.es))
             self.bwd.append(cr)
             self.bwd.append(_TorchCall(lambda: gw.copy_(gstage[:, :, :k, :3].permute(0, 3, 1, 2)), "stem grad unstage"))
         blk.append(emit)
@@ -442,7 +484,7 @@ class Plan:
             self.keep.append(d)
             st = 0 if off is None else y.stats.data_ptr() + off
             self.fwd.append(_Call(self.lib.lh_igemm, (C.byref(d), xbuf.data_ptr(), pk.data_ptr(), ybuf.data_ptr(), 0, _ptr(bias), st, self.dt), nd["w"] + " deconv fwd"))
-            self.profile_meta.append(("fwd", len(self.fwd) - 1, "igemm", 2.0 * d.n * d.ho * d.wo * cin * cout * d.ntaps,
+            self.profile_meta.append(("fwd", len(self.fwd) - 1, self._kname(d), 2.0 * d.n * d.ho * d.wo * cin * cout * d.ntaps,
                                       (x.pixels * x.c + y.pixels * y.c / 4) * self.es))
         if not self.with_bwd:
             return
@@ -468,7 +510,7 @@ class Plan:
                 cw.args, cr.args = tuple(a), tuple(b)
             self._ws_users.append(set_ws)
             self.bwd.append(cw)
-            self.profile_meta.append(("bwd", len(self.bwd) - 1, "wgrad", flops, (x.pixels * x.c + y.pixels * y.c) * self.es))
+            self.profile_meta.append(("bwd", len(self.bwd) - 1, self._kname(dg, (cin, cout)), flops, (x.pixels * x.c + y.pixels * y.c) * self.es))
             self.bwd.append(cr)
             if nd["bias"]:
                 gb_ = self.grads[nd["bias"]]
@@ -477,7 +519,7 @@ class Plan:
                 dx = self._act_grad(x)
                 first = self._first_write(x)
                 self._igemm(self.bwd, dg, dy, gpack, dx, None if first else dx, None, None, nd["w"] + " deconv dgrad")
-                self.profile_meta.append(("bwd", len(self.bwd) - 1, "igemm", flops, (x.pixels * x.c + y.pixels * y.c) * self.es))
+                self.profile_meta.append(("bwd", len(self.bwd) - 1, self._kname(dg), flops, (x.pixels * x.c + y.pixels * y.c) * self.es))
         blk.append(emit)
 
     # ---- BatchNorm + sum + ReLU ------------------------------------------------------------------
@@ -511,7 +553,7 @@ class Plan:
                     P[bn + ".running_var"].data_ptr(), BN_EPS, c, st["scale"].data_ptr(), st["shift"].data_ptr()), bn + " eval affine"))
         self.keep.append(fd)
         self.fwd.append(_Call(self.lib.lh_fuse_fwd, (C.byref(fd), obuf.data_ptr(), out.n, out.h, out.w, c, self.dt), "fuse fwd"))
-        self.profile_meta.append(("fwd", len(self.fwd) - 1, "fuse", 0.0, (sum(a.pixels for a, _, _ in terms) + out.pixels) * c * self.es))
+        self.profile_meta.append(("fwd", len(self.fwd) - 1, "fuse_fwd_kernel", 0.0, (sum(a.pixels for a, _, _ in terms) + out.pixels) * c * self.es))
         if not self.with_bwd:
             return
         self._ws_fuse = max(self._ws_fuse, self.lib.lh_fuse_bwd_workspace_bytes(out.n, out.h, out.w, c))
@@ -542,7 +584,7 @@ class Plan:
                 call.args = tuple(args)
             self._ws_users.append(set_ws)
             self.bwd.append(call)
-            self.profile_meta.append(("bwd", len(self.bwd) - 1, "fuse_bwd", 0.0, 0.0))
+            self.profile_meta.append(("bwd", len(self.bwd) - 1, "fuse_bwd(all kernels)", 0.0, 0.0))
         blk.append(emit)
 
     def _c_maxpool(self, nd, blk):

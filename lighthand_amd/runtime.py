@@ -1,0 +1,211 @@
+"""hipGraph-captured training / inference steps: the fast path of the engine.
+
+The reference's hot loop (src/utils/method.py:160-183) is, per iteration: H2D, forward,
+JointsMSELoss, ``.item()``, full-heatmap D2H + NumPy arg-max, zero_grad, backward, Adam.
+``TrainStep`` runs the same work as ONE replay of a captured HIP graph over static buffers:
+weight packs -> forward -> Gaussian target render (from joints) -> MSE loss + dL/dheatmap ->
+arg-max decode (kept on the device) -> backward -> [gradient all-reduce] -> fused Adam.
+Loss and keypoints stay on the device; ``.loss`` / ``.preds`` are read only when the caller
+asks (no per-iteration stream sync).
+"""
+import torch
+
+from . import _lib, heatmap
+from ._lib import check
+from .optim import Adam
+
+
+class TrainStep:
+    def __init__(self, model, batch, height, width, lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
+                 optimizer=None, decode=True, use_graph=True, grad_sync=None, targets_from_joints=True):
+        self.lib = _lib.load()
+        self.model = model
+        model.train()
+        self.plan = model.plan(batch, height, width, training=True, backward=True)
+        self.arena = model.arena()
+        dev = self.arena.device
+        out = self.plan.out_nchw
+        self.images = self.plan.img_nchw                               # static input: fp32 NCHW
+        self.joints = torch.zeros(batch, out.shape[1], 2, dtype=torch.float32, device=dev)
+        self.target = torch.zeros_like(out)
+        self.targets_from_joints = targets_from_joints
+        self.loss = torch.zeros((), dtype=torch.float32, device=dev)
+        self.preds = torch.zeros(batch, out.shape[1], 2, dtype=torch.float32, device=dev)
+        self.maxvals = torch.zeros(batch, out.shape[1], 1, dtype=torch.float32, device=dev)
+        self.decode = decode
+        self._mse_ws = torch.empty(self.lib.lh_mse_workspace_bytes(out.numel()), dtype=torch.uint8, device=dev)
+        self._patch = heatmap._patch_on(dev)
+        self.optimizer = optimizer or Adam(model.parameters(), lr=lr, betas=betas, eps=eps)
+        self.optimizer.bind_arena(self.arena)
+        self.grad_sync = grad_sync                                     # parallel.GradSync or None
+        self.grad_scale = 1.0 if grad_sync is None else 1.0 / grad_sync.world_size
+        self.graphs = None
+        self.use_graph = use_graph
+        self.heat_scale = float(height // out.shape[2])               # x4 of method.py:157
+        self.steps = 0
+
+    # ---- the work of one iteration, enqueued on the current stream --------------------------------
+    def _fwd_loss(self, stream):
+        self.plan.refresh_packs(stream)
+        self.plan.run_forward(stream)
+        self._fwd_loss_tail(stream)
+
+    def _fwd_loss_tail(self, stream):
+        p, out = self.plan, self.plan.out_nchw
+        if self.targets_from_joints:
+            b, j, hs = self.joints.shape[0], self.joints.shape[1], out.shape[2]
+            check(self.lib.lh_gaussian_target(self.joints.data_ptr(), 2, self._patch.data_ptr(), heatmap.RADIUS,
+                                              self.target.data_ptr(), b, j, hs, stream), "lh_gaussian_target")
+        check(self.lib.lh_mse_heatmap(out.data_ptr(), self.target.data_ptr(), out.numel(), self.loss.data_ptr(),
+                                      p.dout_nchw.data_ptr(), None, self._mse_ws.data_ptr(), stream), "lh_mse_heatmap")
+        if self.decode:
+            check(self.lib.lh_heatmap_argmax(out.data_ptr(), out.shape[0] * out.shape[1], out.shape[2], out.shape[3],
+                                             self.heat_scale, self.preds.data_ptr(), self.maxvals.data_ptr(), None, stream),
+                  "lh_heatmap_argmax")
+
+    def _enqueue_all(self):
+        stream = torch.cuda.current_stream().cuda_stream
+        self._fwd_loss(stream)
+        self.plan.run_backward(stream)
+        self.optimizer.step(grad_scale=self.grad_scale)
+
+    def _capture(self):
+        """One graph for the whole step, or -- with gradient synchronisation -- one graph per
+        backward segment so each gradient bucket's all-reduce (eager RCCL call on the side stream)
+        starts as soon as its segment has been replayed."""
+        warm = torch.cuda.Stream()
+        warm.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(warm):          # warm-up outside capture (allocations, lazy state)
+            self._enqueue_all() if self.grad_sync is None else self._eager_synced()
+        torch.cuda.current_stream().wait_stream(warm)
+        torch.cuda.synchronize()
+        self.optimizer_reset()
+        self.graphs = []
+        if self.grad_sync is None:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._enqueue_all()
+            self.graphs.append((g, None))
+            return
+        segs = self.grad_sync.segments(self.plan)
+        for i, (lo, hi, bucket) in enumerate(segs):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                stream = torch.cuda.current_stream().cuda_stream
+                if i == 0:
+                    self._fwd_loss(stream)
+                for c in self.plan.bwd[lo:hi]:
+                    c(stream)
+            self.graphs.append((g, bucket))
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.optimizer.step(grad_scale=self.grad_scale)
+        self.graphs.append((g, "adam"))
+
+    def _eager_synced(self):
+        stream = torch.cuda.current_stream().cuda_stream
+        self._fwd_loss(stream)
+        for lo, hi, bucket in self.grad_sync.segments(self.plan):
+            for c in self.plan.bwd[lo:hi]:
+                c(stream)
+            if bucket is not None:
+                self.grad_sync.launch(self.arena.flat_grad, bucket)
+        self.grad_sync.wait_all()
+        self.optimizer.step(grad_scale=self.grad_scale)
+
+    def optimizer_reset(self):
+        """Undo the warm-up iteration: restore Adam state / step counter (weights are restored by the caller
+        through the snapshot taken in ``__call__``)."""
+        st = self.optimizer.state.get("flat")
+        if st:
+            st["exp_avg"].zero_()
+            st["exp_avg_sq"].zero_()
+        for d in self.optimizer._dev.values():
+            d["step"].zero_()
+
+    def sync_hyper(self):
+        """Push lr / betas / eps changes (e.g. CosineAnnealingLR.step()) to the device-side Adam state."""
+        for gi, group in enumerate(self.optimizer.param_groups):
+            st = self.optimizer._dev.get(gi)
+            if st is not None:
+                self.optimizer._sync_hyper(st, group)
+
+    def __call__(self, images=None, joints=None, target=None):
+        if self.graphs is not None:
+            self.sync_hyper()
+        if images is not None:
+            self.images.copy_(images, non_blocking=True)
+        if joints is not None:
+            self.joints.copy_(joints[..., :2], non_blocking=True)
+        if target is not None:
+            self.target.copy_(target, non_blocking=True)
+        if not self.use_graph:
+            self._enqueue_all() if self.grad_sync is None else self._eager_synced()
+        else:
+            if self.graphs is None:
+                snap = self.arena.flat.clone()
+                bufs = {k: v.clone() for k, v in self.model.named_buffers()}
+                self._capture()
+                self.arena.flat.copy_(snap)                       # warm-up / capture must not train
+                for k, v in self.model.named_buffers():
+                    v.copy_(bufs[k])
+            for g, bucket in self.graphs:
+                if bucket == "adam":
+                    self.grad_sync.wait_all()
+                g.replay()
+                if bucket is not None and bucket != "adam":
+                    self.grad_sync.launch(self.arena.flat_grad, bucket)
+        self.steps += 1
+        return self.loss
+
+
+class InferStep:
+    """Eval-mode forward + arg-max decode as one captured graph (wearable_eval_2d / pred_store path,
+    src/utils/argparser.py:246-281).  ``bn_train=True`` reproduces the reference quirk of running
+    ``pred_store`` without ``model.eval()`` (batch statistics at evaluation time)."""
+
+    def __init__(self, model, batch, height, width, bn_train=False, use_graph=True):
+        self.lib = _lib.load()
+        self.plan = model.plan(batch, height, width, training=bn_train, backward=False)
+        out = self.plan.out_nchw
+        dev = out.device
+        self.images = self.plan.img_nchw
+        self.heatmaps = out
+        self.preds = torch.zeros(batch, out.shape[1], 2, dtype=torch.float32, device=dev)
+        self.maxvals = torch.zeros(batch, out.shape[1], 1, dtype=torch.float32, device=dev)
+        self.scale = float(height // out.shape[2])
+        self.use_graph = use_graph
+        self.graph = None
+        self._packed = False
+
+    def _enqueue(self):
+        s = torch.cuda.current_stream().cuda_stream
+        self.plan.run_forward(s)
+        out = self.heatmaps
+        check(self.lib.lh_heatmap_argmax(out.data_ptr(), out.shape[0] * out.shape[1], out.shape[2], out.shape[3], self.scale,
+                                         self.preds.data_ptr(), self.maxvals.data_ptr(), None, s), "lh_heatmap_argmax")
+
+    def refresh_weights(self):
+        self.plan.refresh_packs(torch.cuda.current_stream().cuda_stream)
+        self._packed = True
+
+    def __call__(self, images=None):
+        if images is not None:
+            self.images.copy_(images, non_blocking=True)
+        if not self._packed:
+            self.refresh_weights()
+        if not self.use_graph:
+            self._enqueue()
+            return self.preds
+        if self.graph is None:
+            warm = torch.cuda.Stream()
+            warm.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(warm):
+                self._enqueue()
+            torch.cuda.current_stream().wait_stream(warm)
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self._enqueue()
+        self.graph.replay()
+        return self.preds

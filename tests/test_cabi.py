@@ -41,7 +41,7 @@ def test_argument_validation_sets_error_text():
     nbytes = C.c_size_t(0)
     taps = (C.c_int * 2)(0, 0)
     assert lib.lh_pack_weight(None, None, C.byref(nbytes), 21, 256, 256, 1, 0, 0, 1, taps, _lib.LH_BF16, None) == 0
-    assert nbytes.value == 128 * 256 * 2            # rows padded to 128, K padded to the 64-byte step
+    assert nbytes.value == 128 * 256 * 2            # rows padded to 128, K padded to the 128-byte step
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
