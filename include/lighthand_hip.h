@@ -76,7 +76,10 @@ typedef struct {
     signed char r[64];
     signed char s[64];
 } lh_pack_item;
-int lh_pack_weights_multi(const lh_pack_item* items_dev, int n_items, int dtype, void* stream);
+/* chunk tables (device): chunk j rebuilds elements [chunk_start[j], +lh_pack_chunk_elems()) of pack chunk_item[j] */
+int lh_pack_chunk_elems(void);
+int lh_pack_weights_multi(const lh_pack_item* items_dev, const int* chunk_item_dev, const long* chunk_start_dev,
+                          int n_chunks, int dtype, void* stream);
 
 /* ------------------------------------------------------------------ convolutions
  * nn.Conv2d(..., bias=False) + the head conv with bias: pose_resnet.py:23-26,66-72,152,

@@ -33,11 +33,21 @@ __device__ __forceinline__ void slab_totals_then(const TI* slab, int rows, int c
     __shared__ double red[2][16][17];
     const int ch = blockIdx.x * 16 + (threadIdx.x & 15), rl = threadIdx.x >> 4;
     double a = 0.0, b = 0.0;
-    if (ch < c)
-        for (int r = rl; r < rows; r += 16) {
+    if (ch < c) {
+        int r = rl;
+        for (; r + 48 < rows; r += 64) {          // four independent row groups in flight
+            const TI a0 = slab[((long)r * 2) * c + ch], b0 = slab[((long)r * 2 + 1) * c + ch];
+            const TI a1 = slab[((long)(r + 16) * 2) * c + ch], b1 = slab[((long)(r + 16) * 2 + 1) * c + ch];
+            const TI a2 = slab[((long)(r + 32) * 2) * c + ch], b2 = slab[((long)(r + 32) * 2 + 1) * c + ch];
+            const TI a3 = slab[((long)(r + 48) * 2) * c + ch], b3 = slab[((long)(r + 48) * 2 + 1) * c + ch];
+            a += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+            b += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
+        }
+        for (; r < rows; r += 16) {
             a += (double)slab[((long)r * 2) * c + ch];
             b += (double)slab[((long)r * 2 + 1) * c + ch];
         }
+    }
     red[0][rl][threadIdx.x & 15] = a;
     red[1][rl][threadIdx.x & 15] = b;
     __syncthreads();
@@ -431,7 +441,7 @@ __global__ __launch_bounds__(256) void fuse_bwd_coef_fused_kernel(const TI* slab
 }
 
 static long fuse_bwd_strips(long count, int* rows_per_strip) {
-    long rps = (count + 1023) / 1024;
+    long rps = (count + 1023) / 1024;        // <= 1024 strips keep the streaming reduce at >= 4 workgroups per CU
     if (rps < 32) rps = 32;
     *rows_per_strip = (int)rps;
     return (count + rps - 1) / rps;

@@ -145,17 +145,24 @@ extern "C" int lh_pack_weight(const float* w, void* out, size_t* bytes, int n_ou
     return LH_OK;
 }
 
-// All packs of a model in ONE launch: blockIdx.y selects the pack descriptor (device table).
+// All packs of a model in ONE launch: the host cuts every pack into chunks of PACK_CHUNK output elements and
+// blockIdx.x walks the chunk table (device arrays), so big and small packs are balanced over the grid.
+constexpr int PACK_CHUNK = 32768;
+
 template <typename T>
-__global__ void pack_weight_multi_kernel(const lh_pack_item* items) {
-    const lh_pack_item& p = items[blockIdx.y];
+__global__ __launch_bounds__(256) void pack_weight_multi_kernel(const lh_pack_item* items, const int* chunk_item,
+                                                                const long* chunk_start) {
+    const lh_pack_item& p = items[chunk_item[blockIdx.x]];
     const int es = sizeof(T);
     const int kstep = 128 / es;
     const int kpad = (p.n_in + kstep - 1) / kstep * kstep;
     const int rows = (p.n_out + 127) / 128 * 128;
     const long total = (long)rows * p.ntaps * kpad;
+    const long begin = chunk_start[blockIdx.x];
+    long end = begin + PACK_CHUNK;
+    if (end > total) end = total;
     T* out = (T*)p.out;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    for (long i = begin + threadIdx.x; i < end; i += 256) {
         const int k = (int)(i % kpad);
         const long t2 = i / kpad;
         const int t = (int)(t2 % p.ntaps), o = (int)(t2 / p.ntaps);
@@ -165,10 +172,13 @@ __global__ void pack_weight_multi_kernel(const lh_pack_item* items) {
     }
 }
 
-extern "C" int lh_pack_weights_multi(const lh_pack_item* items_dev, int n_items, int dtype, void* stream) {
-    LH_REQUIRE(items_dev && n_items > 0, "lh_pack_weights_multi: bad arguments");
-    LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((pack_weight_multi_kernel<T>), dim3(48, n_items), dim3(256), 0, (hipStream_t)stream,
-                                                   items_dev));
+extern "C" int lh_pack_chunk_elems(void) { return PACK_CHUNK; }
+
+extern "C" int lh_pack_weights_multi(const lh_pack_item* items_dev, const int* chunk_item_dev, const long* chunk_start_dev,
+                                     int n_chunks, int dtype, void* stream) {
+    LH_REQUIRE(items_dev && chunk_item_dev && chunk_start_dev && n_chunks > 0, "lh_pack_weights_multi: bad arguments");
+    LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((pack_weight_multi_kernel<T>), dim3(n_chunks), dim3(256), 0, (hipStream_t)stream,
+                                                   items_dev, chunk_item_dev, chunk_start_dev));
     LH_LAUNCH_CHECK("pack_weights_multi launch");
     return LH_OK;
 }

@@ -287,8 +287,18 @@ class Plan:
         if self._pack_items:       # every weight pack of the model is rebuilt by ONE launch
             arr = (_lib.PackItem * len(self._pack_items))(*self._pack_items)
             table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
-            self.keep.append(table)
-            self.packs.append(_Call(self.lib.lh_pack_weights_multi, (table.data_ptr(), len(self._pack_items), self.dt), "weight packs"))
+            chunk, kstep = self.lib.lh_pack_chunk_elems(), 128 // self.es
+            c_item, c_start = [], []
+            for i, it in enumerate(self._pack_items):
+                total = (it.n_out + 127) // 128 * 128 * it.ntaps * ((it.n_in + kstep - 1) // kstep * kstep)
+                for s0 in range(0, total, chunk):
+                    c_item.append(i)
+                    c_start.append(s0)
+            t_item = torch.tensor(c_item, dtype=torch.int32, device=self.device)
+            t_start = torch.tensor(c_start, dtype=torch.int64, device=self.device)
+            self.keep += [table, t_item, t_start]
+            self.packs.append(_Call(self.lib.lh_pack_weights_multi,
+                                    (table.data_ptr(), t_item.data_ptr(), t_start.data_ptr(), len(c_item), self.dt), "weight packs"))
         self.bwd_marks = []        # (end index in self.bwd, parameter names whose gradient is final there)
         if self.with_bwd:
             for (kind, nd), blk in zip(reversed(self.nodes), reversed(bwd_blocks)):
