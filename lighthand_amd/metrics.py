@@ -1,0 +1,65 @@
+"""Validation / evaluation metrics of the reference loop, host side (NumPy, like the reference):
+``PCK_2d_loss`` and ``EPE_train`` (src/utils/loss.py:116-148, 50-67, used by Runner.run in validation,
+src/utils/method.py:243-250) and ``pred_eval`` (src/utils/argparser.py:326-388).  The reference's quirks are
+kept (they change the reported numbers): EPE_train sums joints 1..J-2 only; pred_eval's 'mean_auc' EPE is
+diluted by 971 zero rows; visible joints only for PCK; px->mm constants 3.7795275591 / 2.83464567.
+"""
+import sys
+
+import numpy as np
+
+PX_PER_MM_EVAL = 3.7795275591
+PX_PER_MM_THRESH = 2.83464567
+
+
+def _np(a):
+    return a.detach().cpu().numpy() if hasattr(a, "detach") else np.asarray(a)
+
+
+def PCK_2d_loss(pred_2d, gt_2d, T=0.1, threshold="proportion"):
+    pred, gt = _np(pred_2d).astype(np.float32), _np(gt_2d).astype(np.float32)[..., :2]
+    diag = np.sqrt((gt[..., 0].max(1) - gt[..., 0].min(1)) ** 2 + (gt[..., 1].max(1) - gt[..., 1].min(1)) ** 2)
+    dist = np.sqrt(((gt - pred) ** 2).sum(2))
+    if threshold == "proportion":
+        wrong = int((dist / diag[:, None] > T).sum())
+    elif threshold == "mm":
+        wrong = int((dist > T * 3.78).sum())
+    else:
+        assert False, "Please check variable threshold is right"
+    return float((dist.size - wrong) / dist.size)
+
+
+def EPE_train(pred_2d_joints, gt_2d_joint):
+    """Returns ((sum, count), per_joint) like the reference; joints 0 and J-1 do not enter the sum."""
+    pred, gt = _np(pred_2d_joints).astype(np.float32), _np(gt_2d_joint).astype(np.float32)[..., :2]
+    b, j = pred.shape[:2]
+    err = np.sqrt(((pred - gt) ** 2).sum(2)).astype(np.float32)
+    distance = {f"{i}": [float(err[:, i].mean()), b] for i in range(1, j)}
+    s = sum(distance[f"{i}"][0] * b for i in range(1, j - 1))
+    return (s, float(b * (j - 2))), distance
+
+
+def pred_eval(meta, T_list, method):
+    """meta: the category dict of evaluation.json ({cat: {bb, pred, gt}}) -> {cat: [auc, epe_mm, pck_curve]}."""
+    if method == "mm":
+        thr = np.linspace(T_list[0], T_list[-1], 101)[1:] * PX_PER_MM_THRESH
+    elif method == "pckb":
+        thr = np.linspace(T_list[0], T_list[-1], 100)
+    else:
+        assert 0, "this method is the wrong"
+    norm = np.trapz(np.ones_like(thr), thr)
+    out, vis_all, diff_all = {}, [], [np.zeros([971, 21])]
+    for cat, d in meta.items():
+        bb, pred, gt = np.array(d["bb"]), np.array(d["pred"]), np.array(d["gt"])
+        diff = np.sqrt(np.sum(np.square(gt[:, :, :2] - pred[:, :, :2]), axis=-1))
+        nd = diff / bb[:, None] if method == "pckb" else diff
+        vis = nd[gt[:, :, -1] == 1]
+        diff_all.append(diff)
+        vis_all.insert(0, vis)
+        curve = np.array([(vis < t).sum() / len(vis) * 100 for t in thr])
+        out[cat] = [float(np.trapz(curve, thr) / (norm + sys.float_info.epsilon)), float(diff.mean() / PX_PER_MM_EVAL), curve]
+    vis = np.concatenate(vis_all)
+    curve = np.array([(vis < t).sum() / len(vis) * 100 for t in thr])
+    out["mean_auc"] = [float(np.trapz(curve, thr) / (norm + sys.float_info.epsilon)),
+                       float(np.concatenate(diff_all, 0).mean() / PX_PER_MM_EVAL), curve]
+    return out

@@ -33,6 +33,7 @@ class ParamArena:
             view.copy_(p.data)
             p.data = view
         self.names = [k for k, _ in named]
+        self.by_param = {id(p): self.offsets[k] for k, p in named}
 
     def grad_view(self, name):
         o, n, shape = self.offsets[name]
@@ -97,6 +98,12 @@ class HipModule(nn.Module):
         self._lh_plans.clear()
         self._lh_arena = None
         return super()._apply(fn, *args, **kwargs)
+
+    def __getstate__(self):
+        # plans hold raw device pointers / ctypes descriptors: never copied or pickled with the module
+        st = dict(self.__dict__)
+        st["_lh_plans"], st["_lh_arena"] = {}, None
+        return st
 
     def load_state_dict(self, state_dict, strict=True, **kw):
         # copies in place, so the arena views and every bound pointer stay valid

@@ -24,6 +24,43 @@ class Adam(torch.optim.Optimizer):
         self._flat = arena
         return self
 
+    # -- checkpoints interoperate with torch.optim.Adam (the reference stores optimizer.state_dict(),
+    #    src/tools/dataset.py:352-360): per-parameter {step, exp_avg, exp_avg_sq} entries.
+    def state_dict(self):
+        sd = super().state_dict()
+        flat = self.state.get("flat")
+        if self._flat is None or not flat:
+            return sd
+        step = float(self._dev[0]["step"].item()) if 0 in self._dev else 0.0
+        state, idx = {}, 0
+        for group in self.param_groups:
+            for p in group["params"]:
+                o, n, shape = self._flat.by_param[id(p)]
+                state[idx] = {"step": torch.tensor(step), "exp_avg": flat["exp_avg"][o:o + n].view(shape).clone(),
+                              "exp_avg_sq": flat["exp_avg_sq"][o:o + n].view(shape).clone()}
+                idx += 1
+        sd["state"] = state
+        return sd
+
+    def load_state_dict(self, state_dict):
+        if self._flat is None or not state_dict.get("state") or "flat" in state_dict["state"]:
+            return super().load_state_dict(state_dict)
+        arena = self._flat
+        flat = self.state.setdefault("flat", {})
+        flat.setdefault("exp_avg", torch.zeros_like(arena.flat))
+        flat.setdefault("exp_avg_sq", torch.zeros_like(arena.flat))
+        params = [p for g in self.param_groups for p in g["params"]]
+        step = 0
+        for idx, st in state_dict["state"].items():
+            o, n, shape = arena.by_param[id(params[int(idx)])]
+            flat["exp_avg"][o:o + n].copy_(st["exp_avg"].reshape(-1))
+            flat["exp_avg_sq"][o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+            step = int(float(st["step"]))
+        for g, saved in zip(self.param_groups, state_dict["param_groups"]):
+            g["lr"], g["betas"], g["eps"] = saved["lr"], tuple(saved["betas"]), saved["eps"]
+        st = self._group_state(0, arena.device, 0)
+        st["step"].fill_(step)
+
     def _group_state(self, gi, device, numel):
         st = self._dev.get(gi)
         if st is None:
@@ -46,16 +83,11 @@ class Adam(torch.optim.Optimizer):
         lib = _lib.load()
         stream = torch.cuda.current_stream().cuda_stream
         for gi, group in enumerate(self.param_groups):
-            params = [p for p in group["params"] if p.grad is not None]
-            if not params:
-                continue
-            dev = params[0].device
-            if dev.type != "cuda":
-                raise _lib.LightHandError("lighthand_amd.optim.Adam runs on the HIP device only")
-            st = self._group_state(gi, dev, 0)
-            self._sync_hyper(st, group)
             arena = self._flat
             if arena is not None and gi == 0 and len(self.param_groups) == 1:
+                # gradients live in the arena (the engine writes them there whether or not .grad is attached)
+                st = self._group_state(gi, arena.device, 0)
+                self._sync_hyper(st, group)
                 s = self.state.setdefault("flat", {})
                 if "exp_avg" not in s:
                     s["exp_avg"] = torch.zeros_like(arena.flat)
@@ -64,6 +96,14 @@ class Adam(torch.optim.Optimizer):
                                        s["exp_avg_sq"].data_ptr(), arena.numel, st["hyper"].data_ptr(), st["step"].data_ptr(),
                                        st["derived"].data_ptr(), float(grad_scale), stream), "lh_adam_step")
                 continue
+            params = [p for p in group["params"] if p.grad is not None]
+            if not params:
+                continue
+            dev = params[0].device
+            if dev.type != "cuda":
+                raise _lib.LightHandError("lighthand_amd.optim.Adam runs on the HIP device only")
+            st = self._group_state(gi, dev, 0)
+            self._sync_hyper(st, group)
             # generic path: per-tensor launches sharing one device step counter per group.
             first = True
             for p in params:

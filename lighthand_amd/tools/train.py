@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Training entry point with the reference's flag surface (src/tools/train.py + src/utils/argparser.py:27-100)
+running the hot loop on the HIP engine.
+
+Same flags / defaults as the reference (``--root --name --root_path --model --dataset --view --batch_size
+--milestone --count --num_our --ratio_of_other --ratio_of_aug --epoch --lr`` and the booleans ``--scale --plt
+--transfer --eval --test --logger --reset --rot --optim --color --D3``), same seeds (9001), Adam(lr) +
+CosineAnnealingLR(T_max=epoch) stepped per epoch, best-validation-loss checkpoint
+``<root_path>/<root>/<name>/checkpoint-good/state_dict.bin`` with the reference's dict keys, early stop on
+``--count``.  New flags (they do not change existing semantics): ``--depth`` (ResNet depth, the reference
+hard-codes 50), ``--hrnet_width``, ``--precision {fp32,bf16,fp16}``, ``--size``, ``--synthetic N`` (seeded
+synthetic samples; the reference's datasets are not redistributable), ``--no_graph``.
+
+What changes vs the reference loop (src/utils/method.py:160-183): the per-iteration ``loss.item()`` and
+full-heatmap D2H + NumPy arg-max are replaced by device-resident loss / keypoints that are read once per
+logging interval; everything else (BN momentum, loss, decode rule, optimizer) is the same arithmetic.
+
+Multi-GPU: launch with ``python -m torch.distributed.run --nproc-per-node N -m lighthand_amd.tools.train ...``
+(one process per GPU, gradients averaged by bucketed RCCL all-reduce; see lighthand_amd/parallel.py).
+"""
+import argparse
+import os
+import random
+import time
+
+import numpy as np
+import torch
+
+
+def parse_args(argv=None, phase="train"):
+    p = argparse.ArgumentParser()
+    p.add_argument("--root", default="simplebaseline/ours", type=str, help="You write down to store the directory path")
+    p.add_argument("--name", default="84k", type=str, help="You write down to store the directory path")
+    p.add_argument("--root_path", default="output", type=str, help="The root directory to save location which you want")
+    known, _ = p.parse_known_args(argv)
+    p.add_argument("--model", default="ours", type=str)
+    p.add_argument("--dataset", default=known.root.split("/")[-1], type=str)
+    p.add_argument("--view", default="wrist", type=str)
+    p.add_argument("--batch_size", default=32, type=int)
+    p.add_argument("--milestone", default=10, type=int)
+    p.add_argument("--count", default=30, type=int)
+    p.add_argument("--num_our", default=300000, type=int)
+    p.add_argument("--ratio_of_other", default=0, type=float)
+    p.add_argument("--ratio_of_aug", default=0.6, type=float)
+    p.add_argument("--epoch", default=100, type=int)
+    p.add_argument("--lr", default=0.001, type=float)
+    for flag in ("scale", "plt", "transfer", "eval", "test", "logger", "reset", "rot", "optim", "color", "D3"):
+        p.add_argument("--" + flag, action="store_true")
+    # additions of this engine
+    p.add_argument("--depth", default=50, type=int, choices=[18, 34, 50, 101, 152])
+    p.add_argument("--hrnet_width", default=48, type=int)
+    p.add_argument("--precision", default="bf16", choices=["fp32", "bf16", "fp16"])
+    p.add_argument("--size", default=256, type=int)
+    p.add_argument("--synthetic", default=0, type=int, help="train on N seeded synthetic samples")
+    p.add_argument("--val_synthetic", default=0, type=int)
+    p.add_argument("--no_graph", action="store_true")
+    args = p.parse_args(argv)
+    args.phase = phase
+    args.model = args.root.split("/")[0]                  # src/tools/dataset.py:59 overwrites it from the name
+    args.name = os.path.join(args.root, args.name)
+    args.output_dir = os.path.join(args.root_path, args.name)      # src/utils/pre_argparser.py:9
+    args.logging_steps, args.num_workers, args.device = 100, 8, "cuda"
+    if args.D3:
+        raise SystemExit("--D3 (3-D joint regression) is outside the heatmap-regression path this engine covers")
+    return args
+
+
+def build_model(args):
+    from lighthand_amd.modeling.hrnet.pose_hrnet import get_hrnet, hrnet_cfg
+    from lighthand_amd.modeling.simplebaseline.config import default_config
+    from lighthand_amd.modeling.simplebaseline.pose_resnet import get_pose_net
+    if args.model == "hrnet":
+        return get_hrnet(hrnet_cfg(args.hrnet_width), is_train=True)
+    return get_pose_net(default_config(args.depth), is_train=True)
+
+
+class SyntheticHands(torch.utils.data.Dataset):
+    """Seeded stand-in for CustomDataset (src/tools/dataset.py:103-163): returns (image[3,S,S] ~ N(0,1) like
+    a normalised crop, joint_2d[21,2] uniform in [20, S-20]).  Heatmaps are rendered on the device."""
+
+    def __init__(self, n, size, seed):
+        rng = np.random.RandomState(seed)
+        self.images = torch.from_numpy(rng.randn(n, 3, size, size).astype(np.float32))
+        self.joints = torch.from_numpy(rng.uniform(20, size - 20, size=(n, 21, 2)).astype(np.float32))
+
+    def __len__(self):
+        return len(self.images)
+
+    def __getitem__(self, i):
+        return self.images[i], self.joints[i]
+
+
+def save_checkpoint(model, args, epoch, optimizer, best_loss, count, ment="good"):
+    """Same file name and dict keys as src/tools/dataset.py:340-367; only rank 0 writes."""
+    d = os.path.join(args.output_dir, "checkpoint-{}".format(ment))
+    if int(os.environ.get("RANK", "0")) != 0:
+        return d
+    os.makedirs(d, exist_ok=True)
+    torch.save({"epoch": epoch, "optimizer_state_dict": optimizer.state_dict(), "best_loss": best_loss, "count": count,
+                "model_state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()}},
+               os.path.join(d, "state_dict.bin"))
+    return d
+
+
+def resume_checkpoint(model, path):
+    """src/utils/dir.py:38-47: strict=False load, epoch + 1."""
+    sd = torch.load(path, map_location="cpu")
+    model.load_state_dict(sd["model_state_dict"], strict=False)
+    return sd["best_loss"], sd["epoch"] + 1, sd["count"], sd.get("optimizer_state_dict")
+
+
+def validate(model, loader, args):
+    """Runner.run validation branch (src/utils/method.py:218-287): loss, PCK@0.2 (bbox-normalised), EPE."""
+    from lighthand_amd.heatmap import JointsMSELoss, max_preds_device, render_targets
+    from lighthand_amd.metrics import EPE_train, PCK_2d_loss
+    model.eval()
+    crit = JointsMSELoss(False)
+    tot_loss = tot_n = 0.0
+    pck_sum = epe_sum = epe_cnt = 0.0
+    with torch.no_grad():
+        for images, joints in loader:
+            images, joints = images.cuda(non_blocking=True), joints.cuda(non_blocking=True)
+            pred = model(images)
+            hs = pred.shape[-1]
+            target = render_targets(joints, size=hs)
+            loss = crit(pred, target, None)
+            kp, _, _ = max_preds_device(pred, scale=float(images.shape[-1] // hs))
+            b = images.shape[0]
+            tot_loss += float(loss) * b
+            tot_n += b
+            pck_sum += PCK_2d_loss(kp, joints, T=0.2, threshold="proportion") * b
+            (s, c), _ = EPE_train(kp, joints)
+            epe_sum, epe_cnt = epe_sum + s, epe_cnt + c
+    model.train()
+    return tot_loss / max(tot_n, 1), 100.0 * pck_sum / max(tot_n, 1), epe_sum / max(epe_cnt, 1)
+
+
+def main(args):
+    from lighthand_amd import parallel
+    from lighthand_amd.optim import Adam
+    from lighthand_amd.runtime import TrainStep
+
+    seed = 9001                                           # src/tools/train.py:15-22
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    random.seed(seed)
+    rank, world, local = parallel.init_distributed()
+    torch.cuda.set_device(local)
+    if not args.synthetic:
+        raise SystemExit("the reference's datasets (LightHand99K / FreiHAND / ...) are not shipped: pass --synthetic N, "
+                         "or plug a Dataset yielding (image[3,S,S], joint_2d[21,2]) into lighthand_amd.tools.train.main")
+    train_set = SyntheticHands(args.synthetic, args.size, seed + rank)
+    val_set = SyntheticHands(args.val_synthetic or max(args.batch_size, args.synthetic // 8), args.size, seed + 1000)
+    train_loader = torch.utils.data.DataLoader(train_set, batch_size=args.batch_size, shuffle=True, drop_last=True, pin_memory=True)
+    val_loader = torch.utils.data.DataLoader(val_set, batch_size=args.batch_size, shuffle=False, drop_last=True, pin_memory=True)
+
+    model = build_model(args).cuda().set_precision(args.precision)
+    best_loss, epo, count, opt_state = np.inf, 0, 0, None
+    ckpt = os.path.join(args.output_dir, "checkpoint-good", "state_dict.bin")
+    if os.path.isfile(ckpt) and not args.reset:
+        best_loss, epo, count, opt_state = resume_checkpoint(model, ckpt)
+    optimizer = Adam(model.parameters(), lr=args.lr)
+    scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, T_max=args.epoch)
+    for _ in range(epo):
+        scheduler.step()
+    sync = parallel.GradSync(world) if world > 1 else None
+    step = TrainStep(model, args.batch_size, args.size, args.size, optimizer=optimizer, use_graph=not args.no_graph, grad_sync=sync)
+    if opt_state and not args.optim:                      # src/tools/train.py:50
+        optimizer.load_state_dict(opt_state)
+
+    for epoch in range(epo, args.epoch):
+        t0, seen, running = time.time(), 0, None
+        for it, (images, joints) in enumerate(train_loader):
+            step(images.cuda(non_blocking=True), joints.cuda(non_blocking=True))
+            seen += images.shape[0]
+            if it % args.logging_steps == 0:            # the ONLY device->host read of the loop
+                running = float(step.loss)
+                if rank == 0:
+                    print(f"epoch {epoch} iter {it}/{len(train_loader)} loss {running:.6f} "
+                          f"{world * seen / (time.time() - t0 + 1e-9):.0f} img/s lr {optimizer.param_groups[0]['lr']:.2e}")
+        val_loss, pck, epe = validate(model, val_loader, args)
+        if rank == 0:
+            print(f"epoch {epoch} valid loss {val_loss:.6f} pck {pck:.2f}% epe {epe * 0.26:.2f} mm")     # method.py:131
+        if best_loss > val_loss:
+            best_loss, count = val_loss, 0
+            save_checkpoint(model, args, epoch, optimizer, best_loss, count, "good")
+        else:
+            count += 1
+            if count == args.count:
+                break
+        scheduler.step()
+    return best_loss
+
+
+if __name__ == "__main__":
+    main(parse_args())

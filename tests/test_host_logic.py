@@ -1,0 +1,112 @@
+"""CPU: host-side logic of the drop-in surface -- flag parsing, configs, metrics (vs the oracle and the
+golden vectors), graph description / bucket planning.  No compute kernels are called."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import resnet_cfg
+
+
+def test_cli_flags_and_defaults_match_reference():
+    from lighthand_amd.tools.train import parse_args
+    a = parse_args([])
+    # src/utils/argparser.py:27-100 defaults
+    assert (a.root, a.batch_size, a.milestone, a.count, a.num_our, a.epoch, a.lr) == ("simplebaseline/ours", 32, 10, 30, 300000, 100, 0.001)
+    assert (a.ratio_of_other, a.ratio_of_aug, a.view, a.dataset) == (0, 0.6, "wrist", "ours")
+    assert a.name == os.path.join("simplebaseline/ours", "84k") and a.output_dir == os.path.join("output", a.name)
+    assert a.model == "simplebaseline" and a.logging_steps == 100 and a.num_workers == 8 and a.device == "cuda"
+    for flag in ("scale", "plt", "transfer", "eval", "test", "logger", "reset", "rot", "optim", "color", "D3"):
+        assert getattr(a, flag) is False
+    b = parse_args(["--root", "hrnet/frei", "--name", "x", "--batch_size", "8", "--reset", "--epoch", "3"])
+    assert b.model == "hrnet" and b.dataset == "frei" and b.reset and b.epoch == 3 and b.batch_size == 8
+    with pytest.raises(SystemExit):
+        parse_args(["--D3"])
+
+
+def test_simplebaseline_config_surface(tmp_path):
+    from lighthand_amd.modeling.simplebaseline.config import config, default_config, get_model_name, update_config
+    assert config.MODEL.EXTRA.NUM_LAYERS == 50 and config.MODEL.STYLE == "pytorch" and config.MODEL.NUM_JOINTS == 21
+    assert config.MODEL.EXTRA.NUM_DECONV_FILTERS == [256, 256, 256] and config.MODEL.EXTRA.FINAL_CONV_KERNEL == 1
+    cfg = default_config()
+    p = tmp_path / "c.yaml"
+    p.write_text("MODEL:\n  EXTRA:\n    NUM_LAYERS: 18\n")
+    update_config(str(p), cfg)
+    assert cfg.MODEL.EXTRA.NUM_LAYERS == 18 and get_model_name(cfg)[0] == "pose_resnet_18"
+    p.write_text("NOPE: 1\n")
+    with pytest.raises(ValueError):
+        update_config(str(p), cfg)
+
+
+def test_metrics_match_oracle_and_golden(golden_dir):
+    from lighthand_amd import metrics as M
+    from oracle import metrics as om
+    g = json.load(open(os.path.join(golden_dir, "g7_metrics.json")))
+    cats = g["evaluation"][0]
+    for key, T, method in (("pckb", [0.1, 0.3], "pckb"), ("mm30", [0, 30], "mm"), ("mm50", [0, 50], "mm")):
+        got, ora = M.pred_eval(cats, T, method), om.pred_eval(cats, T, method)
+        for cat, (auc, epe, curve) in g["pred_eval"][key].items():
+            assert abs(got[cat][0] - auc) < 1e-9 * max(1, abs(auc)) and abs(got[cat][1] - epe) < 1e-9 * max(1, abs(epe))
+            assert got[cat][0] == ora[cat][0] and np.allclose(got[cat][2], curve)
+    pred, gt = torch.tensor(g["val_pred"]), torch.tensor(g["val_gt"])
+    assert abs(M.PCK_2d_loss(pred, gt, T=0.2) - g["pck02"]) < 1e-12
+    assert abs(M.PCK_2d_loss(pred, gt, T=5.0, threshold="mm") - g["pck_mm5"]) < 1e-12
+    (s, c), dist = M.EPE_train(pred, gt)
+    assert c == g["epe_cnt"] and abs(s - g["epe_sum"]) < 1e-4 * g["epe_sum"] and len(dist) == 20
+    with pytest.raises(AssertionError):
+        M.PCK_2d_loss(pred, gt, threshold="bogus")
+
+
+@pytest.mark.parametrize("tag,nodes", [("r18", None), ("r50", None), ("hrnet_w32", None)])
+def test_graph_description_covers_every_parameter(tag, nodes):
+    """describe() must reference each conv / BN parameter exactly once (no layer dropped or duplicated)."""
+    from lighthand_amd.engine import GraphBuilder
+    from lighthand_amd.modeling.hrnet.pose_hrnet import get_hrnet, hrnet_cfg
+    from lighthand_amd.modeling.simplebaseline.pose_resnet import get_pose_net
+    model = get_hrnet(hrnet_cfg(32), True) if tag.startswith("hrnet") else get_pose_net(resnet_cfg(int(tag[1:])), True)
+    params = dict(model.state_dict(keep_vars=True))
+    gb = GraphBuilder(2, 64, 64, params)
+    model.describe(gb)
+    used = []
+    for kind, nd in gb.nodes:
+        if kind in ("conv", "deconv"):
+            used.append(nd["w"] + ".weight")
+            if nd["bias"]:
+                used.append(nd["bias"])
+        elif kind == "fuse":
+            for _, bn, _ in nd["terms"]:
+                if bn:
+                    used += [bn + ".weight", bn + ".bias"]
+    want = sorted(k for k, v in params.items() if isinstance(v, torch.nn.Parameter))
+    assert sorted(used) == want
+    assert gb.out is not None and (gb.out.h, gb.out.w, gb.out.c_valid) == (16, 16, 21)
+
+
+def test_bucket_planner_covers_arena_in_backward_order():
+    from lighthand_amd.parallel import plan_buckets
+    offsets, off = {}, 0
+    names = [f"p{i}" for i in range(10)]
+    for i, k in enumerate(names):
+        offsets[k] = (off, 1000 * (i + 1), (1000 * (i + 1),))
+        off += 1000 * (i + 1)
+    # backward finishes parameters in reverse order, two per mark, with one out-of-order pair
+    order = [["p9", "p8"], ["p6", "p7"], ["p5"], ["p3", "p4"], ["p2"], ["p0", "p1"]]
+    marks = [(10 * (i + 1), ps) for i, ps in enumerate(order)]
+    segs = plan_buckets(marks, offsets, off, bucket_bytes=4 * 12000)
+    covered = sorted(b for _, _, b in segs if b)
+    assert covered[0][0] == 0 and covered[-1][1] == off
+    assert all(covered[i][1] == covered[i + 1][0] for i in range(len(covered) - 1))      # contiguous, no overlap
+    assert [s[0] for s in segs] == [0] + [s[1] for s in segs[:-1]] and segs[-1][1] == marks[-1][0]
+    assert len(segs) > 1
+    with pytest.raises(RuntimeError):
+        plan_buckets(marks[:-1], offsets, off, bucket_bytes=1 << 30)
+
+
+def test_models_refuse_cpu_execution():
+    from lighthand_amd import LightHandError
+    from lighthand_amd.modeling.simplebaseline.pose_resnet import get_pose_net
+    m = get_pose_net(resnet_cfg(18), True)
+    with pytest.raises(LightHandError):
+        m(torch.randn(1, 3, 64, 64))

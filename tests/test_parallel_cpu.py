@@ -1,0 +1,76 @@
+"""CPU, world_size 2 over gloo: the data-parallel gradient path (bucket planning + GradSync) sums every
+arena slice exactly once across ranks, in backward order, and the 1/world scale gives the average."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from lighthand_amd import parallel
+    r, w, _ = parallel.init_distributed(backend="gloo")
+    assert (r, w) == (rank, world)
+    # a fake 3-layer "model": arena offsets and the order in which backward finishes the gradients
+    offsets, off = {}, 0
+    for k, n in (("a.weight", 5000), ("a.bias", 12), ("b.weight", 70000), ("b.bias", 20), ("c.weight", 30000), ("c.bias", 4)):
+        offsets[k] = (off, n, (n,))
+        off += (n + 3) // 4 * 4
+    marks = [(3, ["c.weight", "c.bias"]), (7, ["b.bias", "b.weight"]), (9, ["a.weight", "a.bias"])]
+
+    class FakePlan:
+        bwd_marks, arena_offsets, arena_numel = marks, offsets, off
+
+    sync = parallel.GradSync(world, bucket_bytes=4 * 20000)
+    segs = sync.segments(FakePlan)
+    torch.manual_seed(100 + rank)
+    flat = torch.randn(off)
+    mine = flat.clone()
+    executed = 0
+    for lo, hi, bucket in segs:            # "run bwd[lo:hi]", then reduce the slice that became final
+        assert lo == executed
+        executed = hi
+        if bucket is not None:
+            sync.launch(flat, bucket)
+    sync.wait_all()
+    gathered = [torch.zeros(off) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    want = sum(gathered)
+    ok = bool(torch.allclose(flat, want, rtol=0, atol=1e-6)) and executed == marks[-1][0] and len(segs) >= 2
+    avg_ok = bool(torch.allclose(flat * (1.0 / world), want / world))
+    q.put((rank, ok and avg_ok, [b for _, _, b in segs]))
+    dist.destroy_process_group()
+
+
+def test_gradsync_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
+    assert res[0][2] == res[1][2]                    # both ranks cut identical buckets
+
+
+def test_init_distributed_single_process_is_noop(monkeypatch):
+    from lighthand_amd import parallel
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    assert parallel.init_distributed() == (0, 1, 0)
+    assert not dist.is_initialized()
