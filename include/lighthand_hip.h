@@ -176,6 +176,7 @@ typedef struct {
     const void* out;            /* forward result (ReLU mask); NULL when relu == 0 */
     const void* x[4];           /* raw BN inputs (NULL for identity terms)          */
     const float* scale[4];
+    const float* shift[4];      /* forward shift vectors (lets a single-BN-term ReLU mask be recomputed from x) */
     const float* save_mean[4];
     const float* save_invstd[4];
     void* dx[4];

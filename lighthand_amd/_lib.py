@@ -31,7 +31,7 @@ class FuseDesc(C.Structure):
 
 class FuseBwdDesc(C.Structure):
     _fields_ = [("dout", C.c_void_p), ("out", C.c_void_p), ("x", C.c_void_p * 4), ("scale", C.c_void_p * 4),
-                ("save_mean", C.c_void_p * 4), ("save_invstd", C.c_void_p * 4), ("dx", C.c_void_p * 4),
+                ("shift", C.c_void_p * 4), ("save_mean", C.c_void_p * 4), ("save_invstd", C.c_void_p * 4), ("dx", C.c_void_p * 4),
                 ("dgamma", C.c_void_p * 4), ("dbeta", C.c_void_p * 4), ("log2up", C.c_int * 4),
                 ("accumulate", C.c_int * 4), ("nterms", C.c_int), ("relu", C.c_int)]
 

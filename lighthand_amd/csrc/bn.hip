@@ -2,6 +2,7 @@
 // elementwise op with its backward, and the 3x3/s2 max-pool -- all HBM-bound NHWC kernels:
 // one 16-byte chunk (8 x 16-bit or 4 x fp32 channels) per lane, per-channel vectors in fp32.
 #include "common.h"
+#include <stdlib.h>
 
 // ------------------------------------------------------------------------------------------------
 // Column sums of a [rows][ncol] slab in double: block = 16 columns x 16 row lanes.
@@ -270,6 +271,59 @@ __global__ __launch_bounds__(256) void fuse_fwd_kernel(const FuseArgs p) {
     }
 }
 
+// EPC consecutive floats of a per-channel vector with 16-byte loads.
+template <int EPC> __device__ __forceinline__ void load_vec(const float* p, float* dst) {
+#pragma unroll
+    for (int q = 0; q < EPC / 4; ++q) {
+        const float4 v = reinterpret_cast<const float4*>(p)[q];
+        dst[4 * q] = v.x; dst[4 * q + 1] = v.y; dst[4 * q + 2] = v.z; dst[4 * q + 3] = v.w;
+    }
+}
+template <int EPC> __device__ __forceinline__ void fill_vec(float* dst, float v) {
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) dst[e] = v;
+}
+
+// Fast path: no upsampled term, <= 2 terms, channel chunks a power of two <= 256.  The grid stride is a multiple of
+// the chunk count, so a thread keeps ONE channel chunk: its scale/shift live in registers and the loop has no
+// integer division -- the kernel is a pure 16-byte-per-lane stream.
+template <typename T, int NT>
+__global__ __launch_bounds__(256) void fuse_fwd_flat_kernel(const FuseArgs p, long total) {
+    constexpr int EPC = 16 / sizeof(T);
+    const int nchunk = p.c / EPC;
+    const int ch = threadIdx.x & (nchunk - 1);
+    float sc[NT][EPC], sh[NT][EPC];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (p.scale[t]) { load_vec<EPC>(p.scale[t] + ch * EPC, sc[t]); load_vec<EPC>(p.shift[t] + ch * EPC, sh[t]); }
+        else { fill_vec<EPC>(sc[t], 1.f); fill_vec<EPC>(sh[t], 0.f); }
+    }
+    const long stride = (long)gridDim.x * 256;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += stride) {
+        float acc[EPC];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            float v[EPC];
+            unpack16<T>(*reinterpret_cast<const uint4*>(p.x[t] + idx * 16), v);
+            if (p.scale[t]) {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) v[e] = v[e] * sc[t][e] + sh[t][e];
+                if (NT > 1) {
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) v[e] = to_f<T>(from_f<T>(v[e]));
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) acc[e] = t == 0 ? v[e] : acc[e] + v[e];
+        }
+        if (p.relu) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) acc[e] = fmaxf(acc[e], 0.f);
+        }
+        *reinterpret_cast<uint4*>(p.out + idx * 16) = pack16<T>(acc);
+    }
+}
+
 extern "C" int lh_fuse_fwd(const lh_fuse_desc* d, void* out, int n, int h, int w, int c, int dtype, void* stream) {
     LH_REQUIRE(d && out && d->nterms >= 1 && d->nterms <= 4, "lh_fuse_fwd: bad descriptor");
     const int es = lh_dtype_size(dtype);
@@ -290,6 +344,19 @@ extern "C" int lh_fuse_fwd(const lh_fuse_desc* d, void* out, int n, int h, int w
     a.nterms = d->nterms; a.relu = d->relu; a.out = (unsigned char*)out; a.n = n; a.h = h; a.w = w; a.c = c;
     const long total = (long)n * h * w * (c / (16 / es));
     const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    const int nchunk = c / (16 / es);
+    bool flat = d->nterms <= 2 && (nchunk & (nchunk - 1)) == 0 && nchunk <= 256 && !getenv("LH_NO_FLAT");
+    for (int t = 0; t < d->nterms; ++t) flat = flat && a.log2up[t] == 0;
+    if (flat) {
+        const int grid = (int)((total + 1023) / 1024 > 2048 ? 2048 : (total + 1023) / 1024);      // >= 4 chunks per thread
+        if (d->nterms == 1) {
+            LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((fuse_fwd_flat_kernel<T, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a, total));
+        } else {
+            LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((fuse_fwd_flat_kernel<T, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a, total));
+        }
+        LH_LAUNCH_CHECK("fuse_fwd launch");
+        return LH_OK;
+    }
     LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((fuse_fwd_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a));
     LH_LAUNCH_CHECK("fuse_fwd launch");
     return LH_OK;
@@ -312,6 +379,8 @@ struct FuseBwdArgs {
     float* dbeta;
     int n, h, w, c;              // OUTPUT resolution
     int l, relu, accumulate;
+    int mask_from_x;             // ReLU mask recomputed from x*scale+shift (single BN term): `out` is not read
+    const float* shift;
     int rows_per_strip;
     long count;                  // n * (h>>l) * (w>>l)
 };
@@ -420,6 +489,106 @@ __global__ __launch_bounds__(256) void fuse_bwd_apply_kernel(const FuseBwdArgs p
     }
 }
 
+// ---- l == 0 fast paths: dout / out / x / dx share one flat element offset, the thread keeps one channel chunk.
+template <typename T, bool MASK_X>
+__global__ __launch_bounds__(256) void fuse_bwd_reduce_flat_kernel(const FuseBwdArgs p) {
+    constexpr int EPC = 16 / sizeof(T);
+    __shared__ float red[256 * EPC * 2];
+    const int nchunk = p.c / EPC;                       // power of two <= 256
+    const int lanes = 256 / nchunk;
+    const int chunk = threadIdx.x & (nchunk - 1), rl = threadIdx.x / nchunk;
+    const long r0 = (long)blockIdx.x * p.rows_per_strip;
+    long r1 = r0 + p.rows_per_strip;
+    if (r1 > p.count) r1 = p.count;
+    float mean[EPC], inv[EPC], sc[EPC], sh[EPC], s1[EPC], s2[EPC];
+    load_vec<EPC>(p.mean + chunk * EPC, mean);
+    load_vec<EPC>(p.invstd + chunk * EPC, inv);
+    if (MASK_X) { load_vec<EPC>(p.scale + chunk * EPC, sc); load_vec<EPC>(p.shift + chunk * EPC, sh); }
+    fill_vec<EPC>(s1, 0.f);
+    fill_vec<EPC>(s2, 0.f);
+    const long rowb = (long)p.c * sizeof(T);
+    for (long r = r0 + rl; r < r1; r += lanes) {
+        const long off = r * rowb + chunk * 16;
+        float g[EPC], xv[EPC];
+        unpack16<T>(*reinterpret_cast<const uint4*>(p.dout + off), g);
+        unpack16<T>(*reinterpret_cast<const uint4*>(p.x + off), xv);
+        if (MASK_X) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) g[e] = (xv[e] * sc[e] + sh[e]) > 0.f ? g[e] : 0.f;
+        } else if (p.relu) {
+            float o[EPC];
+            unpack16<T>(*reinterpret_cast<const uint4*>(p.out + off), o);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) { s1[e] += g[e]; s2[e] += g[e] * (xv[e] - mean[e]) * inv[e]; }
+    }
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { red[(threadIdx.x * EPC + e) * 2] = s1[e]; red[(threadIdx.x * EPC + e) * 2 + 1] = s2[e]; }
+    __syncthreads();
+    float* out = p.partial + (long)blockIdx.x * 2 * p.c;
+    for (int t = threadIdx.x; t < nchunk * EPC; t += 256) {
+        const int cl = t / EPC, e = t % EPC;
+        float a = 0.f, b = 0.f;
+        for (int k = 0; k < lanes; ++k) { a += red[((k * nchunk + cl) * EPC + e) * 2]; b += red[((k * nchunk + cl) * EPC + e) * 2 + 1]; }
+        out[cl * EPC + e] = a;
+        out[p.c + cl * EPC + e] = b;
+    }
+}
+
+template <typename T, bool MASK_X>
+__global__ __launch_bounds__(256) void fuse_bwd_apply_flat_kernel(const FuseBwdArgs p, long total) {
+    constexpr int EPC = 16 / sizeof(T);
+    const int nchunk = p.c / EPC;
+    const int chunk = threadIdx.x & (nchunk - 1);
+    // dx = scale*(g - c0 - xhat*c1) = A*g + B*x + C  with  xhat = (x - mean)*invstd
+    float A[EPC], B[EPC], Cc[EPC], sc[EPC], sh[EPC];
+    if (p.x) {
+        float iv[EPC], c0[EPC], c1[EPC], mn[EPC];
+        load_vec<EPC>(p.scale + chunk * EPC, A);
+        load_vec<EPC>(p.invstd + chunk * EPC, iv);
+        load_vec<EPC>(p.coef + chunk * EPC, c0);
+        load_vec<EPC>(p.coef + p.c + chunk * EPC, c1);
+        load_vec<EPC>(p.mean + chunk * EPC, mn);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) { B[e] = -A[e] * iv[e] * c1[e]; Cc[e] = -A[e] * c0[e] - B[e] * mn[e]; }
+        if (MASK_X) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) sc[e] = A[e];
+            load_vec<EPC>(p.shift + chunk * EPC, sh);
+        }
+    } else { fill_vec<EPC>(A, 1.f); fill_vec<EPC>(B, 0.f); fill_vec<EPC>(Cc, 0.f); }
+    const long stride = (long)gridDim.x * 256;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += stride) {
+        const long off = idx * 16;
+        float g[EPC], xv[EPC];
+        unpack16<T>(*reinterpret_cast<const uint4*>(p.dout + off), g);
+        if (p.x) unpack16<T>(*reinterpret_cast<const uint4*>(p.x + off), xv);
+        if (MASK_X) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) g[e] = (xv[e] * sc[e] + sh[e]) > 0.f ? g[e] : 0.f;
+        } else if (p.relu) {
+            float o[EPC];
+            unpack16<T>(*reinterpret_cast<const uint4*>(p.out + off), o);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
+        }
+        if (p.x) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) g[e] = A[e] * g[e] + B[e] * xv[e] + Cc[e];
+        }
+        uint4* dst = reinterpret_cast<uint4*>(p.dx + off);
+        if (p.accumulate) {
+            float o[EPC];
+            unpack16<T>(*dst, o);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) g[e] += o[e];
+        }
+        *dst = pack16<T>(g);
+    }
+}
+
 __global__ void fuse_bwd_coef_kernel(const double* totals, long count, int c, float* coef, float* dgamma, float* dbeta) {
     const int ch = blockIdx.x * blockDim.x + threadIdx.x;
     if (ch >= c) return;
@@ -471,6 +640,12 @@ extern "C" int lh_fuse_bwd(const lh_fuse_bwd_desc* d, int n, int h, int w, int c
         LH_REQUIRE(a.l >= 0 && (h >> a.l) << a.l == h && (w >> a.l) << a.l == w, "lh_fuse_bwd: bad upsampling factor");
         a.count = (long)n * (h >> a.l) * (w >> a.l);
         a.partial = nullptr; a.totals = nullptr; a.coef = nullptr; a.rows_per_strip = 0;
+        a.shift = nullptr;
+        const int nchunk = c / (16 / es);
+        const bool flat = a.l == 0 && (nchunk & (nchunk - 1)) == 0 && nchunk <= 256 && !getenv("LH_NO_FLAT");
+        // single BN term under the ReLU: the mask is sign(x*scale+shift), no need to read the stored activation
+        a.mask_from_x = (flat && d->relu && d->nterms == 1 && a.x && d->shift[t]) ? 1 : 0;
+        if (a.mask_from_x) a.shift = d->shift[t];
         if (a.x) {
             LH_REQUIRE(workspace && a.scale && a.mean && a.invstd, "lh_fuse_bwd: BN term %d lacks workspace/statistics", t);
             const long strips = fuse_bwd_strips(a.count, &a.rows_per_strip);
@@ -479,7 +654,13 @@ extern "C" int lh_fuse_bwd(const lh_fuse_bwd_desc* d, int n, int h, int w, int c
             double* scratch = (double*)((float*)workspace + ((slab_floats + 3) & ~3L));
             double* totals = scratch + (long)ceil_div(strips, 256) * 2 * c;
             a.totals = totals;
-            LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((fuse_bwd_reduce_kernel<T>), dim3((int)strips), dim3(256), 0, s, a));
+            if (flat && a.mask_from_x) {
+                LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((fuse_bwd_reduce_flat_kernel<T, true>), dim3((int)strips), dim3(256), 0, s, a));
+            } else if (flat) {
+                LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((fuse_bwd_reduce_flat_kernel<T, false>), dim3((int)strips), dim3(256), 0, s, a));
+            } else {
+                LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((fuse_bwd_reduce_kernel<T>), dim3((int)strips), dim3(256), 0, s, a));
+            }
             LH_LAUNCH_CHECK("fuse_bwd_reduce launch");
             a.coef = (float*)(totals + 2 * c);
             hipLaunchKernelGGL((fuse_bwd_coef_fused_kernel<float>), dim3(ceil_div(c, 16)), dim3(256), 0, s, (const float*)a.partial,
@@ -488,7 +669,14 @@ extern "C" int lh_fuse_bwd(const lh_fuse_bwd_desc* d, int n, int h, int w, int c
         }
         const long total = a.count * (c / (16 / es));
         const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-        LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((fuse_bwd_apply_kernel<T>), dim3(grid), dim3(256), 0, s, a));
+        const int fgrid = (int)((total + 1023) / 1024 > 2048 ? 2048 : (total + 1023) / 1024);          // >= 4 chunks per thread
+        if (flat && a.mask_from_x) {
+            LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((fuse_bwd_apply_flat_kernel<T, true>), dim3(fgrid), dim3(256), 0, s, a, total));
+        } else if (flat) {
+            LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((fuse_bwd_apply_flat_kernel<T, false>), dim3(fgrid), dim3(256), 0, s, a, total));
+        } else {
+            LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((fuse_bwd_apply_kernel<T>), dim3(grid), dim3(256), 0, s, a));
+        }
         LH_LAUNCH_CHECK("fuse_bwd_apply launch");
     }
     return LH_OK;

@@ -583,6 +583,7 @@ class Plan:
                     st = bn_state[i]
                     bd.x[i] = a.buf.data_ptr()
                     bd.scale[i], bd.save_mean[i], bd.save_invstd[i] = st["scale"].data_ptr(), st["mean"].data_ptr(), st["invstd"].data_ptr()
+                    bd.shift[i] = st["shift"].data_ptr()
                     bd.dgamma[i] = self.grads[bn + ".weight"].data_ptr()
                     bd.dbeta[i] = self.grads[bn + ".bias"].data_ptr()
             self.keep.append(bd)
