@@ -113,10 +113,10 @@ typedef struct {
 int lh_igemm(const lh_igemm_desc* d, const void* in, const void* wpack, void* out,
              const void* addend, const float* bias, float* stats, int dtype, void* stream);
 /* tile (output channels x pixels) the dispatcher picks for this descriptor: names the kernel
- * instantiation a launch uses -- igemm_ring_kernel<T, bm, bp, .., 4> when *ring (LDS-DMA ring path,
- * 16-byte aligned pixel rows) else igemm_kernel<T, bm, bp, ..> (profiling / roofline attribution). */
+ * instantiation a launch uses -- igemm_ring_kernel<T, bm, bp, .., depth, kbytes> when *ring != 0 (LDS-DMA ring
+ * path, 16-byte aligned pixel rows; *ring = kbytes*10 + depth) else igemm_kernel<T, bm, bp, ..>. */
 int lh_igemm_tile(const lh_igemm_desc* d, int dtype, int* bm, int* bp, int* ring);
-int lh_wgrad_tile(const lh_igemm_desc* d, int n_out, int n_in, int dtype, int* bo, int* bi, int* nsplit);
+int lh_wgrad_tile(const lh_igemm_desc* d, int n_out, int n_in, int dtype, int* bo, int* bi, int* nsplit, int* ring);
 /* rows of the stats slab lh_igemm writes for this descriptor (= number of pixel tiles) */
 int lh_igemm_stats_rows(const lh_igemm_desc* d, int dtype);
 

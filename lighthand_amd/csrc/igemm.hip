@@ -276,7 +276,12 @@ static void pick_tile(const lh_igemm_desc* d, int dtype, int* bm, int* bp) {
 extern "C" int lh_igemm_tile(const lh_igemm_desc* d, int dtype, int* bm, int* bp, int* ring) {
     LH_REQUIRE(d && bm && bp && ring, "lh_igemm_tile: null pointer");
     pick_tile(d, dtype, bm, bp);
-    *ring = lh_ring_supported(d, dtype) ? lh_ring_kb() : 0;
+    *ring = 0;
+    if (lh_ring_supported(d, dtype)) {          // encodes K bytes per stage and ring depth: kb * 10 + depth
+        const int es = lh_dtype_size(dtype), kb = lh_ring_kb();
+        const int steps = d->ntaps * ((d->k_run * es + kb - 1) / kb);
+        *ring = kb * 10 + ((kb == 64 && steps <= 4) ? 2 : 4);
+    }
     return LH_OK;
 }
 

@@ -366,23 +366,33 @@ int lh_ring_kb() {
     return kb;
 }
 
-template <typename T, int KB>
+template <typename T, int KB, int D>
 static int ring_dispatch(const IgemmArgs& a, int bm, int bp, hipStream_t s) {
     if (bm == 128 && bp == 128) {
-        if constexpr (sizeof(T) == 4) return launch_ring<T, 128, 64, 4, 1, 4, KB>(a, s);
-        else return launch_ring<T, 128, 128, 2, 2, 4, KB>(a, s);
+        if constexpr (sizeof(T) == 4) return launch_ring<T, 128, 64, 4, 1, D, KB>(a, s);
+        else return launch_ring<T, 128, 128, 2, 2, D, KB>(a, s);
     }
-    if (bm == 128 && bp == 64) return launch_ring<T, 128, 64, 4, 1, 4, KB>(a, s);
-    if (bm == 64 && bp == 128) return launch_ring<T, 64, 128, 1, 4, 4, KB>(a, s);
-    return launch_ring<T, 64, 64, 2, 2, 4, KB>(a, s);
+    if (bm == 128 && bp == 64) return launch_ring<T, 128, 64, 4, 1, D, KB>(a, s);
+    if (bm == 64 && bp == 128) return launch_ring<T, 64, 128, 1, 4, D, KB>(a, s);
+    return launch_ring<T, 64, 64, 2, 2, D, KB>(a, s);
 }
+
+// K loops of <= 4 steps (1x1 convolutions on 64..128 channels) are store-bound: a 2-stage ring keeps the
+// LDS footprint at the epilogue tile's size so 4 workgroups share a CU instead of 2.
+int lh_ring_depth(const IgemmArgs& a) { return a.ntaps * a.kspt <= 4 ? 2 : 4; }
 
 int lh_igemm_ring_launch(const IgemmArgs& a, int bm, int bp, int dtype, hipStream_t s) {
     const int kb = lh_ring_kb();
     switch (dtype) {
-        case LH_BF16: return kb == 128 ? ring_dispatch<bf16, 128>(a, bm, bp, s) : ring_dispatch<bf16, 64>(a, bm, bp, s);
-        case LH_F16: return kb == 128 ? ring_dispatch<f16, 128>(a, bm, bp, s) : ring_dispatch<f16, 64>(a, bm, bp, s);
-        case LH_F32: return kb == 128 ? ring_dispatch<float, 128>(a, bm, bp, s) : ring_dispatch<float, 64>(a, bm, bp, s);
+        case LH_BF16:
+            if (kb == 128) return ring_dispatch<bf16, 128, 4>(a, bm, bp, s);
+            return lh_ring_depth(a) == 2 ? ring_dispatch<bf16, 64, 2>(a, bm, bp, s) : ring_dispatch<bf16, 64, 4>(a, bm, bp, s);
+        case LH_F16:
+            if (kb == 128) return ring_dispatch<f16, 128, 4>(a, bm, bp, s);
+            return lh_ring_depth(a) == 2 ? ring_dispatch<f16, 64, 2>(a, bm, bp, s) : ring_dispatch<f16, 64, 4>(a, bm, bp, s);
+        case LH_F32:
+            if (kb == 128) return ring_dispatch<float, 128, 4>(a, bm, bp, s);
+            return lh_ring_depth(a) == 2 ? ring_dispatch<float, 64, 2>(a, bm, bp, s) : ring_dispatch<float, 64, 4>(a, bm, bp, s);
     }
     lh_set_error("igemm_ring: unsupported dtype %d", dtype);
     return LH_ERR_ARG;

@@ -12,6 +12,7 @@
 //  * split-K over pixels -> fp32 slabs [split][tap][o][i], folded (deterministically, in
 //    split order) into the reference-layout gradient by wgrad_reduce_kernel.
 #include "common.h"
+#include <stdlib.h>
 
 struct WgradArgs {
     const unsigned char* x;
@@ -174,6 +175,165 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
         }
 }
 
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA ring version for the 16-bit types (production path).  Same GEMM as wgrad_kernel, but both
+// operands arrive by global_load_lds_dwordx4 into a D-stage ring (see igemm_ring.hip for the protocol:
+// one raw s_barrier per K step, counted vmcnt leaving D-2 stages in flight).  LDS image per operand:
+// [32 pixel rows][B*2 bytes], unpadded (an LDS-DMA writes 1 KiB lane-linear), 32-byte granules XOR-swizzled by
+// the row so the 8 pixel rows a half-wave touches per transposed read (ds_read_b64_tr_b16) hit distinct banks;
+// the swizzle is applied to the per-lane SOURCE address and to the read address.
+__device__ __attribute__((aligned(16))) unsigned int lh_wzero_page[4] = {0u, 0u, 0u, 0u};
+
+template <int ROWB> __device__ __forceinline__ int wswz(int row) {
+    return ROWB == 256 ? (row & 7) : ((row >> 1) & 3);
+}
+
+template <typename T, int BO, int BI, int WO, int WI, int D>
+__global__ __launch_bounds__(256) void wgrad_ring_kernel(const WgradArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    static_assert(sizeof(T) == 2, "16-bit types only");
+    constexpr int KP = 32;
+    constexpr int RBO = BO * 2, RBI = BI * 2;                 // bytes per pixel row
+    constexpr int RPO = 1024 / RBO, RPI = 1024 / RBI;         // pixel rows per LDS-DMA instruction
+    constexpr int NO = KP / RPO / 4, NI = KP / RPI / 4;       // instructions per wave and stage
+    constexpr int L = NO + NI;
+    constexpr int STAGE = KP * (RBO + RBI);
+    constexpr int TO = BO / WO, TI = BI / WI, OT = TO / 16, IT = TI / 16;
+    static_assert(WO * WI == 4 && NO >= 1 && NI >= 1 && D >= 2 && D <= 4, "bad tile");
+    typedef __attribute__((address_space(3))) void* lds_p;
+    typedef const __attribute__((address_space(1))) void* gbl_p;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wo_ = wave / WI, wi_ = wave % WI;
+    const int otile = blockIdx.x / p.i_tiles, itile = blockIdx.x % p.i_tiles;
+    const int tap = blockIdx.y, split = blockIdx.z;
+    const int dh = p.dh[tap], dw = p.dw[tap];
+    const int hw = p.ho * p.wo;
+    const long m_begin = (long)split * p.steps_per_split * KP;
+    long m_end = m_begin + (long)p.steps_per_split * KP;
+    if (m_end > p.M) m_end = p.M;
+    const int S = m_begin < m_end ? (int)((m_end - m_begin + KP - 1) / KP) : 0;
+    const unsigned char* zero = reinterpret_cast<const unsigned char*>(lh_wzero_page);
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+
+    // per-lane source bookkeeping: instruction q = 4*j + wave covers rows [q*RP, (q+1)*RP)
+    int orow[NO], ocol[NO], irow[NI], icol[NI];
+#pragma unroll
+    for (int j = 0; j < NO; ++j) {
+        const int q = 4 * j + wave;
+        const int r = q * RPO + lane / (RBO / 16), c16 = lane % (RBO / 16);
+        orow[j] = r;
+        ocol[j] = otile * BO + ((((c16 >> 1) ^ wswz<RBO>(r)) << 1) | (c16 & 1)) * 8;
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int q = 4 * j + wave;
+        const int r = q * RPI + lane / (RBI / 16), c16 = lane % (RBI / 16);
+        irow[j] = r;
+        icol[j] = itile * BI + ((((c16 >> 1) ^ wswz<RBI>(r)) << 1) | (c16 & 1)) * 8;
+    }
+
+    auto issue = [&](int s, int slot) {
+        unsigned char* st = smem + slot * STAGE;
+        const long mb = m_begin + (long)s * KP;
+#pragma unroll
+        for (int j = 0; j < NO; ++j) {
+            const long m = mb + orow[j];
+            const bool ok = (int)(m < m_end) & (int)(ocol[j] < p.n_out);
+            const unsigned char* src = p.dy + (m * p.dy_pix_stride + ocol[j]) * 2;
+            src = ok ? src : zero;
+            __builtin_amdgcn_global_load_lds((gbl_p)src, (lds_p)(st + (4 * j + wave) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const long m = mb + irow[j];
+            const int mi = m < m_end ? (int)m : 0;
+            const int n = mi / hw, rem = mi - n * hw;
+            const int a = rem / p.wo, b = rem - a * p.wo;
+            const int ih = a * p.sh + dh, iw = b * p.sw + dw;
+            const bool ok = (int)(m < m_end) & (int)(icol[j] < p.k_run) & (int)((unsigned)ih < (unsigned)p.hi) &
+                            (int)((unsigned)iw < (unsigned)p.wi);
+            const unsigned char* src = p.x + (((long)(n * p.hi + ih) * p.wi + iw) * p.in_pix_stride + icol[j]) * 2;
+            src = ok ? src : zero;
+            __builtin_amdgcn_global_load_lds((gbl_p)src, (lds_p)(st + KP * RBO + (4 * j + wave) * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[OT][IT];
+#pragma unroll
+    for (int i = 0; i < OT; ++i)
+#pragma unroll
+        for (int j = 0; j < IT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int issued = 0;
+#pragma unroll
+    for (int s = 0; s < D - 1; ++s)
+        if (issued < S) { issue(issued, issued % D); ++issued; }
+
+    // transposed-read addresses: lane (group g, q, pp) reads pixel row 4g+q (and +16), 4 channels at 4*pp of a 16-channel tile
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int row0 = 4 * g + q, row1 = row0 + 16;
+    unsigned ao[OT][2], ai[IT][2];
+#pragma unroll
+    for (int i = 0; i < OT; ++i) {
+        const int ct = wo_ * OT + i;                              // 32-byte granule index inside the row
+        ao[i][0] = row0 * RBO + ((ct ^ wswz<RBO>(row0)) << 5) + pp * 8;
+        ao[i][1] = row1 * RBO + ((ct ^ wswz<RBO>(row1)) << 5) + pp * 8;
+    }
+#pragma unroll
+    for (int j = 0; j < IT; ++j) {
+        const int ct = wi_ * IT + j;
+        ai[j][0] = KP * RBO + row0 * RBI + ((ct ^ wswz<RBI>(row0)) << 5) + pp * 8;
+        ai[j][1] = KP * RBO + row1 * RBI + ((ct ^ wswz<RBI>(row1)) << 5) + pp * 8;
+    }
+
+    for (int s = 0; s < S; ++s) {
+        const int ahead = issued - 1 - s;
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * L) : "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (issued < S) { issue(issued, issued % D); ++issued; }
+        const unsigned st = lds_base + (s % D) * STAGE;
+        uint2 fo[OT][2], fi[IT][2];
+#pragma unroll
+        for (int i = 0; i < OT; ++i) {
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fo[i][0]) : "v"(st + ao[i][0]));
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fo[i][1]) : "v"(st + ao[i][1]));
+        }
+#pragma unroll
+        for (int j = 0; j < IT; ++j) {
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fi[j][0]) : "v"(st + ai[j][0]));
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fi[j][1]) : "v"(st + ai[j][1]));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < OT; ++i)
+#pragma unroll
+            for (int j = 0; j < IT; ++j) {
+                const uint4 a = uint4{fo[i][0].x, fo[i][0].y, fo[i][1].x, fo[i][1].y};
+                const uint4 b = uint4{fi[j][0].x, fi[j][0].y, fi[j][1].x, fi[j][1].y};
+                WFrag<T>::mma(a, b, acc[i][j]);
+            }
+    }
+
+    float* slab = p.slab + ((long)split * p.ntaps + tap) * p.n_out * p.n_in;
+    const int qq = lane >> 4, cc = lane & 15;
+#pragma unroll
+    for (int i = 0; i < OT; ++i)
+#pragma unroll
+        for (int j = 0; j < IT; ++j) {
+            const int ci = itile * BI + wi_ * TI + j * 16 + cc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = otile * BO + wo_ * TO + i * 16 + qq * 4 + r;
+                if (o < p.n_out && ci < p.n_in) slab[(long)o * p.n_in + ci] = acc[i][j][r];
+            }
+        }
+}
+
 struct WreduceArgs {
     const float* slab;
     float* grad;
@@ -252,10 +412,12 @@ static void wgrad_plan(const lh_igemm_desc* d, int n_out, int n_in, int dtype, i
     *nsplit = (int)((steps + sps - 1) / sps);
 }
 
-extern "C" int lh_wgrad_tile(const lh_igemm_desc* d, int n_out, int n_in, int dtype, int* bo, int* bi, int* nsplit) {
-    LH_REQUIRE(d && bo && bi && nsplit, "lh_wgrad_tile: null pointer");
+extern "C" int lh_wgrad_tile(const lh_igemm_desc* d, int n_out, int n_in, int dtype, int* bo, int* bi, int* nsplit, int* ring) {
+    LH_REQUIRE(d && bo && bi && nsplit && ring, "lh_wgrad_tile: null pointer");
     int sps;
     wgrad_plan(d, n_out, n_in, dtype, bo, bi, nsplit, &sps);
+    const int es = lh_dtype_size(dtype);
+    *ring = (es == 2 && (d->in_pix_stride * es) % 16 == 0 && !getenv("LH_NO_WGRAD_RING")) ? 4 : 0;
     return LH_OK;
 }
 
@@ -263,6 +425,16 @@ extern "C" size_t lh_wgrad_slab_bytes(const lh_igemm_desc* d, int n_out, int n_i
     int bo, bi, ns, sps;
     wgrad_plan(d, n_out, n_in, dtype, &bo, &bi, &ns, &sps);
     return (size_t)ns * d->ntaps * n_out * n_in * sizeof(float);
+}
+
+template <typename T, int BO, int BI, int WO, int WI>
+static int launch_wgrad_ring(const WgradArgs& a, hipStream_t s) {
+    constexpr int D = 4;
+    constexpr int lds = D * 32 * (BO * 2 + BI * 2);
+    dim3 grid(ceil_div(a.n_out, BO) * a.i_tiles, a.ntaps, a.nsplit);
+    hipLaunchKernelGGL((wgrad_ring_kernel<T, BO, BI, WO, WI, D>), grid, dim3(256), lds, s, a);
+    LH_LAUNCH_CHECK("wgrad_ring launch");
+    return LH_OK;
 }
 
 template <typename T, int BO, int BI, int WO, int WI>
@@ -294,6 +466,16 @@ extern "C" int lh_wgrad(const lh_igemm_desc* d, const void* x, const void* dy, i
     wgrad_plan(d, n_out, n_in, dtype, &bo, &bi, &a.nsplit, &a.steps_per_split);
     a.i_tiles = ceil_div(n_in, bi);
     hipStream_t s = (hipStream_t)stream;
+    // 16-bit types with 16-byte aligned pixel rows take the LDS-DMA ring kernel
+    const bool ring = es == 2 && (d->in_pix_stride * es) % 16 == 0 && !getenv("LH_NO_WGRAD_RING");
+#define LH_WR(T)                                                                  \
+    if (bo == 128 && bi == 128) return launch_wgrad_ring<T, 128, 128, 2, 2>(a, s); \
+    if (bo == 128 && bi == 64) return launch_wgrad_ring<T, 128, 64, 4, 1>(a, s);   \
+    if (bo == 64 && bi == 128) return launch_wgrad_ring<T, 64, 128, 1, 4>(a, s);   \
+    return launch_wgrad_ring<T, 64, 64, 2, 2>(a, s);
+    if (ring && dtype == LH_BF16) { LH_WR(bf16) }
+    if (ring && dtype == LH_F16) { LH_WR(f16) }
+#undef LH_WR
 #define LH_WT(T)                                                             \
     if (bo == 128 && bi == 128) return launch_wgrad<T, 128, 128, 2, 2>(a, s); \
     if (bo == 128 && bi == 64) return launch_wgrad<T, 128, 64, 4, 1>(a, s);   \

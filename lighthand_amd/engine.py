@@ -244,10 +244,13 @@ class Plan:
             self.lib.lh_igemm_tile(C.byref(d), self.dt, C.byref(a), C.byref(b), C.byref(c))
             wc, wp = {(128, 128): (2, 2), (128, 64): (4, 1), (64, 128): (1, 4), (64, 64): (2, 2)}[(a.value, b.value)]
             if c.value:
-                return f"igemm_ring_kernel<{t}, {a.value}, {b.value}, {wc}, {wp}, 4, {c.value}>"
+                return f"igemm_ring_kernel<{t}, {a.value}, {b.value}, {wc}, {wp}, {c.value % 10}, {c.value // 10}>"
             return f"igemm_kernel<{t}, {a.value}, {b.value}, {wc}, {wp}>"
-        self.lib.lh_wgrad_tile(C.byref(d), wgrad[0], wgrad[1], self.dt, C.byref(a), C.byref(b), C.byref(c))
+        r = C.c_int(0)
+        self.lib.lh_wgrad_tile(C.byref(d), wgrad[0], wgrad[1], self.dt, C.byref(a), C.byref(b), C.byref(c), C.byref(r))
         wo, wi = {(128, 128): (2, 2), (128, 64): (4, 1), (64, 128): (1, 4), (64, 64): (2, 2)}[(a.value, b.value)]
+        if r.value:
+            return f"wgrad_ring_kernel<{t}, {a.value}, {b.value}, {wo}, {wi}, {r.value}>"
         return f"wgrad_kernel<{t}, {a.value}, {b.value}, {wo}, {wi}>"
 
     def _first_write(self, a):
