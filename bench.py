@@ -53,8 +53,8 @@ def profile_kernels(step, iters=3, plan=None, fwd_only=False):
     kernels are launched on.  Returns {kernel name: dict(ms, launches, flops, bytes)} per step."""
     plan = plan or step.plan
     meta = {}
-    for which, idx, name, flops, nbytes in plan.profile_meta:
-        meta[(which, idx)] = (name, flops, nbytes)
+    for which, call, name, flops, nbytes in plan.profile_meta:
+        meta[id(call)] = (name, flops, nbytes)
     agg = {}
     stream = torch.cuda.current_stream()
     s = stream.cuda_stream
@@ -65,7 +65,7 @@ def profile_kernels(step, iters=3, plan=None, fwd_only=False):
             if which == "bwd":
                 step._fwd_loss_tail(s)
             for i, call in enumerate(lst):
-                m = meta.get((which, i))
+                m = meta.get(id(call))
                 if m is None:
                     call(s)
                     continue

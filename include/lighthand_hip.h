@@ -107,11 +107,14 @@ typedef struct {
     signed char dw[64];
 } lh_igemm_desc;
 
-/* out[pixel][co] = sum_taps sum_k in[pix(tap)][k] * wpack[co][tap][k] (+bias[co]) (+addend).
- * stats (optional): fp32 [gridM][2][cout_stats_stride] per-block column sums / sums of
- * squares of the stored values, consumed by lh_bn_finalize.  addend may alias out. */
+/* out[pixel][co] = relu?( (sum_taps sum_k in[pix(tap)][k] * wpack[co][tap][k] + bias[co]) * scale[co] + shift[co]
+ *                          + addend[pixel][co] )      (bias / scale+shift / addend optional; relu from the descriptor).
+ * scale/shift fold an eval-mode BatchNorm (and with addend + relu a whole residual-unit tail) into the epilogue.
+ * stats (optional): fp32 [gridM][2][cout] per-block column sums / sums of squares of the stored values,
+ * consumed by lh_bn_finalize.  addend may alias out. */
 int lh_igemm(const lh_igemm_desc* d, const void* in, const void* wpack, void* out,
-             const void* addend, const float* bias, float* stats, int dtype, void* stream);
+             const void* addend, const float* bias, const float* scale, const float* shift, float* stats,
+             int dtype, void* stream);
 /* tile (output channels x pixels) the dispatcher picks for this descriptor: names the kernel
  * instantiation a launch uses -- igemm_ring_kernel<T, bm, bp, .., depth, kbytes> when *ring != 0 (LDS-DMA ring
  * path, 16-byte aligned pixel rows; *ring = kbytes*10 + depth) else igemm_kernel<T, bm, bp, ..>. */

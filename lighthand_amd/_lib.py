@@ -55,7 +55,7 @@ SIGNATURES = {
     "lh_pack_weight": (_I, [_P, _P, C.POINTER(_SZ), _I, _I, _L, _L, _L, _L, _I, C.POINTER(_I), _I, _P]),
     "lh_pack_chunk_elems": (_I, []),
     "lh_pack_weights_multi": (_I, [_P, _P, _P, _I, _I, _P]),
-    "lh_igemm": (_I, [C.POINTER(IgemmDesc), _P, _P, _P, _P, _P, _P, _I, _P]),
+    "lh_igemm": (_I, [C.POINTER(IgemmDesc), _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "lh_igemm_tile": (_I, [C.POINTER(IgemmDesc), _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "lh_wgrad_tile": (_I, [C.POINTER(IgemmDesc), _I, _I, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "lh_igemm_stats_rows": (_I, [C.POINTER(IgemmDesc), _I]),

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
 #pragma unroll
         for (int i = 0; i < CT; ++i) {
             const int col = wc * TC + i * 16 + q * 4;
-            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            float bv[4] = {0.f, 0.f, 0.f, 0.f}, sv[4] = {1.f, 1.f, 1.f, 1.f};
             if (p.bias) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -158,19 +158,27 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
                     bv[r] = gc < p.cout ? p.bias[gc] : 0.f;
                 }
             }
+            if (p.scale) {                      // out = acc * scale + shift (+ bias * scale folded by the host if both are given)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int gc = cblk * BM + col + r;
+                    sv[r] = gc < p.cout ? p.scale[gc] : 1.f;
+                    bv[r] = bv[r] * sv[r] + (gc < p.cout ? p.shift[gc] : 0.f);
+                }
+            }
 #pragma unroll
             for (int j = 0; j < PT; ++j) {
                 const int pr = wp * TP + j * 16 + pl;
                 T* dst = reinterpret_cast<T*>(smem + pr * RS + col * ES);
                 if constexpr (ES == 4) {
-                    float2 lo = {acc[i][j][0] + bv[0], acc[i][j][1] + bv[1]};
-                    float2 hi = {acc[i][j][2] + bv[2], acc[i][j][3] + bv[3]};
+                    float2 lo = {acc[i][j][0] * sv[0] + bv[0], acc[i][j][1] * sv[1] + bv[1]};
+                    float2 hi = {acc[i][j][2] * sv[2] + bv[2], acc[i][j][3] * sv[3] + bv[3]};
                     reinterpret_cast<float2*>(dst)[0] = lo;
                     reinterpret_cast<float2*>(dst)[1] = hi;
                 } else {
                     union { uint2 u; T e[4]; } pk;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) pk.e[r] = from_f<T>(acc[i][j][r] + bv[r]);
+                    for (int r = 0; r < 4; ++r) pk.e[r] = from_f<T>(acc[i][j][r] * sv[r] + bv[r]);
                     *reinterpret_cast<uint2*>(dst) = pk.u;
                 }
             }
@@ -293,7 +301,8 @@ extern "C" int lh_igemm_stats_rows(const lh_igemm_desc* d, int dtype) {
 }
 
 extern "C" int lh_igemm(const lh_igemm_desc* d, const void* in, const void* wpack, void* out,
-                        const void* addend, const float* bias, float* stats, int dtype, void* stream) {
+                        const void* addend, const float* bias, const float* scale, const float* shift, float* stats,
+                        int dtype, void* stream) {
     LH_REQUIRE(d && in && wpack && out, "lh_igemm: null pointer");
     const int es = lh_dtype_size(dtype);
     LH_REQUIRE(es > 0, "lh_igemm: bad dtype %d", dtype);
@@ -309,6 +318,8 @@ extern "C" int lh_igemm(const lh_igemm_desc* d, const void* in, const void* wpac
     IgemmArgs a;
     a.in = (const unsigned char*)in; a.w = (const unsigned char*)wpack; a.out = (unsigned char*)out;
     a.addend = (const unsigned char*)addend; a.bias = bias; a.stats = stats;
+    a.scale = scale; a.shift = shift;
+    LH_REQUIRE((scale == nullptr) == (shift == nullptr), "lh_igemm: scale and shift must come together");
     a.n = d->n; a.hi = d->hi; a.wi = d->wi; a.in_pix_stride = d->in_pix_stride; a.k_run = d->k_run;
     a.kspt = (d->k_run * es + 63) / 64;
     a.kpad = (d->k_run * es + 127) / 128 * (128 / es);

@@ -8,6 +8,8 @@ struct IgemmArgs {
     unsigned char* out;
     const unsigned char* addend;
     const float* bias;
+    const float* scale;      // optional per-output-channel affine applied to the fp32 accumulator (eval-mode BN fold)
+    const float* shift;
     float* stats;
     int n, hi, wi, in_pix_stride, k_run, kspt, kpad;   // kpad: elements per (row, tap) of the weight pack
     int ho, wo, M, sh, sw, cout;

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void igemm_ring_kernel(const IgemmArgs p) {
 #pragma unroll
         for (int i = 0; i < CT; ++i) {
             const int col = wc * TC + i * 16 + q * 4;
-            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            float bv[4] = {0.f, 0.f, 0.f, 0.f}, sv[4] = {1.f, 1.f, 1.f, 1.f};
             if (p.bias) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -212,17 +212,25 @@ __global__ __launch_bounds__(256) void igemm_ring_kernel(const IgemmArgs p) {
                     bv[r] = gc < p.cout ? p.bias[gc] : 0.f;
                 }
             }
+            if (p.scale) {                      // out = acc * scale + shift (+ bias * scale folded by the host if both are given)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int gc = cblk * BM + col + r;
+                    sv[r] = gc < p.cout ? p.scale[gc] : 1.f;
+                    bv[r] = bv[r] * sv[r] + (gc < p.cout ? p.shift[gc] : 0.f);
+                }
+            }
 #pragma unroll
             for (int j = 0; j < PT; ++j) {
                 const int pr = wp * TP + j * 16 + pl;
                 T* dst = reinterpret_cast<T*>(smem + pr * RS + col * ES);
                 if constexpr (ES == 4) {
-                    reinterpret_cast<float2*>(dst)[0] = float2{acc[i][j][0] + bv[0], acc[i][j][1] + bv[1]};
-                    reinterpret_cast<float2*>(dst)[1] = float2{acc[i][j][2] + bv[2], acc[i][j][3] + bv[3]};
+                    reinterpret_cast<float2*>(dst)[0] = float2{acc[i][j][0] * sv[0] + bv[0], acc[i][j][1] * sv[1] + bv[1]};
+                    reinterpret_cast<float2*>(dst)[1] = float2{acc[i][j][2] * sv[2] + bv[2], acc[i][j][3] * sv[3] + bv[3]};
                 } else {
                     union { uint2 u; T e[4]; } pk;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) pk.e[r] = from_f<T>(acc[i][j][r] + bv[r]);
+                    for (int r = 0; r < 4; ++r) pk.e[r] = from_f<T>(acc[i][j][r] * sv[r] + bv[r]);
                     *reinterpret_cast<uint2*>(dst) = pk.u;
                 }
             }
@@ -323,14 +331,17 @@ static int launch_ring(const IgemmArgs& a, hipStream_t s) {
 // Tile choice: the largest tile that still gives >= 2 workgroups per CU, else the smallest.
 void lh_ring_pick_tile(const lh_igemm_desc* d, int dtype, int* bm, int* bp) {
     const long M = (long)d->n * d->ho * d->wo;
-    const int cands[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
+    const int cands[5][2] = {{128, 256}, {128, 128}, {128, 64}, {64, 128}, {64, 64}};
     const bool f32 = dtype == LH_F32;
-    for (int i = 0; i < 4; ++i) {
+    static int big = -1;
+    if (big < 0) big = getenv("LH_NO_BIG_TILE") ? 0 : 1;
+    for (int i = 0; i < 5; ++i) {
         const int BM = cands[i][0], BP = cands[i][1];
         if (BM == 128 && d->cout <= 64) continue;
+        if (BP == 256 && (f32 || !big || lh_ring_kb() != 64 || d->ntaps * ((d->k_run * 2 + 63) / 64) <= 4)) continue;   // 16-bit, deep K only
         if (f32 && BM == 128 && BP == 128) continue;            // fp32 epilogue tile would not fit 64 KiB well
         const long blocks = ((M + BP - 1) / BP) * ((d->cout + BM - 1) / BM);
-        if (blocks >= 512 || i == 3) { *bm = BM; *bp = BP; return; }
+        if (blocks >= (BP == 256 ? 1024 : 512) || i == 4) { *bm = BM; *bp = BP; return; }
     }
     *bm = 64; *bp = 64;
 }
@@ -368,6 +379,10 @@ int lh_ring_kb() {
 
 template <typename T, int KB, int D>
 static int ring_dispatch(const IgemmArgs& a, int bm, int bp, hipStream_t s) {
+    if constexpr (sizeof(T) == 2 && KB == 64 && D == 4) {
+        // 128 x 256 tile: each wave owns 64 x 128 (32 MFMAs per K step), 3-stage ring = 72 KiB -> two workgroups per CU
+        if (bm == 128 && bp == 256) return launch_ring<T, 128, 256, 2, 2, 3, KB>(a, s);
+    }
     if (bm == 128 && bp == 128) {
         if constexpr (sizeof(T) == 4) return launch_ring<T, 128, 64, 4, 1, D, KB>(a, s);
         else return launch_ring<T, 128, 128, 2, 2, D, KB>(a, s);
@@ -379,14 +394,21 @@ static int ring_dispatch(const IgemmArgs& a, int bm, int bp, hipStream_t s) {
 
 // K loops of <= 4 steps (1x1 convolutions on 64..128 channels) are store-bound: a 2-stage ring keeps the
 // LDS footprint at the epilogue tile's size so 4 workgroups share a CU instead of 2.
-int lh_ring_depth(const IgemmArgs& a) { return a.ntaps * a.kspt <= 4 ? 2 : 4; }
+int lh_ring_depth(const IgemmArgs& a) {
+    static int forced = -1;
+    if (forced < 0) { const char* e = getenv("LH_RING_D"); forced = e ? atoi(e) : 0; }
+    if (forced >= 2 && forced <= 4) return forced;
+    return a.ntaps * a.kspt <= 4 ? 2 : 4;
+}
 
 int lh_igemm_ring_launch(const IgemmArgs& a, int bm, int bp, int dtype, hipStream_t s) {
     const int kb = lh_ring_kb();
     switch (dtype) {
-        case LH_BF16:
-            if (kb == 128) return ring_dispatch<bf16, 128, 4>(a, bm, bp, s);
-            return lh_ring_depth(a) == 2 ? ring_dispatch<bf16, 64, 2>(a, bm, bp, s) : ring_dispatch<bf16, 64, 4>(a, bm, bp, s);
+        case LH_BF16: {
+            const int dep = lh_ring_depth(a);
+            if (kb == 128) return dep == 2 ? ring_dispatch<bf16, 128, 2>(a, bm, bp, s) : dep == 3 ? ring_dispatch<bf16, 128, 3>(a, bm, bp, s) : ring_dispatch<bf16, 128, 4>(a, bm, bp, s);
+            return dep == 2 ? ring_dispatch<bf16, 64, 2>(a, bm, bp, s) : dep == 3 ? ring_dispatch<bf16, 64, 3>(a, bm, bp, s) : ring_dispatch<bf16, 64, 4>(a, bm, bp, s);
+        }
         case LH_F16:
             if (kb == 128) return ring_dispatch<f16, 128, 4>(a, bm, bp, s);
             return lh_ring_depth(a) == 2 ? ring_dispatch<f16, 64, 2>(a, bm, bp, s) : ring_dispatch<f16, 64, 4>(a, bm, bp, s);

@@ -134,11 +134,12 @@ def _taps_array(rs):
 
 
 class _Call:
-    """A pre-bound C-ABI call; the stream is appended at run time."""
-    __slots__ = ("fn", "args", "what", "keep")
+    """A pre-bound C-ABI call; the stream is appended at run time.  ``lane`` 1 marks work that may run on
+    the side stream of the backward pass (weight gradients: they only feed the optimizer)."""
+    __slots__ = ("fn", "args", "what", "keep", "lane")
 
-    def __init__(self, fn, args, what, keep=None):
-        self.fn, self.args, self.what, self.keep = fn, args, what, keep
+    def __init__(self, fn, args, what, keep=None, lane=0):
+        self.fn, self.args, self.what, self.keep, self.lane = fn, args, what, keep, lane
 
     def __call__(self, stream):
         rc = self.fn(*self.args, stream)
@@ -148,10 +149,10 @@ class _Call:
 
 class _TorchCall:
     """Host-side glue expressed with torch ops on tiny tensors (layout shuffles of <10k values)."""
-    __slots__ = ("fn", "what")
+    __slots__ = ("fn", "what", "lane")
 
-    def __init__(self, fn, what):
-        self.fn, self.what = fn, what
+    def __init__(self, fn, what, lane=0):
+        self.fn, self.what, self.lane = fn, what, lane
 
     def __call__(self, stream):
         self.fn()
@@ -190,12 +191,14 @@ class Plan:
         self.out_act = gb.out
         self.fwd, self.bwd, self.packs = [], [], []
         self._pack_items = []
+        self._producers = {}               # id(raw conv output Act) -> the igemm calls that write it (eval-mode BN folding)
         self.keep = []                     # ctypes objects / tensors referenced by raw pointer
         self._ws_wgrad = 0
         self._ws_fuse = 0
         self._ws_users = []
+        self._ws_users_fuse = []
         self._written = set()
-        self.profile_meta = []             # (list name, index, kernel family, flops, bytes)
+        self.profile_meta = []             # (list name, call object, kernel name, flops, bytes)
         self._compile()
 
     # ------------------------------------------------------------------ helpers
@@ -231,10 +234,25 @@ class Plan:
             self.keep.append(wt)
         return buf
 
-    def _igemm(self, lst, d, src, pack, dst, addend, bias, stats, what, flops=0):
+    # positions of lh_igemm's arguments inside a _Call.args tuple
+    _IG = dict(desc=0, src=1, pack=2, dst=3, addend=4, bias=5, scale=6, shift=7, stats=8)
+
+    def _igemm(self, lst, d, src, pack, dst, addend, bias, stats, what, flops=0, produces=None):
         self.keep.append(d)
-        lst.append(_Call(self.lib.lh_igemm, (C.byref(d), _ptr(src), _ptr(pack), _ptr(dst), _ptr(addend), _ptr(bias), _ptr(stats), self.dt), what))
-        return lst[-1]
+        c = _Call(self.lib.lh_igemm, (C.byref(d), _ptr(src), _ptr(pack), _ptr(dst), _ptr(addend), _ptr(bias), 0, 0, _ptr(stats), self.dt), what)
+        c.keep = d
+        lst.append(c)
+        if produces is not None:
+            self._producers.setdefault(id(produces), []).append(c)
+        return c
+
+    def _patch(self, call, relu=None, **ptrs):
+        a = list(call.args)
+        for k, v in ptrs.items():
+            a[self._IG[k]] = v
+        call.args = tuple(a)
+        if relu is not None:
+            call.keep.relu = int(relu)
 
     def _kname(self, d, wgrad=None):
         """Kernel instantiation name as rocprofv3 prints it (for roofline attribution)."""
@@ -242,9 +260,10 @@ class Plan:
         a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
         if wgrad is None:
             self.lib.lh_igemm_tile(C.byref(d), self.dt, C.byref(a), C.byref(b), C.byref(c))
-            wc, wp = {(128, 128): (2, 2), (128, 64): (4, 1), (64, 128): (1, 4), (64, 64): (2, 2)}[(a.value, b.value)]
+            wc, wp = {(128, 256): (2, 2), (128, 128): (2, 2), (128, 64): (4, 1), (64, 128): (1, 4), (64, 64): (2, 2)}[(a.value, b.value)]
             if c.value:
-                return f"igemm_ring_kernel<{t}, {a.value}, {b.value}, {wc}, {wp}, {c.value % 10}, {c.value // 10}>"
+                depth = 3 if b.value == 256 else c.value % 10
+                return f"igemm_ring_kernel<{t}, {a.value}, {b.value}, {wc}, {wp}, {depth}, {c.value // 10}>"
             return f"igemm_kernel<{t}, {a.value}, {b.value}, {wc}, {wp}>"
         r = C.c_int(0)
         self.lib.lh_wgrad_tile(C.byref(d), wgrad[0], wgrad[1], self.dt, C.byref(a), C.byref(b), C.byref(c), C.byref(r))
@@ -318,9 +337,13 @@ class Plan:
                             names += [bn + ".weight", bn + ".bias"]
                 if names:
                     self.bwd_marks.append((len(self.bwd), names))
-            ws = self._alloc(max(self._ws_wgrad, self._ws_fuse, 256), dtype=torch.uint8)
+            # two workspaces: the weight-gradient chain may run concurrently with the BN-backward chain
+            ws_w = self._alloc(max(self._ws_wgrad, 256), dtype=torch.uint8)
+            ws_f = self._alloc(max(self._ws_fuse, 256), dtype=torch.uint8)
             for setter in self._ws_users:
-                setter(ws.data_ptr())
+                setter(ws_w.data_ptr())
+            for setter in self._ws_users_fuse:
+                setter(ws_f.data_ptr())
 
     def _c_input(self, a, blk):
         pass        # the consumer (stem conv) owns the image transform
@@ -368,8 +391,8 @@ class Plan:
             self._stats_for(y, [d])
             stats_ptr = y.stats
         flops = 2.0 * y.pixels * cout * cin * k * k
-        self._igemm(self.fwd, d, xbuf, pack, ybuf, None, bias, stats_ptr, nd["w"] + " fwd")
-        self.profile_meta.append(("fwd", len(self.fwd) - 1, self._kname(d), flops, (x.pixels * x.c + y.pixels * y.c) * self.es))
+        self._igemm(self.fwd, d, xbuf, pack, ybuf, None, bias, stats_ptr, nd["w"] + " fwd", produces=y)
+        self.profile_meta.append(("fwd", self.fwd[-1], self._kname(d), flops, (x.pixels * x.c + y.pixels * y.c) * self.es))
         if not self.with_bwd:
             return
         # --- backward: weight gradient, then data gradient
@@ -394,7 +417,7 @@ class Plan:
             dy = self._act_grad(y)
             call_w = [self.lib.lh_wgrad, [C.byref(d), xbuf.data_ptr(), dy.data_ptr(), y.c, y.c, cin, 0, self.dt], nd["w"] + " wgrad"]
             call_r = [self.lib.lh_wgrad_reduce, [C.byref(d), 0, gtmp.data_ptr(), y.c if pad_out else cout, cin, cin * k * k, k * k, k, 1, rs_arr, 0, self.dt], nd["w"] + " wgrad reduce"]
-            cw, cr = _Call(call_w[0], None, call_w[2]), _Call(call_r[0], None, call_r[2], keep=rs_arr)
+            cw, cr = _Call(call_w[0], None, call_w[2], lane=1), _Call(call_r[0], None, call_r[2], keep=rs_arr, lane=1)
 
             def set_ws(ptr, cw=cw, cr=cr, a=call_w[1], b=call_r[1]):
                 a[6] = ptr
@@ -402,10 +425,10 @@ class Plan:
                 cw.args, cr.args = tuple(a), tuple(b)
             self._ws_users.append(set_ws)
             self.bwd.append(cw)
-            self.profile_meta.append(("bwd", len(self.bwd) - 1, self._kname(d, (y.c, cin)), flops, (x.pixels * x.c + y.pixels * y.c) * self.es))
+            self.profile_meta.append(("bwd", self.bwd[-1], self._kname(d, (y.c, cin)), flops, (x.pixels * x.c + y.pixels * y.c) * self.es))
             self.bwd.append(cr)
             if pad_out:
-                self.bwd.append(_TorchCall(lambda: gw.copy_(gtmp[:cout]), "head grad crop"))
+                self.bwd.append(_TorchCall(lambda: gw.copy_(gtmp[:cout]), "head grad crop", lane=1))
             if nd["bias"]:
                 gb_ = self.grads[nd["bias"]]
                 if y is self.out_act:      # the head: reduce the contiguous fp32 NCHW gradient instead of strided bf16
@@ -417,7 +440,7 @@ class Plan:
                 first = self._first_write(x)
                 for dd, pk in zip(ddescs, dpacks):
                     self._igemm(self.bwd, dd, dy, pk, dx, None if first else dx, None, None, nd["w"] + " dgrad")
-                    self.profile_meta.append(("bwd", len(self.bwd) - 1, self._kname(dd), 2.0 * dd.n * dd.ho * dd.wo * cin * cout * dd.ntaps,
+                    self.profile_meta.append(("bwd", self.bwd[-1], self._kname(dd), 2.0 * dd.n * dd.ho * dd.wo * cin * cout * dd.ntaps,
                                               (dd.n * dd.ho * dd.wo * x.c + y.pixels * y.c / (s * s)) * self.es))
         blk.append(emit)
 
@@ -444,8 +467,8 @@ class Plan:
             self._stats_for(y, [d])
             stats_ptr = y.stats
         flops = 2.0 * y.pixels * cout * 3 * k * k
-        self._igemm(self.fwd, d, img, pack, ybuf, None, bias, stats_ptr, nd["w"] + " stem fwd")
-        self.profile_meta.append(("fwd", len(self.fwd) - 1, self._kname(d), flops, (x.pixels * 4 + y.pixels * y.c) * self.es))
+        self._igemm(self.fwd, d, img, pack, ybuf, None, bias, stats_ptr, nd["w"] + " stem fwd", produces=y)
+        self.profile_meta.append(("fwd", self.fwd[-1], self._kname(d), flops, (x.pixels * 4 + y.pixels * y.c) * self.es))
         if not self.with_bwd:
             return
         self._ws_wgrad = max(self._ws_wgrad, self.lib.lh_wgrad_slab_bytes(C.byref(d), y.c, kr, self.dt))
@@ -457,7 +480,7 @@ class Plan:
             dy = self._act_grad(y)
             a = [C.byref(d), img.data_ptr(), dy.data_ptr(), y.c, y.c, kr, 0, self.dt]
             b = [C.byref(d), 0, gstage.data_ptr(), cout, kr, k * kr, 1, kr, 0, rs_arr, 0, self.dt]
-            cw, cr = _Call(self.lib.lh_wgrad, None, "stem wgrad"), _Call(self.lib.lh_wgrad_reduce, None, "stem wgrad reduce", keep=rs_arr)
+            cw, cr = _Call(self.lib.lh_wgrad, None, "stem wgrad", lane=1), _Call(self.lib.lh_wgrad_reduce, None, "stem wgrad reduce", keep=rs_arr, lane=1)
 
             def set_ws(ptr):
                 a[6] = ptr
@@ -465,9 +488,9 @@ class Plan:
                 cw.args, cr.args = tuple(a), tuple(b)
             self._ws_users.append(set_ws)
             self.bwd.append(cw)
-            self.profile_meta.append(("bwd", len(self.bwd) - 1, self._kname(d, (y.c, kr)), flops, (x.pixels * 4 + y.pixels * y.c) * self.es))
+            self.profile_meta.append(("bwd", self.bwd[-1], self._kname(d, (y.c, kr)), flops, (x.pixels * 4 + y.pixels * y.c) * self.es))
             self.bwd.append(cr)
-            self.bwd.append(_TorchCall(lambda: gw.copy_(gstage[:, :, :k, :3].permute(0, 3, 1, 2)), "stem grad unstage"))
+            self.bwd.append(_TorchCall(lambda: gw.copy_(gstage[:, :, :k, :3].permute(0, 3, 1, 2)), "stem grad unstage", lane=1))
         blk.append(emit)
 
     # ---- transposed convolution ------------------------------------------------------------------
@@ -494,10 +517,10 @@ class Plan:
         if id(y) in self._bn_inputs and self.training:
             offs = self._stats_for(y, descs)
         for d, pk, off in zip(descs, packs, offs):
-            self.keep.append(d)
             st = 0 if off is None else y.stats.data_ptr() + off
-            self.fwd.append(_Call(self.lib.lh_igemm, (C.byref(d), xbuf.data_ptr(), pk.data_ptr(), ybuf.data_ptr(), 0, _ptr(bias), st, self.dt), nd["w"] + " deconv fwd"))
-            self.profile_meta.append(("fwd", len(self.fwd) - 1, self._kname(d), 2.0 * d.n * d.ho * d.wo * cin * cout * d.ntaps,
+            c = self._igemm(self.fwd, d, xbuf, pk, ybuf, None, bias, None, nd["w"] + " deconv fwd", produces=y)
+            self._patch(c, stats=st)
+            self.profile_meta.append(("fwd", self.fwd[-1], self._kname(d), 2.0 * d.n * d.ho * d.wo * cin * cout * d.ntaps,
                                       (x.pixels * x.c + y.pixels * y.c / 4) * self.es))
         if not self.with_bwd:
             return
@@ -515,7 +538,7 @@ class Plan:
             dy = self._act_grad(y)
             a = [C.byref(dg), dy.data_ptr(), xbuf.data_ptr(), x.c, cin, cout, 0, self.dt]
             b = [C.byref(dg), 0, gw.data_ptr(), cin, cout, cout * k * k, k * k, k, 1, rs_arr, 0, self.dt]
-            cw, cr = _Call(self.lib.lh_wgrad, None, nd["w"] + " wgrad"), _Call(self.lib.lh_wgrad_reduce, None, nd["w"] + " wgrad reduce", keep=rs_arr)
+            cw, cr = _Call(self.lib.lh_wgrad, None, nd["w"] + " wgrad", lane=1), _Call(self.lib.lh_wgrad_reduce, None, nd["w"] + " wgrad reduce", keep=rs_arr, lane=1)
 
             def set_ws(ptr):
                 a[6] = ptr
@@ -523,7 +546,7 @@ class Plan:
                 cw.args, cr.args = tuple(a), tuple(b)
             self._ws_users.append(set_ws)
             self.bwd.append(cw)
-            self.profile_meta.append(("bwd", len(self.bwd) - 1, self._kname(dg, (cin, cout)), flops, (x.pixels * x.c + y.pixels * y.c) * self.es))
+            self.profile_meta.append(("bwd", self.bwd[-1], self._kname(dg, (cin, cout)), flops, (x.pixels * x.c + y.pixels * y.c) * self.es))
             self.bwd.append(cr)
             if nd["bias"]:
                 gb_ = self.grads[nd["bias"]]
@@ -532,7 +555,7 @@ class Plan:
                 dx = self._act_grad(x)
                 first = self._first_write(x)
                 self._igemm(self.bwd, dg, dy, gpack, dx, None if first else dx, None, None, nd["w"] + " deconv dgrad")
-                self.profile_meta.append(("bwd", len(self.bwd) - 1, self._kname(dg), flops, (x.pixels * x.c + y.pixels * y.c) * self.es))
+                self.profile_meta.append(("bwd", self.bwd[-1], self._kname(dg), flops, (x.pixels * x.c + y.pixels * y.c) * self.es))
         blk.append(emit)
 
     # ---- BatchNorm + sum + ReLU ------------------------------------------------------------------
@@ -565,8 +588,10 @@ class Plan:
                     P[bn + ".weight"].data_ptr(), P[bn + ".bias"].data_ptr(), P[bn + ".running_mean"].data_ptr(),
                     P[bn + ".running_var"].data_ptr(), BN_EPS, c, st["scale"].data_ptr(), st["shift"].data_ptr()), bn + " eval affine"))
         self.keep.append(fd)
+        if not self.training and self._fold_eval_bn(terms, bn_state, out, relu):
+            return
         self.fwd.append(_Call(self.lib.lh_fuse_fwd, (C.byref(fd), obuf.data_ptr(), out.n, out.h, out.w, c, self.dt), "fuse fwd"))
-        self.profile_meta.append(("fwd", len(self.fwd) - 1, "fuse_fwd_kernel", 0.0, (sum(a.pixels for a, _, _ in terms) + out.pixels) * c * self.es))
+        self.profile_meta.append(("fwd", self.fwd[-1], "fuse_fwd_kernel", 0.0, (sum(a.pixels for a, _, _ in terms) + out.pixels) * c * self.es))
         if not self.with_bwd:
             return
         self._ws_fuse = max(self._ws_fuse, self.lib.lh_fuse_bwd_workspace_bytes(out.n, out.h, out.w, c))
@@ -596,10 +621,44 @@ class Plan:
             def set_ws(ptr):
                 args[5] = ptr
                 call.args = tuple(args)
-            self._ws_users.append(set_ws)
+            self._ws_users_fuse.append(set_ws)
             self.bwd.append(call)
-            self.profile_meta.append(("bwd", len(self.bwd) - 1, "fuse_bwd(all kernels)", 0.0, 0.0))
+            self.profile_meta.append(("bwd", self.bwd[-1], "fuse_bwd(all kernels)", 0.0, 0.0))
         blk.append(emit)
+
+    def _fold_eval_bn(self, terms, bn_state, out, relu):
+        """Inference plans: BatchNorm uses running statistics, so `relu(BN(conv) [+ residual | + BN(conv_ds)])` is folded
+        into the producing convolution's epilogue (scale/shift on the fp32 accumulator, addend, ReLU) and the
+        elementwise pass disappears.  Returns False when the pattern does not apply (e.g. HRNet's upsampled terms)."""
+        if self.with_bwd or len(terms) > 2 or any(l for _, _, l in terms) or terms[0][1] is None:
+            return False
+        prods = [self._producers.get(id(a)) if bn else None for a, bn, _ in terms]
+        if prods[0] is None or (len(terms) == 2 and terms[1][1] is not None and prods[1] is None):
+            return False
+        # the eval-affine launches of this node were appended to self.fwd just above: they only depend on the
+        # weights, so they move to the pack list (run when weights change, not per forward)
+        n_aff = sum(1 for _, bn, _ in terms if bn is not None)
+        self.packs += self.fwd[-n_aff:]
+        del self.fwd[-n_aff:]
+        obuf = out.buf.data_ptr()
+        main, st0 = prods[0], bn_state[0]
+        addend = 0
+        if len(terms) == 2:
+            res_act, res_bn, _ = terms[1]
+            addend = res_act.buf.data_ptr()
+            if res_bn is not None:                # projection shortcut: BN folded into ITS conv, written in place
+                st1 = bn_state[1]
+                for c in prods[1]:
+                    self._patch(c, relu=0, scale=st1["scale"].data_ptr(), shift=st1["shift"].data_ptr())
+                # the shortcut must be complete before the main conv adds it
+                last_res = max(self.fwd.index(c) for c in prods[1])
+                for c in main:
+                    i = self.fwd.index(c)
+                    if i < last_res:
+                        self.fwd.insert(last_res, self.fwd.pop(i))
+        for c in main:
+            self._patch(c, relu=relu, dst=obuf, addend=addend, scale=st0["scale"].data_ptr(), shift=st0["shift"].data_ptr())
+        return True
 
     def _c_maxpool(self, nd, blk):
         x, y = nd["x"], nd["y"]
@@ -624,9 +683,32 @@ class Plan:
         for c in self.fwd:
             c(stream)
 
-    def run_backward(self, stream):
-        for c in self.bwd:
-            c(stream)
+    def run_backward(self, stream, lo=0, hi=None, side=None):
+        """Run bwd[lo:hi].  With ``side`` (a torch stream) the weight-gradient launches (lane 1) go to that stream:
+        each waits for the main-stream work enqueued before it (its dy) and the main stream joins at the end, so
+        the data-gradient chain and the weight-gradient chain overlap (also inside a captured hipGraph)."""
+        calls = self.bwd[lo:hi]
+        if side is None:
+            for c in calls:
+                c(stream)
+            return
+        main = torch.cuda.current_stream()
+        sptr = side.cuda_stream
+        pending = False
+        for c in calls:
+            if c.lane == 1:
+                if not pending:                 # first side launch after main-stream work: order it behind that work
+                    side.wait_stream(main)
+                    pending = True
+                if isinstance(c, _TorchCall):
+                    with torch.cuda.stream(side):
+                        c(sptr)
+                else:
+                    c(sptr)
+            else:
+                c(stream)
+                pending = False
+        main.wait_stream(side)
 
     def forward(self, images, repack=True):
         """images: fp32 NCHW on the device.  Returns the plan's fp32 NCHW heatmap buffer."""

@@ -141,7 +141,9 @@ class HipModule(nn.Module):
         if not x.is_cuda:
             raise _lib.LightHandError("input must live on the HIP device (images.cuda() as in the reference loop)")
         n, _, h, w = x.shape
-        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        # gradients flow only in train mode (batch-statistics BN), as in the reference's loops; an eval-mode
+        # forward is inference (running statistics folded into the conv epilogues) and returns a plain tensor
+        need_grad = self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         plan = self.plan(n, h, w, training=self.training, backward=need_grad)
         if need_grad:
             return _ModelFn.apply(self, plan, x, *self.parameters())

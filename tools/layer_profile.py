@@ -20,7 +20,7 @@ step = TrainStep(model, args.batch, args.size, args.size, use_graph=False)
 images, joints = bench.synthetic_batch(args.batch, args.size, "cuda")
 step.images.copy_(images); step.joints.copy_(joints)
 plan = step.plan
-meta = {(w, i): (n, f, b) for w, i, n, f, b in plan.profile_meta}
+meta = {id(c): (n, f, b) for w, c, n, f, b in plan.profile_meta}
 stream = torch.cuda.current_stream(); s = stream.cuda_stream
 rows = []
 for it in range(3):
@@ -30,7 +30,7 @@ for it in range(3):
         if which == "bwd":
             step._fwd_loss_tail(s)
         for i, call in enumerate(lst):
-            m = meta.get((which, i))
+            m = meta.get(id(call))
             if m is None and not args.all:
                 call(s); continue
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
