@@ -25,10 +25,13 @@ def init_distributed(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
+            backend = os.environ.get("LH_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
+            local = local % max(torch.cuda.device_count(), 1)      # rehearsals may put several ranks on one GPU (gloo)
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    if torch.cuda.is_available():
+        local = local % max(torch.cuda.device_count(), 1)
     return rank, world, local
 
 
