@@ -15,6 +15,7 @@
 //  * epilogue through LDS: bias, then full-line NHWC stores with optional addend / ReLU,
 //    and per-block column sums / sums of squares of the STORED values for BatchNorm.
 #include "common.h"
+#include <stdlib.h>
 
 #include "igemm_args.h"
 
@@ -288,7 +289,9 @@ extern "C" int lh_igemm_tile(const lh_igemm_desc* d, int dtype, int* bm, int* bp
     if (lh_ring_supported(d, dtype)) {          // encodes K bytes per stage and ring depth: kb * 10 + depth
         const int es = lh_dtype_size(dtype), kb = lh_ring_kb();
         const int steps = d->ntaps * ((d->k_run * es + kb - 1) / kb);
-        *ring = kb * 10 + ((kb == 64 && steps <= 4) ? 2 : 4);
+        const char* e2 = getenv("LH_RING_T2"); const char* e3 = getenv("LH_RING_T3");
+        const int t2 = e2 ? atoi(e2) : 4, t3 = e3 ? atoi(e3) : 0;
+        *ring = kb * 10 + (kb != 64 ? 4 : steps <= t2 ? 2 : steps <= t3 ? 3 : 4);
     }
     return LH_OK;
 }

@@ -379,9 +379,11 @@ int lh_ring_kb() {
 
 template <typename T, int KB, int D>
 static int ring_dispatch(const IgemmArgs& a, int bm, int bp, hipStream_t s) {
-    if constexpr (sizeof(T) == 2 && KB == 64 && D == 4) {
-        // 128 x 256 tile: each wave owns 64 x 128 (32 MFMAs per K step), 3-stage ring = 72 KiB -> two workgroups per CU
-        if (bm == 128 && bp == 256) return launch_ring<T, 128, 256, 2, 2, 3, KB>(a, s);
+    if (bm == 128 && bp == 256) {
+        // 128 x 256 tile: each wave owns 64 x 128 (32 MFMAs per K step), 3-stage ring = 72 KiB -> two workgroups per CU.
+        // The tile choice (and the stats-slab row count derived from it) must be honoured whatever depth was asked for.
+        if constexpr (sizeof(T) == 2 && KB == 64) return launch_ring<T, 128, 256, 2, 2, 3, KB>(a, s);
+        else { lh_set_error("igemm_ring: 128x256 tile is 16-bit / 64-byte-step only"); return LH_ERR_UNSUPPORTED; }
     }
     if (bm == 128 && bp == 128) {
         if constexpr (sizeof(T) == 4) return launch_ring<T, 128, 64, 4, 1, D, KB>(a, s);
@@ -398,7 +400,10 @@ int lh_ring_depth(const IgemmArgs& a) {
     static int forced = -1;
     if (forced < 0) { const char* e = getenv("LH_RING_D"); forced = e ? atoi(e) : 0; }
     if (forced >= 2 && forced <= 4) return forced;
-    return a.ntaps * a.kspt <= 4 ? 2 : 4;
+    static int t2 = -1, t3 = -1;
+    if (t2 < 0) { const char* e = getenv("LH_RING_T2"); t2 = e ? atoi(e) : 4; e = getenv("LH_RING_T3"); t3 = e ? atoi(e) : 0; }
+    const int steps = a.ntaps * a.kspt;
+    return steps <= t2 ? 2 : steps <= t3 ? 3 : 4;
 }
 
 int lh_igemm_ring_launch(const IgemmArgs& a, int bm, int bp, int dtype, hipStream_t s) {
