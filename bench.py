@@ -31,9 +31,13 @@ PEAK_BF16_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA
 PEAK_HBM_GBS = 8000.0
 
 
-def build_model(depth=50, precision="bf16"):
+def build_model(depth=50, precision="bf16", hrnet_width=0):
     import types
     from lighthand_amd.modeling.simplebaseline.pose_resnet import get_pose_net
+    if hrnet_width:
+        from lighthand_amd.modeling.hrnet.pose_hrnet import get_hrnet, hrnet_cfg
+        torch.manual_seed(9001)
+        return get_hrnet(hrnet_cfg(hrnet_width), True).cuda().set_precision(precision)
     ns = types.SimpleNamespace
     extra = ns(NUM_LAYERS=depth, DECONV_WITH_BIAS=False, NUM_DECONV_LAYERS=3, NUM_DECONV_FILTERS=[256] * 3,
                NUM_DECONV_KERNELS=[4] * 3, FINAL_CONV_KERNEL=1)
@@ -137,6 +141,8 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--hrnet-width", type=int, default=0, help="benchmark HRNet-W<width> instead of SimpleBaseline (configs[3])")
+    ap.add_argument("--infer-only", action="store_true", help="inference graph only (configs[4]: --size 384 --batch 256 --precision fp16)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -150,7 +156,27 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    model = build_model(args.depth, args.precision)
+    model = build_model(args.depth, args.precision, args.hrnet_width)
+    name = f"HRNet-W{args.hrnet_width}" if args.hrnet_width else f"SimpleBaseline-ResNet{args.depth}"
+    if args.infer_only:
+        images, _ = synthetic_batch(args.batch, args.size, dev, seed=9001 + rank)
+        model.eval()
+        inf = InferStep(model, args.batch, args.size, args.size)
+        inf.images.copy_(images)
+        for _ in range(args.warmup):
+            inf()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            inf()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print(json.dumps({"metric": METRIC, "value": round(args.batch * args.steps / dt, 1), "unit": "images/s", "n_gpus": 1,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+                          "config": {"workload": f"{name} {args.size}x{args.size} inference (eval-mode forward, BN folded, + argmax decode), "
+                                                 f"batch {args.batch}, hipGraph replay"}}))
+        return
     sync = parallel.GradSync(world) if world > 1 else None
     step = TrainStep(model, args.batch, args.size, args.size, lr=1e-3, use_graph=not args.no_graph, grad_sync=sync)
     images, joints = synthetic_batch(args.batch, args.size, dev, seed=9001 + rank)
@@ -182,7 +208,7 @@ def main():
         "metric": METRIC, "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-        "config": {"workload": f"SimpleBaseline-ResNet{args.depth} {args.size}x{args.size} training step "
+        "config": {"workload": f"{name} {args.size}x{args.size} training step "
                                f"(fwd + JointsMSELoss + argmax decode + bwd + Adam), batch {args.batch}/GPU, 21 joints, "
                                f"random init (seed 9001), hipGraph replay" + (f", dp{world} RCCL all-reduce" if world > 1 else ""),
                    "global_batch": world * args.batch, "parallelism": f"dp{world}"},

@@ -81,6 +81,24 @@ int lh_pack_chunk_elems(void);
 int lh_pack_weights_multi(const lh_pack_item* items_dev, const int* chunk_item_dev, const long* chunk_start_dev,
                           int n_chunks, int dtype, void* stream);
 
+/* Regular weight tensors w[d0][d1][kH*kW] (Conv2d: d0 = C_out, d1 = C_in; ConvTranspose2d: d0 = C_in, d1 = C_out):
+ * every pack of every such tensor in one launch, through 32 x 32 x taps LDS tiles (coalesced reads, 64-byte writes).
+ * A pack is [rows pad128][ntaps][kpad] with rows = d1 (row_is_d1) or d0; taps[] index kH*kW positions (r*kW + s).
+ * Padding of the pack images must be zero beforehand (it is never written).  chunk tables (device int32): chunk j
+ * handles tile (t0[j], t1[j]) (units of 32) of tensor conv[j]. */
+typedef struct {
+    void* out;
+    int row_is_d1, ntaps, kpad, pad_;
+    int taps[16];
+} lh_pack_out;
+typedef struct {
+    const float* w;
+    int d0, d1, rs, npacks;
+    lh_pack_out packs[5];
+} lh_pack_conv;
+int lh_pack_weights_tiled(const lh_pack_conv* convs_dev, const int* chunk_conv_dev, const int* chunk_t0_dev,
+                          const int* chunk_t1_dev, int n_chunks, int max_rs, int dtype, void* stream);
+
 /* ------------------------------------------------------------------ convolutions
  * nn.Conv2d(..., bias=False) + the head conv with bias: pose_resnet.py:23-26,66-72,152,
  * 169-175,181-182; pose_hrnet.py:22-25,65-71,145-149,200-204,218-222,230-234,282-286,

@@ -42,6 +42,16 @@ class PackItem(C.Structure):
                 ("r", C.c_byte * 64), ("s", C.c_byte * 64)]
 
 
+class PackOut(C.Structure):
+    _fields_ = [("out", C.c_void_p), ("row_is_d1", C.c_int), ("ntaps", C.c_int), ("kpad", C.c_int), ("pad_", C.c_int),
+                ("taps", C.c_int * 16)]
+
+
+class PackConv(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("d0", C.c_int), ("d1", C.c_int), ("rs", C.c_int), ("npacks", C.c_int),
+                ("packs", PackOut * 5)]
+
+
 _P, _I, _L, _F, _SZ = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
 
 # name -> (restype, argtypes); every symbol include/lighthand_hip.h declares
@@ -55,6 +65,7 @@ SIGNATURES = {
     "lh_pack_weight": (_I, [_P, _P, C.POINTER(_SZ), _I, _I, _L, _L, _L, _L, _I, C.POINTER(_I), _I, _P]),
     "lh_pack_chunk_elems": (_I, []),
     "lh_pack_weights_multi": (_I, [_P, _P, _P, _I, _I, _P]),
+    "lh_pack_weights_tiled": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "lh_igemm": (_I, [C.POINTER(IgemmDesc), _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "lh_igemm_tile": (_I, [C.POINTER(IgemmDesc), _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "lh_wgrad_tile": (_I, [C.POINTER(IgemmDesc), _I, _I, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),

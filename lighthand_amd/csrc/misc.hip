@@ -183,6 +183,59 @@ extern "C" int lh_pack_weights_multi(const lh_pack_item* items_dev, const int* c
     return LH_OK;
 }
 
+// Transposing pack for regular weight tensors w[d0][d1][rs] (Conv2d: d0 = C_out, d1 = C_in; ConvTranspose2d:
+// d0 = C_in, d1 = C_out): one workgroup reads a 32 x 32 x rs tile with fully coalesced loads (the strided
+// per-element gather of pack_weight_multi_kernel over-fetches ~16x, profiles/r01_pmc_hbm_traffic.txt), keeps it in
+// LDS and writes every pack that needs it -- "row = d0" packs [d0][tap][d1] and "row = d1" packs [d1][tap][d0] --
+// in 64-byte runs.  Pack padding (rows >= n, K >= n_in) is zeroed once at allocation and never written.
+template <typename T>
+__global__ __launch_bounds__(256) void pack_tiled_kernel(const lh_pack_conv* convs, const int* chunk_conv, const int* chunk_t0,
+                                                         const int* chunk_t1) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
+    T* tile = reinterpret_cast<T*>(psm);                         // [32 d0][32 d1][rs] (+1 pad per d0 row)
+    const lh_pack_conv& c = convs[chunk_conv[blockIdx.x]];
+    const int t0 = chunk_t0[blockIdx.x] * 32, t1 = chunk_t1[blockIdx.x] * 32;
+    const int rs = c.rs;
+    const int rowlen = 32 * rs;                                  // contiguous floats per d0 row of the tile
+    const int ld = rowlen + 2;                                   // LDS row stride in elements
+    for (int i = threadIdx.x; i < 32 * rowlen; i += 256) {
+        const int a = i / rowlen, rem = i - a * rowlen;          // a = d0 offset, rem = d1_off * rs + tap
+        const int d0 = t0 + a, d1 = t1 + rem / rs;
+        float v = 0.f;
+        if (d0 < c.d0 && d1 < c.d1) v = c.w[((long)d0 * c.d1 + t1) * rs + rem];
+        tile[a * ld + rem] = from_f<T>(v);
+    }
+    __syncthreads();
+    for (int p = 0; p < c.npacks; ++p) {
+        const lh_pack_out& o = c.packs[p];
+        T* out = reinterpret_cast<T*>(o.out);
+        const int total = o.ntaps * 32 * 32;
+        for (int i = threadIdx.x; i < total; i += 256) {
+            const int k = i & 31, rest = i >> 5;                 // k runs along the pack's K (fastest in memory)
+            const int t = rest % o.ntaps, row = rest / o.ntaps;
+            const int tap = o.taps[t];
+            int a, b;                                            // a = d0 offset, b = d1 offset inside the tile
+            if (o.row_is_d1) { b = row; a = k; } else { a = row; b = k; }
+            const int grow = (o.row_is_d1 ? t1 : t0) + row, gk = (o.row_is_d1 ? t0 : t1) + k;
+            const int nrow = o.row_is_d1 ? c.d1 : c.d0, nk = o.row_is_d1 ? c.d0 : c.d1;
+            if (grow < nrow && gk < nk) out[((long)grow * o.ntaps + t) * o.kpad + gk] = tile[a * ld + b * rs + tap];
+        }
+    }
+}
+
+extern "C" int lh_pack_weights_tiled(const lh_pack_conv* convs_dev, const int* chunk_conv_dev, const int* chunk_t0_dev,
+                                     const int* chunk_t1_dev, int n_chunks, int max_rs, int dtype, void* stream) {
+    LH_REQUIRE(convs_dev && chunk_conv_dev && chunk_t0_dev && chunk_t1_dev && n_chunks > 0 && max_rs > 0 && max_rs <= 49,
+               "lh_pack_weights_tiled: bad arguments");
+    const int es = lh_dtype_size(dtype);
+    const size_t lds = (size_t)32 * (32 * max_rs + 2) * es;
+    LH_REQUIRE(lds <= 64 * 1024, "lh_pack_weights_tiled: tile of %d taps does not fit LDS for this dtype", max_rs);
+    LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((pack_tiled_kernel<T>), dim3(n_chunks), dim3(256), lds, (hipStream_t)stream,
+                                                   convs_dev, chunk_conv_dev, chunk_t0_dev, chunk_t1_dev));
+    LH_LAUNCH_CHECK("pack_weights_tiled launch");
+    return LH_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ Gaussian target
 __global__ void gaussian_target_kernel(const float* joints, int jstride, const float* patch, int radius, float* target,
                                        int bj, int size) {

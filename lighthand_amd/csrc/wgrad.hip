@@ -406,6 +406,11 @@ static void wgrad_plan(const lh_igemm_desc* d, int n_out, int n_in, int dtype, i
     long max_split = (steps + 7) / 8;                // at least 8 K steps per block
     if (max_split > 128) max_split = 128;            // bound the slab traffic of the fold
     if (want > max_split) want = max_split;
+    // every split writes (and the fold re-reads) a full fp32 copy of the weight tensor: keep the slab <= ~24 MiB
+    const long per_split_bytes = (long)n_out * n_in * d->ntaps * 4;
+    long by_bytes = (24L << 20) / (per_split_bytes > 0 ? per_split_bytes : 1);
+    if (by_bytes < 1) by_bytes = 1;
+    if (want > by_bytes && tiles * by_bytes >= 256) want = by_bytes;
     if (want < 1) want = 1;
     const long sps = (steps + want - 1) / want;
     *steps_per_split = (int)sps;

@@ -191,6 +191,7 @@ class Plan:
         self.out_act = gb.out
         self.fwd, self.bwd, self.packs = [], [], []
         self._pack_items = []
+        self._pack_convs = {}              # id(weight) -> PackConv (LDS-tiled transposing pack)
         self._producers = {}               # id(raw conv output Act) -> the igemm calls that write it (eval-mode BN folding)
         self.keep = []                     # ctypes objects / tensors referenced by raw pointer
         self._ws_wgrad = 0
@@ -223,7 +224,9 @@ class Plan:
         nbytes = C.c_size_t(0)
         arr = _taps_array(taps_rs)
         check(self.lib.lh_pack_weight(None, None, C.byref(nbytes), n_out, n_in, *strides, len(taps_rs), arr, self.dt, None), what)
-        buf = self._alloc(max(nbytes.value, 16), dtype=torch.uint8)
+        buf = self._alloc(max(nbytes.value, 16), dtype=torch.uint8, zero=True)     # padding stays zero for ever
+        if taps_rs and self._pack_regular(wt, buf, n_out, n_in, strides, taps_rs):
+            return buf
         if taps_rs:
             it = _lib.PackItem()
             it.w, it.out, it.n_out, it.n_in, it.ntaps = wt.data_ptr(), buf.data_ptr(), n_out, n_in, len(taps_rs)
@@ -236,6 +239,37 @@ class Plan:
 
     # positions of lh_igemm's arguments inside a _Call.args tuple
     _IG = dict(desc=0, src=1, pack=2, dst=3, addend=4, bias=5, scale=6, shift=7, stats=8)
+
+    def _pack_regular(self, wt, buf, n_out, n_in, strides, taps_rs):
+        """Queue a pack of a plain [d0][d1][kH][kW] weight tensor for the LDS-tiled transposing pack kernel.
+        Returns False when the tensor / strides are not of that form (the stem's staged image, oversize taps)."""
+        if wt.dim() != 4 or not wt.is_contiguous() or len(taps_rs) > 16:
+            return False
+        d0, d1, r, s = wt.shape
+        rs = r * s
+        if 32 * (32 * rs + 2) * self.es > 64 * 1024:
+            return False
+        if tuple(strides) == (d1 * rs, rs, s, 1) and (n_out, n_in) == (d0, d1):
+            row_is_d1 = 0
+        elif tuple(strides) == (rs, d1 * rs, s, 1) and (n_out, n_in) == (d1, d0):
+            row_is_d1 = 1
+        else:
+            return False
+        conv = self._pack_convs.get(id(wt))
+        if conv is None:
+            conv = _lib.PackConv()
+            conv.w, conv.d0, conv.d1, conv.rs, conv.npacks = wt.data_ptr(), d0, d1, rs, 0
+            self._pack_convs[id(wt)] = conv
+            self.keep.append(wt)
+        if conv.npacks >= 5:
+            return False
+        o = conv.packs[conv.npacks]
+        kstep = 128 // self.es
+        o.out, o.row_is_d1, o.ntaps, o.kpad = buf.data_ptr(), row_is_d1, len(taps_rs), (n_in + kstep - 1) // kstep * kstep
+        for i, (rr, ss) in enumerate(taps_rs):
+            o.taps[i] = rr * s + ss
+        conv.npacks += 1
+        return True
 
     def _igemm(self, lst, d, src, pack, dst, addend, bias, stats, what, flops=0, produces=None):
         self.keep.append(d)
@@ -321,6 +355,20 @@ class Plan:
             self.keep += [table, t_item, t_start]
             self.packs.append(_Call(self.lib.lh_pack_weights_multi,
                                     (table.data_ptr(), t_item.data_ptr(), t_start.data_ptr(), len(c_item), self.dt), "weight packs"))
+        if self._pack_convs:       # regular conv / deconv weights: one launch of the tiled transposing pack kernel
+            convs = list(self._pack_convs.values())
+            arr = (_lib.PackConv * len(convs))(*convs)
+            table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+            c_conv, c_t0, c_t1 = [], [], []
+            for i, cv in enumerate(convs):
+                for a in range((cv.d0 + 31) // 32):
+                    for b in range((cv.d1 + 31) // 32):
+                        c_conv.append(i); c_t0.append(a); c_t1.append(b)
+            tabs = [torch.tensor(v, dtype=torch.int32, device=self.device) for v in (c_conv, c_t0, c_t1)]
+            self.keep += [table] + tabs
+            self.packs.append(_Call(self.lib.lh_pack_weights_tiled,
+                                    (table.data_ptr(), tabs[0].data_ptr(), tabs[1].data_ptr(), tabs[2].data_ptr(), len(c_conv),
+                                     max(cv.rs for cv in convs), self.dt), "weight packs (tiled)"))
         self.bwd_marks = []        # (end index in self.bwd, parameter names whose gradient is final there)
         if self.with_bwd:
             for (kind, nd), blk in zip(reversed(self.nodes), reversed(bwd_blocks)):
