@@ -71,22 +71,32 @@ __global__ __launch_bounds__(256) void igemm_ring_kernel(const IgemmArgs p) {
 
     // ---- per-lane source bookkeeping.  Instruction q = 4*j + wave of a stage fills (16-row group,
     //      half) = (q / H, q % H); this lane supplies chunk c = 4*half + (lane>>4) of row (lane&15)^2c.
-    int xbase[NX], xh[NX], xw[NX], xc[NX];
-    bool xok[NX];
+    //      Everything that depends on the lane is folded ONCE into a 64-bit byte offset (tap (0,0), k = 0) and a
+    //      bit mask of the taps that fall inside the image; per K step only a wave-uniform offset is added.
+    long pbase[NX];
+    unsigned hmask[NX], wmask[NX];          // bit ti / tj set when tap row ti / column tj stays inside the image
+    int xc[NX];
+    const int th = p.ntaps / p.tw;
 #pragma unroll
     for (int j = 0; j < NX; ++j) {
         const int q = 4 * j + wave;
         const int g = q / H, c = 4 * (q % H) + (lane >> 4);
         const int row = g * 16 + ((lane & 15) ^ ((2 * c) & 15));
         const int m = pblk * BP + row;
-        xok[j] = m < p.M;
-        const int mm = xok[j] ? m : 0;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
         const int n = mm / hw, rem = mm - n * hw;
         const int a = rem / p.wo, b = rem - a * p.wo;
-        xbase[j] = n * p.hi * p.wi;
-        xh[j] = a * p.sh;
-        xw[j] = b * p.sw;
+        const int ih0 = a * p.sh, iw0 = b * p.sw;
         xc[j] = c * EPC;
+        pbase[j] = ((long)(n * p.hi * p.wi + ih0 * p.wi + iw0) * p.in_pix_stride + xc[j]) * ES;
+        unsigned hm = 0, wm = 0;
+        for (int ti = 0, dh = p.dh0; ti < th; ++ti, dh += p.dhs)
+            if (ok && (unsigned)(ih0 + dh) < (unsigned)p.hi) hm |= 1u << ti;
+        for (int tjj = 0, dw = p.dw0; tjj < p.tw; ++tjj, dw += p.dws)
+            if ((unsigned)(iw0 + dw) < (unsigned)p.wi) wm |= 1u << tjj;
+        hmask[j] = hm;
+        wmask[j] = wm;
     }
     const long kpad = p.kpad;
     const unsigned char* wsrc[NW];
@@ -99,26 +109,37 @@ __global__ __launch_bounds__(256) void igemm_ring_kernel(const IgemmArgs p) {
     }
     const unsigned char* zero = reinterpret_cast<const unsigned char*>(lh_zero_page);
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const bool ktail = (p.k_run % KSTEP) != 0;           // only then a chunk can lie past k_run
 
-    auto issue = [&](int tap, int kc, int slot, int dh, int dw) {
-        unsigned char* st = smem + slot * STAGE;
-        const long woff = ((long)tap * kpad + (long)kc * KSTEP) * ES;
+    // stage index -> (tap, kc) is tracked incrementally; `woff` is the byte offset of the stage inside a weight
+    // row (stages are contiguous there), `toff` the activation byte offset of the tap + K step.
+    int itap = 0, ikc = 0, tj = 0, ti = 0, cdh = p.dh0, cdw = p.dw0;
+    unsigned issued = 0;
+    long woff = 0;
+    auto issue = [&]() {
+        unsigned char* st = smem + (issued % D) * STAGE;
 #pragma unroll
         for (int j = 0; j < NW; ++j) {
             const int q = 4 * j + wave;
-            unsigned char* dst = st + (q / H) * GB + (q % H) * 1024;
-            __builtin_amdgcn_global_load_lds((gbl_void_p)(wsrc[j] + woff), (lds_void_p)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void_p)(wsrc[j] + woff), (lds_void_p)(st + (q / H) * GB + (q % H) * 1024), 16, 0, 0);
         }
-        const int kbase = kc * KSTEP;
+        const long toff = ((long)(cdh * p.wi + cdw) * p.in_pix_stride + ikc * KSTEP) * ES;
+        const int kbase = ikc * KSTEP;
 #pragma unroll
         for (int j = 0; j < NX; ++j) {
             const int q = 4 * j + wave;
-            unsigned char* dst = st + BM * KB + (q / H) * GB + (q % H) * 1024;
-            const int ih = xh[j] + dh, iw = xw[j] + dw, koff = kbase + xc[j];
-            const bool ok = (int)xok[j] & (int)((unsigned)ih < (unsigned)p.hi) & (int)((unsigned)iw < (unsigned)p.wi) & (int)(koff < p.k_run);
-            const unsigned char* src = p.in + ((long)(xbase[j] + ih * p.wi + iw) * p.in_pix_stride + koff) * ES;
-            src = ok ? src : zero;                      // select, not a branch: every lane issues the load
-            __builtin_amdgcn_global_load_lds((gbl_void_p)src, (lds_void_p)dst, 16, 0, 0);
+            bool ok = (((hmask[j] >> ti) & (wmask[j] >> tj)) & 1u) != 0;
+            if (ktail) ok = ok && (kbase + xc[j] < p.k_run);
+            const unsigned char* src = ok ? p.in + pbase[j] + toff : zero;     // select: every lane issues the load
+            __builtin_amdgcn_global_load_lds((gbl_void_p)src, (lds_void_p)(st + BM * KB + (q / H) * GB + (q % H) * 1024), 16, 0, 0);
+        }
+        ++issued;
+        woff += KB;
+        if (++ikc == p.kspt) {
+            ikc = 0; ++itap;
+            woff = (long)itap * kpad * ES;
+            cdw += p.dws;
+            if (++tj == p.tw) { tj = 0; ++ti; cdw = p.dw0; cdh += p.dhs; }
         }
     };
 
@@ -129,24 +150,9 @@ __global__ __launch_bounds__(256) void igemm_ring_kernel(const IgemmArgs p) {
         for (int j = 0; j < PT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int S = p.ntaps * p.kspt;
-    int itap = 0, ikc = 0;                       // (tap, kc) of the next stage to issue
-    int tj = 0, cdh = p.dh0, cdw = p.dw0;        // the tap's (dh, dw), advanced without memory loads
-    int issued = 0;
-    auto advance = [&]() {
-        ++issued;
-        if (++ikc == p.kspt) {
-            ikc = 0; ++itap;
-            cdw += p.dws;
-            if (++tj == p.tw) { tj = 0; cdw = p.dw0; cdh += p.dhs; }
-        }
-    };
 #pragma unroll
-    for (int s = 0; s < D - 1; ++s) {
-        if (issued < S) {
-            issue(itap, ikc, issued % D, cdh, cdw);
-            advance();
-        }
-    }
+    for (int s = 0; s < D - 1; ++s)
+        if ((int)issued < S) issue();
     // fragment read offsets: chunk c = 4*kk + (lane>>4), row = lane&15
     int foff[KSUB];
 #pragma unroll
@@ -156,16 +162,19 @@ __global__ __launch_bounds__(256) void igemm_ring_kernel(const IgemmArgs p) {
     }
 
     for (int s = 0; s < S; ++s) {
-        // stage s must have landed; stages s+1 .. issued-1 may stay in flight
-        const int ahead = issued - 1 - s;
-        if (ahead >= 2) wait_vmcnt<2 * L>();
-        else if (ahead == 1) wait_vmcnt<L>();
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        if (issued < S) {
-            issue(itap, ikc, issued % D, cdh, cdw);
-            advance();
+        // stage s must have landed; stages s+1 .. issued-1 may stay in flight.  In the steady state (a stage is
+        // issued every iteration) that is always D-2 stages: one constant wait, no branches.
+        const bool steady = (int)issued < S;
+        if (steady) {
+            wait_vmcnt<(D - 2) * L>();
+        } else {
+            const int ahead = S - 1 - s;
+            if (D > 3 && ahead >= 2) wait_vmcnt<2 * L>();
+            else if (D > 2 && ahead == 1) wait_vmcnt<L>();
+            else wait_vmcnt<0>();
         }
+        __builtin_amdgcn_s_barrier();
+        if (steady) issue();
         // Fragment reads are inline asm: the compiler cannot tell LDS-DMA writes from these reads
         // and would otherwise drain the whole ring (s_waitcnt vmcnt(0)) in front of every ds_read.
         const unsigned st = lds_base + (s % D) * STAGE;

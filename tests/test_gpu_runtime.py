@@ -171,3 +171,27 @@ def test_train_cli_end_to_end(tmp_path, capsys):
     assert os.path.isfile(os.path.join(args.output_dir, "checkpoint-good", "state_dict.bin"))
     first = float(out.split("valid loss ")[1].split()[0])
     assert best <= first
+
+
+def test_eval_cli_writes_reference_formats(tmp_path):
+    """train -> checkpoint-good/state_dict.bin -> wearable_eval_2d: evaluation.json + three pck_eval_*.txt files whose
+    numbers equal the oracle's pred_eval on the stored predictions."""
+    import json
+    from lighthand_amd.tools import train as T
+    from lighthand_amd.tools import wearable_eval_2d as E
+    from oracle import metrics as om
+    args = T.parse_args(["--root_path", str(tmp_path), "--root", "simplebaseline/frei", "--name", "run1", "--synthetic", "16",
+                         "--val_synthetic", "8", "--batch_size", "8", "--epoch", "1", "--depth", "18", "--size", "64",
+                         "--precision", "fp32", "--reset"])
+    T.main(args)
+    files = E.main(["--root_path", str(tmp_path), "--model_path", "simplebaseline/frei", "--batch_size", "8", "--depth", "18",
+                    "--size", "64", "--synthetic", "20"])
+    assert len(files) == 3 and all(os.path.isfile(f) for f in files)
+    ev = json.load(open(os.path.join(str(tmp_path), "simplebaseline/frei/run1", "evaluation.json")))
+    assert isinstance(ev, list) and set(ev[0]) == set(E.CATEGORIES)
+    n = sum(len(v["bb"]) for v in ev[0].values())
+    assert n == 20 and all(len(p) == 21 for v in ev[0].values() for p in v["pred"])
+    want = om.pred_eval({k: v for k, v in ev[0].items() if v["bb"]}, [0.1, 0.3], "pckb")
+    line = [l for l in open(files[0]) if l.startswith("mean_auc;")][0].split(";")
+    assert line[1] == "simplebaseline/frei/run1"
+    assert abs(float(line[2]) - want["mean_auc"][0]) < 0.006 and abs(float(line[3]) - want["mean_auc"][1]) < 0.006
