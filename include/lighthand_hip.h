@@ -50,6 +50,11 @@ int lh_dtype_size(int dtype);
  * input format of the stem convolution kernel. */
 int lh_image_to_nhwc4(const float* nchw, void* out, int n, int h, int w, int pad, int wp,
                       int dtype, void* stream);
+/* Fused input pipeline (the CPU DataLoader work of src/tools/dataset.py:128-159 moved onto the device): uint8 HWC
+ * [n][hs][ws][3] -> /255 -> bilinear resize to h x w (half-pixel centres, no antialias) -> (x - mean)/std (HOST
+ * float[3] arrays) -> zero-padded NHWC4 in the run dtype, i.e. the stem's input format. */
+int lh_image_u8_to_nhwc4(const unsigned char* hwc, void* out, int n, int hs, int ws, int h, int w, int pad, int wp,
+                         const float* mean3, const float* std3, int dtype, void* stream);
 /* NHWC (run dtype) -> NCHW fp32 heatmaps (what model(images) returns, pose_resnet.py:246)
  * and the inverse for the incoming gradient. c_stride = channel stride of the NHWC side. */
 int lh_nhwc_to_nchw_f32(const void* nhwc, float* nchw, int n, int h, int w, int c, int c_stride,
@@ -237,6 +242,13 @@ int lh_mse_heatmap(const float* pred, const float* target, long numel, float* lo
  * idx int32 [b*j] (first-occurrence arg-max, NaN counts as maximum). */
 int lh_heatmap_argmax(const float* heatmaps, int bj, int h, int w, float scale, float* preds,
                       float* maxvals, int* idx, void* stream);
+
+/* Validation metrics of Runner.run (src/utils/method.py:243-250) on the device: per sample, wrong[b] = number of
+ * joints with error / bbox-diagonal(gt) > T (PCK_2d_loss 'proportion', src/utils/loss.py:116-148) and epe[b] = sum of
+ * the errors of joints 1..J-2 (EPE_train's joint range, src/utils/loss.py:50-67).  pred fp32 [b][j][2],
+ * gt fp32 [b][j][gt_stride]. */
+int lh_keypoint_metrics(const float* pred, const float* gt, int gt_stride, int b, int j, float T, int* wrong,
+                        float* epe, void* stream);
 
 /* ------------------------------------------------------------------ optimiser
  * torch.optim.Adam(lr, betas, eps, weight_decay=0).step(): src/tools/train.py:45-48,

@@ -60,6 +60,7 @@ SIGNATURES = {
     "lh_last_error": (C.c_char_p, []),
     "lh_dtype_size": (_I, [_I]),
     "lh_image_to_nhwc4": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "lh_image_u8_to_nhwc4": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _I, _P]),
     "lh_nhwc_to_nchw_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "lh_nchw_f32_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "lh_pack_weight": (_I, [_P, _P, C.POINTER(_SZ), _I, _I, _L, _L, _L, _L, _I, C.POINTER(_I), _I, _P]),
@@ -87,6 +88,7 @@ SIGNATURES = {
     "lh_mse_workspace_bytes": (_SZ, [_L]),
     "lh_mse_heatmap": (_I, [_P, _P, _L, _P, _P, _P, _P, _P]),
     "lh_heatmap_argmax": (_I, [_P, _I, _I, _I, _F, _P, _P, _P, _P]),
+    "lh_keypoint_metrics": (_I, [_P, _P, _I, _I, _I, _F, _P, _P, _P]),
     "lh_adam_step": (_I, [_P, _P, _P, _P, _L, _P, _P, _P, _F, _P]),
 }
 

@@ -54,6 +54,63 @@ extern "C" int lh_image_to_nhwc4(const float* nchw, void* out, int n, int h, int
     return LH_OK;
 }
 
+// Fused input pipeline: uint8 HWC image -> ToTensor (/255) -> bilinear Resize(h, w)
+// (half-pixel centres, no antialias: torchvision's tensor Resize when upsampling 224 -> 256) -> Normalize(mean, std)
+// -> zero-padded NHWC4 in the run dtype.  Reference CPU path: src/tools/dataset.py:128-159.
+struct U8Args {
+    const unsigned char* src;
+    void* dst;
+    int n, hs, ws, h, w, pad, hp, wp;
+    float mean[3], istd[3];
+};
+
+template <typename T>
+__global__ void image_u8_to_nhwc4_kernel(const U8Args p) {
+    const long total = (long)p.n * p.hp * p.wp;
+    const float sy = (float)p.hs / p.h, sx = (float)p.ws / p.w;
+    T* dst = (T*)p.dst;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % p.wp);
+        const long t = i / p.wp;
+        const int y = (int)(t % p.hp), b = (int)(t / p.hp);
+        const int oy = y - p.pad, ox = x - p.pad;
+        float v[3] = {0.f, 0.f, 0.f};
+        if ((unsigned)oy < (unsigned)p.h && (unsigned)ox < (unsigned)p.w) {
+            float fy = (oy + 0.5f) * sy - 0.5f, fx = (ox + 0.5f) * sx - 0.5f;
+            fy = fy < 0.f ? 0.f : fy;
+            fx = fx < 0.f ? 0.f : fx;
+            const int y0 = (int)fy, x0 = (int)fx;
+            const int y1 = y0 + 1 < p.hs ? y0 + 1 : p.hs - 1, x1 = x0 + 1 < p.ws ? x0 + 1 : p.ws - 1;
+            const float wy = fy - y0, wx = fx - x0;
+            const unsigned char* base = p.src + (long)b * p.hs * p.ws * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float a00 = base[((long)y0 * p.ws + x0) * 3 + c], a01 = base[((long)y0 * p.ws + x1) * 3 + c];
+                const float a10 = base[((long)y1 * p.ws + x0) * 3 + c], a11 = base[((long)y1 * p.ws + x1) * 3 + c];
+                const float top = a00 + (a01 - a00) * wx, bot = a10 + (a11 - a10) * wx;
+                const float pix = (top + (bot - top) * wy) * (1.f / 255.f);
+                v[c] = (pix - p.mean[c]) * p.istd[c];
+            }
+        }
+        T* o = dst + i * 4;
+        o[0] = from_f<T>(v[0]); o[1] = from_f<T>(v[1]); o[2] = from_f<T>(v[2]); o[3] = from_f<T>(0.f);
+    }
+}
+
+extern "C" int lh_image_u8_to_nhwc4(const unsigned char* hwc, void* out, int n, int hs, int ws, int h, int w, int pad, int wp,
+                                    const float* mean3, const float* std3, int dtype, void* stream) {
+    LH_REQUIRE(hwc && out && mean3 && std3 && n > 0 && hs > 0 && ws > 0 && h > 0 && w > 0 && pad >= 0 && wp >= w + 2 * pad,
+               "lh_image_u8_to_nhwc4: bad arguments");
+    U8Args a;
+    a.src = hwc; a.dst = out; a.n = n; a.hs = hs; a.ws = ws; a.h = h; a.w = w; a.pad = pad; a.hp = h + 2 * pad; a.wp = wp;
+    for (int c = 0; c < 3; ++c) { a.mean[c] = mean3[c]; a.istd[c] = 1.f / std3[c]; }
+    const long total = (long)n * a.hp * wp;
+    const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((image_u8_to_nhwc4_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a));
+    LH_LAUNCH_CHECK("image_u8_to_nhwc4 launch");
+    return LH_OK;
+}
+
 template <typename T>
 __global__ void nhwc_to_nchw_kernel(const T* src, float* dst, int n, int hw, int c, int cs) {
     const long total = (long)n * hw;
@@ -373,6 +430,47 @@ extern "C" int lh_heatmap_argmax(const float* heatmaps, int bj, int h, int w, fl
     hipLaunchKernelGGL(heatmap_argmax_kernel, dim3(bj), dim3(256), 0, (hipStream_t)stream, heatmaps, h * w, w, scale, preds,
                        maxvals, idx);
     LH_LAUNCH_CHECK("heatmap_argmax launch");
+    return LH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ validation metrics
+// PCK_2d_loss(T, 'proportion') + EPE_train on the device (src/utils/loss.py:50-67,116-148): one wave per
+// sample.  wrong[b] = #joints whose error / bbox-diagonal(gt) > T; epe[b] = sum of errors of joints 1..J-2 (the
+// reference's joint range quirk).  Sums over the batch are left to the caller (device tensors, no host sync).
+__global__ __launch_bounds__(64) void keypoint_metrics_kernel(const float* pred, const float* gt, int gt_stride, int j, float T,
+                                                              int* wrong, float* epe) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const float* g = gt + (long)b * j * gt_stride;
+    const float* p = pred + (long)b * j * 2;
+    float xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
+    for (int k = lane; k < j; k += 64) {
+        const float x = g[k * gt_stride], y = g[k * gt_stride + 1];
+        xmin = fminf(xmin, x); xmax = fmaxf(xmax, x); ymin = fminf(ymin, y); ymax = fmaxf(ymax, y);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        xmin = fminf(xmin, __shfl_xor(xmin, o)); xmax = fmaxf(xmax, __shfl_xor(xmax, o));
+        ymin = fminf(ymin, __shfl_xor(ymin, o)); ymax = fmaxf(ymax, __shfl_xor(ymax, o));
+    }
+    const float diag = sqrtf((xmax - xmin) * (xmax - xmin) + (ymax - ymin) * (ymax - ymin));
+    int w = 0;
+    float e = 0.f;
+    for (int k = lane; k < j; k += 64) {
+        const float dx = g[k * gt_stride] - p[k * 2], dy = g[k * gt_stride + 1] - p[k * 2 + 1];
+        const float dist = sqrtf(dx * dx + dy * dy);
+        if (dist / diag > T) ++w;
+        if (k >= 1 && k <= j - 2) e += dist;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { w += __shfl_xor(w, o); e += __shfl_xor(e, o); }
+    if (lane == 0) { wrong[b] = w; epe[b] = e; }
+}
+
+extern "C" int lh_keypoint_metrics(const float* pred, const float* gt, int gt_stride, int b, int j, float T, int* wrong,
+                                   float* epe, void* stream) {
+    LH_REQUIRE(pred && gt && wrong && epe && b > 0 && j > 2 && gt_stride >= 2, "lh_keypoint_metrics: bad arguments");
+    hipLaunchKernelGGL(keypoint_metrics_kernel, dim3(b), dim3(64), 0, (hipStream_t)stream, pred, gt, gt_stride, j, T, wrong, epe);
+    LH_LAUNCH_CHECK("keypoint_metrics launch");
     return LH_OK;
 }
 

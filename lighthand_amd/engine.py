@@ -503,7 +503,9 @@ class Plan:
         assert (y.w - 1) * s * 4 + kr <= wp * 4
         self.img_nchw = self._alloc(x.n, 3, x.h, x.w, dtype=torch.float32)
         img = self._alloc(x.n, hp, wp, 4)
+        self.img_nhwc4, self.img_pad, self.img_wp = img, p, wp
         self.fwd.append(_Call(self.lib.lh_image_to_nhwc4, (self.img_nchw.data_ptr(), img.data_ptr(), x.n, x.h, x.w, p, wp, self.dt), "image transform"))
+        self._image_call_index = len(self.fwd) - 1
         stage = self._alloc(cout, k, kr // 4, 4, dtype=torch.float32, zero=True)
         self.packs.append(_TorchCall(lambda: stage[:, :, :k, :3].copy_(wt.detach().permute(0, 2, 3, 1)), "stem weight staging"))
         rows = [(r, 0) for r in range(k)]
@@ -721,6 +723,18 @@ class Plan:
             assert self._first_write(x), "maxpool input gradient must be produced by the pool alone"
             self.bwd.append(_Call(self.lib.lh_maxpool3x3s2_bwd, (dy.data_ptr(), idx.data_ptr(), dx.data_ptr(), x.n, x.h, x.w, x.c, self.dt), "maxpool bwd"))
         blk.append(emit)
+
+    def use_uint8_input(self, hs, ws, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
+        """Switch the plan's input to raw uint8 HWC images [n][hs][ws][3]: ToTensor + bilinear Resize + Normalize
+        (the reference's CPU transform chain, src/tools/dataset.py:128-159, defaults = its ImageNet constants) run in
+        ONE kernel that writes the stem's padded NHWC4 input.  Returns the static uint8 input buffer."""
+        self.img_u8 = self._alloc(self.n, hs, ws, 3, dtype=torch.uint8, zero=True)
+        m3, s3 = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
+        self.keep += [m3, s3]
+        self.fwd[self._image_call_index] = _Call(self.lib.lh_image_u8_to_nhwc4, (
+            self.img_u8.data_ptr(), self.img_nhwc4.data_ptr(), self.n, hs, ws, self.h, self.w, self.img_pad, self.img_wp,
+            m3, s3, self.dt), "uint8 input pipeline")
+        return self.img_u8
 
     # ------------------------------------------------------------------ run
     def refresh_packs(self, stream):

@@ -63,3 +63,19 @@ def pred_eval(meta, T_list, method):
     out["mean_auc"] = [float(np.trapz(curve, thr) / (norm + sys.float_info.epsilon)),
                        float(np.concatenate(diff_all, 0).mean() / PX_PER_MM_EVAL), curve]
     return out
+
+
+def device_pck_epe(pred_2d, gt_2d, T=0.2):
+    """PCK@T ('proportion') and the EPE_train sum/count on the DEVICE (no host round trip): returns 0-d device
+    tensors (pck, epe_sum, epe_count).  Same arithmetic as PCK_2d_loss / EPE_train above, quirks included."""
+    import torch
+    from . import _lib
+    pred = pred_2d.to(torch.float32).contiguous()
+    gt = gt_2d.to(torch.float32).contiguous()
+    b, j = pred.shape[:2]
+    wrong = torch.empty(b, dtype=torch.int32, device=pred.device)
+    epe = torch.empty(b, dtype=torch.float32, device=pred.device)
+    _lib.check(_lib.load().lh_keypoint_metrics(pred.data_ptr(), gt.data_ptr(), gt.shape[2], b, j, float(T), wrong.data_ptr(),
+                                               epe.data_ptr(), torch.cuda.current_stream().cuda_stream), "lh_keypoint_metrics")
+    pck = 1.0 - wrong.sum().to(torch.float32) / float(b * j)
+    return pck, epe.sum(), torch.tensor(float(b * (j - 2)), device=pred.device)

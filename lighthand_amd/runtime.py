@@ -20,7 +20,7 @@ from .optim import Adam
 class TrainStep:
     def __init__(self, model, batch, height, width, lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
                  optimizer=None, decode=True, use_graph=True, grad_sync=None, targets_from_joints=True,
-                 overlap_wgrad=False):
+                 overlap_wgrad=False, input_u8=None):
         self.lib = _lib.load()
         self.model = model
         model.train()
@@ -29,6 +29,8 @@ class TrainStep:
         dev = self.arena.device
         out = self.plan.out_nchw
         self.images = self.plan.img_nchw                               # static input: fp32 NCHW
+        # input_u8=(hs, ws): feed raw uint8 HWC frames instead; ToTensor/Resize/Normalize run fused on the device
+        self.images_u8 = self.plan.use_uint8_input(*input_u8) if input_u8 else None
         self.joints = torch.zeros(batch, out.shape[1], 2, dtype=torch.float32, device=dev)
         self.target = torch.zeros_like(out)
         self.targets_from_joints = targets_from_joints
@@ -140,7 +142,7 @@ class TrainStep:
         if self.graphs is not None:
             self.sync_hyper()
         if images is not None:
-            self.images.copy_(images, non_blocking=True)
+            (self.images_u8 if images.dtype == torch.uint8 and self.images_u8 is not None else self.images).copy_(images, non_blocking=True)
         if joints is not None:
             self.joints.copy_(joints[..., :2], non_blocking=True)
         if target is not None:

@@ -112,11 +112,10 @@ def resume_checkpoint(model, path):
 def validate(model, loader, args):
     """Runner.run validation branch (src/utils/method.py:218-287): loss, PCK@0.2 (bbox-normalised), EPE."""
     from lighthand_amd.heatmap import JointsMSELoss, max_preds_device, render_targets
-    from lighthand_amd.metrics import EPE_train, PCK_2d_loss
+    from lighthand_amd.metrics import device_pck_epe
     model.eval()
     crit = JointsMSELoss(False)
-    tot_loss = tot_n = 0.0
-    pck_sum = epe_sum = epe_cnt = 0.0
+    acc = torch.zeros(5, device="cuda")          # loss*b, b, pck*b, epe sum, epe count -- reduced on the device
     with torch.no_grad():
         for images, joints in loader:
             images, joints = images.cuda(non_blocking=True), joints.cuda(non_blocking=True)
@@ -126,13 +125,11 @@ def validate(model, loader, args):
             loss = crit(pred, target, None)
             kp, _, _ = max_preds_device(pred, scale=float(images.shape[-1] // hs))
             b = images.shape[0]
-            tot_loss += float(loss) * b
-            tot_n += b
-            pck_sum += PCK_2d_loss(kp, joints, T=0.2, threshold="proportion") * b
-            (s, c), _ = EPE_train(kp, joints)
-            epe_sum, epe_cnt = epe_sum + s, epe_cnt + c
+            pck, esum, ecnt = device_pck_epe(kp, joints, T=0.2)
+            acc += torch.stack([loss * b, torch.tensor(float(b), device="cuda"), pck * b, esum, ecnt])
     model.train()
-    return tot_loss / max(tot_n, 1), 100.0 * pck_sum / max(tot_n, 1), epe_sum / max(epe_cnt, 1)
+    a = acc.tolist()                               # the only host read of the validation pass
+    return a[0] / max(a[1], 1), 100.0 * a[2] / max(a[1], 1), a[3] / max(a[4], 1)
 
 
 def main(args):

@@ -274,3 +274,55 @@ def test_adam_matches_torch():
         o_ref.step()
         o_hip.step()
     assert rel_err(pg.detach().cpu(), pr.detach()) < 1e-6
+
+
+@pytest.mark.parametrize("src", [(224, 224), (256, 256), (300, 200)])
+def test_uint8_input_pipeline_matches_torch_transform_chain(src):
+    """uint8 HWC -> /255 -> bilinear resize -> Normalize, fused on the device, vs the same chain in
+    plain PyTorch on the CPU (ToTensor, F.interpolate bilinear half-pixel, Normalize; dataset.py:128-159)."""
+    import torch.nn.functional as F
+    from conftest import resnet_cfg
+    from lighthand_amd.modeling.simplebaseline.pose_resnet import get_pose_net
+    torch.manual_seed(0)
+    m = get_pose_net(resnet_cfg(18), True).cuda()
+    plan = m.plan(2, 64, 64, training=False, backward=False)
+    hs, ws = src
+    hs, ws = hs // 4, ws // 4                    # small: the target is the 64 x 64 test plan
+    u8 = torch.randint(0, 256, (2, hs, ws, 3), dtype=torch.uint8)
+    buf = plan.use_uint8_input(hs, ws)
+    buf.copy_(u8)
+    s = torch.cuda.current_stream().cuda_stream
+    plan.fwd[plan._image_call_index](s)
+    torch.cuda.synchronize()
+    got = plan.img_nhwc4.float().cpu()           # [n][h+2p][wp][4]
+    x = u8.permute(0, 3, 1, 2).float() / 255.0
+    x = F.interpolate(x, size=(64, 64), mode="bilinear", align_corners=False, antialias=False)
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    want = ((x - mean) / std).permute(0, 2, 3, 1)
+    p = plan.img_pad
+    assert torch.allclose(got[:, p:p + 64, p:p + 64, :3], want, atol=2e-5, rtol=1e-5)
+    assert float(got[:, :p].abs().max()) == 0 and float(got[..., 3].abs().max()) == 0      # zero border and pad channel
+    # the model consumes it: same heatmaps as feeding the float tensor
+    plan.refresh_packs(s)
+    plan.run_forward(s)
+    a = plan.out_nchw.clone()
+    m2_out = m.eval()(want.permute(0, 3, 1, 2).contiguous().cuda())
+    assert torch.allclose(a, m2_out, atol=1e-4, rtol=1e-3)
+
+
+def test_device_metrics_match_host_metrics(golden_dir):
+    import json, os
+    from lighthand_amd import metrics as M
+    g = json.load(open(os.path.join(golden_dir, "g7_metrics.json")))
+    pred, gt = torch.tensor(g["val_pred"]), torch.tensor(g["val_gt"])
+    pck, esum, ecnt = M.device_pck_epe(pred.cuda(), gt.cuda(), T=0.2)
+    assert abs(float(pck) - g["pck02"]) < 1e-6
+    assert abs(float(esum) - g["epe_sum"]) < 1e-4 * g["epe_sum"] and float(ecnt) == g["epe_cnt"]
+    rng = np.random.RandomState(2)
+    p2 = torch.from_numpy(rng.uniform(0, 256, (37, 21, 2)).astype(np.float32))
+    g2 = torch.from_numpy(rng.uniform(20, 236, (37, 21, 3)).astype(np.float32))
+    pck, esum, ecnt = M.device_pck_epe(p2.cuda(), g2.cuda(), T=0.5)
+    assert abs(float(pck) - M.PCK_2d_loss(p2, g2, T=0.5)) < 1e-6
+    (s, c), _ = M.EPE_train(p2, g2)
+    assert abs(float(esum) - s) < 1e-4 * s and float(ecnt) == c
