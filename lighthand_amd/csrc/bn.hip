@@ -589,6 +589,76 @@ __global__ __launch_bounds__(256) void fuse_bwd_apply_flat_kernel(const FuseBwdA
     }
 }
 
+// Two terms, no upsampling (the residual-unit tail: BN(main) + identity | BN(shortcut)): ONE pass reads dout / out once
+// and writes both input gradients.  Term k: BN when x[k] != null (dx = A*g + B*x + C) else identity (dx = g).
+struct FuseBwd2Args {
+    const unsigned char* dout;
+    const unsigned char* out;
+    const unsigned char* x[2];
+    const float* scale[2];
+    const float* mean[2];
+    const float* invstd[2];
+    const float* coef[2];
+    unsigned char* dx[2];
+    int accumulate[2];
+    int c, relu;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void fuse_bwd_apply2_flat_kernel(const FuseBwd2Args p, long total) {
+    constexpr int EPC = 16 / sizeof(T);
+    const int nchunk = p.c / EPC;
+    const int chunk = threadIdx.x & (nchunk - 1);
+    float A[2][EPC], B[2][EPC], Cc[2][EPC];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        if (p.x[k]) {
+            float iv[EPC], c0[EPC], c1[EPC], mn[EPC];
+            load_vec<EPC>(p.scale[k] + chunk * EPC, A[k]);
+            load_vec<EPC>(p.invstd[k] + chunk * EPC, iv);
+            load_vec<EPC>(p.coef[k] + chunk * EPC, c0);
+            load_vec<EPC>(p.coef[k] + p.c + chunk * EPC, c1);
+            load_vec<EPC>(p.mean[k] + chunk * EPC, mn);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) { B[k][e] = -A[k][e] * iv[e] * c1[e]; Cc[k][e] = -A[k][e] * c0[e] - B[k][e] * mn[e]; }
+        } else { fill_vec<EPC>(A[k], 1.f); fill_vec<EPC>(B[k], 0.f); fill_vec<EPC>(Cc[k], 0.f); }
+    }
+    const long stride = (long)gridDim.x * 256;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += stride) {
+        const long off = idx * 16;
+        float g[EPC];
+        unpack16<T>(*reinterpret_cast<const uint4*>(p.dout + off), g);
+        if (p.relu) {
+            float o[EPC];
+            unpack16<T>(*reinterpret_cast<const uint4*>(p.out + off), o);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (!p.dx[k]) continue;
+            float r[EPC];
+            if (p.x[k]) {
+                float xv[EPC];
+                unpack16<T>(*reinterpret_cast<const uint4*>(p.x[k] + off), xv);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) r[e] = A[k][e] * g[e] + B[k][e] * xv[e] + Cc[k][e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) r[e] = g[e];
+            }
+            uint4* dst = reinterpret_cast<uint4*>(p.dx[k] + off);
+            if (p.accumulate[k]) {
+                float o[EPC];
+                unpack16<T>(*dst, o);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) r[e] += o[e];
+            }
+            *dst = pack16<T>(r);
+        }
+    }
+}
+
 __global__ void fuse_bwd_coef_kernel(const double* totals, long count, int c, float* coef, float* dgamma, float* dbeta) {
     const int ch = blockIdx.x * blockDim.x + threadIdx.x;
     if (ch >= c) return;
@@ -620,7 +690,7 @@ extern "C" size_t lh_fuse_bwd_workspace_bytes(int n, int h, int w, int c) {
     int rps;
     const long strips = fuse_bwd_strips((long)n * h * w, &rps);
     // partial slab + colsum scratch + totals (doubles)
-    return (size_t)strips * 2 * c * 4 + 16 + (size_t)(ceil_div(strips, 256) + 1) * 2 * c * 8 + (size_t)2 * c * 4;
+    return (size_t)strips * 2 * c * 4 + 16 + (size_t)(ceil_div(strips, 256) + 1) * 2 * c * 8 + (size_t)4 * c * 4;
 }
 
 extern "C" int lh_fuse_bwd(const lh_fuse_bwd_desc* d, int n, int h, int w, int c, void* workspace, int dtype,
@@ -630,6 +700,18 @@ extern "C" int lh_fuse_bwd(const lh_fuse_bwd_desc* d, int n, int h, int w, int c
     const int es = lh_dtype_size(dtype);
     LH_REQUIRE(es > 0 && c % (16 / es) == 0, "lh_fuse_bwd: c %d not a multiple of the 16-byte chunk", c);
     hipStream_t s = (hipStream_t)stream;
+    const int nchunk0 = c / (16 / es);
+    const bool merge2 = d->nterms == 2 && d->log2up[0] == 0 && d->log2up[1] == 0 && (nchunk0 & (nchunk0 - 1)) == 0 &&
+                        nchunk0 <= 256 && (d->dx[0] || d->dx[1]) && !getenv("LH_NO_FLAT") && !getenv("LH_NO_MERGE2");
+    FuseBwd2Args m2;
+    if (merge2) {
+        m2.dout = (const unsigned char*)d->dout; m2.out = (const unsigned char*)d->out; m2.c = c; m2.relu = d->relu;
+        for (int k = 0; k < 2; ++k) {
+            m2.x[k] = (const unsigned char*)d->x[k]; m2.scale[k] = d->scale[k]; m2.mean[k] = d->save_mean[k];
+            m2.invstd[k] = d->save_invstd[k]; m2.coef[k] = nullptr; m2.dx[k] = (unsigned char*)d->dx[k];
+            m2.accumulate[k] = d->accumulate[k];
+        }
+    }
     for (int t = 0; t < d->nterms; ++t) {
         if (!d->dx[t]) continue;
         FuseBwdArgs a;
@@ -662,11 +744,13 @@ extern "C" int lh_fuse_bwd(const lh_fuse_bwd_desc* d, int n, int h, int w, int c
                 LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((fuse_bwd_reduce_kernel<T>), dim3((int)strips), dim3(256), 0, s, a));
             }
             LH_LAUNCH_CHECK("fuse_bwd_reduce launch");
-            a.coef = (float*)(totals + 2 * c);
+            a.coef = (float*)(totals + 2 * c) + (size_t)(merge2 ? t : 0) * 2 * c;   // merging keeps one coefficient block per term
             hipLaunchKernelGGL((fuse_bwd_coef_fused_kernel<float>), dim3(ceil_div(c, 16)), dim3(256), 0, s, (const float*)a.partial,
                                (int)strips, a.count, c, a.coef, a.dgamma, a.dbeta);
             LH_LAUNCH_CHECK("fuse_bwd_coef launch");
+            if (merge2) m2.coef[t] = a.coef;
         }
+        if (merge2) continue;                 // both gradients are written by ONE pass below
         const long total = a.count * (c / (16 / es));
         const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
         const int fgrid = (int)((total + 1023) / 1024 > 2048 ? 2048 : (total + 1023) / 1024);          // >= 4 chunks per thread
@@ -678,6 +762,12 @@ extern "C" int lh_fuse_bwd(const lh_fuse_bwd_desc* d, int n, int h, int w, int c
             LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((fuse_bwd_apply_kernel<T>), dim3(grid), dim3(256), 0, s, a));
         }
         LH_LAUNCH_CHECK("fuse_bwd_apply launch");
+    }
+    if (merge2) {
+        const long total = (long)n * h * w * nchunk0;
+        const int fgrid = (int)((total + 1023) / 1024 > 2048 ? 2048 : (total + 1023) / 1024);
+        LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((fuse_bwd_apply2_flat_kernel<T>), dim3(fgrid), dim3(256), 0, s, m2, total));
+        LH_LAUNCH_CHECK("fuse_bwd_apply2 launch");
     }
     return LH_OK;
 }
