@@ -138,6 +138,21 @@ typedef struct {
 int lh_igemm(const lh_igemm_desc* d, const void* in, const void* wpack, void* out,
              const void* addend, const float* bias, const float* scale, const float* shift, float* stats,
              int dtype, void* stream);
+/* Data gradient with the FOLLOWING BatchNorm-backward reduction fused into its epilogue (loss.backward() through
+ * conv -> relu -> BN, e.g. pose_resnet.py:83-93 walked in reverse): `out` receives the plain data gradient dA of the
+ * activation a = relu(x*scale + shift); `partial` receives lh_igemm_stats_rows(d) rows [2][cout] of
+ *   (sum g, sum g * (x - mean) * invstd),  g = dA masked by (x*scale + shift > 0),
+ * i.e. exactly the per-strip sums lh_fuse_bwd's reduce pass would produce, so that pass (one read of dA and x) is
+ * skipped via lh_fuse_bwd_desc.ext_partial.  x has out's layout (same pixel stride and placement). */
+typedef struct lh_bn_tap {
+    const void* x;
+    const float* scale;
+    const float* shift;
+    const float* mean;
+    const float* invstd;
+} lh_bn_tap;
+int lh_igemm_bntap(const lh_igemm_desc* d, const void* in, const void* wpack, void* out,
+                   const lh_bn_tap* tap, float* partial, int dtype, void* stream);
 /* tile (output channels x pixels) the dispatcher picks for this descriptor: names the kernel
  * instantiation a launch uses -- igemm_ring_kernel<T, bm, bp, .., depth, kbytes> when *ring != 0 (LDS-DMA ring
  * path, 16-byte aligned pixel rows; *ring = kbytes*10 + depth) else igemm_kernel<T, bm, bp, ..>. */
@@ -212,6 +227,8 @@ typedef struct {
     int accumulate[4];
     int nterms;
     int relu;
+    const float* ext_partial[4];   /* reduce sums already produced by lh_igemm_bntap (rows x [2][c]); NULL = run the reduce pass */
+    int ext_rows[4];
 } lh_fuse_bwd_desc;
 size_t lh_fuse_bwd_workspace_bytes(int n, int h, int w, int c);
 int lh_fuse_bwd(const lh_fuse_bwd_desc* d, int n, int h, int w, int c, void* workspace,

@@ -195,6 +195,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
     float s1[EPC], s2[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) s1[e] = s2[e] = 0.f;
+    float tsc[EPC], tsh[EPC], tmn[EPC], tiv[EPC];
+    if (p.tap_x && col_ok) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            tsc[e] = p.tap_scale[col0 + e]; tsh[e] = p.tap_shift[col0 + e];
+            tmn[e] = p.tap_mean[col0 + e]; tiv[e] = p.tap_invstd[col0 + e];
+        }
+    }
 
     for (int pr = r0; pr < BP; pr += RPP) {
         const int m = pblk * BP + pr;
@@ -226,8 +234,19 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
         if (p.stats) {
             float sv[EPC];
             unpack16<T>(u, sv);
+            if (p.tap_x) {
+                float xv[EPC];
+                unpack16<T>(*reinterpret_cast<const uint4*>(p.tap_x + eoff * ES), xv);
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) { s1[e] += sv[e]; s2[e] += sv[e] * sv[e]; }
+                for (int e = 0; e < EPC; ++e) {
+                    const float g = (xv[e] * tsc[e] + tsh[e]) > 0.f ? sv[e] : 0.f;
+                    s1[e] += g;
+                    s2[e] += g * (xv[e] - tmn[e]) * tiv[e];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) { s1[e] += sv[e]; s2[e] += sv[e] * sv[e]; }
+            }
         }
         *reinterpret_cast<uint4*>(p.out + eoff * ES) = u;
     }
@@ -303,9 +322,9 @@ extern "C" int lh_igemm_stats_rows(const lh_igemm_desc* d, int dtype) {
     return (int)((M + bp - 1) / bp);
 }
 
-extern "C" int lh_igemm(const lh_igemm_desc* d, const void* in, const void* wpack, void* out,
-                        const void* addend, const float* bias, const float* scale, const float* shift, float* stats,
-                        int dtype, void* stream) {
+static int igemm_impl(const lh_igemm_desc* d, const void* in, const void* wpack, void* out,
+                      const void* addend, const float* bias, const float* scale, const float* shift, float* stats,
+                      const lh_bn_tap* tap, int dtype, void* stream) {
     LH_REQUIRE(d && in && wpack && out, "lh_igemm: null pointer");
     const int es = lh_dtype_size(dtype);
     LH_REQUIRE(es > 0, "lh_igemm: bad dtype %d", dtype);
@@ -322,6 +341,12 @@ extern "C" int lh_igemm(const lh_igemm_desc* d, const void* in, const void* wpac
     a.in = (const unsigned char*)in; a.w = (const unsigned char*)wpack; a.out = (unsigned char*)out;
     a.addend = (const unsigned char*)addend; a.bias = bias; a.stats = stats;
     a.scale = scale; a.shift = shift;
+    a.tap_x = nullptr; a.tap_scale = a.tap_shift = a.tap_mean = a.tap_invstd = nullptr;
+    if (tap) {
+        LH_REQUIRE(tap->x && tap->scale && tap->shift && tap->mean && tap->invstd && stats, "lh_igemm_bntap: incomplete tap");
+        a.tap_x = (const unsigned char*)tap->x; a.tap_scale = tap->scale; a.tap_shift = tap->shift;
+        a.tap_mean = tap->mean; a.tap_invstd = tap->invstd;
+    }
     LH_REQUIRE((scale == nullptr) == (shift == nullptr), "lh_igemm: scale and shift must come together");
     a.n = d->n; a.hi = d->hi; a.wi = d->wi; a.in_pix_stride = d->in_pix_stride; a.k_run = d->k_run;
     a.kspt = (d->k_run * es + 63) / 64;
@@ -356,4 +381,16 @@ extern "C" int lh_igemm(const lh_igemm_desc* d, const void* in, const void* wpac
 #undef LH_TILE
     lh_set_error("lh_igemm: unsupported dtype %d", dtype);
     return LH_ERR_ARG;
+}
+
+extern "C" int lh_igemm(const lh_igemm_desc* d, const void* in, const void* wpack, void* out,
+                        const void* addend, const float* bias, const float* scale, const float* shift, float* stats,
+                        int dtype, void* stream) {
+    return igemm_impl(d, in, wpack, out, addend, bias, scale, shift, stats, nullptr, dtype, stream);
+}
+
+extern "C" int lh_igemm_bntap(const lh_igemm_desc* d, const void* in, const void* wpack, void* out,
+                              const lh_bn_tap* tap, float* partial, int dtype, void* stream) {
+    LH_REQUIRE(tap && partial, "lh_igemm_bntap: null tap / partial slab");
+    return igemm_impl(d, in, wpack, out, nullptr, nullptr, nullptr, nullptr, partial, tap, dtype, stream);
 }

@@ -11,6 +11,13 @@ struct IgemmArgs {
     const float* scale;      // optional per-output-channel affine applied to the fp32 accumulator (eval-mode BN fold)
     const float* shift;
     float* stats;
+    // optional BN-backward reduction fused into a data-gradient epilogue (lh_igemm_bntap): with tap_x set, `stats`
+    // receives (sum g, sum g*xhat) of g = stored value masked by (x*scale+shift > 0) instead of (sum, sum of squares)
+    const unsigned char* tap_x;
+    const float* tap_scale;
+    const float* tap_shift;
+    const float* tap_mean;
+    const float* tap_invstd;
     int n, hi, wi, in_pix_stride, k_run, kspt, kpad;   // kpad: elements per (row, tap) of the weight pack
     int ho, wo, M, sh, sw, cout;
     int OH, OW, osh, osw, ooh, oow, out_pix_stride;

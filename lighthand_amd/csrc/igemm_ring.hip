@@ -255,6 +255,14 @@ __global__ __launch_bounds__(256) void igemm_ring_kernel(const IgemmArgs p) {
     float s1[EPC], s2[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) s1[e] = s2[e] = 0.f;
+    float tsc[EPC], tsh[EPC], tmn[EPC], tiv[EPC];
+    if (p.tap_x && col_ok) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            tsc[e] = p.tap_scale[col0 + e]; tsh[e] = p.tap_shift[col0 + e];
+            tmn[e] = p.tap_mean[col0 + e]; tiv[e] = p.tap_invstd[col0 + e];
+        }
+    }
 
     for (int pr = r0; pr < BP; pr += RPP) {
         const int m = pblk * BP + pr;
@@ -285,8 +293,19 @@ __global__ __launch_bounds__(256) void igemm_ring_kernel(const IgemmArgs p) {
         if (p.stats) {
             float sv[EPC];
             unpack16<T>(u, sv);
+            if (p.tap_x) {
+                float xv[EPC];
+                unpack16<T>(*reinterpret_cast<const uint4*>(p.tap_x + eoff * ES), xv);
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) { s1[e] += sv[e]; s2[e] += sv[e] * sv[e]; }
+                for (int e = 0; e < EPC; ++e) {
+                    const float g = (xv[e] * tsc[e] + tsh[e]) > 0.f ? sv[e] : 0.f;
+                    s1[e] += g;
+                    s2[e] += g * (xv[e] - tmn[e]) * tiv[e];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) { s1[e] += sv[e]; s2[e] += sv[e] * sv[e]; }
+            }
         }
         *reinterpret_cast<uint4*>(p.out + eoff * ES) = u;
     }

@@ -9,11 +9,12 @@ of ctypes calls on the caller's HIP stream -- which is exactly what a hipGraph c
 (``lighthand_amd.runtime.TrainStep``).
 """
 import ctypes as C
+import os
 
 import torch
 
 from . import _lib
-from ._lib import FuseBwdDesc, FuseDesc, IgemmDesc, check
+from ._lib import BnTap, FuseBwdDesc, FuseDesc, IgemmDesc, check
 
 PRECISIONS = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}
 BN_MOMENTUM = 0.1   # src/modeling/simplebaseline/pose_resnet.py:19, src/modeling/hrnet/pose_hrnet.py:18
@@ -27,7 +28,7 @@ def _ptr(t):
 class Act:
     """One NHWC activation (and, in training plans, its gradient)."""
     __slots__ = ("n", "h", "w", "c", "c_valid", "buf", "grad", "needs_grad", "stats", "stats_rows",
-                 "is_image", "name")
+                 "is_image", "name", "bn_tap")
 
     def __init__(self, n, h, w, c, c_valid=None, name=""):
         self.n, self.h, self.w, self.c = n, h, w, c
@@ -37,6 +38,7 @@ class Act:
         self.needs_grad = True
         self.is_image = False
         self.name = name
+        self.bn_tap = None       # set by a single-BN-term fuse node whose output feeds exactly one convolution
 
     @property
     def pixels(self):
@@ -280,6 +282,33 @@ class Plan:
             self._producers.setdefault(id(produces), []).append(c)
         return c
 
+    def _dgrad(self, descs, dy, packs, x, what):
+        """Data-gradient launches into x.grad.  When x is the output of a conv -> BN -> ReLU fuse node and this is its
+        only consumer, the launches also produce that node's BN-backward reduction (lh_igemm_bntap)."""
+        dx = self._act_grad(x)
+        first = self._first_write(x)
+        tap = x.bn_tap if first else None
+        if tap is None:
+            for dd, pk in zip(descs, packs):
+                self._igemm(self.bwd, dd, dy, pk, dx, None if first else dx, None, None, what)
+                yield dd
+            return
+        rows = [self.lib.lh_igemm_stats_rows(C.byref(dd), self.dt) for dd in descs]
+        slab = self._alloc(sum(rows) * 2 * x.c, dtype=torch.float32)
+        st = tap["st"]
+        bt = BnTap(tap["x"].buf.data_ptr(), st["scale"].data_ptr(), st["shift"].data_ptr(), st["mean"].data_ptr(), st["invstd"].data_ptr())
+        self.keep.append(bt)
+        off = 0
+        for dd, pk, r in zip(descs, packs, rows):
+            self.keep.append(dd)
+            c = _Call(self.lib.lh_igemm_bntap, (C.byref(dd), dy.data_ptr(), pk.data_ptr(), dx.data_ptr(), C.byref(bt),
+                                                slab.data_ptr() + off, self.dt), what + " (+BN-bwd reduce)")
+            c.keep = dd
+            self.bwd.append(c)
+            off += r * 2 * x.c * 4
+            yield dd
+        tap["slab"] = (slab, sum(rows))
+
     def _patch(self, call, relu=None, **ptrs):
         a = list(call.args)
         for k, v in ptrs.items():
@@ -334,6 +363,18 @@ class Plan:
                     if bn is not None:
                         consumers_bn.add(id(a))
         self._bn_inputs = consumers_bn
+        # activations with exactly one consumer (a convolution): their data gradient is written once, by that
+        # consumer's dgrad, which can therefore carry the BN-backward reduction of the producing fuse node
+        uses = {}
+        for kind, nd in self.nodes:
+            if kind in ("conv", "deconv", "maxpool"):
+                uses.setdefault(id(nd["x"]), []).append(kind)
+            elif kind == "fuse":
+                for a, _, _ in nd["terms"]:
+                    uses.setdefault(id(a), []).append(kind)
+            elif kind == "output":
+                uses.setdefault(id(nd["y"]), []).append(kind)
+        self._sole_conv_input = {k for k, v in uses.items() if len(v) == 1 and v[0] in ("conv", "deconv")}
         bwd_blocks = []
         for kind, nd in self.nodes:
             blk = []
@@ -484,10 +525,7 @@ class Plan:
                 else:
                     self.bwd.append(_TorchCall(lambda: gb_.copy_(dy.view(-1, y.c)[:, :cout].sum(0, dtype=torch.float32)), "bias grad"))
             if x.needs_grad:
-                dx = self._act_grad(x)
-                first = self._first_write(x)
-                for dd, pk in zip(ddescs, dpacks):
-                    self._igemm(self.bwd, dd, dy, pk, dx, None if first else dx, None, None, nd["w"] + " dgrad")
+                for dd in self._dgrad(ddescs, dy, dpacks, x, nd["w"] + " dgrad"):
                     self.profile_meta.append(("bwd", self.bwd[-1], self._kname(dd), 2.0 * dd.n * dd.ho * dd.wo * cin * cout * dd.ntaps,
                                               (dd.n * dd.ho * dd.wo * x.c + y.pixels * y.c / (s * s)) * self.es))
         blk.append(emit)
@@ -602,10 +640,8 @@ class Plan:
                 gb_ = self.grads[nd["bias"]]
                 self.bwd.append(_TorchCall(lambda: gb_.copy_(dy.view(-1, y.c)[:, :cout].sum(0, dtype=torch.float32)), "bias grad"))
             if x.needs_grad:
-                dx = self._act_grad(x)
-                first = self._first_write(x)
-                self._igemm(self.bwd, dg, dy, gpack, dx, None if first else dx, None, None, nd["w"] + " deconv dgrad")
-                self.profile_meta.append(("bwd", self.bwd[-1], self._kname(dg), flops, (x.pixels * x.c + y.pixels * y.c) * self.es))
+                for _ in self._dgrad([dg], dy, [gpack], x, nd["w"] + " deconv dgrad"):
+                    self.profile_meta.append(("bwd", self.bwd[-1], self._kname(dg), flops, (x.pixels * x.c + y.pixels * y.c) * self.es))
         blk.append(emit)
 
     # ---- BatchNorm + sum + ReLU ------------------------------------------------------------------
@@ -645,6 +681,9 @@ class Plan:
         if not self.with_bwd:
             return
         self._ws_fuse = max(self._ws_fuse, self.lib.lh_fuse_bwd_workspace_bytes(out.n, out.h, out.w, c))
+        if (len(terms) == 1 and terms[0][1] is not None and terms[0][2] == 0 and relu and terms[0][0].needs_grad
+                and id(out) in self._sole_conv_input and not os.environ.get("LH_NO_BNTAP")):
+            out.bn_tap = {"x": terms[0][0], "st": bn_state[0], "slab": None}
 
         def emit():
             bd = FuseBwdDesc()
@@ -664,6 +703,9 @@ class Plan:
                     bd.shift[i] = st["shift"].data_ptr()
                     bd.dgamma[i] = self.grads[bn + ".weight"].data_ptr()
                     bd.dbeta[i] = self.grads[bn + ".bias"].data_ptr()
+                    if out.bn_tap is not None and out.bn_tap["slab"] is not None:     # reduced by the consumer's dgrad
+                        bd.ext_partial[i] = out.bn_tap["slab"][0].data_ptr()
+                        bd.ext_rows[i] = out.bn_tap["slab"][1]
             self.keep.append(bd)
             args = [C.byref(bd), out.n, out.h, out.w, c, 0, self.dt]
             call = _Call(self.lib.lh_fuse_bwd, None, "fuse bwd")

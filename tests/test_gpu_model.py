@@ -193,3 +193,49 @@ def test_reduced_precision_trains_like_fp32(precision):
     assert abs(b[0] - a[0]) < 0.05 * a[0]
     assert a[-1] < 0.5 * a[0] and b[-1] < 0.5 * b[0]
     assert abs(b[-1] - a[-1]) < 0.25 * a[-1]
+
+
+def _grads_with_env(tag, precision, env, monkeypatch, expect_fused):
+    from lighthand_amd.heatmap import JointsMSELoss
+    for k in ("LH_NO_BNTAP", "LH_NO_FLAT"):
+        monkeypatch.delenv(k, raising=False)
+    for k in env:
+        monkeypatch.setenv(k, "1")
+    rng = np.random.RandomState(3)
+    x = torch.from_numpy(rng.randn(4, 3, 64, 64).astype(np.float32)).cuda()
+    torch.manual_seed(0)
+    model, _ = _build(tag)
+    model = model.cuda().train().set_precision(precision)
+    out = model(x)
+    JointsMSELoss(False)(out, torch.zeros_like(out), None).backward()
+    plan = next(iter(model._lh_plans.values()))
+    fused_calls = sum(1 for c in plan.bwd if "BN-bwd reduce" in c.what)
+    assert (fused_calls > 0) == expect_fused
+    return {k: p.grad.detach().double().cpu().numpy().copy() for k, p in model.named_parameters()}
+
+
+def _tensor_diffs(a, b):
+    return np.array([np.abs(a[k] - b[k]).max() / (np.abs(b[k]).max() + 1e-20) for k in b])
+
+
+@pytest.mark.parametrize("tag", ["r18", "r50", "hrnet_w32"])
+def test_fused_bn_backward_reduce_matches_separate_pass(tag, monkeypatch):
+    """conv -> BN -> ReLU -> conv chains: the consumer's data-gradient kernel also produces the BN-backward sums
+    (lh_igemm_bntap).  Same arithmetic as lh_fuse_bwd's own reduce pass up to the fp32 summation order inside a tile:
+    in fp32 every parameter gradient agrees to 1e-4 of its tensor's scale (measured <= 1e-5)."""
+    fused = _grads_with_env(tag, "fp32", [], monkeypatch, True)
+    separate = _grads_with_env(tag, "fp32", ["LH_NO_BNTAP"], monkeypatch, False)
+    d = _tensor_diffs(fused, separate)
+    print(tag, "worst rel diff", d.max())
+    assert d.max() < 1e-4
+
+
+def test_fused_bn_backward_reduce_bf16_within_summation_noise(monkeypatch):
+    """In bf16 a 1e-7 change of a BN-backward coefficient flips the rounding of a few stored gradients, and the
+    backward chain of a random-init network amplifies that to percents in the first layers -- for ANY reordering of the
+    sums.  Yardstick: the separate pass with its generic (LH_NO_FLAT) reduce kernel, which also only reorders sums."""
+    separate = _grads_with_env("r50", "bf16", ["LH_NO_BNTAP"], monkeypatch, False)
+    fused = _tensor_diffs(_grads_with_env("r50", "bf16", [], monkeypatch, True), separate)
+    yard = _tensor_diffs(_grads_with_env("r50", "bf16", ["LH_NO_BNTAP", "LH_NO_FLAT"], monkeypatch, False), separate)
+    print("bf16 fused-vs-separate median/max", np.median(fused), fused.max(), "| reorder yardstick", np.median(yard), yard.max())
+    assert np.median(fused) < 3 * np.median(yard) + 1e-4 and fused.max() < 3 * yard.max() + 1e-3
