@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblighthand_hip.so")
+LIB_PATH = os.environ.get("LH_LIB_PATH") or os.path.join(_HERE, "liblighthand_hip.so")   # override: kernel experiments only
 
 LH_F32, LH_BF16, LH_F16 = 0, 1, 2
 

@@ -5,9 +5,12 @@
 // stages of (BM + BP) rows x 128 bytes of K, ONE raw s_barrier per K step and a COUNTED
 // s_waitcnt vmcnt(N) that leaves D-2 later stages in flight across the barrier, so HBM/L2 latency
 // is covered by the ring and not by occupancy (one or two workgroups per CU).
-//  * the LDS destination of an LDS-DMA is lane-linear (wave base + lane*16), so the image's
-//    XOR swizzle is applied to the per-lane SOURCE: lane L of the instruction that fills 16-byte
-//    chunk c = 4*half + (L>>4) of a 16-row group fetches row (L&15) ^ 2c of that group;
+//  * the LDS destination of an LDS-DMA is lane-linear (wave base + lane*16) and the texture-address unit handles
+//    four lanes per cycle, so CONSECUTIVE LANES FETCH CONSECUTIVE 16-BYTE CHUNKS OF ONE ROW (one cache-line tag per
+//    cycle; lanes in 16 different rows cost 4 tag look-ups per cycle and a quarter of the L1 rate).  The LDS image of
+//    a 16-row group is therefore row-major, [row][KB/16 slots], and the bank swizzle is a permutation of the slots
+//    INSIDE a row applied to the per-lane source: slot s of row r holds chunk s ^ f(r), f(r) = r >> 2 (KB = 64) or
+//    r >> 1 (KB = 128), which makes the 16 rows x one chunk of a ds_read_b128 quarter-wave hit all 64 banks once;
 //  * rows that fall into the zero padding (or past k_run / past the last pixel) read a 16-byte
 //    zero page instead, so every lane issues every load and the vmcnt bookkeeping is exact;
 //  * the pixel operand needs 16-byte aligned pixel rows (in_pix_stride * sizeof(T) % 16 == 0); the
@@ -40,6 +43,12 @@ template <> struct MmaR<float> {
     }
 };
 
+// Debug-only ablation builds (tools/ablate.sh): -DLH_ABL=<bits>  1 = drop the MFMAs, 2 = drop the fragment reads,
+// 4 = drop the LDS-DMA loads, 8 = drop the epilogue.  Results are garbage; only the timing is of interest.  Never set in the product build.
+#ifndef LH_ABL
+#define LH_ABL 0
+#endif
+
 typedef __attribute__((address_space(3))) void* lds_void_p;
 typedef const __attribute__((address_space(1))) void* gbl_void_p;
 
@@ -57,6 +66,8 @@ __global__ __launch_bounds__(256) void igemm_ring_kernel(const IgemmArgs p) {
     constexpr int CT = TC / 16, PT = TP / 16;
     constexpr int STAGE = (BM + BP) * KB;
     constexpr int H = KB / 64;                        // LDS-DMA instructions per 16-row group (1 KiB each)
+    constexpr int SL = KB / 16;                       // 16-byte slots per row
+    constexpr int RPI = 64 / SL;                      // rows one LDS-DMA instruction covers
     constexpr int GB = 16 * KB;                       // bytes of one 16-row group
     constexpr int NW = BM / 16 * H / 4, NX = BP / 16 * H / 4;   // instructions per wave and stage
     constexpr int L = NW + NX;
@@ -80,8 +91,9 @@ __global__ __launch_bounds__(256) void igemm_ring_kernel(const IgemmArgs p) {
 #pragma unroll
     for (int j = 0; j < NX; ++j) {
         const int q = 4 * j + wave;
-        const int g = q / H, c = 4 * (q % H) + (lane >> 4);
-        const int row = g * 16 + ((lane & 15) ^ ((2 * c) & 15));
+        const int g = q / H, lrow = (q % H) * RPI + lane / SL;
+        const int c = (lane % SL) ^ ((lrow / (16 / SL)) & (SL - 1));
+        const int row = g * 16 + lrow;
         const int m = pblk * BP + row;
         const bool ok = m < p.M;
         const int mm = ok ? m : 0;
@@ -103,8 +115,9 @@ __global__ __launch_bounds__(256) void igemm_ring_kernel(const IgemmArgs p) {
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
         const int q = 4 * j + wave;
-        const int g = q / H, c = 4 * (q % H) + (lane >> 4);
-        const int row = g * 16 + ((lane & 15) ^ ((2 * c) & 15));
+        const int g = q / H, lrow = (q % H) * RPI + lane / SL;
+        const int c = (lane % SL) ^ ((lrow / (16 / SL)) & (SL - 1));
+        const int row = g * 16 + lrow;
         wsrc[j] = p.w + ((long)(cblk * BM + row) * p.ntaps * kpad + c * EPC) * ES;
     }
     const unsigned char* zero = reinterpret_cast<const unsigned char*>(lh_zero_page);
@@ -121,7 +134,8 @@ __global__ __launch_bounds__(256) void igemm_ring_kernel(const IgemmArgs p) {
 #pragma unroll
         for (int j = 0; j < NW; ++j) {
             const int q = 4 * j + wave;
-            __builtin_amdgcn_global_load_lds((gbl_void_p)(wsrc[j] + woff), (lds_void_p)(st + (q / H) * GB + (q % H) * 1024), 16, 0, 0);
+            if (!(LH_ABL & 4))
+                __builtin_amdgcn_global_load_lds((gbl_void_p)(wsrc[j] + woff), (lds_void_p)(st + (q / H) * GB + (q % H) * 1024), 16, 0, 0);
         }
         const long toff = ((long)(cdh * p.wi + cdw) * p.in_pix_stride + ikc * KSTEP) * ES;
         const int kbase = ikc * KSTEP;
@@ -131,7 +145,8 @@ __global__ __launch_bounds__(256) void igemm_ring_kernel(const IgemmArgs p) {
             bool ok = (((hmask[j] >> ti) & (wmask[j] >> tj)) & 1u) != 0;
             if (ktail) ok = ok && (kbase + xc[j] < p.k_run);
             const unsigned char* src = ok ? p.in + pbase[j] + toff : zero;     // select: every lane issues the load
-            __builtin_amdgcn_global_load_lds((gbl_void_p)src, (lds_void_p)(st + BM * KB + (q / H) * GB + (q % H) * 1024), 16, 0, 0);
+            if (!(LH_ABL & 4))
+                __builtin_amdgcn_global_load_lds((gbl_void_p)src, (lds_void_p)(st + BM * KB + (q / H) * GB + (q % H) * 1024), 16, 0, 0);
         }
         ++issued;
         woff += KB;
@@ -157,8 +172,8 @@ __global__ __launch_bounds__(256) void igemm_ring_kernel(const IgemmArgs p) {
     int foff[KSUB];
 #pragma unroll
     for (int kk = 0; kk < KSUB; ++kk) {
-        const int c = 4 * kk + (lane >> 4);
-        foff[kk] = c * 256 + (((lane & 15) ^ ((2 * c) & 15)) << 4);
+        const int c = 4 * kk + (lane >> 4), r = lane & 15;
+        foff[kk] = r * KB + ((c ^ ((r / (16 / SL)) & (SL - 1))) << 4);
     }
 
     for (int s = 0; s < S; ++s) {
@@ -182,18 +197,24 @@ __global__ __launch_bounds__(256) void igemm_ring_kernel(const IgemmArgs p) {
 #pragma unroll
         for (int kk = 0; kk < KSUB; ++kk) {
 #pragma unroll
-            for (int i = 0; i < CT; ++i)
-                asm volatile("ds_read_b128 %0, %1" : "=v"(fa[kk][i]) : "v"(st + (wc * CT + i) * GB + foff[kk]));
+            for (int i = 0; i < CT; ++i) {
+                if (LH_ABL & 2) fa[kk][i] = uint4{st, st, st, st};
+                else asm volatile("ds_read_b128 %0, %1" : "=v"(fa[kk][i]) : "v"(st + (wc * CT + i) * GB + foff[kk]));
+            }
 #pragma unroll
-            for (int j = 0; j < PT; ++j)
-                asm volatile("ds_read_b128 %0, %1" : "=v"(fb[kk][j]) : "v"(st + BM * KB + (wp * PT + j) * GB + foff[kk]));
+            for (int j = 0; j < PT; ++j) {
+                if (LH_ABL & 2) fb[kk][j] = uint4{st, st, st, st};
+                else asm volatile("ds_read_b128 %0, %1" : "=v"(fb[kk][j]) : "v"(st + BM * KB + (wp * PT + j) * GB + foff[kk]));
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"((KSUB - 1) * (CT + PT)) : "memory");
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < CT; ++i)
 #pragma unroll
-            for (int j = 0; j < PT; ++j) MmaR<T>::run(fa[0][i], fb[0][j], acc[i][j]);
+            for (int j = 0; j < PT; ++j) {
+                if (!(LH_ABL & 1)) MmaR<T>::run(fa[0][i], fb[0][j], acc[i][j]);     // (the volatile reads above stay)
+            }
         if constexpr (KSUB == 2) {
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -207,6 +228,7 @@ __global__ __launch_bounds__(256) void igemm_ring_kernel(const IgemmArgs p) {
 
     // ---- epilogue (identical to igemm.hip): D -> LDS tile [BP][BM], full-line stores, BN partial sums
     constexpr int RS = BM * ES + 8;
+    if (LH_ABL & 8) { if (acc[0][0][0] == 123.456f) p.out[0] = 1; return; }
     __syncthreads();
     {
         const int q = lane >> 4, pl = lane & 15;
@@ -363,13 +385,19 @@ void lh_ring_pick_tile(const lh_igemm_desc* d, int dtype, int* bm, int* bp) {
     const bool f32 = dtype == LH_F32;
     static int big = -1;
     if (big < 0) big = getenv("LH_NO_BIG_TILE") ? 0 : 1;
+    static int min_blocks = 0, min_big = 0;     // smallest grid for which a tile shape is preferred (tuning knobs)
+    if (!min_blocks) {
+        const char* e1 = getenv("LH_TILE_MIN"); const char* e2 = getenv("LH_TILE_MIN_BIG");
+        min_blocks = e1 ? atoi(e1) : 512;
+        min_big = e2 ? atoi(e2) : 1024;
+    }
     for (int i = 0; i < 5; ++i) {
         const int BM = cands[i][0], BP = cands[i][1];
         if (BM == 128 && d->cout <= 64) continue;
         if (BP == 256 && (f32 || !big || lh_ring_kb() != 64 || d->ntaps * ((d->k_run * 2 + 63) / 64) <= 4)) continue;   // 16-bit, deep K only
         if (f32 && BM == 128 && BP == 128) continue;            // fp32 epilogue tile would not fit 64 KiB well
         const long blocks = ((M + BP - 1) / BP) * ((d->cout + BM - 1) / BM);
-        if (blocks >= (BP == 256 ? 1024 : 512) || i == 4) { *bm = BM; *bp = BP; return; }
+        if (blocks >= (BP == 256 ? min_big : min_blocks) || i == 4) { *bm = BM; *bp = BP; return; }
     }
     *bm = 64; *bp = 64;
 }
