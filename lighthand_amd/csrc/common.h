@@ -67,3 +67,11 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+// XCD-aware work-item index (speed only, never correctness).  Workgroup ids are dealt round-robin over the 8 XCDs,
+// each with a private L2, so ids b and b+8 share an L2 while neighbours b, b+1 do not.  The remap gives every XCD a
+// CONTIGUOUS range of work items (bijective for any nwg), so that tiles sharing an operand panel hit the same L2.
+__device__ __forceinline__ int lh_xcd_remap(int orig, int nwg) {
+    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}

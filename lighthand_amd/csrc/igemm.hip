@@ -359,6 +359,9 @@ static int igemm_impl(const lh_igemm_desc* d, const void* in, const void* wpack,
     pick_tile(d, dtype, &bm, &bp);
     hipStream_t s = (hipStream_t)stream;
     a.tw = 1; a.dh0 = a.dhs = a.dw0 = a.dws = 0;
+    static int xcd = -1;
+    if (xcd < 0) xcd = getenv("LH_NO_XCD") ? 0 : 1;
+    a.xcd = xcd;
     if (lh_ring_supported(d, dtype)) {
         lh_tap_grid(d, &a.tw, &a.dh0, &a.dhs, &a.dw0, &a.dws);
         a.kspt = (d->k_run * es + lh_ring_kb() - 1) / lh_ring_kb();

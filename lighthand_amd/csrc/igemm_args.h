@@ -22,6 +22,7 @@ struct IgemmArgs {
     int ho, wo, M, sh, sw, cout;
     int OH, OW, osh, osw, ooh, oow, out_pix_stride;
     int ntaps, relu;
+    int xcd;                         // ring kernel: XCD-aware work-item order (LH_NO_XCD=1 disables)
     int tw, dh0, dhs, dw0, dws;      // regular tap grid (ring kernel): tap t = (t / tw, t % tw)
     signed char dh[64];
     signed char dw[64];

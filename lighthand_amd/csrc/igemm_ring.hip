@@ -77,7 +77,11 @@ __global__ __launch_bounds__(256) void igemm_ring_kernel(const IgemmArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wc = wave / WP, wp = wave % WP;
-    const int pblk = blockIdx.x, cblk = blockIdx.y;
+    // 1-D grid; work item w = (pixel tile, channel tile) with the channel tile fastest: the channel tiles of one pixel
+    // tile and neighbouring pixel tiles (3x3 halos) run on one XCD at about the same time and share its L2.
+    const int CB = (p.cout + BM - 1) / BM;
+    const int w = p.xcd ? lh_xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int pblk = w / CB, cblk = w - pblk * CB;
     const int hw = p.ho * p.wo;
 
     // ---- per-lane source bookkeeping.  Instruction q = 4*j + wave of a stage fills (16-row group,
@@ -372,7 +376,7 @@ static int launch_ring(const IgemmArgs& a, hipStream_t s) {
         }
         attr_done = true;
     }
-    dim3 grid(ceil_div(a.M, BP), ceil_div(a.cout, BM));
+    dim3 grid(ceil_div(a.M, BP) * ceil_div(a.cout, BM));
     hipLaunchKernelGGL((igemm_ring_kernel<T, BM, BP, WC, WP, D, KB>), grid, dim3(256), lds, s, a);
     LH_LAUNCH_CHECK("igemm_ring launch");
     return LH_OK;

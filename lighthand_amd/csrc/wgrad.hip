@@ -22,6 +22,7 @@ struct WgradArgs {
     int ho, wo, M, sh, sw;
     int dy_pix_stride, n_out, n_in;
     int ntaps, nsplit, steps_per_split, i_tiles;
+    int tiles, xcd;              // ring kernel: 1-D grid of tiles * ntaps * nsplit work items, XCD-aware order
     signed char dh[64];
     signed char dw[64];
 };
@@ -184,6 +185,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
 // the swizzle is applied to the per-lane SOURCE address and to the read address.
 __device__ __attribute__((aligned(16))) unsigned int lh_wzero_page[4] = {0u, 0u, 0u, 0u};
 
+#ifndef LH_ABL      // debug-only ablation builds, see igemm_ring.hip / tools/ablate.sh
+#define LH_ABL 0
+#endif
+
 template <int ROWB> __device__ __forceinline__ int wswz(int row) {
     return ROWB == 256 ? (row & 7) : ((row >> 1) & 3);
 }
@@ -206,8 +211,11 @@ __global__ __launch_bounds__(256) void wgrad_ring_kernel(const WgradArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wo_ = wave / WI, wi_ = wave % WI;
-    const int otile = blockIdx.x / p.i_tiles, itile = blockIdx.x % p.i_tiles;
-    const int tap = blockIdx.y, split = blockIdx.z;
+    // work item w = (split, tap, tile), tile fastest: every XCD gets a contiguous range of pixel splits with all their
+    // taps and tiles, which re-read the same dy / x rows from that XCD's L2 instead of the Infinity Cache
+    const int w = p.xcd ? lh_xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int tile = w % p.tiles, tap = (w / p.tiles) % p.ntaps, split = w / (p.tiles * p.ntaps);
+    const int otile = tile / p.i_tiles, itile = tile % p.i_tiles;
     const int dh = p.dh[tap], dw = p.dw[tap];
     const int hw = p.ho * p.wo;
     const long m_begin = (long)split * p.steps_per_split * KP;
@@ -243,7 +251,7 @@ __global__ __launch_bounds__(256) void wgrad_ring_kernel(const WgradArgs p) {
             const bool ok = (int)(m < m_end) & (int)(ocol[j] < p.n_out);
             const unsigned char* src = p.dy + (m * p.dy_pix_stride + ocol[j]) * 2;
             src = ok ? src : zero;
-            __builtin_amdgcn_global_load_lds((gbl_p)src, (lds_p)(st + (4 * j + wave) * 1024), 16, 0, 0);
+            if (!(LH_ABL & 4)) __builtin_amdgcn_global_load_lds((gbl_p)src, (lds_p)(st + (4 * j + wave) * 1024), 16, 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
@@ -256,7 +264,7 @@ __global__ __launch_bounds__(256) void wgrad_ring_kernel(const WgradArgs p) {
                             (int)((unsigned)iw < (unsigned)p.wi);
             const unsigned char* src = p.x + (((long)(n * p.hi + ih) * p.wi + iw) * p.in_pix_stride + icol[j]) * 2;
             src = ok ? src : zero;
-            __builtin_amdgcn_global_load_lds((gbl_p)src, (lds_p)(st + KP * RBO + (4 * j + wave) * 1024), 16, 0, 0);
+            if (!(LH_ABL & 4)) __builtin_amdgcn_global_load_lds((gbl_p)src, (lds_p)(st + KP * RBO + (4 * j + wave) * 1024), 16, 0, 0);
         }
     };
 
@@ -299,11 +307,13 @@ __global__ __launch_bounds__(256) void wgrad_ring_kernel(const WgradArgs p) {
         uint2 fo[OT][2], fi[IT][2];
 #pragma unroll
         for (int i = 0; i < OT; ++i) {
+            if (LH_ABL & 2) { fo[i][0] = fo[i][1] = uint2{st, st}; continue; }
             asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fo[i][0]) : "v"(st + ao[i][0]));
             asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fo[i][1]) : "v"(st + ao[i][1]));
         }
 #pragma unroll
         for (int j = 0; j < IT; ++j) {
+            if (LH_ABL & 2) { fi[j][0] = fi[j][1] = uint2{st, st}; continue; }
             asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fi[j][0]) : "v"(st + ai[j][0]));
             asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fi[j][1]) : "v"(st + ai[j][1]));
         }
@@ -315,10 +325,11 @@ __global__ __launch_bounds__(256) void wgrad_ring_kernel(const WgradArgs p) {
             for (int j = 0; j < IT; ++j) {
                 const uint4 a = uint4{fo[i][0].x, fo[i][0].y, fo[i][1].x, fo[i][1].y};
                 const uint4 b = uint4{fi[j][0].x, fi[j][0].y, fi[j][1].x, fi[j][1].y};
-                WFrag<T>::mma(a, b, acc[i][j]);
+                if (!(LH_ABL & 1)) WFrag<T>::mma(a, b, acc[i][j]);
             }
     }
 
+    if (LH_ABL & 8) { if (acc[0][0][0] == 123.456f) p.slab[0] = 1.f; return; }
     float* slab = p.slab + ((long)split * p.ntaps + tap) * p.n_out * p.n_in;
     const int qq = lane >> 4, cc = lane & 15;
 #pragma unroll
@@ -436,8 +447,13 @@ template <typename T, int BO, int BI, int WO, int WI>
 static int launch_wgrad_ring(const WgradArgs& a, hipStream_t s) {
     constexpr int D = 4;
     constexpr int lds = D * 32 * (BO * 2 + BI * 2);
-    dim3 grid(ceil_div(a.n_out, BO) * a.i_tiles, a.ntaps, a.nsplit);
-    hipLaunchKernelGGL((wgrad_ring_kernel<T, BO, BI, WO, WI, D>), grid, dim3(256), lds, s, a);
+    WgradArgs b = a;
+    static int xcd = -1;
+    if (xcd < 0) xcd = getenv("LH_NO_XCD") ? 0 : 1;
+    b.tiles = ceil_div(a.n_out, BO) * a.i_tiles;
+    b.xcd = xcd;
+    dim3 grid(b.tiles * a.ntaps * a.nsplit);
+    hipLaunchKernelGGL((wgrad_ring_kernel<T, BO, BI, WO, WI, D>), grid, dim3(256), lds, s, b);
     LH_LAUNCH_CHECK("wgrad_ring launch");
     return LH_OK;
 }

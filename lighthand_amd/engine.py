@@ -197,6 +197,12 @@ class Plan:
         self._producers = {}               # id(raw conv output Act) -> the igemm calls that write it (eval-mode BN folding)
         self.keep = []                     # ctypes objects / tensors referenced by raw pointer
         self._ws_wgrad = 0
+        # LH_OWN_WGRAD_SLABS=1: every convolution keeps its own split-K slab, so its fold kernel (and the other small
+        # gradient tails, lane 2) may run on a side stream beside the next layer.  Measured on R50 bs64 inside the
+        # captured step: 14.16 ms with the tails on a side stream vs 13.22 ms in order on one stream with ONE shared,
+        # cache-resident slab -- every cross-stream edge of the hipGraph costs more than the 5-8 us kernel it hides,
+        # so the default is the shared slab and a single stream.
+        self.own_slabs = bool(os.environ.get("LH_OWN_WGRAD_SLABS"))
         self._ws_fuse = 0
         self._ws_users = []
         self._ws_users_fuse = []
@@ -427,10 +433,10 @@ class Plan:
                 if names:
                     self.bwd_marks.append((len(self.bwd), names))
             # two workspaces: the weight-gradient chain may run concurrently with the BN-backward chain
-            ws_w = self._alloc(max(self._ws_wgrad, 256), dtype=torch.uint8)
+            ws_w = None if self.own_slabs else self._alloc(max(self._ws_wgrad, 256), dtype=torch.uint8)
             ws_f = self._alloc(max(self._ws_fuse, 256), dtype=torch.uint8)
-            for setter in self._ws_users:
-                setter(ws_w.data_ptr())
+            for setter, nbytes in self._ws_users:
+                setter((self._alloc(max(nbytes, 256), dtype=torch.uint8) if ws_w is None else ws_w).data_ptr())
             for setter in self._ws_users_fuse:
                 setter(ws_f.data_ptr())
 
@@ -506,18 +512,19 @@ class Plan:
             dy = self._act_grad(y)
             call_w = [self.lib.lh_wgrad, [C.byref(d), xbuf.data_ptr(), dy.data_ptr(), y.c, y.c, cin, 0, self.dt], nd["w"] + " wgrad"]
             call_r = [self.lib.lh_wgrad_reduce, [C.byref(d), 0, gtmp.data_ptr(), y.c if pad_out else cout, cin, cin * k * k, k * k, k, 1, rs_arr, 0, self.dt], nd["w"] + " wgrad reduce"]
-            cw, cr = _Call(call_w[0], None, call_w[2], lane=1), _Call(call_r[0], None, call_r[2], keep=rs_arr, lane=1)
+            tail = 2 if self.own_slabs else 1
+            cw, cr = _Call(call_w[0], None, call_w[2], lane=1), _Call(call_r[0], None, call_r[2], keep=rs_arr, lane=tail)
 
             def set_ws(ptr, cw=cw, cr=cr, a=call_w[1], b=call_r[1]):
                 a[6] = ptr
                 b[1] = ptr
                 cw.args, cr.args = tuple(a), tuple(b)
-            self._ws_users.append(set_ws)
+            self._ws_users.append((set_ws, slab_bytes))
             self.bwd.append(cw)
             self.profile_meta.append(("bwd", self.bwd[-1], self._kname(d, (y.c, cin)), flops, (x.pixels * x.c + y.pixels * y.c) * self.es))
             self.bwd.append(cr)
             if pad_out:
-                self.bwd.append(_TorchCall(lambda: gw.copy_(gtmp[:cout]), "head grad crop", lane=1))
+                self.bwd.append(_TorchCall(lambda: gw.copy_(gtmp[:cout]), "head grad crop", lane=tail))
             if nd["bias"]:
                 gb_ = self.grads[nd["bias"]]
                 if y is self.out_act:      # the head: reduce the contiguous fp32 NCHW gradient instead of strided bf16
@@ -559,7 +566,8 @@ class Plan:
         self.profile_meta.append(("fwd", self.fwd[-1], self._kname(d), flops, (x.pixels * 4 + y.pixels * y.c) * self.es))
         if not self.with_bwd:
             return
-        self._ws_wgrad = max(self._ws_wgrad, self.lib.lh_wgrad_slab_bytes(C.byref(d), y.c, kr, self.dt))
+        slab_bytes = self.lib.lh_wgrad_slab_bytes(C.byref(d), y.c, kr, self.dt)
+        self._ws_wgrad = max(self._ws_wgrad, slab_bytes)
         rs_arr = _taps_array(rows)
         gstage = self._alloc(cout, k, kr // 4, 4, dtype=torch.float32)
         gw = self.grads[nd["w"] + ".weight"]
@@ -568,17 +576,18 @@ class Plan:
             dy = self._act_grad(y)
             a = [C.byref(d), img.data_ptr(), dy.data_ptr(), y.c, y.c, kr, 0, self.dt]
             b = [C.byref(d), 0, gstage.data_ptr(), cout, kr, k * kr, 1, kr, 0, rs_arr, 0, self.dt]
-            cw, cr = _Call(self.lib.lh_wgrad, None, "stem wgrad", lane=1), _Call(self.lib.lh_wgrad_reduce, None, "stem wgrad reduce", keep=rs_arr, lane=1)
+            tail = 2 if self.own_slabs else 1
+            cw, cr = _Call(self.lib.lh_wgrad, None, "stem wgrad", lane=1), _Call(self.lib.lh_wgrad_reduce, None, "stem wgrad reduce", keep=rs_arr, lane=tail)
 
             def set_ws(ptr):
                 a[6] = ptr
                 b[1] = ptr
                 cw.args, cr.args = tuple(a), tuple(b)
-            self._ws_users.append(set_ws)
+            self._ws_users.append((set_ws, slab_bytes))
             self.bwd.append(cw)
             self.profile_meta.append(("bwd", self.bwd[-1], self._kname(d, (y.c, kr)), flops, (x.pixels * 4 + y.pixels * y.c) * self.es))
             self.bwd.append(cr)
-            self.bwd.append(_TorchCall(lambda: gw.copy_(gstage[:, :, :k, :3].permute(0, 3, 1, 2)), "stem grad unstage", lane=1))
+            self.bwd.append(_TorchCall(lambda: gw.copy_(gstage[:, :, :k, :3].permute(0, 3, 1, 2)), "stem grad unstage", lane=tail))
         blk.append(emit)
 
     # ---- transposed convolution ------------------------------------------------------------------
@@ -617,7 +626,8 @@ class Plan:
         dg = _desc(y.n, y.h, y.w, y.c, cout, x.h, x.w, 2, 2, x.c, x.h, x.w, 1, 1, 0, 0, x.c, taps)
         self.keep.append(dg)
         gpack = self._pack(wt, cin, cout, (cout * k * k, k * k, k, 1), all_rs, nd["w"] + " deconv dgrad pack")
-        self._ws_wgrad = max(self._ws_wgrad, self.lib.lh_wgrad_slab_bytes(C.byref(dg), cin, cout, self.dt))
+        slab_bytes = self.lib.lh_wgrad_slab_bytes(C.byref(dg), cin, cout, self.dt)
+        self._ws_wgrad = max(self._ws_wgrad, slab_bytes)
         rs_arr = _taps_array(all_rs)
         gw = self.grads[nd["w"] + ".weight"]
         flops = 2.0 * x.pixels * cin * cout * k * k
@@ -626,13 +636,14 @@ class Plan:
             dy = self._act_grad(y)
             a = [C.byref(dg), dy.data_ptr(), xbuf.data_ptr(), x.c, cin, cout, 0, self.dt]
             b = [C.byref(dg), 0, gw.data_ptr(), cin, cout, cout * k * k, k * k, k, 1, rs_arr, 0, self.dt]
-            cw, cr = _Call(self.lib.lh_wgrad, None, nd["w"] + " wgrad", lane=1), _Call(self.lib.lh_wgrad_reduce, None, nd["w"] + " wgrad reduce", keep=rs_arr, lane=1)
+            tail = 2 if self.own_slabs else 1
+            cw, cr = _Call(self.lib.lh_wgrad, None, nd["w"] + " wgrad", lane=1), _Call(self.lib.lh_wgrad_reduce, None, nd["w"] + " wgrad reduce", keep=rs_arr, lane=tail)
 
             def set_ws(ptr):
                 a[6] = ptr
                 b[1] = ptr
                 cw.args, cr.args = tuple(a), tuple(b)
-            self._ws_users.append(set_ws)
+            self._ws_users.append((set_ws, slab_bytes))
             self.bwd.append(cw)
             self.profile_meta.append(("bwd", self.bwd[-1], self._kname(dg, (cin, cout)), flops, (x.pixels * x.c + y.pixels * y.c) * self.es))
             self.bwd.append(cr)
@@ -787,12 +798,13 @@ class Plan:
         for c in self.fwd:
             c(stream)
 
-    def run_backward(self, stream, lo=0, hi=None, side=None):
-        """Run bwd[lo:hi].  With ``side`` (a torch stream) the weight-gradient launches (lane 1) go to that stream:
-        each waits for the main-stream work enqueued before it (its dy) and the main stream joins at the end, so
-        the data-gradient chain and the weight-gradient chain overlap (also inside a captured hipGraph)."""
+    def run_backward(self, stream, lo=0, hi=None, side=None, side_lanes=(1, 2)):
+        """Run bwd[lo:hi].  With ``side`` (a torch stream) the launches whose lane is in ``side_lanes`` go to that
+        stream (lane 1: weight-gradient kernels, lane 2: their small tails -- split-K fold, crops): each waits for the
+        main-stream work enqueued before it and the main stream joins at the end, so they overlap the data-gradient
+        chain (also inside a captured hipGraph)."""
         calls = self.bwd[lo:hi]
-        if side is None:
+        if side is None or not side_lanes:
             for c in calls:
                 c(stream)
             return
@@ -800,7 +812,7 @@ class Plan:
         sptr = side.cuda_stream
         pending = False
         for c in calls:
-            if c.lane == 1:
+            if c.lane in side_lanes:
                 if not pending:                 # first side launch after main-stream work: order it behind that work
                     side.wait_stream(main)
                     pending = True

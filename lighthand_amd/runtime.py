@@ -52,7 +52,11 @@ class TrainStep:
         # (every kernel already fills the CUs' LDS), so the overlap is opt-in (LH_OVERLAP_WGRAD=1 or the argument)
         if os.environ.get("LH_OVERLAP_WGRAD"):
             overlap_wgrad = True
-        self.side = torch.cuda.Stream() if overlap_wgrad else None    # weight-gradient chain runs beside the dgrad chain
+        # lane 2 (split-K folds and other small gradient tails) can also go to the side stream when the plan keeps one
+        # slab per layer (LH_OWN_WGRAD_SLABS=1); measured slower as well (see Plan.__init__), so off by default
+        tails = self.plan.own_slabs
+        self.side = torch.cuda.Stream() if (overlap_wgrad or tails) else None
+        self.side_lanes = (1, 2) if overlap_wgrad else (2,)
 
     # ---- the work of one iteration, enqueued on the current stream --------------------------------
     def _fwd_loss(self, stream):
@@ -76,7 +80,7 @@ class TrainStep:
     def _enqueue_all(self):
         stream = torch.cuda.current_stream().cuda_stream
         self._fwd_loss(stream)
-        self.plan.run_backward(stream, side=self.side)
+        self.plan.run_backward(stream, side=self.side, side_lanes=self.side_lanes)
         self.optimizer.step(grad_scale=self.grad_scale)
 
     def _capture(self):
@@ -104,7 +108,7 @@ class TrainStep:
                 stream = torch.cuda.current_stream().cuda_stream
                 if i == 0:
                     self._fwd_loss(stream)
-                self.plan.run_backward(stream, lo, hi, side=self.side)
+                self.plan.run_backward(stream, lo, hi, side=self.side, side_lanes=self.side_lanes)
             self.graphs.append((g, bucket))
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
@@ -115,7 +119,7 @@ class TrainStep:
         stream = torch.cuda.current_stream().cuda_stream
         self._fwd_loss(stream)
         for lo, hi, bucket in self.grad_sync.segments(self.plan):
-            self.plan.run_backward(stream, lo, hi, side=self.side)
+            self.plan.run_backward(stream, lo, hi, side=self.side, side_lanes=self.side_lanes)
             if bucket is not None:
                 self.grad_sync.launch(self.arena.flat_grad, bucket)
         self.grad_sync.wait_all()

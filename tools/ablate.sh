@@ -7,5 +7,6 @@ mkdir -p ../../tools/abl
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -ffp-contract=off"
 for v in "$@"; do
   /opt/rocm/bin/hipcc $FLAGS -DLH_ABL=$v -c igemm_ring.hip -o /tmp/igemm_ring_abl$v.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC igemm.o /tmp/igemm_ring_abl$v.o wgrad.o bn.o misc.o -o ../../tools/abl/lib_abl$v.so
+  /opt/rocm/bin/hipcc $FLAGS -DLH_ABL=$v -c wgrad.hip -o /tmp/wgrad_abl$v.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC igemm.o /tmp/igemm_ring_abl$v.o /tmp/wgrad_abl$v.o bn.o misc.o -o ../../tools/abl/lib_abl$v.so
 done
