@@ -249,23 +249,51 @@ template <typename T>
 __global__ __launch_bounds__(256) void pack_tiled_kernel(const lh_pack_conv* convs, const int* chunk_conv, const int* chunk_t0,
                                                          const int* chunk_t1) {
     extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
-    T* tile = reinterpret_cast<T*>(psm);                         // [32 d0][32 d1][rs] (+1 pad per d0 row)
+    T* tile = reinterpret_cast<T*>(psm);                         // [32 d0][32 d1][rs] (+4 pad per d0 row)
     const lh_pack_conv& c = convs[chunk_conv[blockIdx.x]];
     const int t0 = chunk_t0[blockIdx.x] * 32, t1 = chunk_t1[blockIdx.x] * 32;
     const int rs = c.rs;
     const int rowlen = 32 * rs;                                  // contiguous floats per d0 row of the tile
-    const int ld = rowlen + 2;                                   // LDS row stride in elements
-    for (int i = threadIdx.x; i < 32 * rowlen; i += 256) {
-        const int a = i / rowlen, rem = i - a * rowlen;          // a = d0 offset, rem = d1_off * rs + tap
-        const int d0 = t0 + a, d1 = t1 + rem / rs;
-        float v = 0.f;
-        if (d0 < c.d0 && d1 < c.d1) v = c.w[((long)d0 * c.d1 + t1) * rs + rem];
-        tile[a * ld + rem] = from_f<T>(v);
+    const int ld = rowlen + 4;                                   // LDS row stride in elements (8-byte aligned rows)
+    const bool full = t0 + 32 <= c.d0 && t1 + 32 <= c.d1 && ((long)c.d1 * rs) % 4 == 0 && sizeof(T) == 2;
+    if (full) {                                                  // interior tile: 16-byte loads, 8-byte LDS stores
+        const int vpr = rowlen / 4;                              // float4 per row
+        for (int i = threadIdx.x; i < 32 * vpr; i += 256) {
+            const int a = i / vpr, v4 = i - a * vpr;
+            const float4 v = *reinterpret_cast<const float4*>(c.w + ((long)(t0 + a) * c.d1 + t1) * rs + v4 * 4);
+            union { uint2 u; T e[4]; } pk;
+            pk.e[0] = from_f<T>(v.x); pk.e[1] = from_f<T>(v.y); pk.e[2] = from_f<T>(v.z); pk.e[3] = from_f<T>(v.w);
+            *reinterpret_cast<uint2*>(tile + a * ld + v4 * 4) = pk.u;
+        }
+    } else {
+        for (int i = threadIdx.x; i < 32 * rowlen; i += 256) {
+            const int a = i / rowlen, rem = i - a * rowlen;      // a = d0 offset, rem = d1_off * rs + tap
+            const int d0 = t0 + a, d1 = t1 + rem / rs;
+            float v = 0.f;
+            if (d0 < c.d0 && d1 < c.d1) v = c.w[((long)d0 * c.d1 + t1) * rs + rem];
+            tile[a * ld + rem] = from_f<T>(v);
+        }
     }
     __syncthreads();
     for (int p = 0; p < c.npacks; ++p) {
         const lh_pack_out& o = c.packs[p];
         T* out = reinterpret_cast<T*>(o.out);
+        const int nrow = o.row_is_d1 ? c.d1 : c.d0, nk = o.row_is_d1 ? c.d0 : c.d1;
+        const int r0 = o.row_is_d1 ? t1 : t0, k0 = o.row_is_d1 ? t0 : t1;
+        if (full && (o.kpad & 3) == 0) {                         // four K values per thread: one 8-byte store
+            const int total = o.ntaps * 32 * 8;
+            for (int i = threadIdx.x; i < total; i += 256) {
+                const int k = (i & 7) * 4, rest = i >> 3;
+                const int t = rest % o.ntaps, row = rest / o.ntaps;
+                const int tap = o.taps[t];
+                union { uint2 u; T e[4]; } pk;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    pk.e[e] = o.row_is_d1 ? tile[(k + e) * ld + row * rs + tap] : tile[row * ld + (k + e) * rs + tap];
+                *reinterpret_cast<uint2*>(out + ((long)(r0 + row) * o.ntaps + t) * o.kpad + k0 + k) = pk.u;
+            }
+            continue;
+        }
         const int total = o.ntaps * 32 * 32;
         for (int i = threadIdx.x; i < total; i += 256) {
             const int k = i & 31, rest = i >> 5;                 // k runs along the pack's K (fastest in memory)
@@ -273,8 +301,7 @@ __global__ __launch_bounds__(256) void pack_tiled_kernel(const lh_pack_conv* con
             const int tap = o.taps[t];
             int a, b;                                            // a = d0 offset, b = d1 offset inside the tile
             if (o.row_is_d1) { b = row; a = k; } else { a = row; b = k; }
-            const int grow = (o.row_is_d1 ? t1 : t0) + row, gk = (o.row_is_d1 ? t0 : t1) + k;
-            const int nrow = o.row_is_d1 ? c.d1 : c.d0, nk = o.row_is_d1 ? c.d0 : c.d1;
+            const int grow = r0 + row, gk = k0 + k;
             if (grow < nrow && gk < nk) out[((long)grow * o.ntaps + t) * o.kpad + gk] = tile[a * ld + b * rs + tap];
         }
     }
@@ -285,7 +312,7 @@ extern "C" int lh_pack_weights_tiled(const lh_pack_conv* convs_dev, const int* c
     LH_REQUIRE(convs_dev && chunk_conv_dev && chunk_t0_dev && chunk_t1_dev && n_chunks > 0 && max_rs > 0 && max_rs <= 49,
                "lh_pack_weights_tiled: bad arguments");
     const int es = lh_dtype_size(dtype);
-    const size_t lds = (size_t)32 * (32 * max_rs + 2) * es;
+    const size_t lds = (size_t)32 * (32 * max_rs + 4) * es;
     LH_REQUIRE(lds <= 64 * 1024, "lh_pack_weights_tiled: tile of %d taps does not fit LDS for this dtype", max_rs);
     LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((pack_tiled_kernel<T>), dim3(n_chunks), dim3(256), lds, (hipStream_t)stream,
                                                    convs_dev, chunk_conv_dev, chunk_t0_dev, chunk_t1_dev));
