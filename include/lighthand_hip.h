@@ -138,20 +138,23 @@ typedef struct {
 int lh_igemm(const lh_igemm_desc* d, const void* in, const void* wpack, void* out,
              const void* addend, const float* bias, const float* scale, const float* shift, float* stats,
              int dtype, void* stream);
-/* Data gradient with the FOLLOWING BatchNorm-backward reduction fused into its epilogue (loss.backward() through
- * conv -> relu -> BN, e.g. pose_resnet.py:83-93 walked in reverse): `out` receives the plain data gradient dA of the
- * activation a = relu(x*scale + shift); `partial` receives lh_igemm_stats_rows(d) rows [2][cout] of
- *   (sum g, sum g * (x - mean) * invstd),  g = dA masked by (x*scale + shift > 0),
- * i.e. exactly the per-strip sums lh_fuse_bwd's reduce pass would produce, so that pass (one read of dA and x) is
- * skipped via lh_fuse_bwd_desc.ext_partial.  x has out's layout (same pixel stride and placement). */
+/* Data gradient with the BatchNorm-backward reduction of the node that PRODUCED the differentiated activation fused
+ * into its epilogue (loss.backward() through conv -> relu -> BN, e.g. pose_resnet.py:83-97 walked in reverse).
+ * `out` receives the data gradient dA (+ addend: the launch must then be the LAST writer of dA, so that the stored
+ * value is final); `partial` receives lh_igemm_stats_rows(d) rows [2][cout] of
+ *   (sum g, sum g * (x - mean) * invstd),  g = dA masked by the activation's ReLU,
+ * i.e. the per-strip sums lh_fuse_bwd's reduce pass would produce, so that pass (one read of dA, x and the mask) is
+ * skipped via lh_fuse_bwd_desc.ext_partial.  The mask is (x*scale + shift > 0) for a = relu(BN(x)), or the relu_mask
+ * bits lh_fuse_fwd stored for a = relu(BN(x) + other terms).  x has out's layout (same pixel stride and placement). */
 typedef struct lh_bn_tap {
     const void* x;
-    const float* scale;
+    const float* scale;        /* may be NULL when relu_mask is given */
     const float* shift;
     const float* mean;
     const float* invstd;
+    const void* relu_mask;     /* optional: one byte per 16-byte chunk of the (dense) activation */
 } lh_bn_tap;
-int lh_igemm_bntap(const lh_igemm_desc* d, const void* in, const void* wpack, void* out,
+int lh_igemm_bntap(const lh_igemm_desc* d, const void* in, const void* wpack, void* out, const void* addend,
                    const lh_bn_tap* tap, float* partial, int dtype, void* stream);
 /* tile (output channels x pixels) the dispatcher picks for this descriptor: names the kernel
  * instantiation a launch uses -- igemm_ring_kernel<T, bm, bp, .., depth, kbytes> when *ring != 0 (LDS-DMA ring
@@ -204,6 +207,8 @@ typedef struct {
     int log2up[4];
     int nterms;
     int relu;
+    void* relu_mask;            /* optional output: one byte per 16-byte chunk of `out`, bit e = (element e > 0); lets the
+                                 * backward pass read n*h*w*c/8 mask bytes instead of the whole stored activation */
 } lh_fuse_desc;
 int lh_fuse_fwd(const lh_fuse_desc* d, void* out, int n, int h, int w, int c, int dtype, void* stream);
 
@@ -227,6 +232,7 @@ typedef struct {
     int accumulate[4];
     int nterms;
     int relu;
+    const void* relu_mask;      /* mask bits written by lh_fuse_fwd; when set, `out` is not read and may be NULL */
     const float* ext_partial[4];   /* reduce sums already produced by lh_igemm_bntap (rows x [2][c]); NULL = run the reduce pass */
     int ext_rows[4];
 } lh_fuse_bwd_desc;

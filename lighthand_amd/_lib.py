@@ -26,7 +26,7 @@ class IgemmDesc(C.Structure):
 
 class FuseDesc(C.Structure):
     _fields_ = [("x", C.c_void_p * 4), ("scale", C.c_void_p * 4), ("shift", C.c_void_p * 4),
-                ("log2up", C.c_int * 4), ("nterms", C.c_int), ("relu", C.c_int)]
+                ("log2up", C.c_int * 4), ("nterms", C.c_int), ("relu", C.c_int), ("relu_mask", C.c_void_p)]
 
 
 class FuseBwdDesc(C.Structure):
@@ -34,11 +34,12 @@ class FuseBwdDesc(C.Structure):
                 ("shift", C.c_void_p * 4), ("save_mean", C.c_void_p * 4), ("save_invstd", C.c_void_p * 4), ("dx", C.c_void_p * 4),
                 ("dgamma", C.c_void_p * 4), ("dbeta", C.c_void_p * 4), ("log2up", C.c_int * 4),
                 ("accumulate", C.c_int * 4), ("nterms", C.c_int), ("relu", C.c_int),
-                ("ext_partial", C.c_void_p * 4), ("ext_rows", C.c_int * 4)]
+                ("relu_mask", C.c_void_p), ("ext_partial", C.c_void_p * 4), ("ext_rows", C.c_int * 4)]
 
 
 class BnTap(C.Structure):
-    _fields_ = [("x", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p)]
+    _fields_ = [("x", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p),
+                ("relu_mask", C.c_void_p)]
 
 
 class PackItem(C.Structure):
@@ -73,7 +74,7 @@ SIGNATURES = {
     "lh_pack_weights_multi": (_I, [_P, _P, _P, _I, _I, _P]),
     "lh_pack_weights_tiled": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "lh_igemm": (_I, [C.POINTER(IgemmDesc), _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
-    "lh_igemm_bntap": (_I, [C.POINTER(IgemmDesc), _P, _P, _P, C.POINTER(BnTap), _P, _I, _P]),
+    "lh_igemm_bntap": (_I, [C.POINTER(IgemmDesc), _P, _P, _P, _P, C.POINTER(BnTap), _P, _I, _P]),
     "lh_igemm_tile": (_I, [C.POINTER(IgemmDesc), _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "lh_wgrad_tile": (_I, [C.POINTER(IgemmDesc), _I, _I, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "lh_igemm_stats_rows": (_I, [C.POINTER(IgemmDesc), _I]),

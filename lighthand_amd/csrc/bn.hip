@@ -227,8 +227,24 @@ struct FuseArgs {
     int log2up[4];
     int nterms, relu;
     unsigned char* out;
+    unsigned char* mask;         // optional: one byte per 16-byte chunk of `out`, bit e = (element e > 0)
     int n, h, w, c;
 };
+
+// bit e of the result = (stored element e > 0): computed from the ROUNDED values so that it equals `out > 0`
+template <typename T> __device__ __forceinline__ unsigned char positive_bits(const uint4& u) {
+    constexpr int EPC = 16 / sizeof(T);
+    float r[EPC];
+    unpack16<T>(u, r);
+    unsigned m = 0;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) m |= (r[e] > 0.f ? 1u : 0u) << e;
+    return (unsigned char)m;
+}
+template <int EPC> __device__ __forceinline__ void mask_by_bits(unsigned m, float* g) {
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) g[e] = ((m >> e) & 1u) ? g[e] : 0.f;
+}
 
 template <typename T>
 __global__ __launch_bounds__(256) void fuse_fwd_kernel(const FuseArgs p) {
@@ -267,7 +283,9 @@ __global__ __launch_bounds__(256) void fuse_fwd_kernel(const FuseArgs p) {
 #pragma unroll
             for (int e = 0; e < EPC; ++e) acc[e] = fmaxf(acc[e], 0.f);
         }
-        *reinterpret_cast<uint4*>(p.out + idx * 16) = pack16<T>(acc);
+        const uint4 u = pack16<T>(acc);
+        *reinterpret_cast<uint4*>(p.out + idx * 16) = u;
+        if (p.mask) p.mask[idx] = positive_bits<T>(u);
     }
 }
 
@@ -320,7 +338,9 @@ __global__ __launch_bounds__(256) void fuse_fwd_flat_kernel(const FuseArgs p, lo
 #pragma unroll
             for (int e = 0; e < EPC; ++e) acc[e] = fmaxf(acc[e], 0.f);
         }
-        *reinterpret_cast<uint4*>(p.out + idx * 16) = pack16<T>(acc);
+        const uint4 u = pack16<T>(acc);
+        *reinterpret_cast<uint4*>(p.out + idx * 16) = u;
+        if (p.mask) p.mask[idx] = positive_bits<T>(u);
     }
 }
 
@@ -341,7 +361,7 @@ extern "C" int lh_fuse_fwd(const lh_fuse_desc* d, void* out, int n, int h, int w
             LH_REQUIRE((a.scale[t] == nullptr) == (a.shift[t] == nullptr), "lh_fuse_fwd: scale/shift must come together");
         }
     }
-    a.nterms = d->nterms; a.relu = d->relu; a.out = (unsigned char*)out; a.n = n; a.h = h; a.w = w; a.c = c;
+    a.nterms = d->nterms; a.relu = d->relu; a.out = (unsigned char*)out; a.mask = (unsigned char*)d->relu_mask; a.n = n; a.h = h; a.w = w; a.c = c;
     const long total = (long)n * h * w * (c / (16 / es));
     const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     const int nchunk = c / (16 / es);
@@ -367,6 +387,7 @@ extern "C" int lh_fuse_fwd(const lh_fuse_desc* d, void* out, int n, int h, int w
 struct FuseBwdArgs {
     const unsigned char* dout;
     const unsigned char* out;
+    const unsigned char* mask;   // optional ReLU mask bits written by lh_fuse_fwd (replaces reading `out`)
     const unsigned char* x;      // raw BN input of this term (null: identity)
     const float* scale;
     const float* mean;
@@ -396,7 +417,9 @@ __device__ __forceinline__ void cell_grad(const FuseBwdArgs& p, int n, int ys, i
             const long off = (pix * p.c + chunk * EPC) * sizeof(T);
             float d[EPC];
             unpack16<T>(*reinterpret_cast<const uint4*>(p.dout + off), d);
-            if (p.relu) {
+            if (p.relu && p.mask) {
+                mask_by_bits<EPC>(p.mask[off >> 4], d);
+            } else if (p.relu) {
                 float o[EPC];
                 unpack16<T>(*reinterpret_cast<const uint4*>(p.out + off), o);
 #pragma unroll
@@ -515,6 +538,8 @@ __global__ __launch_bounds__(256) void fuse_bwd_reduce_flat_kernel(const FuseBwd
         if (MASK_X) {
 #pragma unroll
             for (int e = 0; e < EPC; ++e) g[e] = (xv[e] * sc[e] + sh[e]) > 0.f ? g[e] : 0.f;
+        } else if (p.relu && p.mask) {
+            mask_by_bits<EPC>(p.mask[off >> 4], g);
         } else if (p.relu) {
             float o[EPC];
             unpack16<T>(*reinterpret_cast<const uint4*>(p.out + off), o);
@@ -568,6 +593,8 @@ __global__ __launch_bounds__(256) void fuse_bwd_apply_flat_kernel(const FuseBwdA
         if (MASK_X) {
 #pragma unroll
             for (int e = 0; e < EPC; ++e) g[e] = (xv[e] * sc[e] + sh[e]) > 0.f ? g[e] : 0.f;
+        } else if (p.relu && p.mask) {
+            mask_by_bits<EPC>(p.mask[off >> 4], g);
         } else if (p.relu) {
             float o[EPC];
             unpack16<T>(*reinterpret_cast<const uint4*>(p.out + off), o);
@@ -594,6 +621,7 @@ __global__ __launch_bounds__(256) void fuse_bwd_apply_flat_kernel(const FuseBwdA
 struct FuseBwd2Args {
     const unsigned char* dout;
     const unsigned char* out;
+    const unsigned char* mask;
     const unsigned char* x[2];
     const float* scale[2];
     const float* mean[2];
@@ -628,7 +656,9 @@ __global__ __launch_bounds__(256) void fuse_bwd_apply2_flat_kernel(const FuseBwd
         const long off = idx * 16;
         float g[EPC];
         unpack16<T>(*reinterpret_cast<const uint4*>(p.dout + off), g);
-        if (p.relu) {
+        if (p.relu && p.mask) {
+            mask_by_bits<EPC>(p.mask[idx], g);
+        } else if (p.relu) {
             float o[EPC];
             unpack16<T>(*reinterpret_cast<const uint4*>(p.out + off), o);
 #pragma unroll
@@ -696,7 +726,7 @@ extern "C" size_t lh_fuse_bwd_workspace_bytes(int n, int h, int w, int c) {
 extern "C" int lh_fuse_bwd(const lh_fuse_bwd_desc* d, int n, int h, int w, int c, void* workspace, int dtype,
                            void* stream) {
     LH_REQUIRE(d && d->dout && d->nterms >= 1 && d->nterms <= 4, "lh_fuse_bwd: bad descriptor");
-    LH_REQUIRE(!d->relu || d->out, "lh_fuse_bwd: relu needs the forward output");
+    LH_REQUIRE(!d->relu || d->out || d->relu_mask, "lh_fuse_bwd: relu needs the forward output or its mask bits");
     const int es = lh_dtype_size(dtype);
     LH_REQUIRE(es > 0 && c % (16 / es) == 0, "lh_fuse_bwd: c %d not a multiple of the 16-byte chunk", c);
     hipStream_t s = (hipStream_t)stream;
@@ -706,6 +736,7 @@ extern "C" int lh_fuse_bwd(const lh_fuse_bwd_desc* d, int n, int h, int w, int c
     FuseBwd2Args m2;
     if (merge2) {
         m2.dout = (const unsigned char*)d->dout; m2.out = (const unsigned char*)d->out; m2.c = c; m2.relu = d->relu;
+        m2.mask = (const unsigned char*)d->relu_mask;
         for (int k = 0; k < 2; ++k) {
             m2.x[k] = (const unsigned char*)d->x[k]; m2.scale[k] = d->scale[k]; m2.mean[k] = d->save_mean[k];
             m2.invstd[k] = d->save_invstd[k]; m2.coef[k] = nullptr; m2.dx[k] = (unsigned char*)d->dx[k];
@@ -716,6 +747,7 @@ extern "C" int lh_fuse_bwd(const lh_fuse_bwd_desc* d, int n, int h, int w, int c
         if (!d->dx[t]) continue;
         FuseBwdArgs a;
         a.dout = (const unsigned char*)d->dout; a.out = (const unsigned char*)d->out;
+        a.mask = (const unsigned char*)d->relu_mask;
         a.x = (const unsigned char*)d->x[t]; a.scale = d->scale[t]; a.mean = d->save_mean[t]; a.invstd = d->save_invstd[t];
         a.dx = (unsigned char*)d->dx[t]; a.dgamma = d->dgamma[t]; a.dbeta = d->dbeta[t];
         a.n = n; a.h = h; a.w = w; a.c = c; a.l = d->log2up[t]; a.relu = d->relu; a.accumulate = d->accumulate[t];
@@ -733,7 +765,8 @@ extern "C" int lh_fuse_bwd(const lh_fuse_bwd_desc* d, int n, int h, int w, int c
             long strips = fuse_bwd_strips(a.count, &a.rows_per_strip);
             a.partial = (float*)workspace;
             const bool ext = d->ext_partial[t] != nullptr;
-            LH_REQUIRE(!ext || (a.mask_from_x && d->ext_rows[t] > 0), "lh_fuse_bwd: ext_partial needs a single flat BN term under ReLU");
+            LH_REQUIRE(!ext || (flat && d->relu && d->ext_rows[t] > 0 && (a.mask_from_x || d->relu_mask)),
+                       "lh_fuse_bwd: ext_partial needs a flat BN term under ReLU (mask from x or from relu_mask bits)");
             const long slab_floats = strips * 2 * c;
             double* scratch = (double*)((float*)workspace + ((slab_floats + 3) & ~3L));
             double* totals = scratch + (long)ceil_div(strips, 256) * 2 * c;

@@ -196,10 +196,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
 #pragma unroll
     for (int e = 0; e < EPC; ++e) s1[e] = s2[e] = 0.f;
     float tsc[EPC], tsh[EPC], tmn[EPC], tiv[EPC];
+    const bool use_bits = p.tap_bits != nullptr;
     if (p.tap_x && col_ok) {
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
-            tsc[e] = p.tap_scale[col0 + e]; tsh[e] = p.tap_shift[col0 + e];
+            tsc[e] = p.tap_bits ? 0.f : p.tap_scale[col0 + e]; tsh[e] = p.tap_bits ? 0.f : p.tap_shift[col0 + e];
             tmn[e] = p.tap_mean[col0 + e]; tiv[e] = p.tap_invstd[col0 + e];
         }
     }
@@ -237,9 +238,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
             if (p.tap_x) {
                 float xv[EPC];
                 unpack16<T>(*reinterpret_cast<const uint4*>(p.tap_x + eoff * ES), xv);
+                const unsigned mbits = use_bits ? p.tap_bits[eoff / EPC] : 0u;
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) {
-                    const float g = (xv[e] * tsc[e] + tsh[e]) > 0.f ? sv[e] : 0.f;
+                    const bool on = use_bits ? ((mbits >> e) & 1u) != 0 : (xv[e] * tsc[e] + tsh[e]) > 0.f;
+                    const float g = on ? sv[e] : 0.f;
                     s1[e] += g;
                     s2[e] += g * (xv[e] - tmn[e]) * tiv[e];
                 }
@@ -341,11 +344,13 @@ static int igemm_impl(const lh_igemm_desc* d, const void* in, const void* wpack,
     a.in = (const unsigned char*)in; a.w = (const unsigned char*)wpack; a.out = (unsigned char*)out;
     a.addend = (const unsigned char*)addend; a.bias = bias; a.stats = stats;
     a.scale = scale; a.shift = shift;
-    a.tap_x = nullptr; a.tap_scale = a.tap_shift = a.tap_mean = a.tap_invstd = nullptr;
+    a.tap_x = nullptr; a.tap_scale = a.tap_shift = a.tap_mean = a.tap_invstd = nullptr; a.tap_bits = nullptr;
     if (tap) {
-        LH_REQUIRE(tap->x && tap->scale && tap->shift && tap->mean && tap->invstd && stats, "lh_igemm_bntap: incomplete tap");
+        LH_REQUIRE(tap->x && tap->mean && tap->invstd && stats && (tap->relu_mask || (tap->scale && tap->shift)),
+                   "lh_igemm_bntap: incomplete tap");
+        LH_REQUIRE(!tap->relu_mask || d->out_pix_stride == d->cout, "lh_igemm_bntap: mask bits need a dense output");
         a.tap_x = (const unsigned char*)tap->x; a.tap_scale = tap->scale; a.tap_shift = tap->shift;
-        a.tap_mean = tap->mean; a.tap_invstd = tap->invstd;
+        a.tap_mean = tap->mean; a.tap_invstd = tap->invstd; a.tap_bits = (const unsigned char*)tap->relu_mask;
     }
     LH_REQUIRE((scale == nullptr) == (shift == nullptr), "lh_igemm: scale and shift must come together");
     a.n = d->n; a.hi = d->hi; a.wi = d->wi; a.in_pix_stride = d->in_pix_stride; a.k_run = d->k_run;
@@ -392,8 +397,8 @@ extern "C" int lh_igemm(const lh_igemm_desc* d, const void* in, const void* wpac
     return igemm_impl(d, in, wpack, out, addend, bias, scale, shift, stats, nullptr, dtype, stream);
 }
 
-extern "C" int lh_igemm_bntap(const lh_igemm_desc* d, const void* in, const void* wpack, void* out,
+extern "C" int lh_igemm_bntap(const lh_igemm_desc* d, const void* in, const void* wpack, void* out, const void* addend,
                               const lh_bn_tap* tap, float* partial, int dtype, void* stream) {
     LH_REQUIRE(tap && partial, "lh_igemm_bntap: null tap / partial slab");
-    return igemm_impl(d, in, wpack, out, nullptr, nullptr, nullptr, nullptr, partial, tap, dtype, stream);
+    return igemm_impl(d, in, wpack, out, addend, nullptr, nullptr, nullptr, partial, tap, dtype, stream);
 }

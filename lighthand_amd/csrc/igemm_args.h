@@ -18,6 +18,7 @@ struct IgemmArgs {
     const float* tap_shift;
     const float* tap_mean;
     const float* tap_invstd;
+    const unsigned char* tap_bits;   // ReLU mask bits of the activation (lh_fuse_fwd relu_mask): replace the x*scale+shift test
     int n, hi, wi, in_pix_stride, k_run, kspt, kpad;   // kpad: elements per (row, tap) of the weight pack
     int ho, wo, M, sh, sw, cout;
     int OH, OW, osh, osw, ooh, oow, out_pix_stride;

@@ -282,10 +282,11 @@ __global__ __launch_bounds__(256) void igemm_ring_kernel(const IgemmArgs p) {
 #pragma unroll
     for (int e = 0; e < EPC; ++e) s1[e] = s2[e] = 0.f;
     float tsc[EPC], tsh[EPC], tmn[EPC], tiv[EPC];
+    const bool use_bits = p.tap_bits != nullptr;
     if (p.tap_x && col_ok) {
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
-            tsc[e] = p.tap_scale[col0 + e]; tsh[e] = p.tap_shift[col0 + e];
+            tsc[e] = p.tap_bits ? 0.f : p.tap_scale[col0 + e]; tsh[e] = p.tap_bits ? 0.f : p.tap_shift[col0 + e];
             tmn[e] = p.tap_mean[col0 + e]; tiv[e] = p.tap_invstd[col0 + e];
         }
     }
@@ -322,9 +323,11 @@ __global__ __launch_bounds__(256) void igemm_ring_kernel(const IgemmArgs p) {
             if (p.tap_x) {
                 float xv[EPC];
                 unpack16<T>(*reinterpret_cast<const uint4*>(p.tap_x + eoff * ES), xv);
+                const unsigned mbits = use_bits ? p.tap_bits[eoff / EPC] : 0u;
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) {
-                    const float g = (xv[e] * tsc[e] + tsh[e]) > 0.f ? sv[e] : 0.f;
+                    const bool on = use_bits ? ((mbits >> e) & 1u) != 0 : (xv[e] * tsc[e] + tsh[e]) > 0.f;
+                    const float g = on ? sv[e] : 0.f;
                     s1[e] += g;
                     s2[e] += g * (xv[e] - tmn[e]) * tiv[e];
                 }

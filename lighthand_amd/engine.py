@@ -206,7 +206,6 @@ class Plan:
         self._ws_fuse = 0
         self._ws_users = []
         self._ws_users_fuse = []
-        self._written = set()
         self.profile_meta = []             # (list name, call object, kernel name, flops, bytes)
         self._compile()
 
@@ -289,11 +288,16 @@ class Plan:
         return c
 
     def _dgrad(self, descs, dy, packs, x, what):
-        """Data-gradient launches into x.grad.  When x is the output of a conv -> BN -> ReLU fuse node and this is its
-        only consumer, the launches also produce that node's BN-backward reduction (lh_igemm_bntap)."""
+        """Data-gradient launches into x.grad.  When x is the output of a fuse node that registered a BN tap, and this
+        launch set writes the FINAL value of x.grad (sole consumer of a conv -> BN -> ReLU output, or last of the
+        writers of a residual tail's output), the launches also produce that node's BN-backward reduction
+        (lh_igemm_bntap) so the separate reduce pass over dA / x / mask disappears."""
         dx = self._act_grad(x)
+        n_before = self._nwrites.get(id(x), 0)
         first = self._first_write(x)
-        tap = x.bn_tap if first else None
+        tap = x.bn_tap
+        if tap is not None and n_before != self._n_uses.get(id(x), 1) - 1:
+            tap = None                            # a later launch still adds to this gradient
         if tap is None:
             for dd, pk in zip(descs, packs):
                 self._igemm(self.bwd, dd, dy, pk, dx, None if first else dx, None, None, what)
@@ -301,14 +305,16 @@ class Plan:
             return
         rows = [self.lib.lh_igemm_stats_rows(C.byref(dd), self.dt) for dd in descs]
         slab = self._alloc(sum(rows) * 2 * x.c, dtype=torch.float32)
-        st = tap["st"]
-        bt = BnTap(tap["x"].buf.data_ptr(), st["scale"].data_ptr(), st["shift"].data_ptr(), st["mean"].data_ptr(), st["invstd"].data_ptr())
+        st, bits = tap["st"], tap.get("bits")
+        bt = BnTap(tap["x"].buf.data_ptr(), None if bits is not None else st["scale"].data_ptr(),
+                   None if bits is not None else st["shift"].data_ptr(), st["mean"].data_ptr(), st["invstd"].data_ptr(),
+                   None if bits is None else bits.data_ptr())
         self.keep.append(bt)
         off = 0
         for dd, pk, r in zip(descs, packs, rows):
             self.keep.append(dd)
-            c = _Call(self.lib.lh_igemm_bntap, (C.byref(dd), dy.data_ptr(), pk.data_ptr(), dx.data_ptr(), C.byref(bt),
-                                                slab.data_ptr() + off, self.dt), what + " (+BN-bwd reduce)")
+            c = _Call(self.lib.lh_igemm_bntap, (C.byref(dd), dy.data_ptr(), pk.data_ptr(), dx.data_ptr(), None if first else dx.data_ptr(),
+                                                C.byref(bt), slab.data_ptr() + off, self.dt), what + " (+BN-bwd reduce)")
             c.keep = dd
             self.bwd.append(c)
             off += r * 2 * x.c * 4
@@ -342,11 +348,10 @@ class Plan:
         return f"wgrad_kernel<{t}, {a.value}, {b.value}, {wo}, {wi}>"
 
     def _first_write(self, a):
-        """True the first time a gradient buffer is produced in the backward list."""
-        if id(a) in self._written:
-            return False
-        self._written.add(id(a))
-        return True
+        """True the first time a gradient buffer is produced in the backward list (every writer calls this once)."""
+        n = self._nwrites.get(id(a), 0)
+        self._nwrites[id(a)] = n + 1
+        return n == 0
 
     def _stats_for(self, y, descs):
         rows = [self.lib.lh_igemm_stats_rows(C.byref(d), self.dt) for d in descs]
@@ -381,6 +386,9 @@ class Plan:
             elif kind == "output":
                 uses.setdefault(id(nd["y"]), []).append(kind)
         self._sole_conv_input = {k for k, v in uses.items() if len(v) == 1 and v[0] in ("conv", "deconv")}
+        self._n_uses = {k: len(v) for k, v in uses.items()}       # gradient writers per activation
+        self._last_use_is_conv = {k for k, v in uses.items() if v[0] in ("conv", "deconv")}   # first consumer = last writer
+        self._nwrites = {}
         bwd_blocks = []
         for kind, nd in self.nodes:
             blk = []
@@ -687,19 +695,38 @@ class Plan:
         self.keep.append(fd)
         if not self.training and self._fold_eval_bn(terms, bn_state, out, relu):
             return
+        # multi-term ReLU nodes (residual tails, HRNet fuse sums) keep the ReLU mask as one bit per element, so the
+        # backward pass reads n*h*w*c/8 bytes instead of the stored activation (single-BN-term nodes recompute the
+        # mask from x*scale+shift and need neither)
+        relu_bits = None
+        if relu and self.with_bwd and len(terms) > 1 and not os.environ.get("LH_NO_RELU_BITS"):
+            relu_bits = self._alloc(out.pixels * c // (16 // self.es), dtype=torch.uint8)
+            fd.relu_mask = relu_bits.data_ptr()
         self.fwd.append(_Call(self.lib.lh_fuse_fwd, (C.byref(fd), obuf.data_ptr(), out.n, out.h, out.w, c, self.dt), "fuse fwd"))
         self.profile_meta.append(("fwd", self.fwd[-1], "fuse_fwd_kernel", 0.0, (sum(a.pixels for a, _, _ in terms) + out.pixels) * c * self.es))
         if not self.with_bwd:
             return
         self._ws_fuse = max(self._ws_fuse, self.lib.lh_fuse_bwd_workspace_bytes(out.n, out.h, out.w, c))
-        if (len(terms) == 1 and terms[0][1] is not None and terms[0][2] == 0 and relu and terms[0][0].needs_grad
-                and id(out) in self._sole_conv_input and not os.environ.get("LH_NO_BNTAP")):
+        # BN-backward reduction inside the consumer's data-gradient epilogue (lh_igemm_bntap): opt-in (LH_BNTAP=1).
+        # Measured on R50 bs64 after the ring kernel's load path was fixed: 13.41 ms with the taps vs 13.20 ms without --
+        # the epilogue is the one phase of the convolution that nothing overlaps, and lengthening it by a read of x
+        # costs more than the streaming reduce pass (two reads at HBM rate) it replaces.
+        nchunk = c // (16 // self.es)
+        flat = nchunk & (nchunk - 1) == 0 and nchunk <= 256         # lh_fuse_bwd's flat kernels (the ones that take ext_partial)
+        can_tap = flat and relu and terms[0][1] is not None and terms[0][0].needs_grad and bool(os.environ.get("LH_BNTAP"))
+        if can_tap and len(terms) == 1 and terms[0][2] == 0 and id(out) in self._sole_conv_input:
             out.bn_tap = {"x": terms[0][0], "st": bn_state[0], "slab": None}
+        elif (can_tap and len(terms) == 2 and terms[0][2] == 0 and terms[1][2] == 0 and relu_bits is not None
+              and id(out) in self._last_use_is_conv and not os.environ.get("LH_NO_TAILTAP")):
+            # residual tail relu(BN(conv3) + shortcut): its output's gradient is finished by the first consumer's dgrad
+            # (the last writer in backward order), which then carries the reduction of the main BN term
+            out.bn_tap = {"x": terms[0][0], "st": bn_state[0], "slab": None, "bits": relu_bits}
 
         def emit():
             bd = FuseBwdDesc()
             bd.dout = self._act_grad(out).data_ptr()
             bd.out = obuf.data_ptr() if relu else None
+            bd.relu_mask = relu_bits.data_ptr() if relu_bits is not None else None
             bd.nterms, bd.relu = len(terms), int(relu)
             for i, (a, bn, l) in enumerate(terms):
                 bd.log2up[i] = l
@@ -714,7 +741,7 @@ class Plan:
                     bd.shift[i] = st["shift"].data_ptr()
                     bd.dgamma[i] = self.grads[bn + ".weight"].data_ptr()
                     bd.dbeta[i] = self.grads[bn + ".bias"].data_ptr()
-                    if out.bn_tap is not None and out.bn_tap["slab"] is not None:     # reduced by the consumer's dgrad
+                    if i == 0 and out.bn_tap is not None and out.bn_tap["slab"] is not None:     # reduced by a consumer's dgrad
                         bd.ext_partial[i] = out.bn_tap["slab"][0].data_ptr()
                         bd.ext_rows[i] = out.bn_tap["slab"][1]
             self.keep.append(bd)

@@ -197,7 +197,7 @@ def test_reduced_precision_trains_like_fp32(precision):
 
 def _grads_with_env(tag, precision, env, monkeypatch, expect_fused):
     from lighthand_amd.heatmap import JointsMSELoss
-    for k in ("LH_NO_BNTAP", "LH_NO_FLAT"):
+    for k in ("LH_BNTAP", "LH_NO_TAILTAP", "LH_NO_FLAT"):
         monkeypatch.delenv(k, raising=False)
     for k in env:
         monkeypatch.setenv(k, "1")
@@ -220,11 +220,11 @@ def _tensor_diffs(a, b):
 
 @pytest.mark.parametrize("tag", ["r18", "r50", "hrnet_w32"])
 def test_fused_bn_backward_reduce_matches_separate_pass(tag, monkeypatch):
-    """conv -> BN -> ReLU -> conv chains: the consumer's data-gradient kernel also produces the BN-backward sums
-    (lh_igemm_bntap).  Same arithmetic as lh_fuse_bwd's own reduce pass up to the fp32 summation order inside a tile:
+    """Opt-in path (LH_BNTAP=1).  conv -> BN -> ReLU -> conv chains and residual tails: the data-gradient kernel that
+    finishes an activation's gradient also produces the BN-backward sums (lh_igemm_bntap).  Same arithmetic as lh_fuse_bwd's own reduce pass up to the fp32 summation order inside a tile:
     in fp32 every parameter gradient agrees to 1e-4 of its tensor's scale (measured <= 1e-5)."""
-    fused = _grads_with_env(tag, "fp32", [], monkeypatch, True)
-    separate = _grads_with_env(tag, "fp32", ["LH_NO_BNTAP"], monkeypatch, False)
+    fused = _grads_with_env(tag, "fp32", ["LH_BNTAP"], monkeypatch, True)
+    separate = _grads_with_env(tag, "fp32", [], monkeypatch, False)
     d = _tensor_diffs(fused, separate)
     print(tag, "worst rel diff", d.max())
     assert d.max() < 1e-4
@@ -234,8 +234,8 @@ def test_fused_bn_backward_reduce_bf16_within_summation_noise(monkeypatch):
     """In bf16 a 1e-7 change of a BN-backward coefficient flips the rounding of a few stored gradients, and the
     backward chain of a random-init network amplifies that to percents in the first layers -- for ANY reordering of the
     sums.  Yardstick: the separate pass with its generic (LH_NO_FLAT) reduce kernel, which also only reorders sums."""
-    separate = _grads_with_env("r50", "bf16", ["LH_NO_BNTAP"], monkeypatch, False)
-    fused = _tensor_diffs(_grads_with_env("r50", "bf16", [], monkeypatch, True), separate)
-    yard = _tensor_diffs(_grads_with_env("r50", "bf16", ["LH_NO_BNTAP", "LH_NO_FLAT"], monkeypatch, False), separate)
+    separate = _grads_with_env("r50", "bf16", [], monkeypatch, False)
+    fused = _tensor_diffs(_grads_with_env("r50", "bf16", ["LH_BNTAP"], monkeypatch, True), separate)
+    yard = _tensor_diffs(_grads_with_env("r50", "bf16", ["LH_NO_FLAT"], monkeypatch, False), separate)
     print("bf16 fused-vs-separate median/max", np.median(fused), fused.max(), "| reorder yardstick", np.median(yard), yard.max())
     assert np.median(fused) < 3 * np.median(yard) + 1e-4 and fused.max() < 3 * yard.max() + 1e-3
