@@ -34,4 +34,6 @@ bool lh_ring_supported(const lh_igemm_desc* d, int dtype);
 bool lh_tap_grid(const lh_igemm_desc* d, int* tw, int* dh0, int* dhs, int* dw0, int* dws);
 void lh_ring_pick_tile(const lh_igemm_desc* d, int dtype, int* bm, int* bp);
 int lh_ring_kb();
+
+// igemm_patch.hip
 int lh_igemm_ring_launch(const IgemmArgs& a, int bm, int bp, int dtype, hipStream_t s);

@@ -1,0 +1,145 @@
+// Epilogue of the LDS-DMA convolution kernel (igemm_ring.hip), kept apart from its K loop: accumulators -> LDS tile
+// [BP pixels][BM channels] (bias / per-channel affine applied on the fp32 accumulator), then full-line NHWC stores with
+// optional addend / ReLU and the BN partial sums (or the BN-backward tap sums) of the STORED values.
+#pragma once
+#include "common.h"
+#include "igemm_args.h"
+
+#ifndef LH_ABL
+#define LH_ABL 0
+#endif
+
+template <typename T, int BM, int BP, int WC, int WP>
+__device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, unsigned char* smem, f32x4 (&acc)[BM / WC / 16][BP / WP / 16],
+                                               int pblk, int cblk, int tid, int lane, int wc, int wp, int hw) {
+    constexpr int ES = sizeof(T);
+    constexpr int EPC = 16 / ES;
+    constexpr int TC = BM / WC, TP = BP / WP;
+    constexpr int CT = TC / 16, PT = TP / 16;
+    constexpr int RS = BM * ES + 8;
+    if (LH_ABL & 8) { if (acc[0][0][0] == 123.456f) p.out[0] = 1; return; }
+    __syncthreads();
+    {
+        const int q = lane >> 4, pl = lane & 15;
+#pragma unroll
+        for (int i = 0; i < CT; ++i) {
+            const int col = wc * TC + i * 16 + q * 4;
+            float bv[4] = {0.f, 0.f, 0.f, 0.f}, sv[4] = {1.f, 1.f, 1.f, 1.f};
+            if (p.bias) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int gc = cblk * BM + col + r;
+                    bv[r] = gc < p.cout ? p.bias[gc] : 0.f;
+                }
+            }
+            if (p.scale) {                      // out = acc * scale + shift (+ bias * scale folded by the host if both are given)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int gc = cblk * BM + col + r;
+                    sv[r] = gc < p.cout ? p.scale[gc] : 1.f;
+                    bv[r] = bv[r] * sv[r] + (gc < p.cout ? p.shift[gc] : 0.f);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < PT; ++j) {
+                const int pr = wp * TP + j * 16 + pl;
+                T* dst = reinterpret_cast<T*>(smem + pr * RS + col * ES);
+                if constexpr (ES == 4) {
+                    reinterpret_cast<float2*>(dst)[0] = float2{acc[i][j][0] * sv[0] + bv[0], acc[i][j][1] * sv[1] + bv[1]};
+                    reinterpret_cast<float2*>(dst)[1] = float2{acc[i][j][2] * sv[2] + bv[2], acc[i][j][3] * sv[3] + bv[3]};
+                } else {
+                    union { uint2 u; T e[4]; } pk;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pk.e[r] = from_f<T>(acc[i][j][r] * sv[r] + bv[r]);
+                    *reinterpret_cast<uint2*>(dst) = pk.u;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    constexpr int CH = BM * ES / 16;
+    constexpr int RPP = 256 / CH;
+    const int chunk = tid % CH, r0 = tid / CH;
+    const int col0 = cblk * BM + chunk * EPC;
+    const bool col_ok = col0 < p.cout;
+    float s1[EPC], s2[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) s1[e] = s2[e] = 0.f;
+    float tsc[EPC], tsh[EPC], tmn[EPC], tiv[EPC];
+    const bool use_bits = p.tap_bits != nullptr;
+    if (p.tap_x && col_ok) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            tsc[e] = p.tap_bits ? 0.f : p.tap_scale[col0 + e]; tsh[e] = p.tap_bits ? 0.f : p.tap_shift[col0 + e];
+            tmn[e] = p.tap_mean[col0 + e]; tiv[e] = p.tap_invstd[col0 + e];
+        }
+    }
+
+    for (int pr = r0; pr < BP; pr += RPP) {
+        const int m = pblk * BP + pr;
+        if (m >= p.M || !col_ok) continue;
+        const int n = m / hw, rem = m - n * hw;
+        const int a = rem / p.wo, b = rem - a * p.wo;
+        const long opix = ((long)n * p.OH + a * p.osh + p.ooh) * p.OW + b * p.osw + p.oow;
+        const long eoff = opix * p.out_pix_stride + col0;
+        const unsigned char* src = smem + pr * RS + chunk * 16;
+        const uint2 lo = *reinterpret_cast<const uint2*>(src);
+        const uint2 hi = *reinterpret_cast<const uint2*>(src + 8);
+        uint4 u = uint4{lo.x, lo.y, hi.x, hi.y};
+        if (p.addend || p.relu) {
+            float v[EPC];
+            unpack16<T>(u, v);
+            if (p.addend) {
+                float av[EPC];
+                unpack16<T>(*reinterpret_cast<const uint4*>(p.addend + eoff * ES), av);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) v[e] += av[e];
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            u = pack16<T>(v);
+        }
+        if (p.stats) {
+            float sv[EPC];
+            unpack16<T>(u, sv);
+            if (p.tap_x) {
+                float xv[EPC];
+                unpack16<T>(*reinterpret_cast<const uint4*>(p.tap_x + eoff * ES), xv);
+                const unsigned mbits = use_bits ? p.tap_bits[eoff / EPC] : 0u;
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const bool on = use_bits ? ((mbits >> e) & 1u) != 0 : (xv[e] * tsc[e] + tsh[e]) > 0.f;
+                    const float g = on ? sv[e] : 0.f;
+                    s1[e] += g;
+                    s2[e] += g * (xv[e] - tmn[e]) * tiv[e];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) { s1[e] += sv[e]; s2[e] += sv[e] * sv[e]; }
+            }
+        }
+        *reinterpret_cast<uint4*>(p.out + eoff * ES) = u;
+    }
+
+    if (p.stats) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            red[(r0 * 2 + 0) * BM + chunk * EPC + e] = s1[e];
+            red[(r0 * 2 + 1) * BM + chunk * EPC + e] = s2[e];
+        }
+        __syncthreads();
+        for (int t = tid; t < 2 * BM; t += 256) {
+            const int which = t / BM, col = t - which * BM;
+            float a = 0.f;
+#pragma unroll 4
+            for (int r = 0; r < RPP; ++r) a += red[(r * 2 + which) * BM + col];
+            const int gc = cblk * BM + col;
+            if (gc < p.cout) p.stats[((long)pblk * 2 + which) * p.cout + gc] = a;
+        }
+    }
+}
