@@ -265,6 +265,12 @@ int lh_mse_heatmap(const float* pred, const float* target, long numel, float* lo
  * idx int32 [b*j] (first-occurrence arg-max, NaN counts as maximum). */
 int lh_heatmap_argmax(const float* heatmaps, int bj, int h, int w, float scale, float* preds,
                       float* maxvals, int* idx, void* stream);
+/* Opt-in quarter-pixel refinement of lh_heatmap_argmax's result (NOT in the reference: its config carries the unused
+ * switch TEST.POST_PROCESS, src/modeling/simplebaseline/config.py:109; this is the published SimpleBaseline rule
+ * coord += 0.25 * sign(hm[+1] - hm[-1]) per axis for peaks strictly inside the map).  idx / maxvals / preds are
+ * lh_heatmap_argmax's outputs (same scale); preds is updated in place. */
+int lh_heatmap_refine(const float* heatmaps, const int* idx, const float* maxvals, int bj, int h, int w,
+                      float scale, float* preds, void* stream);
 
 /* Validation metrics of Runner.run (src/utils/method.py:243-250) on the device: per sample, wrong[b] = number of
  * joints with error / bbox-diagonal(gt) > T (PCK_2d_loss 'proportion', src/utils/loss.py:116-148) and epe[b] = sum of

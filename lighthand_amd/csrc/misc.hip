@@ -460,6 +460,36 @@ extern "C" int lh_heatmap_argmax(const float* heatmaps, int bj, int h, int w, fl
     return LH_OK;
 }
 
+// Opt-in quarter-pixel refinement of the hard arg-max (the reference carries the switch
+// TEST.POST_PROCESS, src/modeling/simplebaseline/config.py:109, but never uses it): the published SimpleBaseline
+// `get_final_preds` rule -- when the peak (px, py) is strictly inside the map (1 < px < W-1, 1 < py < H-1) move it a
+// quarter pixel toward the higher neighbour on each axis: coord += 0.25 * sign(hm[..+1] - hm[..-1]).  Works on the
+// UNSCALED peak; `scale` is the factor lh_heatmap_argmax already applied to `preds`.
+__global__ void heatmap_refine_kernel(const float* hm, const int* idx, const float* maxvals, int bj, int h, int w,
+                                      float scale, float* preds) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= bj) return;
+    if (!(maxvals[t] > 0.f)) return;                      // get_max_preds zeroed the coordinate: px = py = 0, never interior
+    const int k = idx[t];
+    const int px = k % w, py = k / w;
+    if (!(1 < px && px < w - 1 && 1 < py && py < h - 1)) return;
+    const float* m = hm + (long)t * h * w;
+    const float dx = m[py * w + px + 1] - m[py * w + px - 1];
+    const float dy = m[(py + 1) * w + px] - m[(py - 1) * w + px];
+    const float sx = dx > 0.f ? 1.f : (dx < 0.f ? -1.f : 0.f), sy = dy > 0.f ? 1.f : (dy < 0.f ? -1.f : 0.f);
+    preds[t * 2 + 0] = ((float)px + 0.25f * sx) * scale;
+    preds[t * 2 + 1] = ((float)py + 0.25f * sy) * scale;
+}
+
+extern "C" int lh_heatmap_refine(const float* heatmaps, const int* idx, const float* maxvals, int bj, int h, int w,
+                                 float scale, float* preds, void* stream) {
+    LH_REQUIRE(heatmaps && idx && maxvals && preds && bj > 0 && h > 0 && w > 0, "lh_heatmap_refine: bad arguments");
+    hipLaunchKernelGGL(heatmap_refine_kernel, dim3((bj + 255) / 256), dim3(256), 0, (hipStream_t)stream, heatmaps, idx, maxvals,
+                       bj, h, w, scale, preds);
+    LH_LAUNCH_CHECK("heatmap_refine launch");
+    return LH_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ validation metrics
 // PCK_2d_loss(T, 'proportion') + EPE_train on the device (src/utils/loss.py:50-67,116-148): one wave per
 // sample.  wrong[b] = #joints whose error / bbox-diagonal(gt) > T; epe[b] = sum of errors of joints 1..J-2 (the

@@ -101,9 +101,10 @@ class JointsMSELoss(nn.Module):
         return _MseFn.apply(output, target)
 
 
-def max_preds_device(heatmaps, scale=1.0):
+def max_preds_device(heatmaps, scale=1.0, post_process=False):
     """Device overload: heatmaps float32 [B, J, H, W] on the device ->
-    (preds [B, J, 2], maxvals [B, J, 1], flat indices [B, J]) device tensors."""
+    (preds [B, J, 2], maxvals [B, J, 1], flat indices [B, J]) device tensors.  ``post_process=True`` adds the opt-in
+    quarter-pixel refinement (an extension: the reference's TEST.POST_PROCESS flag exists but is unused)."""
     if heatmaps.dim() != 4:
         raise AssertionError("batch_images should be 4-ndim")
     hm = heatmaps.to(torch.float32).contiguous()
@@ -113,17 +114,22 @@ def max_preds_device(heatmaps, scale=1.0):
     idx = torch.empty(b, j, dtype=torch.int32, device=hm.device)
     check(_lib.load().lh_heatmap_argmax(hm.data_ptr(), b * j, h, w, float(scale), preds.data_ptr(), maxvals.data_ptr(),
                                          idx.data_ptr(), _stream()), "lh_heatmap_argmax")
+    if post_process:
+        check(_lib.load().lh_heatmap_refine(hm.data_ptr(), idx.data_ptr(), maxvals.data_ptr(), b * j, h, w, float(scale),
+                                            preds.data_ptr(), _stream()), "lh_heatmap_refine")
     return preds, maxvals, idx
 
 
-def get_max_preds(batch_heatmaps):
+def get_max_preds(batch_heatmaps, post_process=False):
     """Reference signature (src/utils/loss.py:327-355): numpy [B, J, H, W] -> (preds float32
     [B, J, 2], maxvals [B, J, 1]) numpy arrays; device tensors are accepted too and then
-    device tensors are returned (no host round trip)."""
+    device tensors are returned (no host round trip).  ``post_process`` (default off = reference behaviour) enables
+    the quarter-pixel refinement."""
     if isinstance(batch_heatmaps, torch.Tensor):
-        p, m, _ = max_preds_device(batch_heatmaps)
+        p, m, _ = max_preds_device(batch_heatmaps, post_process=post_process)
         return p, m
     assert isinstance(batch_heatmaps, np.ndarray), "batch_heatmaps should be numpy.ndarray"
     assert batch_heatmaps.ndim == 4, "batch_images should be 4-ndim"
-    p, m, _ = max_preds_device(torch.from_numpy(np.ascontiguousarray(batch_heatmaps, dtype=np.float32)).cuda())
+    p, m, _ = max_preds_device(torch.from_numpy(np.ascontiguousarray(batch_heatmaps, dtype=np.float32)).cuda(),
+                               post_process=post_process)
     return p.cpu().numpy(), m.cpu().numpy().astype(batch_heatmaps.dtype)

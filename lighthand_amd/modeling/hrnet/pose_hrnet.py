@@ -133,6 +133,29 @@ class PoseHighResolutionNet(HipModule):
         self.final_layer = nn.Conv2d(pre[0], cfg["MODEL"]["NUM_JOINTS"], fk, 1, 1 if fk == 3 else 0)
         self.pretrained_layers = extra["PRETRAINED_LAYERS"]
 
+    def init_weights(self, pretrained=""):
+        """pose_hrnet.py:462-492 (the reference's factory has the call commented out): normal(0, 0.001)
+        conv / deconv weights, zero biases, unit BN; then, if `pretrained` is a file, load the entries whose first key
+        component is listed in EXTRA.PRETRAINED_LAYERS ('*' = all) with strict=False; a non-empty path that does not
+        exist raises ValueError like the reference."""
+        import os
+        import torch
+        for m in self.modules():
+            if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+                nn.init.normal_(m.weight, std=0.001)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        if os.path.isfile(pretrained):
+            sd = torch.load(pretrained, map_location="cpu")
+            keep = {k: v for k, v in sd.items()
+                    if k.split(".")[0] in self.pretrained_layers or self.pretrained_layers[0] == "*"}
+            self.load_state_dict(keep, strict=False)
+        elif pretrained:
+            raise ValueError("{} is not exist!".format(pretrained))
+
     @staticmethod
     def _make_transition(pre, cur):
         layers = []

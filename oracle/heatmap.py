@@ -126,3 +126,22 @@ def get_max_preds(heatmaps):
             preds[bi, ji, 0] = np.float32(k % w) * keep
             preds[bi, ji, 1] = np.float32(math.floor(k / w)) * keep
     return preds, maxvals
+
+
+def refine_quarter_pixel(heatmaps, preds, maxvals):
+    """Opt-in extension, NOT in the reference (its TEST.POST_PROCESS switch, src/modeling/simplebaseline/config.py:109,
+    is never read): restates the published SimpleBaseline `get_final_preds` post-processing on top of
+    get_max_preds' UNSCALED output.  px = int(floor(x + 0.5)); if 1 < px < W-1 and 1 < py < H-1:
+    coords += 0.25 * sign([hm[py][px+1] - hm[py][px-1], hm[py+1][px] - hm[py-1][px]])."""
+    b, j, h, w = heatmaps.shape
+    out = preds.astype(np.float32).copy()
+    for bi in range(b):
+        for ji in range(j):
+            hm = heatmaps[bi, ji]
+            px = int(math.floor(out[bi, ji, 0] + 0.5))
+            py = int(math.floor(out[bi, ji, 1] + 0.5))
+            if 1 < px < w - 1 and 1 < py < h - 1:
+                diff = np.array([hm[py][px + 1] - hm[py][px - 1], hm[py + 1][px] - hm[py - 1][px]], np.float32)
+                out[bi, ji] += np.sign(diff).astype(np.float32) * np.float32(0.25)
+    return out
+

@@ -259,6 +259,31 @@ def test_argmax_decode_golden_bit_exact(golden_dir):
         assert np.array_equal(pd.cpu().numpy(), p * 4)
 
 
+def test_quarter_pixel_refinement_opt_in(golden_dir):
+    """SURVEY 8f rank 4, an EXTENSION (no reference oracle: TEST.POST_PROCESS exists in the reference's config but is
+    never read).  Checked bit-exactly against the numpy restatement of the published SimpleBaseline rule on the G3
+    heatmaps (ties, NaN, all-negative, corner peaks -> no move) and on smooth Gaussians (-> +-0.25 moves)."""
+    import os
+    from lighthand_amd.heatmap import get_max_preds, max_preds_device, render_targets
+    from oracle.heatmap import get_max_preds as oracle_max, refine_quarter_pixel
+    g = np.load(os.path.join(golden_dir, "g3_decode.npz"))
+    rng = np.random.RandomState(5)
+    joints = torch.from_numpy(rng.uniform(8, 248, size=(4, 21, 2)).astype(np.float32)).cuda()
+    smooth = render_targets(joints).cpu().numpy() + 0.01 * rng.rand(4, 21, 64, 64).astype(np.float32)
+    moved = 0
+    for hm in (g["hm"], g["hm2"], smooth):
+        p0, m0 = oracle_max(hm)
+        want = refine_quarter_pixel(hm, p0, m0)
+        got, _ = get_max_preds(hm, post_process=True)
+        assert np.array_equal(got, want)
+        moved += int((want != p0).any(-1).sum())
+        dev, _, _ = max_preds_device(torch.from_numpy(hm).cuda(), scale=4.0, post_process=True)
+        assert np.array_equal(dev.cpu().numpy(), want * 4)
+        off, _ = get_max_preds(hm)                       # default stays the reference's hard arg-max
+        assert np.array_equal(off, p0)
+    assert moved > 50
+
+
 def test_adam_matches_torch():
     from lighthand_amd.optim import Adam
     torch.manual_seed(7)

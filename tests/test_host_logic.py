@@ -110,3 +110,36 @@ def test_models_refuse_cpu_execution():
     m = get_pose_net(resnet_cfg(18), True)
     with pytest.raises(LightHandError):
         m(torch.randn(1, 3, 64, 64))
+
+
+def test_init_weights_rules_of_both_factories(tmp_path):
+    """init_weights (pose_resnet.py:250-298, pose_hrnet.py:462-492; never called by the reference's factories, kept for
+    API parity): head re-initialisation, 'module.' prefix stripping, strict=False, PRETRAINED_LAYERS filter, errors."""
+    from collections import OrderedDict
+    from lighthand_amd.modeling.hrnet.pose_hrnet import get_hrnet, hrnet_cfg
+    from lighthand_amd.modeling.simplebaseline.pose_resnet import get_pose_net
+    torch.manual_seed(0)
+    m = get_pose_net(resnet_cfg(18), True)
+    w1, w2 = torch.randn_like(m.conv1.weight), torch.randn_like(m.layer1[0].conv1.weight)
+    path = str(tmp_path / "imagenet.pth")
+    torch.save({"state_dict": OrderedDict([("module.conv1.weight", w1), ("layer1.0.conv1.weight", w2),
+                                           ("module.fc.weight", torch.zeros(10, 512))])}, path)
+    before = m.layer2[0].conv1.weight.detach().clone()
+    m.init_weights(path)
+    assert torch.equal(m.conv1.weight, w1) and torch.equal(m.layer1[0].conv1.weight, w2)
+    assert torch.equal(m.layer2[0].conv1.weight, before)                    # keys absent from the file stay
+    assert 5e-4 < float(m.deconv_layers[0].weight.std()) < 2e-3 and float(m.final_layer.bias.abs().max()) == 0.0
+    assert float((m.deconv_layers[1].weight - 1).abs().max()) == 0.0
+    with pytest.raises(ValueError):
+        m.init_weights(str(tmp_path / "missing.pth"))
+
+    h = get_hrnet(hrnet_cfg(32), True)
+    c1, fl = torch.randn_like(h.conv1.weight), torch.randn_like(h.final_layer.weight)
+    hpath = str(tmp_path / "hrnet.pth")
+    torch.save(OrderedDict([("conv1.weight", c1), ("final_layer.weight", fl)]), hpath)
+    h.init_weights(hpath)
+    assert torch.equal(h.conv1.weight, c1)                                    # 'conv1' is in PRETRAINED_LAYERS
+    assert not torch.equal(h.final_layer.weight, fl) and float(h.final_layer.weight.std()) < 2e-3   # 'final_layer' is not
+    h.init_weights("")                                                        # no file requested: re-initialise only
+    with pytest.raises(ValueError):
+        h.init_weights(str(tmp_path / "missing.pth"))
