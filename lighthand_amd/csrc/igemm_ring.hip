@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void igemm_ring_kernel(const IgemmArgs p) {
     constexpr int NW = BM / 16 * H / 4, NX = BP / 16 * H / 4;   // instructions per wave and stage
     constexpr int L = NW + NX;
     constexpr int KSUB = KB / 64;                     // MFMA K sub-steps per stage
-    static_assert(WC * WP == 4 && D >= 2 && D <= 4 && (KB == 64 || KB == 128) && NW >= 1 && NX >= 1, "bad configuration");
+    static_assert(WC * WP == 4 && D >= 2 && D <= 5 && (KB == 64 || KB == 128) && NW >= 1 && NX >= 1, "bad configuration");
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -188,8 +188,9 @@ __global__ __launch_bounds__(256) void igemm_ring_kernel(const IgemmArgs p) {
         if (steady) {
             wait_vmcnt<(D - 2) * L>();
         } else {
-            const int ahead = S - 1 - s;
-            if (D > 3 && ahead >= 2) wait_vmcnt<2 * L>();
+            const int ahead = S - 1 - s;          // <= D - 2 here
+            if (D > 4 && ahead >= 3) wait_vmcnt<3 * L>();
+            else if (D > 3 && ahead >= 2) wait_vmcnt<2 * L>();
             else if (D > 2 && ahead == 1) wait_vmcnt<L>();
             else wait_vmcnt<0>();
         }
@@ -322,6 +323,12 @@ int lh_ring_kb() {
     return kb;
 }
 
+static bool lh_ring_five(const IgemmArgs& a) {
+    static int thr = -1;
+    if (thr < 0) { const char* e = getenv("LH_RING_T5"); thr = e ? atoi(e) : 0; }      // 0 = never
+    return thr > 0 && a.ntaps * a.kspt >= thr;
+}
+
 template <typename T, int KB, int D>
 static int ring_dispatch(const IgemmArgs& a, int bm, int bp, hipStream_t s) {
     if (bm == 128 && bp == 256) {
@@ -332,7 +339,11 @@ static int ring_dispatch(const IgemmArgs& a, int bm, int bp, hipStream_t s) {
     }
     if (bm == 128 && bp == 128) {
         if constexpr (sizeof(T) == 4) return launch_ring<T, 128, 64, 4, 1, D, KB>(a, s);
-        else return launch_ring<T, 128, 128, 2, 2, D, KB>(a, s);
+        else {
+            // deep K: a 5-stage ring (2 x 80 KiB = the whole LDS of a CU) keeps 128 KiB of loads in flight per CU
+            if constexpr (D == 4 && KB == 64) { if (lh_ring_five(a)) return launch_ring<T, 128, 128, 2, 2, 5, KB>(a, s); }
+            return launch_ring<T, 128, 128, 2, 2, D, KB>(a, s);
+        }
     }
     if (bm == 128 && bp == 64) return launch_ring<T, 128, 64, 4, 1, D, KB>(a, s);
     if (bm == 64 && bp == 128) return launch_ring<T, 64, 128, 1, 4, D, KB>(a, s);

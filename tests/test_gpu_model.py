@@ -65,7 +65,7 @@ def test_g5_forward_fp32_matches_reference(golden_dir, tag):
     assert np.array_equal(get_max_preds(y_tr)[0], oracle_decode(y_tr)[0])
 
 
-@pytest.mark.parametrize("tag", ["mini_basic", "mini_bottleneck", "r18", "r50", "hrnet_w32"])
+@pytest.mark.parametrize("tag", ["mini_basic", "mini_bottleneck", "r18", "r50", "hrnet_w32", "mini_basic@3x96x160", "mini_bottleneck@5x160x96"])
 def test_gradients_match_oracle(tag):
     """dL/dtheta of every parameter, HIP fp32 vs autograd through the CPU oracle.
 
@@ -77,10 +77,14 @@ def test_gradients_match_oracle(tag):
     from oracle import models as omod
     from lighthand_amd.heatmap import JointsMSELoss
     torch.manual_seed(11)
+    b, h, w = 4, 128, 128
+    if "@" in tag:                # ragged case: odd batch (pixel-tile tails), non-square map
+        tag, dims = tag.split("@")
+        b, h, w = (int(v) for v in dims.split("x"))
     model, fwd = _build(tag)
     rng = np.random.RandomState(5)
-    x = torch.from_numpy(rng.randn(4, 3, 128, 128).astype(np.float32))
-    tgt = torch.from_numpy(rng.rand(4, 21, 32, 32).astype(np.float32))
+    x = torch.from_numpy(rng.randn(b, 3, h, w).astype(np.float32))
+    tgt = torch.from_numpy(rng.rand(b, 21, h // 4, w // 4).astype(np.float32))
     sd = omod.clone_state(model.state_dict())
     loss_ref, pred_ref, g32 = omod.loss_and_grads(sd, lambda s, xx: fwd(s, xx, True), x, tgt)
     sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in model.state_dict().items()}
@@ -239,3 +243,29 @@ def test_fused_bn_backward_reduce_bf16_within_summation_noise(monkeypatch):
     yard = _tensor_diffs(_grads_with_env("r50", "bf16", ["LH_NO_FLAT"], monkeypatch, False), separate)
     print("bf16 fused-vs-separate median/max", np.median(fused), fused.max(), "| reorder yardstick", np.median(yard), yard.max())
     assert np.median(fused) < 3 * np.median(yard) + 1e-4 and fused.max() < 3 * yard.max() + 1e-3
+
+
+@pytest.mark.parametrize("tag,shape", [("r18", (3, 3, 96, 160)), ("r34", (1, 3, 64, 64)), ("r50", (5, 3, 128, 96)),
+                                       ("r50caffe", (2, 3, 192, 64)), ("hrnet_w32", (3, 3, 64, 96)), ("hrnet_w48", (1, 3, 128, 128))])
+def test_forward_odd_shapes_match_oracle(tag, shape):
+    """Ragged cases the fixed goldens do not hold: odd batch sizes (pixel-tile tails), batch 1, non-square and
+    non-power-of-two maps, every block kind -- train- and eval-mode forward in fp32 vs the CPU oracle on the same
+    seeded weights, plus bf16 eval within the 16-bit tolerance."""
+    torch.manual_seed(11)
+    model, oracle_fwd = _build(tag)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    x = torch.from_numpy(np.random.RandomState(4).randn(*shape).astype(np.float32))
+    with torch.no_grad():
+        want_tr = oracle_fwd({k: v.clone() for k, v in sd.items()}, x, True).numpy()
+        want_ev = oracle_fwd({k: v.clone() for k, v in sd.items()}, x, False).numpy()
+    model = model.cuda()
+    with torch.no_grad():
+        model.train()
+        got_tr = model(x.cuda()).cpu().numpy()
+        model.load_state_dict(sd)                      # undo the running-statistics update of the train-mode pass
+        model.eval()
+        got_ev = model(x.cuda()).cpu().numpy()
+        got_bf = model.set_precision("bf16")(x.cuda()).cpu().numpy()
+    assert got_tr.shape == want_tr.shape == (shape[0], 21, shape[2] // 4, shape[3] // 4)
+    assert rel(got_tr, want_tr) < FP32_REL and rel(got_ev, want_ev) < FP32_REL
+    assert rel(got_bf, want_ev) < 5e-2
