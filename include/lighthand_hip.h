@@ -138,6 +138,15 @@ typedef struct {
 int lh_igemm(const lh_igemm_desc* d, const void* in, const void* wpack, void* out,
              const void* addend, const float* bias, const float* scale, const float* shift, float* stats,
              int dtype, void* stream);
+/* Phase batching: 2..4 lh_igemm launches that share input, output tensor, sizes and epilogue and differ only in weight
+ * pack, tap list and output placement (ooh, oow) -- the sub-pixel phases of a 4x4/s2 transposed convolution
+ * (pose_resnet.py:194-232) or of a stride-2 convolution's data gradient -- as ONE grid.  Phases may have zero taps
+ * (they store addend / bias only).  stats: nphase * lh_igemm_phases_rows(..) rows, phase p's rows at p * rows.
+ * Requires the LDS-DMA kernel (16-byte aligned rows, regular tap grids); returns LH_ERR_* otherwise. */
+int lh_igemm_phases_rows(const lh_igemm_desc* const* descs, int nphase, int dtype);
+int lh_igemm_phases(const lh_igemm_desc* const* descs, int nphase, const void* in, const void* const* wpacks,
+                    void* out, const void* addend, const float* bias, const float* scale, const float* shift,
+                    float* stats, int dtype, void* stream);
 /* Data gradient with the BatchNorm-backward reduction of the node that PRODUCED the differentiated activation fused
  * into its epilogue (loss.backward() through conv -> relu -> BN, e.g. pose_resnet.py:83-97 walked in reverse).
  * `out` receives the data gradient dA (+ addend: the launch must then be the LAST writer of dA, so that the stored

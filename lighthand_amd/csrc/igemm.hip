@@ -325,9 +325,15 @@ extern "C" int lh_igemm_stats_rows(const lh_igemm_desc* d, int dtype) {
     return (int)((M + bp - 1) / bp);
 }
 
+struct PhaseSet {                 // lh_igemm_phases: the other descriptors / packs of the batch (lead = descs[lead])
+    const lh_igemm_desc* const* descs;
+    const void* const* wpacks;
+    int n;
+};
+
 static int igemm_impl(const lh_igemm_desc* d, const void* in, const void* wpack, void* out,
                       const void* addend, const float* bias, const float* scale, const float* shift, float* stats,
-                      const lh_bn_tap* tap, int dtype, void* stream) {
+                      const lh_bn_tap* tap, int dtype, void* stream, const PhaseSet* phases = nullptr) {
     LH_REQUIRE(d && in && wpack && out, "lh_igemm: null pointer");
     const int es = lh_dtype_size(dtype);
     LH_REQUIRE(es > 0, "lh_igemm: bad dtype %d", dtype);
@@ -367,6 +373,22 @@ static int igemm_impl(const lh_igemm_desc* d, const void* in, const void* wpack,
     static int xcd = -1;
     if (xcd < 0) xcd = getenv("LH_NO_XCD") ? 0 : 1;
     a.xcd = xcd;
+    a.nphase = 1; a.phase_blocks = 0;
+    if (phases) {
+        LH_REQUIRE(lh_ring_supported(d, dtype), "lh_igemm_phases: the form is not supported by the LDS-DMA kernel");
+        a.nphase = phases->n;
+        a.phase_blocks = ceil_div(a.M, bp) * ceil_div(a.cout, bm);
+        for (int i = 0; i < phases->n; ++i) {
+            const lh_igemm_desc* q = phases->descs[i];
+            a.ph_w[i] = (const unsigned char*)phases->wpacks[i];
+            a.ph_ntaps[i] = q->ntaps; a.ph_tw[i] = 1; a.ph_dh0[i] = a.ph_dhs[i] = a.ph_dw0[i] = a.ph_dws[i] = 0;
+            if (q->ntaps > 0)
+                LH_REQUIRE(lh_tap_grid(q, &a.ph_tw[i], &a.ph_dh0[i], &a.ph_dhs[i], &a.ph_dw0[i], &a.ph_dws[i]) && a.ph_w[i],
+                           "lh_igemm_phases: phase %d has an irregular tap list or no weights", i);
+            a.ph_ooh[i] = q->ooh; a.ph_oow[i] = q->oow;
+            a.ph_row0[i] = i * ceil_div(a.M, bp);
+        }
+    }
     if (lh_ring_supported(d, dtype)) {
         lh_tap_grid(d, &a.tw, &a.dh0, &a.dhs, &a.dw0, &a.dws);
         a.kspt = (d->k_run * es + lh_ring_kb() - 1) / lh_ring_kb();
@@ -401,4 +423,42 @@ extern "C" int lh_igemm_bntap(const lh_igemm_desc* d, const void* in, const void
                               const lh_bn_tap* tap, float* partial, int dtype, void* stream) {
     LH_REQUIRE(tap && partial, "lh_igemm_bntap: null tap / partial slab");
     return igemm_impl(d, in, wpack, out, addend, nullptr, nullptr, nullptr, partial, tap, dtype, stream);
+}
+
+// ---- phase batching ------------------------------------------------------------------------------------------------
+static int phase_lead(const lh_igemm_desc* const* descs, int nphase) {
+    int lead = 0;
+    for (int i = 1; i < nphase; ++i)
+        if (descs[i]->ntaps > descs[lead]->ntaps) lead = i;
+    return lead;
+}
+
+static bool phases_ok(const lh_igemm_desc* const* descs, int nphase) {
+    if (!descs || nphase < 2 || nphase > 4) return false;
+    const lh_igemm_desc* a = descs[0];
+    for (int i = 0; i < nphase; ++i) {
+        const lh_igemm_desc* b = descs[i];
+        if (!b || b->n != a->n || b->hi != a->hi || b->wi != a->wi || b->in_pix_stride != a->in_pix_stride || b->k_run != a->k_run ||
+            b->ho != a->ho || b->wo != a->wo || b->sh != a->sh || b->sw != a->sw || b->cout != a->cout || b->OH != a->OH ||
+            b->OW != a->OW || b->osh != a->osh || b->osw != a->osw || b->out_pix_stride != a->out_pix_stride || b->relu != a->relu)
+            return false;
+    }
+    return true;
+}
+
+extern "C" int lh_igemm_phases_rows(const lh_igemm_desc* const* descs, int nphase, int dtype) {
+    if (!phases_ok(descs, nphase)) return -1;
+    const lh_igemm_desc* d = descs[phase_lead(descs, nphase)];
+    if (!lh_ring_supported(d, dtype)) return -1;
+    return lh_igemm_stats_rows(d, dtype);
+}
+
+extern "C" int lh_igemm_phases(const lh_igemm_desc* const* descs, int nphase, const void* in, const void* const* wpacks,
+                               void* out, const void* addend, const float* bias, const float* scale, const float* shift,
+                               float* stats, int dtype, void* stream) {
+    LH_REQUIRE(phases_ok(descs, nphase) && wpacks, "lh_igemm_phases: 2..4 descriptors that differ only in taps / placement are required");
+    const int lead = phase_lead(descs, nphase);
+    LH_REQUIRE(descs[lead]->ntaps > 0 && wpacks[lead], "lh_igemm_phases: no phase has taps");
+    PhaseSet ps = {descs, wpacks, nphase};
+    return igemm_impl(descs[lead], in, wpacks[lead], out, addend, bias, scale, shift, stats, nullptr, dtype, stream, &ps);
 }

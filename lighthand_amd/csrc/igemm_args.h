@@ -23,6 +23,11 @@ struct IgemmArgs {
     int ho, wo, M, sh, sw, cout;
     int OH, OW, osh, osw, ooh, oow, out_pix_stride;
     int ntaps, relu;
+    // Phase batching (lh_igemm_phases): up to 4 launches that differ only in weight pack, tap grid, output placement and
+    // stats rows (the sub-pixel phases of stride-2 transposed forms) run as ONE grid of nphase * phase_blocks work items.
+    int nphase, phase_blocks;
+    const unsigned char* ph_w[4];
+    int ph_ntaps[4], ph_tw[4], ph_dh0[4], ph_dhs[4], ph_dw0[4], ph_dws[4], ph_ooh[4], ph_oow[4], ph_row0[4];
     int xcd;                         // ring kernel: XCD-aware work-item order (LH_NO_XCD=1 disables)
     int tw, dh0, dhs, dw0, dws;      // regular tap grid (ring kernel): tap t = (t / tw, t % tw)
     signed char dh[64];

@@ -11,7 +11,8 @@
 
 template <typename T, int BM, int BP, int WC, int WP>
 __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, unsigned char* smem, f32x4 (&acc)[BM / WC / 16][BP / WP / 16],
-                                               int pblk, int cblk, int tid, int lane, int wc, int wp, int hw) {
+                                               int pblk, int cblk, int tid, int lane, int wc, int wp, int hw,
+                                               int ooh, int oow, float* stats) {
     constexpr int ES = sizeof(T);
     constexpr int EPC = 16 / ES;
     constexpr int TC = BM / WC, TP = BP / WP;
@@ -81,7 +82,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, unsigned char
         if (m >= p.M || !col_ok) continue;
         const int n = m / hw, rem = m - n * hw;
         const int a = rem / p.wo, b = rem - a * p.wo;
-        const long opix = ((long)n * p.OH + a * p.osh + p.ooh) * p.OW + b * p.osw + p.oow;
+        const long opix = ((long)n * p.OH + a * p.osh + ooh) * p.OW + b * p.osw + oow;
         const long eoff = opix * p.out_pix_stride + col0;
         const unsigned char* src = smem + pr * RS + chunk * 16;
         const uint2 lo = *reinterpret_cast<const uint2*>(src);
@@ -102,7 +103,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, unsigned char
             }
             u = pack16<T>(v);
         }
-        if (p.stats) {
+        if (stats) {
             float sv[EPC];
             unpack16<T>(u, sv);
             if (p.tap_x) {
@@ -124,7 +125,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, unsigned char
         *reinterpret_cast<uint4*>(p.out + eoff * ES) = u;
     }
 
-    if (p.stats) {
+    if (stats) {
         __syncthreads();
         float* red = reinterpret_cast<float*>(smem);
 #pragma unroll
@@ -139,7 +140,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, unsigned char
 #pragma unroll 4
             for (int r = 0; r < RPP; ++r) a += red[(r * 2 + which) * BM + col];
             const int gc = cblk * BM + col;
-            if (gc < p.cout) p.stats[((long)pblk * 2 + which) * p.cout + gc] = a;
+            if (gc < p.cout) stats[((long)pblk * 2 + which) * p.cout + gc] = a;
         }
     }
 }

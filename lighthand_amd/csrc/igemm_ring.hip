@@ -81,7 +81,19 @@ __global__ __launch_bounds__(256) void igemm_ring_kernel(const IgemmArgs p) {
     // 1-D grid; work item w = (pixel tile, channel tile) with the channel tile fastest: the channel tiles of one pixel
     // tile and neighbouring pixel tiles (3x3 halos) run on one XCD at about the same time and share its L2.
     const int CB = (p.cout + BM - 1) / BM;
-    const int w = p.xcd ? lh_xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    int w = p.xcd ? lh_xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    // per-phase quantities (scalars; the kernel argument block itself is never copied)
+    const unsigned char* wgt = p.w;
+    int ntaps = p.ntaps, tw = p.tw, dh0 = p.dh0, dhs = p.dhs, dw0 = p.dw0, dws = p.dws, ooh = p.ooh, oow = p.oow;
+    float* stats = p.stats;
+    if (p.nphase > 1) {                               // phase fastest: the phases of one tile read the same input rows
+        const int ph = w % p.nphase;
+        w /= p.nphase;
+        wgt = p.ph_w[ph]; ntaps = p.ph_ntaps[ph]; tw = p.ph_tw[ph];
+        dh0 = p.ph_dh0[ph]; dhs = p.ph_dhs[ph]; dw0 = p.ph_dw0[ph]; dws = p.ph_dws[ph];
+        ooh = p.ph_ooh[ph]; oow = p.ph_oow[ph];
+        if (stats) stats += (long)p.ph_row0[ph] * 2 * p.cout;
+    }
     const int pblk = w / CB, cblk = w - pblk * CB;
     const int hw = p.ho * p.wo;
 
@@ -92,7 +104,7 @@ __global__ __launch_bounds__(256) void igemm_ring_kernel(const IgemmArgs p) {
     long pbase[NX];
     unsigned hmask[NX], wmask[NX];          // bit ti / tj set when tap row ti / column tj stays inside the image
     int xc[NX];
-    const int th = p.ntaps / p.tw;
+    const int th = ntaps / tw;
 #pragma unroll
     for (int j = 0; j < NX; ++j) {
         const int q = 4 * j + wave;
@@ -108,9 +120,9 @@ __global__ __launch_bounds__(256) void igemm_ring_kernel(const IgemmArgs p) {
         xc[j] = c * EPC;
         pbase[j] = ((long)(n * p.hi * p.wi + ih0 * p.wi + iw0) * p.in_pix_stride + xc[j]) * ES;
         unsigned hm = 0, wm = 0;
-        for (int ti = 0, dh = p.dh0; ti < th; ++ti, dh += p.dhs)
+        for (int ti = 0, dh = dh0; ti < th; ++ti, dh += dhs)
             if (ok && (unsigned)(ih0 + dh) < (unsigned)p.hi) hm |= 1u << ti;
-        for (int tjj = 0, dw = p.dw0; tjj < p.tw; ++tjj, dw += p.dws)
+        for (int tjj = 0, dw = dw0; tjj < tw; ++tjj, dw += dws)
             if ((unsigned)(iw0 + dw) < (unsigned)p.wi) wm |= 1u << tjj;
         hmask[j] = hm;
         wmask[j] = wm;
@@ -123,7 +135,7 @@ __global__ __launch_bounds__(256) void igemm_ring_kernel(const IgemmArgs p) {
         const int g = q / H, lrow = (q % H) * RPI + lane / SL;
         const int c = (lane % SL) ^ ((lrow / (16 / SL)) & (SL - 1));
         const int row = g * 16 + lrow;
-        wsrc[j] = p.w + ((long)(cblk * BM + row) * p.ntaps * kpad + c * EPC) * ES;
+        wsrc[j] = wgt + ((long)(cblk * BM + row) * ntaps * kpad + c * EPC) * ES;
     }
     const unsigned char* zero = reinterpret_cast<const unsigned char*>(lh_zero_page);
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
@@ -131,7 +143,7 @@ __global__ __launch_bounds__(256) void igemm_ring_kernel(const IgemmArgs p) {
 
     // stage index -> (tap, kc) is tracked incrementally; `woff` is the byte offset of the stage inside a weight
     // row (stages are contiguous there), `toff` the activation byte offset of the tap + K step.
-    int itap = 0, ikc = 0, tj = 0, ti = 0, cdh = p.dh0, cdw = p.dw0;
+    int itap = 0, ikc = 0, tj = 0, ti = 0, cdh = dh0, cdw = dw0;
     unsigned issued = 0;
     long woff = 0;
     auto issue = [&]() {
@@ -158,8 +170,8 @@ __global__ __launch_bounds__(256) void igemm_ring_kernel(const IgemmArgs p) {
         if (++ikc == p.kspt) {
             ikc = 0; ++itap;
             woff = (long)itap * kpad * ES;
-            cdw += p.dws;
-            if (++tj == p.tw) { tj = 0; ++ti; cdw = p.dw0; cdh += p.dhs; }
+            cdw += dws;
+            if (++tj == tw) { tj = 0; ++ti; cdw = dw0; cdh += dhs; }
         }
     };
 
@@ -169,7 +181,7 @@ __global__ __launch_bounds__(256) void igemm_ring_kernel(const IgemmArgs p) {
 #pragma unroll
         for (int j = 0; j < PT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int S = p.ntaps * p.kspt;
+    const int S = ntaps * p.kspt;
 #pragma unroll
     for (int s = 0; s < D - 1; ++s)
         if ((int)issued < S) issue();
@@ -232,7 +244,7 @@ __global__ __launch_bounds__(256) void igemm_ring_kernel(const IgemmArgs p) {
         }
     }
 
-    igemm_epilogue<T, BM, BP, WC, WP>(p, smem, acc, pblk, cblk, tid, lane, wc, wp, hw);
+    igemm_epilogue<T, BM, BP, WC, WP>(p, smem, acc, pblk, cblk, tid, lane, wc, wp, hw, ooh, oow, stats);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -255,7 +267,7 @@ static int launch_ring(const IgemmArgs& a, hipStream_t s) {
         }
         attr_done = true;
     }
-    dim3 grid(ceil_div(a.M, BP) * ceil_div(a.cout, BM));
+    dim3 grid(ceil_div(a.M, BP) * ceil_div(a.cout, BM) * (a.nphase > 1 ? a.nphase : 1));
     hipLaunchKernelGGL((igemm_ring_kernel<T, BM, BP, WC, WP, D, KB>), grid, dim3(256), lds, s, a);
     LH_LAUNCH_CHECK("igemm_ring launch");
     return LH_OK;

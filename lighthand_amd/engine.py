@@ -138,10 +138,11 @@ def _taps_array(rs):
 class _Call:
     """A pre-bound C-ABI call; the stream is appended at run time.  ``lane`` 1 marks work that may run on
     the side stream of the backward pass (weight gradients: they only feed the optimizer)."""
-    __slots__ = ("fn", "args", "what", "keep", "lane")
+    __slots__ = ("fn", "args", "what", "keep", "lane", "ig")
 
     def __init__(self, fn, args, what, keep=None, lane=0):
         self.fn, self.args, self.what, self.keep, self.lane = fn, args, what, keep, lane
+        self.ig = None               # argument positions for Plan._patch (lh_igemm layout unless set)
 
     def __call__(self, stream):
         rc = self.fn(*self.args, stream)
@@ -298,10 +299,14 @@ class Plan:
         tap = x.bn_tap
         if tap is not None and n_before != self._n_uses.get(id(x), 1) - 1:
             tap = None                            # a later launch still adds to this gradient
+        if tap is None and self._phase_rows(descs) > 0:
+            self._igemm_phases(self.bwd, descs, dy, packs, dx, None if first else dx, None, None, what)
+            yield max(descs, key=lambda d: d.ntaps), sum(d.ntaps for d in descs)
+            return
         if tap is None:
             for dd, pk in zip(descs, packs):
                 self._igemm(self.bwd, dd, dy, pk, dx, None if first else dx, None, None, what)
-                yield dd
+                yield dd, dd.ntaps
             return
         rows = [self.lib.lh_igemm_stats_rows(C.byref(dd), self.dt) for dd in descs]
         slab = self._alloc(sum(rows) * 2 * x.c, dtype=torch.float32)
@@ -318,16 +323,40 @@ class Plan:
             c.keep = dd
             self.bwd.append(c)
             off += r * 2 * x.c * 4
-            yield dd
+            yield dd, dd.ntaps
         tap["slab"] = (slab, sum(rows))
 
     def _patch(self, call, relu=None, **ptrs):
         a = list(call.args)
+        ig = call.ig or self._IG
         for k, v in ptrs.items():
-            a[self._IG[k]] = v
+            a[ig[k]] = v
         call.args = tuple(a)
         if relu is not None:
-            call.keep.relu = int(relu)
+            for d in (call.keep if isinstance(call.keep, list) else [call.keep]):
+                d.relu = int(relu)
+
+    _IGP = dict(src=2, dst=4, addend=5, bias=6, scale=7, shift=8, stats=9)      # lh_igemm_phases argument positions
+
+    def _phase_rows(self, descs):
+        """Rows of the stats slab ONE phase of a batched launch writes, or -1 when the phases cannot be batched."""
+        if len(descs) < 2 or len(descs) > 4 or os.environ.get("LH_NO_PHASES"):
+            return -1
+        arr = (C.POINTER(IgemmDesc) * len(descs))(*[C.pointer(d) for d in descs])
+        return self.lib.lh_igemm_phases_rows(arr, len(descs), self.dt)
+
+    def _igemm_phases(self, lst, descs, src, packs, dst, addend, bias, stats, what, produces=None):
+        """The sub-pixel phases of a stride-2 transposed form as one launch (lh_igemm_phases)."""
+        arr = (C.POINTER(IgemmDesc) * len(descs))(*[C.pointer(d) for d in descs])
+        parr = (C.c_void_p * len(descs))(*[pk.data_ptr() if pk is not None else None for pk in packs])
+        self.keep += [arr, parr] + list(descs)
+        c = _Call(self.lib.lh_igemm_phases, (arr, len(descs), _ptr(src), parr, _ptr(dst), _ptr(addend), _ptr(bias), 0, 0,
+                                             _ptr(stats), self.dt), what + f" ({len(descs)} phases)")
+        c.keep, c.ig = list(descs), self._IGP
+        lst.append(c)
+        if produces is not None:
+            self._producers.setdefault(id(produces), []).append(c)
+        return c
 
     def _kname(self, d, wgrad=None):
         """Kernel instantiation name as rocprofv3 prints it (for roofline attribution)."""
@@ -540,8 +569,10 @@ class Plan:
                 else:
                     self.bwd.append(_TorchCall(lambda: gb_.copy_(dy.view(-1, y.c)[:, :cout].sum(0, dtype=torch.float32)), "bias grad"))
             if x.needs_grad:
-                for dd in self._dgrad(ddescs, dy, dpacks, x, nd["w"] + " dgrad"):
-                    self.profile_meta.append(("bwd", self.bwd[-1], self._kname(dd), 2.0 * dd.n * dd.ho * dd.wo * cin * cout * dd.ntaps,
+                for dd, ntaps in self._dgrad(ddescs, dy, dpacks, x, nd["w"] + " dgrad"):
+                    batched = ntaps != dd.ntaps or (len(ddescs) > 1 and self.bwd[-1].ig is not None)
+                    self.profile_meta.append(("bwd", self.bwd[-1], self._kname(dd), 2.0 * dd.n * dd.ho * dd.wo * cin * cout * ntaps,
+                                              (x.pixels * x.c + y.pixels * y.c) * self.es if batched else
                                               (dd.n * dd.ho * dd.wo * x.c + y.pixels * y.c / (s * s)) * self.es))
         blk.append(emit)
 
@@ -618,8 +649,19 @@ class Plan:
                 gh, gw_ = (y.h - ph + 1) // 2, (y.w - pw + 1) // 2
                 descs.append(_desc(x.n, x.h, x.w, x.c, cin, gh, gw_, 1, 1, cout, y.h, y.w, 2, 2, ph, pw, y.c, tp))
                 packs.append(self._pack(wt, cout, cin, (k * k, cout * k * k, k, 1), sub, nd["w"] + " deconv pack"))
+        prow = self._phase_rows(descs)
+        if prow > 0:                          # the four sub-pixel phases as ONE launch
+            stats = None
+            if id(y) in self._bn_inputs and self.training:
+                nbytes = self.lib.lh_bn_stats_slab_bytes(4 * prow, y.c)
+                y.stats, y.stats_rows = self._alloc((nbytes + 3) // 4, dtype=torch.float32), 4 * prow
+                stats = y.stats
+            self._igemm_phases(self.fwd, descs, xbuf, packs, ybuf, None, bias, stats, nd["w"] + " deconv fwd", produces=y)
+            self.profile_meta.append(("fwd", self.fwd[-1], self._kname(descs[0]), 2.0 * x.pixels * cin * cout * k * k,
+                                      (x.pixels * x.c + y.pixels * y.c) * self.es))
+            descs = []
         offs = [None] * 4
-        if id(y) in self._bn_inputs and self.training:
+        if descs and id(y) in self._bn_inputs and self.training:
             offs = self._stats_for(y, descs)
         for d, pk, off in zip(descs, packs, offs):
             st = 0 if off is None else y.stats.data_ptr() + off
@@ -659,7 +701,7 @@ class Plan:
                 gb_ = self.grads[nd["bias"]]
                 self.bwd.append(_TorchCall(lambda: gb_.copy_(dy.view(-1, y.c)[:, :cout].sum(0, dtype=torch.float32)), "bias grad"))
             if x.needs_grad:
-                for _ in self._dgrad([dg], dy, [gpack], x, nd["w"] + " deconv dgrad"):
+                for _dd, _nt in self._dgrad([dg], dy, [gpack], x, nd["w"] + " deconv dgrad"):
                     self.profile_meta.append(("bwd", self.bwd[-1], self._kname(dg), flops, (x.pixels * x.c + y.pixels * y.c) * self.es))
         blk.append(emit)
 
