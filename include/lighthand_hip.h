@@ -297,6 +297,14 @@ int lh_keypoint_metrics(const float* pred, const float* gt, int gt_stride, int b
 int lh_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long numel,
                  const double* hyper, int* step, float* derived, float grad_scale, void* stream);
 
+/* PCK curve of pred_eval (src/utils/argparser.py:326-388) on the device: counts[t] += visible joints (gt[..][2] == 1) whose
+ * error (pixel distance; divided by bb[sample] when bb != NULL, the 'pckb' mode) is < thr[t]; *nvis += visible joints;
+ * diff_row[s] = sum of pixel errors over ALL joints of sample s.  float64 arithmetic like the NumPy original; counts /
+ * nvis ACCUMULATE (zero them first) with integer atomics, so the result is exact and ranks can be summed by one small
+ * all-reduce.  AUC = trapz(100*counts/nvis, thr) / trapz(1, thr) on the host (lighthand_amd.metrics.auc_from_counts). */
+int lh_pck_curve(const float* pred, const float* gt, int gt_stride, const float* bb, int n, int j, const double* thr,
+                 int nthr, unsigned long long* counts, unsigned long long* nvis, double* diff_row, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

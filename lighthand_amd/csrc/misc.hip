@@ -584,3 +584,50 @@ extern "C" int lh_adam_step(float* param, const float* grad, float* exp_avg, flo
     LH_LAUNCH_CHECK("adam launch");
     return LH_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ PCK curve / AUC
+// pred_eval (src/utils/argparser.py:326-388) on the device: for every threshold, the number of VISIBLE
+// joints (gt[..][2] == 1) whose error -- pixel distance, divided by the sample's bbox size when bb is given ('pckb') --
+// is < thr[t].  float64 like the NumPy original, integer atomics (exact, order independent: ranks add their counts with one
+// small all-reduce).  diff_row[s] = sum of the pixel errors of ALL joints of sample s (the EPE numerator).
+__global__ void pck_curve_kernel(const float* pred, const float* gt, int gt_stride, const float* bb, int n, int j,
+                                 const double* thr, int nthr, unsigned long long* counts, unsigned long long* nvis,
+                                 double* diff_row) {
+    const int sidx = blockIdx.x;
+    if (sidx >= n) return;
+    __shared__ double err[64];
+    __shared__ int vis[64];
+    for (int k = threadIdx.x; k < j; k += blockDim.x) {
+        const float* g = gt + ((long)sidx * j + k) * gt_stride;
+        const float* q = pred + ((long)sidx * j + k) * 2;
+        const double dx = (double)g[0] - (double)q[0], dy = (double)g[1] - (double)q[1];
+        err[k] = sqrt(dx * dx + dy * dy);
+        vis[k] = g[2] == 1.f ? 1 : 0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double sum = 0.0;
+        int nv = 0;
+        for (int k = 0; k < j; ++k) { sum += err[k]; nv += vis[k]; }
+        diff_row[sidx] = sum;
+        if (nv) atomicAdd(nvis, (unsigned long long)nv);
+    }
+    const double scale = bb ? (double)bb[sidx] : 1.0;
+    for (int t = threadIdx.x; t < nthr; t += blockDim.x) {
+        int c = 0;
+        for (int k = 0; k < j; ++k)
+            if (vis[k] && err[k] / scale < thr[t]) ++c;
+        if (c) atomicAdd(counts + t, (unsigned long long)c);
+    }
+}
+
+extern "C" int lh_pck_curve(const float* pred, const float* gt, int gt_stride, const float* bb, int n, int j, const double* thr,
+                            int nthr, unsigned long long* counts, unsigned long long* nvis, double* diff_row, void* stream) {
+    LH_REQUIRE(pred && gt && thr && counts && nvis && diff_row && n > 0 && j > 0 && j <= 64 && gt_stride >= 3 && nthr > 0,
+               "lh_pck_curve: bad arguments (j <= 64, gt rows of >= 3 values: x, y, visibility)");
+    hipLaunchKernelGGL(pck_curve_kernel, dim3(n), dim3(128), 0, (hipStream_t)stream, pred, gt, gt_stride, bb, n, j, thr, nthr,
+                       counts, nvis, diff_row);
+    LH_LAUNCH_CHECK("pck_curve launch");
+    return LH_OK;
+}
+

@@ -413,8 +413,14 @@ static void wgrad_plan(const lh_igemm_desc* d, int n_out, int n_in, int dtype, i
     const long M = (long)d->n * d->ho * d->wo;
     const long steps = (M + kp - 1) / kp;
     const long tiles = (long)((n_out + *bo - 1) / *bo) * ((n_in + *bi - 1) / *bi) * d->ntaps;
-    long want = (1024 + tiles - 1) / tiles;          // aim at >= ~3 workgroups per CU
-    long max_split = (steps + 7) / 8;                // at least 8 K steps per block
+    static long target = 0, min_steps = 0;           // tuning knobs: workgroups aimed at, fewest K steps per workgroup
+    if (!target) {
+        const char* e1 = getenv("LH_WGRAD_WANT"); const char* e2 = getenv("LH_WGRAD_MINSTEPS");
+        target = e1 ? atol(e1) : 1024;
+        min_steps = e2 ? atol(e2) : 8;
+    }
+    long want = (target + tiles - 1) / tiles;        // aim at >= ~3 workgroups per CU
+    long max_split = (steps + min_steps - 1) / min_steps;
     if (max_split > 128) max_split = 128;            // bound the slab traffic of the fold
     if (want > max_split) want = max_split;
     // every split writes (and the fold re-reads) a full fp32 copy of the weight tensor: keep the slab <= ~24 MiB

@@ -79,3 +79,51 @@ def device_pck_epe(pred_2d, gt_2d, T=0.2):
                                                epe.data_ptr(), torch.cuda.current_stream().cuda_stream), "lh_keypoint_metrics")
     pck = 1.0 - wrong.sum().to(torch.float32) / float(b * j)
     return pck, epe.sum(), torch.tensor(float(b * (j - 2)), device=pred.device)
+
+
+def eval_thresholds(T_list, method):
+    """The threshold grid of pred_eval (src/utils/argparser.py:334-341)."""
+    if method == "mm":
+        return np.linspace(T_list[0], T_list[-1], 101)[1:] * PX_PER_MM_THRESH
+    if method == "pckb":
+        return np.linspace(T_list[0], T_list[-1], 100)
+    assert 0, "this method is the wrong"
+
+
+def device_pck_curve(pred_2d, gt_3, bb, T_list, method, out=None):
+    """pred_eval's counting on the DEVICE: pred [N, J, 2], gt [N, J, >=3] (x, y, visibility), bb [N] device tensors ->
+    (counts int64 [T], nvis int64 [1], diff_sum float64 [1], n_joints int64 [1]) device tensors; pass ``out`` (a previous
+    result) to accumulate over batches.  Integer counts: exact, so data-parallel ranks add them with one all-reduce and
+    every rank then gets the same AUC (``auc_from_counts``)."""
+    import torch
+    from . import _lib
+    thr = eval_thresholds(T_list, method)
+    dev = pred_2d.device
+    pred = pred_2d.to(torch.float32).contiguous()
+    gt = gt_3.to(torch.float32).contiguous()
+    n, j = pred.shape[:2]
+    if out is None:
+        out = (torch.zeros(len(thr), dtype=torch.int64, device=dev), torch.zeros(1, dtype=torch.int64, device=dev),
+               torch.zeros(1, dtype=torch.float64, device=dev), torch.zeros(1, dtype=torch.int64, device=dev))
+    counts, nvis, diff_sum, n_all = out
+    thr_dev = torch.from_numpy(np.ascontiguousarray(thr, dtype=np.float64)).to(dev)
+    rows = torch.empty(n, dtype=torch.float64, device=dev)
+    bbp = None
+    if method == "pckb":
+        bbt = bb.to(torch.float32).contiguous()
+        bbp = bbt.data_ptr()
+    _lib.check(_lib.load().lh_pck_curve(pred.data_ptr(), gt.data_ptr(), gt.shape[2], bbp, n, j, thr_dev.data_ptr(), len(thr),
+                                        counts.data_ptr(), nvis.data_ptr(), rows.data_ptr(),
+                                        torch.cuda.current_stream().cuda_stream), "lh_pck_curve")
+    diff_sum += rows.sum()
+    n_all += n * j
+    return counts, nvis, diff_sum, n_all
+
+
+def auc_from_counts(counts, nvis, diff_sum, n_all, T_list, method):
+    """[auc, epe_mm, pck_curve] exactly as pred_eval reports one category (src/utils/argparser.py:362-375)."""
+    thr = eval_thresholds(T_list, method)
+    norm = np.trapz(np.ones_like(thr), thr)
+    curve = np.asarray(counts, dtype=np.float64) / float(nvis) * 100
+    return [float(np.trapz(curve, thr) / (norm + sys.float_info.epsilon)), float(diff_sum) / float(n_all) / PX_PER_MM_EVAL, curve]
+

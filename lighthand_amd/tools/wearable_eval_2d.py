@@ -67,6 +67,36 @@ def pred_store(model, loader, out_json, batch, size, bn_train=True):
     return meta
 
 
+def device_eval(model, loader, batch, size, bn_train=True):
+    """Same evaluation reduced ON THE DEVICE: per threshold set the PCK-curve counts of all visible
+    joints are accumulated by lh_pck_curve, summed across data-parallel ranks with one small all-reduce, and read by
+    the host once.  Returns {(type, T1): [auc, epe_mm, curve]}; the AUC equals pred_eval's 'mean_auc' AUC (whose EPE is
+    diluted by the reference's zeros quirk; the EPE here is the plain mean)."""
+    from lighthand_amd.metrics import auc_from_counts, device_pck_curve
+    from lighthand_amd.runtime import InferStep
+    step = InferStep(model, batch, size, size, bn_train=bn_train)
+    acc = {(t, tuple(T)): None for t, T in THRESHOLDS}
+    for images, joints_v, _ in loader:
+        n = images.shape[0]
+        if n != batch:
+            images = torch.cat([images, images[:1].expand(batch - n, -1, -1, -1)])
+        preds = step(images.cuda(non_blocking=True))[:n]
+        gt = joints_v.cuda(non_blocking=True)
+        w = gt[..., 0].max(1).values - gt[..., 0].min(1).values
+        h = gt[..., 1].max(1).values - gt[..., 1].min(1).values
+        bb = torch.sqrt(w ** 2 + h ** 2)
+        for key in acc:
+            acc[key] = device_pck_curve(preds, gt, bb, list(key[1]), key[0], out=acc[key])
+    out = {}
+    for key, tensors in acc.items():
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            for t in tensors:
+                torch.distributed.all_reduce(t)
+        counts, nvis, diff_sum, n_all = (t.cpu().numpy() for t in tensors)
+        out[(key[0], key[1][1])] = auc_from_counts(counts, nvis[0], diff_sum[0], n_all[0], list(key[1]), key[0])
+    return out
+
+
 def write_report(path, results):
     """wearable_eval_2d.py:64-79: `category;model;auc;epe;pck...;` one line per category."""
     with open(path, "w") as f:
@@ -93,6 +123,7 @@ def main(argv=None):
     ap.add_argument("--size", default=256, type=int)
     ap.add_argument("--synthetic", default=0, type=int)
     ap.add_argument("--bn_eval", action="store_true")
+    ap.add_argument("--device_metrics", action="store_true", help="also reduce the PCK curves / AUC on the device and print them")
     args = ap.parse_args(argv)
     if not args.synthetic:
         raise SystemExit("the Armo_hand evaluation set is not shipped: pass --synthetic N or plug your own Dataset")
@@ -114,6 +145,10 @@ def main(argv=None):
             out_json = os.path.join(args.root_path, name, "evaluation.json")
             meta = pred_store(model, loader, out_json, args.batch_size, args.size, bn_train=not args.bn_eval)
             results.append([pred_eval({k: v for k, v in meta.items() if v["bb"]}, T_list, t_type), name])
+            if args.device_metrics and t_type == THRESHOLDS[0][0] and T_list == THRESHOLDS[0][1]:
+                for (ty, t1), (auc, epe, _) in device_eval(model, loader, args.batch_size, args.size, bn_train=not args.bn_eval).items():
+                    host = pred_eval({k: v for k, v in meta.items() if v["bb"]}, [t for n_, t in THRESHOLDS if n_ == ty and t[1] == t1][0], ty)
+                    print(f"device metrics {name} {ty} {t1}: auc {auc:.4f} (host mean_auc {host['mean_auc'][0]:.4f}) epe {epe:.3f} mm")
         fn = os.path.join(args.root_path, f"pck_eval_{'_'.join(args.model_path.split('/'))}_{t_type}_{T_list[1]}.txt")
         write_report(fn, results)
         written.append(fn)

@@ -351,3 +351,25 @@ def test_device_metrics_match_host_metrics(golden_dir):
     assert abs(float(pck) - M.PCK_2d_loss(p2, g2, T=0.5)) < 1e-6
     (s, c), _ = M.EPE_train(p2, g2)
     assert abs(float(esum) - s) < 1e-4 * s and float(ecnt) == c
+
+
+def test_device_pck_curve_equals_pred_eval():
+    """pred_eval's per-category PCK curve / AUC / EPE (src/utils/argparser.py:326-388) counted on the
+    device, accumulated over batches; integer counts, so the curve is EXACTLY the host one and AUC / EPE agree to 1e-12."""
+    from lighthand_amd.metrics import auc_from_counts, device_pck_curve, pred_eval
+    rng = np.random.RandomState(8)
+    n, j = 37, 21
+    gt = np.concatenate([rng.uniform(20, 236, (n, j, 2)), (rng.rand(n, j, 1) < 0.7).astype(np.float64)], -1).astype(np.float32)
+    pred = (gt[..., :2] + rng.randn(n, j, 2) * 9).astype(np.float32)
+    bb = rng.uniform(60, 200, n).astype(np.float32)
+    meta = {"cat": {"bb": bb.astype(np.float64).tolist(), "pred": pred.astype(np.float64).tolist(), "gt": gt.astype(np.float64).tolist()}}
+    for T_list, method in (([0.1, 0.3], "pckb"), ([0, 30], "mm"), ([0, 50], "mm")):
+        want = pred_eval(meta, T_list, method)["cat"]
+        acc = None
+        for lo, hi in ((0, 16), (16, 37)):              # two batches, accumulated on the device
+            acc = device_pck_curve(torch.from_numpy(pred[lo:hi]).cuda(), torch.from_numpy(gt[lo:hi]).cuda(),
+                                   torch.from_numpy(bb[lo:hi]).cuda(), T_list, method, out=acc)
+        counts, nvis, diff_sum, n_all = (t.cpu().numpy() for t in acc)
+        got = auc_from_counts(counts, nvis[0], diff_sum[0], n_all[0], T_list, method)
+        assert np.array_equal(got[2], want[2])
+        assert abs(got[0] - want[0]) < 1e-12 and abs(got[1] - want[1]) < 1e-9 * max(1.0, abs(want[1]))

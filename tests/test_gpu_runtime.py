@@ -195,3 +195,13 @@ def test_eval_cli_writes_reference_formats(tmp_path):
     line = [l for l in open(files[0]) if l.startswith("mean_auc;")][0].split(";")
     assert line[1] == "simplebaseline/frei/run1"
     assert abs(float(line[2]) - want["mean_auc"][0]) < 0.006 and abs(float(line[3]) - want["mean_auc"][1]) < 0.006
+    # the device-side reduction (lh_pck_curve; one host read at the end) reproduces the AUC of all visible joints
+    torch.manual_seed(9001)
+    model = T.build_model(args).cuda()
+    model.load_state_dict(torch.load(os.path.join(str(tmp_path), "simplebaseline/frei/run1/checkpoint-good/state_dict.bin"),
+                                     map_location="cpu")["model_state_dict"], strict=False)
+    loader = torch.utils.data.DataLoader(E.SyntheticEvalSet(20, 64), batch_size=8, shuffle=False)
+    dev = E.device_eval(model.train(), loader, 8, 64, bn_train=True)
+    for ty, T_list in E.THRESHOLDS:
+        host = om.pred_eval({k: v for k, v in ev[0].items() if v["bb"]}, T_list, ty)["mean_auc"]
+        assert abs(dev[(ty, T_list[1])][0] - host[0]) < 1e-6, (ty, T_list)
