@@ -190,21 +190,22 @@ __device__ __attribute__((aligned(16))) unsigned int lh_wzero_page[4] = {0u, 0u,
 #endif
 
 template <int ROWB> __device__ __forceinline__ int wswz(int row) {
-    return ROWB == 256 ? (row & 7) : ((row >> 1) & 3);
+    return ROWB >= 256 ? (row & 7) : ((row >> 1) & 3);
 }
 
 template <typename T, int BO, int BI, int WO, int WI, int D>
-__global__ __launch_bounds__(256) void wgrad_ring_kernel(const WgradArgs p) {
+__global__ __launch_bounds__(64 * WO * WI) void wgrad_ring_kernel(const WgradArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     static_assert(sizeof(T) == 2, "16-bit types only");
     constexpr int KP = 32;
     constexpr int RBO = BO * 2, RBI = BI * 2;                 // bytes per pixel row
     constexpr int RPO = 1024 / RBO, RPI = 1024 / RBI;         // pixel rows per LDS-DMA instruction
-    constexpr int NO = KP / RPO / 4, NI = KP / RPI / 4;       // instructions per wave and stage
+    constexpr int NWAVE = WO * WI;                           // 4 waves, or 8 for the 256 x 256 tile
+    constexpr int NO = KP / RPO / NWAVE, NI = KP / RPI / NWAVE;   // instructions per wave and stage
     constexpr int L = NO + NI;
     constexpr int STAGE = KP * (RBO + RBI);
     constexpr int TO = BO / WO, TI = BI / WI, OT = TO / 16, IT = TI / 16;
-    static_assert(WO * WI == 4 && NO >= 1 && NI >= 1 && D >= 2 && D <= 4, "bad tile");
+    static_assert((NWAVE == 4 || NWAVE == 8) && NO >= 1 && NI >= 1 && D >= 2 && D <= 4, "bad tile");
     typedef __attribute__((address_space(3))) void* lds_p;
     typedef const __attribute__((address_space(1))) void* gbl_p;
 
@@ -229,14 +230,14 @@ __global__ __launch_bounds__(256) void wgrad_ring_kernel(const WgradArgs p) {
     int orow[NO], ocol[NO], irow[NI], icol[NI];
 #pragma unroll
     for (int j = 0; j < NO; ++j) {
-        const int q = 4 * j + wave;
+        const int q = NWAVE * j + wave;
         const int r = q * RPO + lane / (RBO / 16), c16 = lane % (RBO / 16);
         orow[j] = r;
         ocol[j] = otile * BO + ((((c16 >> 1) ^ wswz<RBO>(r)) << 1) | (c16 & 1)) * 8;
     }
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-        const int q = 4 * j + wave;
+        const int q = NWAVE * j + wave;
         const int r = q * RPI + lane / (RBI / 16), c16 = lane % (RBI / 16);
         irow[j] = r;
         icol[j] = itile * BI + ((((c16 >> 1) ^ wswz<RBI>(r)) << 1) | (c16 & 1)) * 8;
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(256) void wgrad_ring_kernel(const WgradArgs p) {
             const bool ok = (int)(m < m_end) & (int)(ocol[j] < p.n_out);
             const unsigned char* src = p.dy + (m * p.dy_pix_stride + ocol[j]) * 2;
             src = ok ? src : zero;
-            if (!(LH_ABL & 4)) __builtin_amdgcn_global_load_lds((gbl_p)src, (lds_p)(st + (4 * j + wave) * 1024), 16, 0, 0);
+            if (!(LH_ABL & 4)) __builtin_amdgcn_global_load_lds((gbl_p)src, (lds_p)(st + (NWAVE * j + wave) * 1024), 16, 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(256) void wgrad_ring_kernel(const WgradArgs p) {
                             (int)((unsigned)iw < (unsigned)p.wi);
             const unsigned char* src = p.x + (((long)(n * p.hi + ih) * p.wi + iw) * p.in_pix_stride + icol[j]) * 2;
             src = ok ? src : zero;
-            if (!(LH_ABL & 4)) __builtin_amdgcn_global_load_lds((gbl_p)src, (lds_p)(st + KP * RBO + (4 * j + wave) * 1024), 16, 0, 0);
+            if (!(LH_ABL & 4)) __builtin_amdgcn_global_load_lds((gbl_p)src, (lds_p)(st + KP * RBO + (NWAVE * j + wave) * 1024), 16, 0, 0);
         }
     };
 
@@ -405,20 +406,13 @@ __global__ void wgrad_reduce_kernel(const WreduceArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-static void wgrad_plan(const lh_igemm_desc* d, int n_out, int n_in, int dtype, int* bo, int* bi,
-                       int* nsplit, int* steps_per_split) {
-    const int kp = dtype == LH_F32 ? 16 : 32;
-    *bo = n_out > 64 ? 128 : 64;
-    *bi = n_in > 64 ? 128 : 64;
+// Split-K plan of one tile shape: how many pixel splits, steps per split.
+static void wgrad_splits(const lh_igemm_desc* d, int n_out, int n_in, int bo, int bi, int kp, long target, long* nsplit, long* sps) {
     const long M = (long)d->n * d->ho * d->wo;
     const long steps = (M + kp - 1) / kp;
-    const long tiles = (long)((n_out + *bo - 1) / *bo) * ((n_in + *bi - 1) / *bi) * d->ntaps;
-    static long target = 0, min_steps = 0;           // tuning knobs: workgroups aimed at, fewest K steps per workgroup
-    if (!target) {
-        const char* e1 = getenv("LH_WGRAD_WANT"); const char* e2 = getenv("LH_WGRAD_MINSTEPS");
-        target = e1 ? atol(e1) : 1024;
-        min_steps = e2 ? atol(e2) : 8;
-    }
+    const long tiles = (long)((n_out + bo - 1) / bo) * ((n_in + bi - 1) / bi) * d->ntaps;
+    static long min_steps = 0;                       // tuning knob: fewest K steps per workgroup
+    if (!min_steps) { const char* e = getenv("LH_WGRAD_MINSTEPS"); min_steps = e ? atol(e) : 8; }
     long want = (target + tiles - 1) / tiles;        // aim at >= ~3 workgroups per CU
     long max_split = (steps + min_steps - 1) / min_steps;
     if (max_split > 128) max_split = 128;            // bound the slab traffic of the fold
@@ -429,9 +423,39 @@ static void wgrad_plan(const lh_igemm_desc* d, int n_out, int n_in, int dtype, i
     if (by_bytes < 1) by_bytes = 1;
     if (want > by_bytes && tiles * by_bytes >= 256) want = by_bytes;
     if (want < 1) want = 1;
-    const long sps = (steps + want - 1) / want;
+    *sps = (steps + want - 1) / want;
+    *nsplit = (steps + *sps - 1) / *sps;
+}
+
+static void wgrad_plan(const lh_igemm_desc* d, int n_out, int n_in, int dtype, int* bo, int* bi,
+                       int* nsplit, int* steps_per_split) {
+    const int kp = dtype == LH_F32 ? 16 : 32;
+    *bo = n_out > 64 ? 128 : 64;
+    *bi = n_in > 64 ? 128 : 64;
+    static long target = 0;                          // tuning knob: workgroups aimed at
+    if (!target) { const char* e = getenv("LH_WGRAD_WANT"); target = e ? atol(e) : 1024; }
+    long ns, sps;
+    wgrad_splits(d, n_out, n_in, *bo, *bi, kp, target, &ns, &sps);
+    // 256 x 256 tile (8 waves, one workgroup per CU, LDS-DMA ring kernel only): half the operand bytes per FLOP of the
+    // 128 x 128 tile, but a quarter of the tiles, so more pixel splits -- each of which writes a full fp32 copy of the
+    // weight tensor that the fold re-reads.  Chosen where the estimated saving on operand traffic (served at the LDS-DMA
+    // rate) exceeds the extra slab traffic (HBM rate).  LH_WGRAD_BIG=0 never, 2 always (where the shape allows).
+    const char* be = getenv("LH_WGRAD_BIG");          // read per call: the parity test flips it inside one process
+    const int big = be ? atoi(be) : 1;
+    const bool ringable = dtype != LH_F32 && (d->in_pix_stride * 2) % 16 == 0 && !getenv("LH_NO_WGRAD_RING");
+    if (big && ringable && *bo == 128 && *bi == 128 && n_out % 256 == 0 && n_in % 256 == 0) {
+        long nb, sb;
+        wgrad_splits(d, n_out, n_in, 256, 256, kp, target / 2, &nb, &sb);
+        const double M = (double)d->n * d->ho * d->wo, wbytes = (double)n_out * n_in * d->ntaps * 4;
+        const double tiles_s = (double)(n_out / 128) * (n_in / 128) * d->ntaps, tiles_b = tiles_s / 4;
+        const double t_small = M * 512 * tiles_s / 10e12 + 2 * ns * wbytes / 5e12;
+        const double t_big = M * 1024 * tiles_b / 10e12 + 2 * nb * wbytes / 5e12;
+        static double margin = 0.0;
+        if (margin == 0.0) { const char* e = getenv("LH_WGRAD_BIG_MARGIN"); margin = e ? atof(e) : 0.85; }
+        if (big > 1 || (t_big < margin * t_small && tiles_b * nb >= 192)) { *bo = 256; *bi = 256; ns = nb; sps = sb; }
+    }
+    *nsplit = (int)ns;
     *steps_per_split = (int)sps;
-    *nsplit = (int)((steps + sps - 1) / sps);
 }
 
 extern "C" int lh_wgrad_tile(const lh_igemm_desc* d, int n_out, int n_in, int dtype, int* bo, int* bi, int* nsplit, int* ring) {
@@ -453,13 +477,23 @@ template <typename T, int BO, int BI, int WO, int WI>
 static int launch_wgrad_ring(const WgradArgs& a, hipStream_t s) {
     constexpr int D = 4;
     constexpr int lds = D * 32 * (BO * 2 + BI * 2);
+    static bool attr_done = false;
+    if (!attr_done && lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_ring_kernel<T, BO, BI, WO, WI, D>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) {
+            lh_set_error("wgrad_ring: cannot raise dynamic LDS to %d bytes: %s", lds, hipGetErrorString(e));
+            return LH_ERR_HIP;
+        }
+        attr_done = true;
+    }
     WgradArgs b = a;
     static int xcd = -1;
     if (xcd < 0) xcd = getenv("LH_NO_XCD") ? 0 : 1;
     b.tiles = ceil_div(a.n_out, BO) * a.i_tiles;
     b.xcd = xcd;
     dim3 grid(b.tiles * a.ntaps * a.nsplit);
-    hipLaunchKernelGGL((wgrad_ring_kernel<T, BO, BI, WO, WI, D>), grid, dim3(256), lds, s, b);
+    hipLaunchKernelGGL((wgrad_ring_kernel<T, BO, BI, WO, WI, D>), grid, dim3(64 * WO * WI), lds, s, b);
     LH_LAUNCH_CHECK("wgrad_ring launch");
     return LH_OK;
 }
@@ -496,6 +530,7 @@ extern "C" int lh_wgrad(const lh_igemm_desc* d, const void* x, const void* dy, i
     // 16-bit types with 16-byte aligned pixel rows take the LDS-DMA ring kernel
     const bool ring = es == 2 && (d->in_pix_stride * es) % 16 == 0 && !getenv("LH_NO_WGRAD_RING");
 #define LH_WR(T)                                                                  \
+    if (bo == 256 && bi == 256) return launch_wgrad_ring<T, 256, 256, 2, 4>(a, s); \
     if (bo == 128 && bi == 128) return launch_wgrad_ring<T, 128, 128, 2, 2>(a, s); \
     if (bo == 128 && bi == 64) return launch_wgrad_ring<T, 128, 64, 4, 1>(a, s);   \
     if (bo == 64 && bi == 128) return launch_wgrad_ring<T, 64, 128, 1, 4>(a, s);   \

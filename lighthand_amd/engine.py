@@ -371,7 +371,7 @@ class Plan:
             return f"igemm_kernel<{t}, {a.value}, {b.value}, {wc}, {wp}>"
         r = C.c_int(0)
         self.lib.lh_wgrad_tile(C.byref(d), wgrad[0], wgrad[1], self.dt, C.byref(a), C.byref(b), C.byref(c), C.byref(r))
-        wo, wi = {(128, 128): (2, 2), (128, 64): (4, 1), (64, 128): (1, 4), (64, 64): (2, 2)}[(a.value, b.value)]
+        wo, wi = {(256, 256): (2, 4), (128, 128): (2, 2), (128, 64): (4, 1), (64, 128): (1, 4), (64, 64): (2, 2)}[(a.value, b.value)]
         if r.value:
             return f"wgrad_ring_kernel<{t}, {a.value}, {b.value}, {wo}, {wi}, {r.value}>"
         return f"wgrad_kernel<{t}, {a.value}, {b.value}, {wo}, {wi}>"

@@ -140,6 +140,33 @@ def test_conv_fwd_bwd(case, precision):
         assert rel_err(grads["conv.bias"], ref_m.bias.grad) < tol
 
 
+def test_wgrad_big_tile_matches_small_tile(monkeypatch):
+    """The 256 x 256 (8-wave) weight-gradient tile is chosen by a cost model only for large layers; forced on a small
+    256->256 3x3 layer (LH_WGRAD_BIG=2) it must give the gradient of the 128 x 128 tile (LH_WGRAD_BIG=0) up to the fp32
+    summation order of the pixel splits, and both must match PyTorch."""
+    ConvNet, _ = _mods()
+    torch.manual_seed(3)
+    x = torch.randn(2, 256, 16, 16).to(torch.bfloat16).float()
+    ref_m = nn.Conv2d(256, 256, 3, 1, 1, bias=False)
+    with torch.no_grad():
+        ref_m.weight.copy_(ref_m.weight.to(torch.bfloat16).float())
+    ref = ref_m(x)
+    dy = torch.randn_like(ref).to(torch.bfloat16).float()
+    ref.backward(dy)
+    grads = {}
+    for mode in ("2", "0"):
+        monkeypatch.setenv("LH_WGRAD_BIG", mode)
+        m = ConvNet(256, 256, 3, 1, 1, bias=False)
+        m.conv.load_state_dict(ref_m.state_dict())
+        _, _, g = _run_plan(m, x, lambda o: dy, "bf16")
+        grads[mode] = g["conv.weight"]
+        plan = next(iter(m._lh_plans.values()))
+        names = [meta[2] for meta in plan.profile_meta if "wgrad" in meta[2]]
+        assert any("256, 256" in n for n in names) == (mode == "2"), names
+    assert rel_err(grads["2"], grads["0"]) < 1e-5
+    assert rel_err(grads["2"], ref_m.weight.grad) < TOL["bf16"]
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 @pytest.mark.parametrize("case", [(64, 32, 4, 2, 8, 8), (128, 64, 4, 1, 6, 10), (32, 32, 3, 1, 4, 4), (32, 16, 2, 1, 4, 4)])
 def test_deconv_fwd_bwd(case, precision):
