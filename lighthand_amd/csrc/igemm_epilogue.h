@@ -60,7 +60,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, unsigned char
     __syncthreads();
 
     constexpr int CH = BM * ES / 16;
-    constexpr int RPP = 256 / CH;
+    constexpr int NT = 64 * WC * WP;                  // threads of the workgroup
+    constexpr int RPP = NT / CH;
     const int chunk = tid % CH, r0 = tid / CH;
     const int col0 = cblk * BM + chunk * EPC;
     const bool col_ok = col0 < p.cout;
@@ -134,7 +135,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, unsigned char
             red[(r0 * 2 + 1) * BM + chunk * EPC + e] = s2[e];
         }
         __syncthreads();
-        for (int t = tid; t < 2 * BM; t += 256) {
+        for (int t = tid; t < 2 * BM; t += NT) {
             const int which = t / BM, col = t - which * BM;
             float a = 0.f;
 #pragma unroll 4

@@ -58,7 +58,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 }
 
 template <typename T, int BM, int BP, int WC, int WP, int D, int KB>
-__global__ __launch_bounds__(256) void igemm_ring_kernel(const IgemmArgs p) {
+__global__ __launch_bounds__(64 * WC * WP) void igemm_ring_kernel(const IgemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int ES = sizeof(T);
     constexpr int EPC = 16 / ES;
@@ -70,10 +70,11 @@ __global__ __launch_bounds__(256) void igemm_ring_kernel(const IgemmArgs p) {
     constexpr int SL = KB / 16;                       // 16-byte slots per row
     constexpr int RPI = 64 / SL;                      // rows one LDS-DMA instruction covers
     constexpr int GB = 16 * KB;                       // bytes of one 16-row group
-    constexpr int NW = BM / 16 * H / 4, NX = BP / 16 * H / 4;   // instructions per wave and stage
+    constexpr int NWAVE = WC * WP;                    // 4 waves, or 8 for the 256 x 256 tile
+    constexpr int NW = BM / 16 * H / NWAVE, NX = BP / 16 * H / NWAVE;   // instructions per wave and stage
     constexpr int L = NW + NX;
     constexpr int KSUB = KB / 64;                     // MFMA K sub-steps per stage
-    static_assert(WC * WP == 4 && D >= 2 && D <= 5 && (KB == 64 || KB == 128) && NW >= 1 && NX >= 1, "bad configuration");
+    static_assert((NWAVE == 4 || NWAVE == 8) && D >= 2 && D <= 5 && (KB == 64 || KB == 128) && NW >= 1 && NX >= 1, "bad configuration");
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256) void igemm_ring_kernel(const IgemmArgs p) {
     const int th = ntaps / tw;
 #pragma unroll
     for (int j = 0; j < NX; ++j) {
-        const int q = 4 * j + wave;
+        const int q = NWAVE * j + wave;
         const int g = q / H, lrow = (q % H) * RPI + lane / SL;
         const int c = (lane % SL) ^ ((lrow / (16 / SL)) & (SL - 1));
         const int row = g * 16 + lrow;
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256) void igemm_ring_kernel(const IgemmArgs p) {
     const unsigned char* wsrc[NW];
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
-        const int q = 4 * j + wave;
+        const int q = NWAVE * j + wave;
         const int g = q / H, lrow = (q % H) * RPI + lane / SL;
         const int c = (lane % SL) ^ ((lrow / (16 / SL)) & (SL - 1));
         const int row = g * 16 + lrow;
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(256) void igemm_ring_kernel(const IgemmArgs p) {
         unsigned char* st = smem + (issued % D) * STAGE;
 #pragma unroll
         for (int j = 0; j < NW; ++j) {
-            const int q = 4 * j + wave;
+            const int q = NWAVE * j + wave;
             if (!(LH_ABL & 4))
                 __builtin_amdgcn_global_load_lds((gbl_void_p)(wsrc[j] + woff), (lds_void_p)(st + (q / H) * GB + (q % H) * 1024), 16, 0, 0);
         }
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(256) void igemm_ring_kernel(const IgemmArgs p) {
         const int kbase = ikc * KSTEP;
 #pragma unroll
         for (int j = 0; j < NX; ++j) {
-            const int q = 4 * j + wave;
+            const int q = NWAVE * j + wave;
             bool ok = (((hmask[j] >> ti) & (wmask[j] >> tj)) & 1u) != 0;
             if (ktail) ok = ok && (kbase + xc[j] < p.k_run);
             const unsigned char* src = ok ? p.in + pbase[j] + toff : zero;     // select: every lane issues the load
@@ -268,7 +269,7 @@ static int launch_ring(const IgemmArgs& a, hipStream_t s) {
         attr_done = true;
     }
     dim3 grid(ceil_div(a.M, BP) * ceil_div(a.cout, BM) * (a.nphase > 1 ? a.nphase : 1));
-    hipLaunchKernelGGL((igemm_ring_kernel<T, BM, BP, WC, WP, D, KB>), grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL((igemm_ring_kernel<T, BM, BP, WC, WP, D, KB>), grid, dim3(64 * WC * WP), lds, s, a);
     LH_LAUNCH_CHECK("igemm_ring launch");
     return LH_OK;
 }
@@ -276,6 +277,14 @@ static int launch_ring(const IgemmArgs& a, hipStream_t s) {
 // Tile choice: the largest tile that still gives >= 2 workgroups per CU, else the smallest.
 void lh_ring_pick_tile(const lh_igemm_desc* d, int dtype, int* bm, int* bp) {
     const long M = (long)d->n * d->ho * d->wo;
+    const char* e256 = getenv("LH_TILE_MIN_256");   // smallest grid for the 256 x 256 tile (0 = never; default one round of one
+    // workgroup per CU); read per call: the
+    const int min_256 = e256 ? atoi(e256) : 256;    // parity test flips it inside one process
+    if (min_256 > 0 && dtype != LH_F32 && lh_ring_kb() == 64 && d->cout % 256 == 0 && d->ntaps * ((d->k_run * 2 + 63) / 64) > 8 &&
+        ((M + 255) / 256) * (d->cout / 256) >= min_256) {
+        *bm = 256; *bp = 256;
+        return;
+    }
     const int cands[5][2] = {{128, 256}, {128, 128}, {128, 64}, {64, 128}, {64, 64}};
     const bool f32 = dtype == LH_F32;
     static int big = -1;
@@ -343,6 +352,12 @@ static bool lh_ring_five(const IgemmArgs& a) {
 
 template <typename T, int KB, int D>
 static int ring_dispatch(const IgemmArgs& a, int bm, int bp, hipStream_t s) {
+    if (bm == 256 && bp == 256) {
+        // 256 x 256 tile, 8 waves of 128 x 64 (32 MFMAs per K step each), one workgroup per CU: half the operand bytes per
+        // FLOP of the 128 x 128 tile.  3-stage ring = 96 KiB; the epilogue tile (133 KiB) sets the LDS size.
+        if constexpr (sizeof(T) == 2 && KB == 64) return launch_ring<T, 256, 256, 2, 4, 3, KB>(a, s);
+        else { lh_set_error("igemm_ring: 256x256 tile is 16-bit / 64-byte-step only"); return LH_ERR_UNSUPPORTED; }
+    }
     if (bm == 128 && bp == 256) {
         // 128 x 256 tile: each wave owns 64 x 128 (32 MFMAs per K step), 3-stage ring = 72 KiB -> two workgroups per CU.
         // The tile choice (and the stats-slab row count derived from it) must be honoured whatever depth was asked for.

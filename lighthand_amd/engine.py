@@ -364,9 +364,9 @@ class Plan:
         a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
         if wgrad is None:
             self.lib.lh_igemm_tile(C.byref(d), self.dt, C.byref(a), C.byref(b), C.byref(c))
-            wc, wp = {(128, 256): (2, 2), (128, 128): (2, 2), (128, 64): (4, 1), (64, 128): (1, 4), (64, 64): (2, 2)}[(a.value, b.value)]
+            wc, wp = {(256, 256): (2, 4), (128, 256): (2, 2), (128, 128): (2, 2), (128, 64): (4, 1), (64, 128): (1, 4), (64, 64): (2, 2)}[(a.value, b.value)]
             if c.value:
-                depth = 3 if b.value == 256 else c.value % 10
+                depth = 3 if b.value == 256 else c.value % 10       # both 256-pixel tiles run a 3-stage ring
                 return f"igemm_ring_kernel<{t}, {a.value}, {b.value}, {wc}, {wp}, {depth}, {c.value // 10}>"
             return f"igemm_kernel<{t}, {a.value}, {b.value}, {wc}, {wp}>"
         r = C.c_int(0)

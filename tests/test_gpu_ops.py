@@ -140,6 +140,35 @@ def test_conv_fwd_bwd(case, precision):
         assert rel_err(grads["conv.bias"], ref_m.bias.grad) < tol
 
 
+@pytest.mark.parametrize("case", [(256, 256, 3, 1, 1, 2, 16, 16), (512, 256, 1, 1, 0, 3, 12, 20), (256, 512, 3, 2, 1, 2, 16, 16)])
+def test_conv_256_tile_matches_torch(case, monkeypatch):
+    """The 256 x 256 (8-wave) convolution tile, forced on small layers (LH_TILE_MIN_256=1): forward, data gradient and
+    BN statistics path against PyTorch, and against the default tiles on the same inputs."""
+    ConvNet, _ = _mods()
+    cin, cout, k, s_, p, n, h, w = case
+    torch.manual_seed(5)
+    x = torch.randn(n, cin, h, w).to(torch.bfloat16).float()
+    ref_m = nn.Conv2d(cin, cout, k, s_, p, bias=False)
+    with torch.no_grad():
+        ref_m.weight.copy_(ref_m.weight.to(torch.bfloat16).float())
+    xr = x.clone().requires_grad_(True)
+    ref = ref_m(xr)
+    dy = torch.randn_like(ref).to(torch.bfloat16).float()
+    ref.backward(dy)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("LH_TILE_MIN_256", mode)
+        m = ConvNet(cin, cout, k, s_, p, bias=False)
+        m.conv.load_state_dict(ref_m.state_dict())
+        res[mode] = _run_plan(m, x, lambda o: dy, "bf16")
+        plan = next(iter(m._lh_plans.values()))
+        names = [meta[2] for meta in plan.profile_meta if meta[2].startswith("igemm")]
+        assert any("256, 256" in nm for nm in names) == (mode == "1"), names
+    out, dx, _ = res["1"]
+    assert rel_err(out, ref.detach()) < TOL["bf16"] and rel_err(dx, xr.grad) < TOL["bf16"]
+    assert rel_err(out, res["0"][0]) < 1e-2 and rel_err(dx, res["0"][1]) < 1e-2
+
+
 def test_wgrad_big_tile_matches_small_tile(monkeypatch):
     """The 256 x 256 (8-wave) weight-gradient tile is chosen by a cost model only for large layers; forced on a small
     256->256 3x3 layer (LH_WGRAD_BIG=2) it must give the gradient of the 128 x 128 tile (LH_WGRAD_BIG=0) up to the fp32
