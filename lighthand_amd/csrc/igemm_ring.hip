@@ -277,10 +277,12 @@ static int launch_ring(const IgemmArgs& a, hipStream_t s) {
 // Tile choice: the largest tile that still gives >= 2 workgroups per CU, else the smallest.
 void lh_ring_pick_tile(const lh_igemm_desc* d, int dtype, int* bm, int* bp) {
     const long M = (long)d->n * d->ho * d->wo;
-    const char* e256 = getenv("LH_TILE_MIN_256");   // smallest grid for the 256 x 256 tile (0 = never; default one round of one
-    // workgroup per CU); read per call: the
-    const int min_256 = e256 ? atoi(e256) : 256;    // parity test flips it inside one process
-    if (min_256 > 0 && dtype != LH_F32 && lh_ring_kb() == 64 && d->cout % 256 == 0 && d->ntaps * ((d->k_run * 2 + 63) / 64) > 8 &&
+    // 256 x 256 tile: for grids of at least LH_TILE_MIN_256 workgroups (default 256 = one round of one workgroup per CU,
+    // 0 = never) and K loops longer than LH_TILE_256_STEPS steps.  Read per call: the parity test flips it in one process.
+    const char* e256 = getenv("LH_TILE_MIN_256");
+    const char* s256 = getenv("LH_TILE_256_STEPS");
+    const int min_256 = e256 ? atoi(e256) : 256, steps_256 = s256 ? atoi(s256) : 4;
+    if (min_256 > 0 && dtype != LH_F32 && lh_ring_kb() == 64 && d->cout % 256 == 0 && d->ntaps * ((d->k_run * 2 + 63) / 64) > steps_256 &&
         ((M + 255) / 256) * (d->cout / 256) >= min_256) {
         *bm = 256; *bp = 256;
         return;
