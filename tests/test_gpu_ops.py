@@ -169,6 +169,37 @@ def test_conv_256_tile_matches_torch(case, monkeypatch):
     assert rel_err(out, res["0"][0]) < 1e-2 and rel_err(dx, res["0"][1]) < 1e-2
 
 
+def test_conv_256_tile_bn_statistics(monkeypatch):
+    """conv -> BN -> ReLU (+ residual) with the 256 x 256 tile forced: the tile's epilogue writes the BN partial sums, so
+    running statistics, BN parameter gradients and the data gradient must equal the default tiles' (bf16: same stored
+    activations, fp32 folds) and PyTorch's within the 16-bit tolerance."""
+    import copy
+    _, BnNet = _mods()
+    for mode in ("plain", "residual"):
+        torch.manual_seed(7)
+        proto = BnNet(256, mode)
+        x = torch.randn(2, 256, 16, 16).to(torch.bfloat16).float()
+        dy = None
+        res = {}
+        for tile in ("1", "0"):
+            monkeypatch.setenv("LH_TILE_MIN_256", tile)
+            m = copy.deepcopy(proto)
+            torch.manual_seed(8)
+            out, dx, grads = _run_plan(m, x, lambda o: torch.randn_like(o), "bf16")
+            res[tile] = (out, dx, grads, {k: v.cpu().clone() for k, v in m.state_dict().items() if "running" in k})
+            plan = next(iter(m._lh_plans.values()))
+            assert any("256, 256" in meta[2] for meta in plan.profile_meta if meta[2].startswith("igemm")) == (tile == "1")
+        a, b = res["1"], res["0"]
+        assert rel_err(a[0], b[0]) < 1e-2 and rel_err(a[1], b[1]) < 2e-2
+        for k in a[3]:
+            assert rel_err(a[3][k], b[3][k]) < 1e-5, k
+        for k in ("bn.weight", "bn.bias"):
+            assert rel_err(a[2][k], b[2][k]) < 2e-2, k
+        ref = copy.deepcopy(proto).train()
+        y = ref.torch_forward(x)
+        assert rel_err(a[0], y.detach()) < TOL["bf16"]
+
+
 def test_wgrad_big_tile_matches_small_tile(monkeypatch):
     """The 256 x 256 (8-wave) weight-gradient tile is chosen by a cost model only for large layers; forced on a small
     256->256 3x3 layer (LH_WGRAD_BIG=2) it must give the gradient of the 128 x 128 tile (LH_WGRAD_BIG=0) up to the fp32
