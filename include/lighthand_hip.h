@@ -297,6 +297,11 @@ int lh_keypoint_metrics(const float* pred, const float* gt, int gt_stride, int b
 int lh_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long numel,
                  const double* hyper, int* step, float* derived, float grad_scale, void* stream);
 
+/* Bias gradient of the head's 1x1 convolution (pose_resnet.py:169-175; loss.backward()): out[c] = sum over n, h, w of an
+ * NCHW fp32 gradient.  fp64 partials in a fixed order (deterministic).  workspace >= lh_channel_sum_workspace_bytes(c). */
+size_t lh_channel_sum_workspace_bytes(int c);
+int lh_channel_sum_nchw(const float* x, int n, int c, int hw, float* out, void* workspace, void* stream);
+
 /* PCK curve of pred_eval (src/utils/argparser.py:326-388) on the device: counts[t] += visible joints (gt[..][2] == 1) whose
  * error (pixel distance; divided by bb[sample] when bb != NULL, the 'pckb' mode) is < thr[t]; *nvis += visible joints;
  * diff_row[s] = sum of pixel errors over ALL joints of sample s.  float64 arithmetic like the NumPy original; counts /

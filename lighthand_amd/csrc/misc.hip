@@ -585,6 +585,44 @@ extern "C" int lh_adam_step(float* param, const float* grad, float* exp_avg, flo
     return LH_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ head bias gradient
+// d(bias)[c] = sum over n, h, w of an NCHW fp32 gradient (the head's 1x1 convolution with bias, pose_resnet.py:169-175):
+// one workgroup per (channel, slice of the batch), fp64 partials, fixed order -> deterministic.
+__global__ __launch_bounds__(256) void channel_sum_nchw_kernel(const float* x, int n, int c, int hw, double* partial, int slices) {
+    __shared__ double red[4];
+    const int ch = blockIdx.x, sl = blockIdx.y;
+    const int n0 = (int)((long)n * sl / slices), n1 = (int)((long)n * (sl + 1) / slices);
+    double acc = 0.0;
+    for (int b = n0; b < n1; ++b) {
+        const float* p = x + ((long)b * c + ch) * hw;
+        for (int i = threadIdx.x; i < hw; i += 256) acc += (double)p[i];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(long)ch * slices + sl] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ void channel_sum_final_kernel(const double* partial, int c, int slices, float* out) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    double a = 0.0;
+    for (int s = 0; s < slices; ++s) a += partial[(long)ch * slices + s];
+    out[ch] = (float)a;
+}
+
+extern "C" size_t lh_channel_sum_workspace_bytes(int c) { return (size_t)c * 16 * sizeof(double); }
+
+extern "C" int lh_channel_sum_nchw(const float* x, int n, int c, int hw, float* out, void* workspace, void* stream) {
+    LH_REQUIRE(x && out && workspace && n > 0 && c > 0 && hw > 0, "lh_channel_sum_nchw: bad arguments");
+    const int slices = n < 16 ? n : 16;
+    hipLaunchKernelGGL(channel_sum_nchw_kernel, dim3(c, slices), dim3(256), 0, (hipStream_t)stream, x, n, c, hw, (double*)workspace, slices);
+    hipLaunchKernelGGL(channel_sum_final_kernel, dim3((c + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const double*)workspace, c, slices, out);
+    LH_LAUNCH_CHECK("channel_sum launch");
+    return LH_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ PCK curve / AUC
 // pred_eval (src/utils/argparser.py:326-388) on the device: for every threshold, the number of VISIBLE
 // joints (gt[..][2] == 1) whose error -- pixel distance, divided by the sample's bbox size when bb is given ('pckb') --

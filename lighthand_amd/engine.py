@@ -565,7 +565,10 @@ class Plan:
             if nd["bias"]:
                 gb_ = self.grads[nd["bias"]]
                 if y is self.out_act:      # the head: reduce the contiguous fp32 NCHW gradient instead of strided bf16
-                    self.bwd.append(_TorchCall(lambda: torch.sum(self.dout_nchw, dim=(0, 2, 3), out=gb_), "head bias grad"))
+                    dn = self.dout_nchw
+                    ws = self._alloc(self.lib.lh_channel_sum_workspace_bytes(dn.shape[1]), dtype=torch.uint8)
+                    self.bwd.append(_Call(self.lib.lh_channel_sum_nchw, (dn.data_ptr(), dn.shape[0], dn.shape[1], dn.shape[2] * dn.shape[3],
+                                                                          gb_.data_ptr(), ws.data_ptr()), "head bias grad"))
                 else:
                     self.bwd.append(_TorchCall(lambda: gb_.copy_(dy.view(-1, y.c)[:, :cout].sum(0, dtype=torch.float32)), "bias grad"))
             if x.needs_grad:
