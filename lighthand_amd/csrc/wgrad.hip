@@ -406,6 +406,19 @@ __global__ void wgrad_reduce_kernel(const WreduceArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// The LDS-DMA kernel needs every x row it fetches 16-byte aligned: 16-byte pixel rows, or (NHWC4 stem: 8-byte pixels)
+// an even horizontal stride, an aligned image pitch and tap column offsets that are multiples of two pixels.
+static bool wgrad_ring_ok(const lh_igemm_desc* d, int es) {
+    if (es != 2 || getenv("LH_NO_WGRAD_RING")) return false;
+    const long ps = (long)d->in_pix_stride * es;
+    if (ps % 16 == 0) return true;
+    if (getenv("LH_NO_STEM_RING")) return false;
+    if ((ps * d->sw) % 16 != 0 || (ps * d->wi) % 16 != 0) return false;
+    for (int t = 0; t < d->ntaps; ++t)
+        if ((ps * d->dw[t]) % 16 != 0) return false;
+    return true;
+}
+
 // Split-K plan of one tile shape: how many pixel splits, steps per split.
 static void wgrad_splits(const lh_igemm_desc* d, int n_out, int n_in, int bo, int bi, int kp, long target, long* nsplit, long* sps) {
     const long M = (long)d->n * d->ho * d->wo;
@@ -442,7 +455,7 @@ static void wgrad_plan(const lh_igemm_desc* d, int n_out, int n_in, int dtype, i
     // rate) exceeds the extra slab traffic (HBM rate).  LH_WGRAD_BIG=0 never, 2 always (where the shape allows).
     const char* be = getenv("LH_WGRAD_BIG");          // read per call: the parity test flips it inside one process
     const int big = be ? atoi(be) : 1;
-    const bool ringable = dtype != LH_F32 && (d->in_pix_stride * 2) % 16 == 0 && !getenv("LH_NO_WGRAD_RING");
+    const bool ringable = wgrad_ring_ok(d, lh_dtype_size(dtype));
     if (big && ringable && *bo == 128 && *bi == 128 && n_out % 256 == 0 && n_in % 256 == 0) {
         long nb, sb;
         wgrad_splits(d, n_out, n_in, 256, 256, kp, target / 2, &nb, &sb);
@@ -463,7 +476,7 @@ extern "C" int lh_wgrad_tile(const lh_igemm_desc* d, int n_out, int n_in, int dt
     int sps;
     wgrad_plan(d, n_out, n_in, dtype, bo, bi, nsplit, &sps);
     const int es = lh_dtype_size(dtype);
-    *ring = (es == 2 && (d->in_pix_stride * es) % 16 == 0 && !getenv("LH_NO_WGRAD_RING")) ? 4 : 0;
+    *ring = wgrad_ring_ok(d, es) ? 4 : 0;
     return LH_OK;
 }
 
@@ -528,7 +541,7 @@ extern "C" int lh_wgrad(const lh_igemm_desc* d, const void* x, const void* dy, i
     a.i_tiles = ceil_div(n_in, bi);
     hipStream_t s = (hipStream_t)stream;
     // 16-bit types with 16-byte aligned pixel rows take the LDS-DMA ring kernel
-    const bool ring = es == 2 && (d->in_pix_stride * es) % 16 == 0 && !getenv("LH_NO_WGRAD_RING");
+    const bool ring = wgrad_ring_ok(d, es);
 #define LH_WR(T)                                                                  \
     if (bo == 256 && bi == 256) return launch_wgrad_ring<T, 256, 256, 2, 4>(a, s); \
     if (bo == 128 && bi == 128) return launch_wgrad_ring<T, 128, 128, 2, 2>(a, s); \
