@@ -53,19 +53,34 @@ class GraphBuilder:
         self.n, self.h, self.w = n, h, w
         self.params = params
         self.nodes = []
+        self.node_lanes = []          # stream lane of every node (0 = main); see fork() / join()
+        self.lane = 0
         self.out = None
+
+    def _add(self, kind, nd):
+        self.nodes.append((kind, nd))
+        self.node_lanes.append(self.lane)
+
+    def fork(self):
+        """Nodes described between fork() and join() with ``gb.lane = i`` (i > 0) form chains that are independent of the
+        other lanes' chains (HRNet's parallel branches): the plan may run them on separate HIP streams."""
+        self._add("fork", {})
+
+    def join(self):
+        self.lane = 0
+        self._add("join", {})
 
     def input(self):
         a = Act(self.n, self.h, self.w, 3, name="input")
         a.is_image = True
         a.needs_grad = False
-        self.nodes.append(("input", a))
+        self._add("input", a)
         return a
 
     def input_act(self, c, h=None, w=None):
         """A dense NHWC activation fed directly (kernel tests, sub-networks); it takes gradients."""
         a = Act(self.n, h or self.h, w or self.w, c, name="input_act")
-        self.nodes.append(("input_act", a))
+        self._add("input_act", a)
         return a
 
     def conv(self, x, wname, k, stride, pad, bias=None):
@@ -76,7 +91,7 @@ class GraphBuilder:
         ho = (x.h + 2 * pad - k) // stride + 1
         wo = (x.w + 2 * pad - k) // stride + 1
         y = Act(x.n, ho, wo, (cout + 31) // 32 * 32 if cout % 8 else cout, cout, name=wname)
-        self.nodes.append(("conv", dict(x=x, y=y, w=wname, k=k, s=stride, p=pad, bias=bias)))
+        self._add("conv", dict(x=x, y=y, w=wname, k=k, s=stride, p=pad, bias=bias))
         return y
 
     def deconv(self, x, wname, k, bias=None):
@@ -86,7 +101,7 @@ class GraphBuilder:
         ho = (x.h - 1) * 2 - 2 * pad + k + opad
         wo = (x.w - 1) * 2 - 2 * pad + k + opad
         y = Act(x.n, ho, wo, w.shape[1], name=wname)
-        self.nodes.append(("deconv", dict(x=x, y=y, w=wname, k=k, p=pad, bias=bias)))
+        self._add("deconv", dict(x=x, y=y, w=wname, k=k, p=pad, bias=bias))
         return y
 
     def fuse(self, terms, relu=True):
@@ -104,17 +119,17 @@ class GraphBuilder:
         for a, _, l in norm:
             assert (a.h << l, a.w << l) == (h, w) and a.c == norm[0][0].c
         out = Act(norm[0][0].n, h, w, norm[0][0].c, name="fuse")
-        self.nodes.append(("fuse", dict(terms=norm, out=out, relu=relu)))
+        self._add("fuse", dict(terms=norm, out=out, relu=relu))
         return out
 
     def maxpool(self, x):
         y = Act(x.n, (x.h + 2 - 3) // 2 + 1, (x.w + 2 - 3) // 2 + 1, x.c, name="maxpool")
-        self.nodes.append(("maxpool", dict(x=x, y=y)))
+        self._add("maxpool", dict(x=x, y=y))
         return y
 
     def output(self, y):
         self.out = y
-        self.nodes.append(("output", dict(y=y)))
+        self._add("output", dict(y=y))
 
 
 def _desc(n, hi, wi, pix_stride, k_run, ho, wo, sh, sw, cout, OH, OW, osh, osw, ooh, oow, out_stride, taps):
@@ -138,11 +153,12 @@ def _taps_array(rs):
 class _Call:
     """A pre-bound C-ABI call; the stream is appended at run time.  ``lane`` 1 marks work that may run on
     the side stream of the backward pass (weight gradients: they only feed the optimizer)."""
-    __slots__ = ("fn", "args", "what", "keep", "lane", "ig")
+    __slots__ = ("fn", "args", "what", "keep", "lane", "ig", "slane")
 
     def __init__(self, fn, args, what, keep=None, lane=0):
         self.fn, self.args, self.what, self.keep, self.lane = fn, args, what, keep, lane
         self.ig = None               # argument positions for Plan._patch (lh_igemm layout unless set)
+        self.slane = 0               # stream lane (branch) the call belongs to
 
     def __call__(self, stream):
         rc = self.fn(*self.args, stream)
@@ -150,12 +166,20 @@ class _Call:
             check(rc, self.what)
 
 
+class _Marker:
+    """fork / join point of the stream lanes inside a launch list."""
+    __slots__ = ("kind", "what", "lane", "slane")
+
+    def __init__(self, kind):
+        self.kind, self.what, self.lane, self.slane = kind, kind, 0, 0
+
+
 class _TorchCall:
     """Host-side glue expressed with torch ops on tiny tensors (layout shuffles of <10k values)."""
-    __slots__ = ("fn", "what", "lane")
+    __slots__ = ("fn", "what", "lane", "slane")
 
     def __init__(self, fn, what, lane=0):
-        self.fn, self.what, self.lane = fn, what, lane
+        self.fn, self.what, self.lane, self.slane = fn, what, lane, 0
 
     def __call__(self, stream):
         self.fn()
@@ -191,6 +215,12 @@ class Plan:
         gb = GraphBuilder(n, h, w, self.params)
         model.describe(gb)
         self.nodes = gb.nodes
+        self.node_lanes = gb.node_lanes
+        self.n_lanes = max(gb.node_lanes) + 1 if gb.node_lanes else 1
+        self.use_lanes = self.n_lanes > 1 and not os.environ.get("LH_NO_LANES")
+        self._lane_streams = {L: torch.cuda.Stream(device=self.device) for L in range(1, self.n_lanes)} if self.use_lanes else {}
+        self._cur_lane = 0
+        self._ready = {}
         self.out_act = gb.out
         self.fwd, self.bwd, self.packs = [], [], []
         self._pack_items = []
@@ -419,9 +449,15 @@ class Plan:
         self._last_use_is_conv = {k for k, v in uses.items() if v[0] in ("conv", "deconv")}   # first consumer = last writer
         self._nwrites = {}
         bwd_blocks = []
-        for kind, nd in self.nodes:
+        for (kind, nd), lane in zip(self.nodes, self.node_lanes):
             blk = []
+            n0 = len(self.fwd)
             getattr(self, "_c_" + kind)(nd, blk)
+            for c in self.fwd[n0:]:
+                c.slane = lane
+            out_act = nd.get("y", nd.get("out")) if isinstance(nd, dict) else nd
+            if out_act is not None:
+                self._ready[id(out_act)] = len(self.fwd)      # list position from which this activation is complete
             bwd_blocks.append(blk)
         # backward list: node blocks in reverse order; accumulate flags resolved in that order
         if self._pack_items:       # every weight pack of the model is rebuilt by ONE launch
@@ -455,9 +491,13 @@ class Plan:
                                      max(cv.rs for cv in convs), self.dt), "weight packs (tiled)"))
         self.bwd_marks = []        # (end index in self.bwd, parameter names whose gradient is final there)
         if self.with_bwd:
-            for (kind, nd), blk in zip(reversed(self.nodes), reversed(bwd_blocks)):
+            for (kind, nd), blk, lane in zip(reversed(self.nodes), reversed(bwd_blocks), reversed(self.node_lanes)):
+                self._cur_lane = lane
+                n0 = len(self.bwd)
                 for emit in blk:
                     emit()
+                for c in self.bwd[n0:]:
+                    c.slane = lane
                 names = []
                 if kind in ("conv", "deconv"):
                     names.append(nd["w"] + ".weight")
@@ -470,12 +510,34 @@ class Plan:
                 if names:
                     self.bwd_marks.append((len(self.bwd), names))
             # two workspaces: the weight-gradient chain may run concurrently with the BN-backward chain
-            ws_w = None if self.own_slabs else self._alloc(max(self._ws_wgrad, 256), dtype=torch.uint8)
-            ws_f = self._alloc(max(self._ws_fuse, 256), dtype=torch.uint8)
-            for setter, nbytes in self._ws_users:
-                setter((self._alloc(max(nbytes, 256), dtype=torch.uint8) if ws_w is None else ws_w).data_ptr())
-            for setter in self._ws_users_fuse:
-                setter(ws_f.data_ptr())
+            # (stream lanes run concurrently: each lane has its own pair)
+            lanes = range(self.n_lanes if self.use_lanes else 1)
+            need_w = {L: max([nb for _, nb, l in self._ws_users if (l if self.use_lanes else 0) == L] + [256]) for L in lanes}
+            ws_w = {L: None if self.own_slabs else self._alloc(need_w[L], dtype=torch.uint8) for L in lanes}
+            ws_f = {L: self._alloc(max(self._ws_fuse, 256), dtype=torch.uint8) for L in lanes}
+            for setter, nbytes, lane in self._ws_users:
+                L = lane if self.use_lanes else 0
+                setter((self._alloc(max(nbytes, 256), dtype=torch.uint8) if ws_w[L] is None else ws_w[L]).data_ptr())
+            for setter, lane in self._ws_users_fuse:
+                setter(ws_f[lane if self.use_lanes else 0].data_ptr())
+
+    def _c_fork(self, nd, blk):
+        self.fwd.append(_Marker("fork"))
+        self._region = [self.fwd[-1], None]
+        blk.append(lambda: self.bwd.append(_Marker("join")))          # backward walks the region in reverse
+
+    def _c_join(self, nd, blk):
+        self.fwd.append(_Marker("join"))
+        self._region[1] = self.fwd[-1]
+        blk.append(lambda: self.bwd.append(_Marker("fork")))
+
+    def _in_closed_region(self, call):
+        """True when `call` sits inside the most recent fork..join region and that region is already closed: work moved
+        into it from a later node (eval-mode folding of a cross-branch sum) would read another lane's output unordered."""
+        r = getattr(self, "_region", None)
+        if not self.use_lanes or r is None or r[1] is None:
+            return False
+        return self.fwd.index(r[0]) < self.fwd.index(call) < self.fwd.index(r[1])
 
     def _c_input(self, a, blk):
         pass        # the consumer (stem conv) owns the image transform
@@ -556,7 +618,7 @@ class Plan:
                 a[6] = ptr
                 b[1] = ptr
                 cw.args, cr.args = tuple(a), tuple(b)
-            self._ws_users.append((set_ws, slab_bytes))
+            self._ws_users.append((set_ws, slab_bytes, self._cur_lane))
             self.bwd.append(cw)
             self.profile_meta.append(("bwd", self.bwd[-1], self._kname(d, (y.c, cin)), flops, (x.pixels * x.c + y.pixels * y.c) * self.es))
             self.bwd.append(cr)
@@ -625,7 +687,7 @@ class Plan:
                 a[6] = ptr
                 b[1] = ptr
                 cw.args, cr.args = tuple(a), tuple(b)
-            self._ws_users.append((set_ws, slab_bytes))
+            self._ws_users.append((set_ws, slab_bytes, self._cur_lane))
             self.bwd.append(cw)
             self.profile_meta.append(("bwd", self.bwd[-1], self._kname(d, (y.c, kr)), flops, (x.pixels * 4 + y.pixels * y.c) * self.es))
             self.bwd.append(cr)
@@ -696,7 +758,7 @@ class Plan:
                 a[6] = ptr
                 b[1] = ptr
                 cw.args, cr.args = tuple(a), tuple(b)
-            self._ws_users.append((set_ws, slab_bytes))
+            self._ws_users.append((set_ws, slab_bytes, self._cur_lane))
             self.bwd.append(cw)
             self.profile_meta.append(("bwd", self.bwd[-1], self._kname(dg, (cin, cout)), flops, (x.pixels * x.c + y.pixels * y.c) * self.es))
             self.bwd.append(cr)
@@ -796,7 +858,7 @@ class Plan:
             def set_ws(ptr):
                 args[5] = ptr
                 call.args = tuple(args)
-            self._ws_users_fuse.append(set_ws)
+            self._ws_users_fuse.append((set_ws, self._cur_lane))
             self.bwd.append(call)
             self.profile_meta.append(("bwd", self.bwd[-1], "fuse_bwd(all kernels)", 0.0, 0.0))
         blk.append(emit)
@@ -810,6 +872,10 @@ class Plan:
         prods = [self._producers.get(id(a)) if bn else None for a, bn, _ in terms]
         if prods[0] is None or (len(terms) == 2 and terms[1][1] is not None and prods[1] is None):
             return False
+        if any(self._in_closed_region(c) for pl in prods if pl for c in pl):
+            return False            # HRNet exchange sums: the producer runs on a branch lane, the other term on another
+        if len(terms) == 2 and self._ready.get(id(terms[1][0]), 0) > min(self.fwd.index(c) for c in prods[0]):
+            return False            # the other term is produced AFTER the convolution that would have to add it
         # the eval-affine launches of this node were appended to self.fwd just above: they only depend on the
         # weights, so they move to the pack list (run when weights change, not per forward)
         n_aff = sum(1 for _, bn, _ in terms if bn is not None)
@@ -866,9 +932,51 @@ class Plan:
         for c in self.packs:
             c(stream)
 
+    def _run_lanes(self, calls, stream):
+        """Launch `calls` with the independent branch chains (stream lane > 0) on side streams: a lane's first launch
+        after a fork waits for the fork's event on the main stream, the join makes the main stream wait for every lane
+        used since; outside fork/join regions (and at the end of the slice) everything is ordered on the main stream.
+        Works eagerly and under hipGraph capture (the side streams join the capture through the events)."""
+        main = torch.cuda.current_stream()
+        assert main.cuda_stream == stream, "lanes need the launch stream to be torch's current stream"
+        ev, forked, used = None, set(), set()
+        for c in calls:
+            if isinstance(c, _Marker):
+                if c.kind == "fork":
+                    ev, forked = main.record_event(), set()
+                else:
+                    for L in used:
+                        main.wait_stream(self._lane_streams[L])
+                    ev, used = None, set()
+                continue
+            L = c.slane
+            if L == 0:
+                c(stream)
+                continue
+            s = self._lane_streams.get(L)
+            if s is None:
+                s = self._lane_streams[L] = torch.cuda.Stream()
+            if L not in forked:
+                if ev is not None:
+                    s.wait_event(ev)
+                else:
+                    s.wait_stream(main)
+                forked.add(L)
+            used.add(L)
+            if isinstance(c, _TorchCall):
+                with torch.cuda.stream(s):
+                    c(s.cuda_stream)
+            else:
+                c(s.cuda_stream)
+        for L in used:
+            main.wait_stream(self._lane_streams[L])
+
     def run_forward(self, stream):
+        if self.use_lanes:
+            return self._run_lanes(self.fwd, stream)
         for c in self.fwd:
-            c(stream)
+            if not isinstance(c, _Marker):
+                c(stream)
 
     def run_backward(self, stream, lo=0, hi=None, side=None, side_lanes=(1, 2)):
         """Run bwd[lo:hi].  With ``side`` (a torch stream) the launches whose lane is in ``side_lanes`` go to that
@@ -876,6 +984,9 @@ class Plan:
         main-stream work enqueued before it and the main stream joins at the end, so they overlap the data-gradient
         chain (also inside a captured hipGraph)."""
         calls = self.bwd[lo:hi]
+        if self.use_lanes:
+            return self._run_lanes(calls, stream)
+        calls = [c for c in calls if not isinstance(c, _Marker)]
         if side is None or not side_lanes:
             for c in calls:
                 c(stream)

@@ -85,18 +85,22 @@ class HighResolutionModule(nn.Module):
         return self.num_inchannels
 
     def describe(self, gb, prefix, xs):
-        xs = [describe_stage(gb, self.branches[i], f"{prefix}.branches.{i}", xs[i]) for i in range(self.num_branches)]
         if self.num_branches == 1:
-            return xs
-        outs = []
-        for i in range(len(self.fuse_layers)):
-            terms = []
-            for j in range(self.num_branches):
+            return [describe_stage(gb, self.branches[0], f"{prefix}.branches.0", xs[0])]
+        # The branches -- and the exchange convolutions that read branch j's output -- are independent chains: each runs
+        # on its own stream lane between fork and join; the cross-resolution sums follow on the main lane.
+        gb.fork()
+        xs = list(xs)
+        pre = {}                                           # (i, j) -> term of output i that comes from branch j
+        for j in range(self.num_branches):
+            gb.lane = j
+            xs[j] = describe_stage(gb, self.branches[j], f"{prefix}.branches.{j}", xs[j])
+            for i in range(len(self.fuse_layers)):
                 q = f"{prefix}.fuse_layers.{i}.{j}"
                 if j == i:
-                    terms.append(xs[j])
+                    pre[(i, j)] = xs[j]
                 elif j > i:
-                    terms.append((gb.conv(xs[j], q + ".0", 1, 1, 0), q + ".1", j - i))
+                    pre[(i, j)] = (gb.conv(xs[j], q + ".0", 1, 1, 0), q + ".1", j - i)
                 else:
                     t = xs[j]
                     for k in range(i - j):
@@ -104,9 +108,9 @@ class HighResolutionModule(nn.Module):
                         if k != i - j - 1:
                             t = gb.fuse([(y, f"{q}.{k}.1")])
                         else:
-                            terms.append((y, f"{q}.{k}.1"))
-            outs.append(gb.fuse(terms))
-        return outs
+                            pre[(i, j)] = (y, f"{q}.{k}.1")
+        gb.join()
+        return [gb.fuse([pre[(i, j)] for j in range(self.num_branches)]) for i in range(len(self.fuse_layers))]
 
 
 class PoseHighResolutionNet(HipModule):
