@@ -220,6 +220,28 @@ class Plan:
         self.use_lanes = self.n_lanes > 1 and not os.environ.get("LH_NO_LANES")
         self._lane_streams = {L: torch.cuda.Stream(device=self.device) for L in range(1, self.n_lanes)} if self.use_lanes else {}
         self._cur_lane = 0
+        # Deferred weight gradients (single-lane networks): the weight-gradient launches of a group of layers run on ONE
+        # side stream while the main stream already walks the next group's data-gradient / BatchNorm chain; a group costs
+        # one event (LH_WGRAD_GROUP layers per group, 0 = in place on the main stream).
+        self.own_slabs = bool(os.environ.get("LH_OWN_WGRAD_SLABS"))
+        self.wgrad_group = int(os.environ.get("LH_WGRAD_GROUP", "16")) if (self.n_lanes == 1 and self.with_bwd and not self.own_slabs) else 0
+        if self.wgrad_group > 0 and not os.environ.get("LH_NO_LANES"):
+            self.use_lanes = True
+            self._w_lanes = max(1, int(os.environ.get("LH_WGRAD_STREAMS", "2")))     # groups alternate over this many side streams
+            for i in range(self._w_lanes):
+                self._lane_streams[-1 - i] = torch.cuda.Stream(device=self.device)
+        else:
+            self.wgrad_group = 0
+        self._pending_w, self._pending_names, self._pending_layers = [], [], 0
+        self._pending_ws, self._w_flushes = [], 0
+        # group boundaries by weight-gradient FLOPs (LH_WGRAD_PARTS equal parts) instead of layer counts when set
+        self._w_parts = int(os.environ.get("LH_WGRAD_PARTS", "0"))
+        self._w_total = sum(2.0 * nd["y"].pixels * self.params[nd["w"] + ".weight"].numel() / (4 if k == "deconv" else 1)
+                            for k, nd in self.nodes if k in ("conv", "deconv"))
+        self._w_acc = 0.0
+        cuts = os.environ.get("LH_WGRAD_CUTS", "")       # explicit boundaries: flush after the k-th convolution (backward order)
+        self._w_cuts = {int(v) for v in cuts.split(",") if v.strip()}
+        self._w_seen = 0
         self._ready = {}
         self.out_act = gb.out
         self.fwd, self.bwd, self.packs = [], [], []
@@ -406,6 +428,34 @@ class Plan:
             return f"wgrad_ring_kernel<{t}, {a.value}, {b.value}, {wo}, {wi}, {r.value}>"
         return f"wgrad_kernel<{t}, {a.value}, {b.value}, {wo}, {wi}>"
 
+    def _ws_note(self, setter, nbytes):
+        ent = [setter, nbytes, -1 if self.wgrad_group > 0 else self._cur_lane]
+        self._ws_users.append(ent)
+        if self.wgrad_group > 0:
+            self._pending_ws.append((setter, ent))
+
+    def _wl(self):
+        """List that takes the weight-gradient work of the node being emitted (deferred group or the backward list)."""
+        return self._pending_w if self.wgrad_group > 0 else self.bwd
+
+    def _flush_wgrads(self):
+        if not self._pending_w:
+            return
+        lane = -1 - (self._w_flushes % self._w_lanes)
+        self._w_flushes += 1
+        m = _Marker("wfork")
+        m.slane = lane
+        self.bwd.append(m)
+        for c in self._pending_w:
+            c.slane = lane
+        for setter, lst in self._pending_ws:          # the group's slab workspace follows its stream
+            lst[2] = lane
+        self._pending_ws = []
+        self.bwd += self._pending_w
+        if self._pending_names:
+            self.bwd_marks.append((len(self.bwd), self._pending_names))
+        self._pending_w, self._pending_names, self._pending_layers = [], [], 0
+
     def _first_write(self, a):
         """True the first time a gradient buffer is produced in the backward list (every writer calls this once)."""
         n = self._nwrites.get(id(a), 0)
@@ -500,18 +550,34 @@ class Plan:
                     c.slane = lane
                 names = []
                 if kind in ("conv", "deconv"):
-                    names.append(nd["w"] + ".weight")
-                    if nd["bias"]:
-                        names.append(nd["bias"])
+                    wnames = [nd["w"] + ".weight"] + ([nd["bias"]] if nd["bias"] else [])
+                    if self.wgrad_group > 0:
+                        self._pending_names += wnames
+                        self._pending_layers += 1
+                        self._w_acc += 2.0 * nd["y"].pixels * self.params[nd["w"] + ".weight"].numel() / (4 if kind == "deconv" else 1)
+                        self._w_seen += 1
+                        if self._w_cuts:
+                            if self._w_seen in self._w_cuts:
+                                self._flush_wgrads()
+                        elif self._w_parts > 0:
+                            if self._w_acc >= self._w_total / self._w_parts:
+                                self._flush_wgrads()
+                                self._w_acc = 0.0
+                        elif self._pending_layers >= self.wgrad_group:
+                            self._flush_wgrads()
+                    else:
+                        names += wnames
                 elif kind == "fuse":
                     for _, bn, _ in nd["terms"]:
                         if bn is not None:
                             names += [bn + ".weight", bn + ".bias"]
                 if names:
                     self.bwd_marks.append((len(self.bwd), names))
+            self._flush_wgrads()
+            self.bwd_marks.sort(key=lambda m: m[0])
             # two workspaces: the weight-gradient chain may run concurrently with the BN-backward chain
             # (stream lanes run concurrently: each lane has its own pair)
-            lanes = range(self.n_lanes if self.use_lanes else 1)
+            lanes = list(range(self.n_lanes if self.use_lanes else 1)) + ([-1 - i for i in range(self._w_lanes)] if self.wgrad_group > 0 else [])
             need_w = {L: max([nb for _, nb, l in self._ws_users if (l if self.use_lanes else 0) == L] + [256]) for L in lanes}
             ws_w = {L: None if self.own_slabs else self._alloc(need_w[L], dtype=torch.uint8) for L in lanes}
             ws_f = {L: self._alloc(max(self._ws_fuse, 256), dtype=torch.uint8) for L in lanes}
@@ -618,21 +684,22 @@ class Plan:
                 a[6] = ptr
                 b[1] = ptr
                 cw.args, cr.args = tuple(a), tuple(b)
-            self._ws_users.append((set_ws, slab_bytes, self._cur_lane))
-            self.bwd.append(cw)
-            self.profile_meta.append(("bwd", self.bwd[-1], self._kname(d, (y.c, cin)), flops, (x.pixels * x.c + y.pixels * y.c) * self.es))
-            self.bwd.append(cr)
+            self._ws_note(set_ws, slab_bytes)
+            wl = self._wl()
+            wl.append(cw)
+            self.profile_meta.append(("bwd", wl[-1], self._kname(d, (y.c, cin)), flops, (x.pixels * x.c + y.pixels * y.c) * self.es))
+            wl.append(cr)
             if pad_out:
-                self.bwd.append(_TorchCall(lambda: gw.copy_(gtmp[:cout]), "head grad crop", lane=tail))
+                wl.append(_TorchCall(lambda: gw.copy_(gtmp[:cout]), "head grad crop", lane=tail))
             if nd["bias"]:
                 gb_ = self.grads[nd["bias"]]
                 if y is self.out_act:      # the head: reduce the contiguous fp32 NCHW gradient instead of strided bf16
                     dn = self.dout_nchw
                     ws = self._alloc(self.lib.lh_channel_sum_workspace_bytes(dn.shape[1]), dtype=torch.uint8)
-                    self.bwd.append(_Call(self.lib.lh_channel_sum_nchw, (dn.data_ptr(), dn.shape[0], dn.shape[1], dn.shape[2] * dn.shape[3],
+                    wl.append(_Call(self.lib.lh_channel_sum_nchw, (dn.data_ptr(), dn.shape[0], dn.shape[1], dn.shape[2] * dn.shape[3],
                                                                           gb_.data_ptr(), ws.data_ptr()), "head bias grad"))
                 else:
-                    self.bwd.append(_TorchCall(lambda: gb_.copy_(dy.view(-1, y.c)[:, :cout].sum(0, dtype=torch.float32)), "bias grad"))
+                    wl.append(_TorchCall(lambda: gb_.copy_(dy.view(-1, y.c)[:, :cout].sum(0, dtype=torch.float32)), "bias grad"))
             if x.needs_grad:
                 for dd, ntaps in self._dgrad(ddescs, dy, dpacks, x, nd["w"] + " dgrad"):
                     batched = ntaps != dd.ntaps or (len(ddescs) > 1 and self.bwd[-1].ig is not None)
@@ -687,11 +754,12 @@ class Plan:
                 a[6] = ptr
                 b[1] = ptr
                 cw.args, cr.args = tuple(a), tuple(b)
-            self._ws_users.append((set_ws, slab_bytes, self._cur_lane))
-            self.bwd.append(cw)
-            self.profile_meta.append(("bwd", self.bwd[-1], self._kname(d, (y.c, kr)), flops, (x.pixels * 4 + y.pixels * y.c) * self.es))
-            self.bwd.append(cr)
-            self.bwd.append(_TorchCall(lambda: gw.copy_(gstage[:, :, :k, :3].permute(0, 3, 1, 2)), "stem grad unstage", lane=tail))
+            self._ws_note(set_ws, slab_bytes)
+            wl = self._wl()
+            wl.append(cw)
+            self.profile_meta.append(("bwd", wl[-1], self._kname(d, (y.c, kr)), flops, (x.pixels * 4 + y.pixels * y.c) * self.es))
+            wl.append(cr)
+            wl.append(_TorchCall(lambda: gw.copy_(gstage[:, :, :k, :3].permute(0, 3, 1, 2)), "stem grad unstage", lane=tail))
         blk.append(emit)
 
     # ---- transposed convolution ------------------------------------------------------------------
@@ -758,13 +826,14 @@ class Plan:
                 a[6] = ptr
                 b[1] = ptr
                 cw.args, cr.args = tuple(a), tuple(b)
-            self._ws_users.append((set_ws, slab_bytes, self._cur_lane))
-            self.bwd.append(cw)
-            self.profile_meta.append(("bwd", self.bwd[-1], self._kname(dg, (cin, cout)), flops, (x.pixels * x.c + y.pixels * y.c) * self.es))
-            self.bwd.append(cr)
+            self._ws_note(set_ws, slab_bytes)
+            wl = self._wl()
+            wl.append(cw)
+            self.profile_meta.append(("bwd", wl[-1], self._kname(dg, (cin, cout)), flops, (x.pixels * x.c + y.pixels * y.c) * self.es))
+            wl.append(cr)
             if nd["bias"]:
                 gb_ = self.grads[nd["bias"]]
-                self.bwd.append(_TorchCall(lambda: gb_.copy_(dy.view(-1, y.c)[:, :cout].sum(0, dtype=torch.float32)), "bias grad"))
+                wl.append(_TorchCall(lambda: gb_.copy_(dy.view(-1, y.c)[:, :cout].sum(0, dtype=torch.float32)), "bias grad"))
             if x.needs_grad:
                 for _dd, _nt in self._dgrad([dg], dy, [gpack], x, nd["w"] + " deconv dgrad"):
                     self.profile_meta.append(("bwd", self.bwd[-1], self._kname(dg), flops, (x.pixels * x.c + y.pixels * y.c) * self.es))
@@ -942,7 +1011,10 @@ class Plan:
         ev, forked, used = None, set(), set()
         for c in calls:
             if isinstance(c, _Marker):
-                if c.kind == "fork":
+                if c.kind == "wfork":          # the deferred weight gradients that follow may start once main got here
+                    ev = main.record_event()
+                    forked.discard(c.slane)
+                elif c.kind == "fork":
                     ev, forked = main.record_event(), set()
                 else:
                     for L in used:

@@ -7,7 +7,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from lighthand_amd.runtime import TrainStep
 
-width, batch = int(sys.argv[1]) if len(sys.argv) > 1 else 32, 32
+width = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+batch = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 steps = []
 for i in range(2):
     m = bench.build_model(50, "bf16", width)
