@@ -173,6 +173,9 @@ class _Marker:
     def __init__(self, kind):
         self.kind, self.what, self.lane, self.slane = kind, kind, 0, 0
 
+    def __call__(self, stream):          # a plain in-order replay of a launch list (profilers) just skips it
+        return None
+
 
 class _TorchCall:
     """Host-side glue expressed with torch ops on tiny tensors (layout shuffles of <10k values)."""
