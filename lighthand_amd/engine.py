@@ -223,28 +223,23 @@ class Plan:
         self.use_lanes = self.n_lanes > 1 and not os.environ.get("LH_NO_LANES")
         self._lane_streams = {L: torch.cuda.Stream(device=self.device) for L in range(1, self.n_lanes)} if self.use_lanes else {}
         self._cur_lane = 0
-        # Deferred weight gradients (single-lane networks): the weight-gradient launches of a group of layers run on ONE
-        # side stream while the main stream already walks the next group's data-gradient / BatchNorm chain; a group costs
-        # one event (LH_WGRAD_GROUP layers per group, 0 = in place on the main stream).
+        # Deferred weight gradients: the weight-gradient launches (+ folds) of a GROUP of layers are appended behind one
+        # event and run on a side stream while the stream that produced their dy walks on (the main stream of a
+        # single-lane network: LH_WGRAD_GROUP layers per group; a branch lane of HRNet: its chain inside one module).
+        # 0 = in place.  Groups alternate over LH_WGRAD_STREAMS side streams, each with its own split-K slab.
         self.own_slabs = bool(os.environ.get("LH_OWN_WGRAD_SLABS"))
-        self.wgrad_group = int(os.environ.get("LH_WGRAD_GROUP", "16")) if (self.n_lanes == 1 and self.with_bwd and not self.own_slabs) else 0
+        self.wgrad_group = int(os.environ.get("LH_WGRAD_GROUP", "16")) if (self.with_bwd and not self.own_slabs) else 0
+        if self.n_lanes > 1 and os.environ.get("LH_NO_WGRAD_DEFER_LANES"):
+            self.wgrad_group = 0
         if self.wgrad_group > 0 and not os.environ.get("LH_NO_LANES"):
             self.use_lanes = True
-            self._w_lanes = max(1, int(os.environ.get("LH_WGRAD_STREAMS", "2")))     # groups alternate over this many side streams
+            self._w_lanes = max(1, int(os.environ.get("LH_WGRAD_STREAMS", "2" if self.n_lanes == 1 else "4")))
             for i in range(self._w_lanes):
                 self._lane_streams[-1 - i] = torch.cuda.Stream(device=self.device)
         else:
             self.wgrad_group = 0
-        self._pending_w, self._pending_names, self._pending_layers = [], [], 0
-        self._pending_ws, self._w_flushes = [], 0
-        # group boundaries by weight-gradient FLOPs (LH_WGRAD_PARTS equal parts) instead of layer counts when set
-        self._w_parts = int(os.environ.get("LH_WGRAD_PARTS", "0"))
-        self._w_total = sum(2.0 * nd["y"].pixels * self.params[nd["w"] + ".weight"].numel() / (4 if k == "deconv" else 1)
-                            for k, nd in self.nodes if k in ("conv", "deconv"))
-        self._w_acc = 0.0
-        cuts = os.environ.get("LH_WGRAD_CUTS", "")       # explicit boundaries: flush after the k-th convolution (backward order)
-        self._w_cuts = {int(v) for v in cuts.split(",") if v.strip()}
-        self._w_seen = 0
+        self._pend = {}                    # source lane -> dict(calls, names, layers, ws)
+        self._w_flushes = 0
         self._ready = {}
         self.out_act = gb.out
         self.fwd, self.bwd, self.packs = [], [], []
@@ -431,33 +426,37 @@ class Plan:
             return f"wgrad_ring_kernel<{t}, {a.value}, {b.value}, {wo}, {wi}, {r.value}>"
         return f"wgrad_kernel<{t}, {a.value}, {b.value}, {wo}, {wi}>"
 
+    def _pending(self):
+        return self._pend.setdefault(self._cur_lane, dict(calls=[], names=[], layers=0, ws=[]))
+
     def _ws_note(self, setter, nbytes):
-        ent = [setter, nbytes, -1 if self.wgrad_group > 0 else self._cur_lane]
+        ent = [setter, nbytes, self._cur_lane]
         self._ws_users.append(ent)
         if self.wgrad_group > 0:
-            self._pending_ws.append((setter, ent))
+            self._pending()["ws"].append(ent)
 
     def _wl(self):
         """List that takes the weight-gradient work of the node being emitted (deferred group or the backward list)."""
-        return self._pending_w if self.wgrad_group > 0 else self.bwd
+        return self._pending()["calls"] if self.wgrad_group > 0 else self.bwd
 
-    def _flush_wgrads(self):
-        if not self._pending_w:
+    def _flush_wgrads(self, src):
+        """Append the deferred weight-gradient group of source lane `src` behind a 'wfork' event of that lane."""
+        p = self._pend.get(src)
+        if not p or not p["calls"]:
             return
         lane = -1 - (self._w_flushes % self._w_lanes)
         self._w_flushes += 1
         m = _Marker("wfork")
-        m.slane = lane
+        m.slane, m.lane = lane, src          # .lane of a wfork marker = the stream whose progress the group waits for
         self.bwd.append(m)
-        for c in self._pending_w:
+        for c in p["calls"]:
             c.slane = lane
-        for setter, lst in self._pending_ws:          # the group's slab workspace follows its stream
-            lst[2] = lane
-        self._pending_ws = []
-        self.bwd += self._pending_w
-        if self._pending_names:
-            self.bwd_marks.append((len(self.bwd), self._pending_names))
-        self._pending_w, self._pending_names, self._pending_layers = [], [], 0
+        for ent in p["ws"]:                  # the group's slab workspace follows its stream
+            ent[2] = lane
+        self.bwd += p["calls"]
+        if p["names"]:
+            self.bwd_marks.append((len(self.bwd), p["names"]))
+        self._pend[src] = dict(calls=[], names=[], layers=0, ws=[])
 
     def _first_write(self, a):
         """True the first time a gradient buffer is produced in the backward list (every writer calls this once)."""
@@ -546,6 +545,9 @@ class Plan:
         if self.with_bwd:
             for (kind, nd), blk, lane in zip(reversed(self.nodes), reversed(bwd_blocks), reversed(self.node_lanes)):
                 self._cur_lane = lane
+                if kind == "fork" and self.wgrad_group > 0:      # end of a branch region in backward order: every lane hands
+                    for src in sorted(self._pend):                # its group over before the main stream joins
+                        self._flush_wgrads(src)
                 n0 = len(self.bwd)
                 for emit in blk:
                     emit()
@@ -555,19 +557,11 @@ class Plan:
                 if kind in ("conv", "deconv"):
                     wnames = [nd["w"] + ".weight"] + ([nd["bias"]] if nd["bias"] else [])
                     if self.wgrad_group > 0:
-                        self._pending_names += wnames
-                        self._pending_layers += 1
-                        self._w_acc += 2.0 * nd["y"].pixels * self.params[nd["w"] + ".weight"].numel() / (4 if kind == "deconv" else 1)
-                        self._w_seen += 1
-                        if self._w_cuts:
-                            if self._w_seen in self._w_cuts:
-                                self._flush_wgrads()
-                        elif self._w_parts > 0:
-                            if self._w_acc >= self._w_total / self._w_parts:
-                                self._flush_wgrads()
-                                self._w_acc = 0.0
-                        elif self._pending_layers >= self.wgrad_group:
-                            self._flush_wgrads()
+                        p = self._pending()
+                        p["names"] += wnames
+                        p["layers"] += 1
+                        if p["layers"] >= self.wgrad_group:
+                            self._flush_wgrads(lane)
                     else:
                         names += wnames
                 elif kind == "fuse":
@@ -576,7 +570,8 @@ class Plan:
                             names += [bn + ".weight", bn + ".bias"]
                 if names:
                     self.bwd_marks.append((len(self.bwd), names))
-            self._flush_wgrads()
+            for src in sorted(self._pend):
+                self._flush_wgrads(src)
             self.bwd_marks.sort(key=lambda m: m[0])
             # two workspaces: the weight-gradient chain may run concurrently with the BN-backward chain
             # (stream lanes run concurrently: each lane has its own pair)
@@ -1012,11 +1007,12 @@ class Plan:
         main = torch.cuda.current_stream()
         assert main.cuda_stream == stream, "lanes need the launch stream to be torch's current stream"
         ev, forked, used = None, set(), set()
+        wev, wused = {}, set()                 # weight-gradient side streams: pending event per stream, streams used
         for c in calls:
             if isinstance(c, _Marker):
-                if c.kind == "wfork":          # the deferred weight gradients that follow may start once main got here
-                    ev = main.record_event()
-                    forked.discard(c.slane)
+                if c.kind == "wfork":          # the deferred weight gradients that follow may start once their source
+                    src = main if c.lane == 0 else self._lane_streams[c.lane]      # stream got here
+                    wev[c.slane] = src.record_event()
                 elif c.kind == "fork":
                     ev, forked = main.record_event(), set()
                 else:
@@ -1027,6 +1023,20 @@ class Plan:
             L = c.slane
             if L == 0:
                 c(stream)
+                continue
+            if L < 0:                          # deferred weight-gradient group
+                s = self._lane_streams[L]
+                e = wev.pop(L, None)
+                if e is not None:
+                    s.wait_event(e)
+                elif L not in wused:
+                    s.wait_stream(main)        # slice starts inside a group (data-parallel segments)
+                wused.add(L)
+                if isinstance(c, _TorchCall):
+                    with torch.cuda.stream(s):
+                        c(s.cuda_stream)
+                else:
+                    c(s.cuda_stream)
                 continue
             s = self._lane_streams.get(L)
             if s is None:
@@ -1043,7 +1053,7 @@ class Plan:
                     c(s.cuda_stream)
             else:
                 c(s.cuda_stream)
-        for L in used:
+        for L in used | wused:
             main.wait_stream(self._lane_streams[L])
 
     def run_forward(self, stream):
