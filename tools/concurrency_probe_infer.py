@@ -5,11 +5,13 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from lighthand_amd.runtime import InferStep
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 steps = []
-for i in range(2):
+for i in range(N):
     m = bench.build_model(50, "bf16", 0).eval()
-    s = InferStep(m, 64, 256, 256)
-    im, _ = bench.synthetic_batch(64, 256, "cuda", seed=9001 + i)
+    s = InferStep(m, B, 256, 256)
+    im, _ = bench.synthetic_batch(B, 256, "cuda", seed=9001 + i)
     s.images.copy_(im)
     for _ in range(3):
         s()
@@ -17,12 +19,11 @@ for i in range(2):
 torch.cuda.synchronize()
 def run(n, both):
     t0 = time.perf_counter()
-    st = [torch.cuda.Stream(), torch.cuda.Stream()]
+    st = [torch.cuda.Stream() for _ in range(N)]
     for _ in range(n):
-        for k in range(2 if both else 1):
+        for k in range(N if both else 1):
             with torch.cuda.stream(st[k]):
                 steps[k]()
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / n * 1e3
-print("one graph  : %.3f ms/batch" % run(20, False))
-print("two streams: %.3f ms per PAIR of batches" % run(20, True))
+print("batch %d: one graph %.3f ms; %d graphs in flight %.3f ms per round (%d images)" % (B, run(20, False), N, run(20, True), B * N))
