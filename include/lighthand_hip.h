@@ -278,6 +278,10 @@ int lh_heatmap_argmax(const float* heatmaps, int bj, int h, int w, float scale, 
  * switch TEST.POST_PROCESS, src/modeling/simplebaseline/config.py:109; this is the published SimpleBaseline rule
  * coord += 0.25 * sign(hm[+1] - hm[-1]) per axis for peaks strictly inside the map).  idx / maxvals / preds are
  * lh_heatmap_argmax's outputs (same scale); preds is updated in place. */
+/* Opt-in soft-arg-max decode (the project brief names it; the reference decodes with the hard arg-max above, so this is an
+ * extension without a reference oracle): preds[b*j] = sum_p softmax(beta * hm)[p] * (x_p, y_p) * scale. */
+int lh_heatmap_soft_argmax(const float* heatmaps, int bj, int h, int w, float beta, float scale, float* preds,
+                           void* stream);
 int lh_heatmap_refine(const float* heatmaps, const int* idx, const float* maxvals, int bj, int h, int w,
                       float scale, float* preds, void* stream);
 

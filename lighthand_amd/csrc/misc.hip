@@ -490,6 +490,46 @@ extern "C" int lh_heatmap_refine(const float* heatmaps, const int* idx, const fl
     return LH_OK;
 }
 
+// Opt-in soft-arg-max decode (named in the project's north star; NOT in the reference, which decodes with the hard arg-max
+// of get_max_preds): preds = sum_p softmax(beta * hm)[p] * (x_p, y_p), computed per map with the usual max subtraction,
+// fp32 exponentials and fp64 sums.  One workgroup per (sample, joint).
+__global__ __launch_bounds__(256) void heatmap_soft_argmax_kernel(const float* hm, int hw, int w, float beta, float scale, float* preds) {
+    __shared__ float rmax[4];
+    __shared__ double rs[4][3];
+    const float* m = hm + (long)blockIdx.x * hw;
+    float mx = -INFINITY;
+    for (int i = threadIdx.x; i < hw; i += 256) mx = fmaxf(mx, m[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) rmax[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(rmax[0], rmax[1]), fmaxf(rmax[2], rmax[3]));
+    double s0 = 0.0, sx = 0.0, sy = 0.0;
+    for (int i = threadIdx.x; i < hw; i += 256) {
+        const double e = (double)expf(beta * (m[i] - mx));
+        s0 += e; sx += e * (double)(i % w); sy += e * (double)(i / w);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o); sx += __shfl_xor(sx, o); sy += __shfl_xor(sy, o); }
+    if ((threadIdx.x & 63) == 0) { rs[threadIdx.x >> 6][0] = s0; rs[threadIdx.x >> 6][1] = sx; rs[threadIdx.x >> 6][2] = sy; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double t0 = rs[0][0] + rs[1][0] + rs[2][0] + rs[3][0];
+        const double tx = rs[0][1] + rs[1][1] + rs[2][1] + rs[3][1];
+        const double ty = rs[0][2] + rs[1][2] + rs[2][2] + rs[3][2];
+        preds[blockIdx.x * 2 + 0] = (float)(tx / t0) * scale;
+        preds[blockIdx.x * 2 + 1] = (float)(ty / t0) * scale;
+    }
+}
+
+extern "C" int lh_heatmap_soft_argmax(const float* heatmaps, int bj, int h, int w, float beta, float scale, float* preds,
+                                      void* stream) {
+    LH_REQUIRE(heatmaps && preds && bj > 0 && h > 0 && w > 0, "lh_heatmap_soft_argmax: bad arguments");
+    hipLaunchKernelGGL(heatmap_soft_argmax_kernel, dim3(bj), dim3(256), 0, (hipStream_t)stream, heatmaps, h * w, w, beta, scale, preds);
+    LH_LAUNCH_CHECK("heatmap_soft_argmax launch");
+    return LH_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ validation metrics
 // PCK_2d_loss(T, 'proportion') + EPE_train on the device (src/utils/loss.py:50-67,116-148): one wave per
 // sample.  wrong[b] = #joints whose error / bbox-diagonal(gt) > T; epe[b] = sum of errors of joints 1..J-2 (the

@@ -120,6 +120,19 @@ def max_preds_device(heatmaps, scale=1.0, post_process=False):
     return preds, maxvals, idx
 
 
+def soft_argmax_device(heatmaps, beta=100.0, scale=1.0):
+    """Opt-in differentiable-style decode (an extension: the reference only has the hard arg-max): heatmaps float32
+    [B, J, H, W] on the device -> expected (x, y) under softmax(beta * heatmap), [B, J, 2] device tensor."""
+    if heatmaps.dim() != 4:
+        raise AssertionError("batch_images should be 4-ndim")
+    hm = heatmaps.to(torch.float32).contiguous()
+    b, j, h, w = hm.shape
+    preds = torch.empty(b, j, 2, dtype=torch.float32, device=hm.device)
+    check(_lib.load().lh_heatmap_soft_argmax(hm.data_ptr(), b * j, h, w, float(beta), float(scale), preds.data_ptr(), _stream()),
+          "lh_heatmap_soft_argmax")
+    return preds
+
+
 def get_max_preds(batch_heatmaps, post_process=False):
     """Reference signature (src/utils/loss.py:327-355): numpy [B, J, H, W] -> (preds float32
     [B, J, 2], maxvals [B, J, 1]) numpy arrays; device tensors are accepted too and then

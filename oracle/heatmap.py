@@ -145,3 +145,15 @@ def refine_quarter_pixel(heatmaps, preds, maxvals):
                 out[bi, ji] += np.sign(diff).astype(np.float32) * np.float32(0.25)
     return out
 
+
+def soft_argmax(heatmaps, beta=100.0):
+    """Opt-in extension named in the project brief, NOT in the reference: expected pixel coordinate under
+    softmax(beta * heatmap) per (sample, joint), float64."""
+    b, j, h, w = heatmaps.shape
+    z = beta * heatmaps.reshape(b, j, -1).astype(np.float64)
+    z -= z.max(-1, keepdims=True)
+    p = np.exp(z)
+    p /= p.sum(-1, keepdims=True)
+    idx = np.arange(h * w)
+    return np.stack([(p * (idx % w)).sum(-1), (p * (idx // w)).sum(-1)], -1)
+

@@ -371,6 +371,23 @@ def test_quarter_pixel_refinement_opt_in(golden_dir):
     assert moved > 50
 
 
+def test_soft_argmax_opt_in():
+    """Soft-arg-max decode (named in the brief, absent from the reference: extension without a reference oracle) against
+    its float64 numpy restatement; on sharp single peaks it coincides with the hard arg-max."""
+    from lighthand_amd.heatmap import get_max_preds, render_targets, soft_argmax_device
+    from oracle.heatmap import soft_argmax
+    rng = np.random.RandomState(2)
+    hm = rng.randn(3, 21, 48, 64).astype(np.float32)
+    for beta in (1.0, 25.0):
+        got = soft_argmax_device(torch.from_numpy(hm).cuda(), beta=beta, scale=4.0).cpu().numpy()
+        assert np.allclose(got, soft_argmax(hm, beta) * 4, rtol=1e-5, atol=1e-4)
+    joints = torch.from_numpy(rng.uniform(40, 216, size=(2, 21, 2)).astype(np.float32)).cuda()
+    peaks = render_targets(joints)
+    hard, _ = get_max_preds(peaks)
+    soft = soft_argmax_device(peaks, beta=200.0)
+    assert float((soft - hard).abs().max()) < 0.51
+
+
 def test_adam_matches_torch():
     from lighthand_amd.optim import Adam
     torch.manual_seed(7)
