@@ -346,9 +346,13 @@ class Plan:
         dx = self._act_grad(x)
         n_before = self._nwrites.get(id(x), 0)
         first = self._first_write(x)
+
         tap = x.bn_tap
         if tap is not None and n_before != self._n_uses.get(id(x), 1) - 1:
             tap = None                            # a later launch still adds to this gradient
+        if tap is None and not first and len(descs) > 1:      # accumulating: a phase without taps would add zeros -- drop
+            keep = [i for i, dd in enumerate(descs) if dd.ntaps > 0]       # it (a BN tap must visit every pixel, though)
+            descs, packs = [descs[i] for i in keep], [packs[i] for i in keep]
         if tap is None and self._phase_rows(descs) > 0:
             self._igemm_phases(self.bwd, descs, dy, packs, dx, None if first else dx, None, None, what)
             yield max(descs, key=lambda d: d.ntaps), sum(d.ntaps for d in descs)

@@ -47,7 +47,10 @@ class ResidualUnit(nn.Module):
         self.downsample = downsample
 
     def describe(self, gb, prefix, x):
-        """Emit this unit's nodes; returns the output activation."""
+        """Emit this unit's nodes; returns the output activation.  The projection shortcut is described FIRST: in the
+        reversed (backward) order its data gradient then comes after conv1's, which is dense, so conv1 stores the block
+        input's gradient outright and the shortcut's stride-2 gradient only adds its one non-zero sub-pixel phase."""
+        r = gb.conv(x, prefix + ".downsample.0", 1, self.stride, 0) if self.downsample is not None else None
         if self.kind == "basic":
             y = gb.conv(x, prefix + ".conv1", 3, self.stride, 1)
             a = gb.fuse([(y, prefix + ".bn1")])
@@ -62,7 +65,6 @@ class ResidualUnit(nn.Module):
             y = gb.conv(a, prefix + ".conv3", 1, 1, 0)
             last = prefix + ".bn3"
         if self.downsample is not None:
-            r = gb.conv(x, prefix + ".downsample.0", 1, self.stride, 0)
             return gb.fuse([(y, last), (r, prefix + ".downsample.1")])
         return gb.fuse([(y, last), x])
 
