@@ -169,6 +169,13 @@ int lh_igemm_bntap(const lh_igemm_desc* d, const void* in, const void* wpack, vo
  * instantiation a launch uses -- igemm_ring_kernel<T, bm, bp, .., depth, kbytes> when *ring != 0 (LDS-DMA ring
  * path, 16-byte aligned pixel rows; *ring = kbytes*10 + depth) else igemm_kernel<T, bm, bp, ..>. */
 int lh_igemm_tile(const lh_igemm_desc* d, int dtype, int* bm, int* bp, int* ring);
+/* Weight gradient of a convolution whose kernel rows are separate "row taps" (the C_in = 3 stem on NHWC4: a kernel row =
+ * one contiguous run of k pixels x 4 channels, pose_resnet.py:152) with ALL rows in one pass: d describes ONE tap (the
+ * first kernel row) and has k_run = rows * run; gradient input index i = row * run + k is read at input row ih + row,
+ * element k of the run.  dy is read once per input tile instead of once per kernel row.  Slab / fold as for lh_wgrad with
+ * the same descriptor (ntaps = 1, n_in = d->k_run).  LDS-DMA kernel only (16-bit types, 16-byte aligned runs). */
+int lh_wgrad_rowfold(const lh_igemm_desc* d, int rows, const void* x, const void* dy, int dy_pix_stride,
+                     int n_out, float* slab, int dtype, void* stream);
 int lh_wgrad_tile(const lh_igemm_desc* d, int n_out, int n_in, int dtype, int* bo, int* bi, int* nsplit, int* ring);
 /* rows of the stats slab lh_igemm writes for this descriptor (= number of pixel tiles) */
 int lh_igemm_stats_rows(const lh_igemm_desc* d, int dtype);

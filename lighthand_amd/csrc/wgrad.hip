@@ -23,6 +23,7 @@ struct WgradArgs {
     int dy_pix_stride, n_out, n_in;
     int ntaps, nsplit, steps_per_split, i_tiles;
     int tiles, xcd;              // ring kernel: 1-D grid of tiles * ntaps * nsplit work items, XCD-aware order
+    int fold_k;                  // ring kernel, row fold (lh_wgrad_rowfold): input index i = row * fold_k + k, 0 = off
     signed char dh[64];
     signed char dw[64];
 };
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(64 * WO * WI) void wgrad_ring_kernel(const WgradArg
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
 
     // per-lane source bookkeeping: instruction q = 4*j + wave covers rows [q*RP, (q+1)*RP)
-    int orow[NO], ocol[NO], irow[NI], icol[NI];
+    int orow[NO], ocol[NO], irow[NI], icol[NI], idh[NI], ick[NI];
 #pragma unroll
     for (int j = 0; j < NO; ++j) {
         const int q = NWAVE * j + wave;
@@ -241,6 +242,10 @@ __global__ __launch_bounds__(64 * WO * WI) void wgrad_ring_kernel(const WgradArg
         const int r = q * RPI + lane / (RBI / 16), c16 = lane % (RBI / 16);
         irow[j] = r;
         icol[j] = itile * BI + ((((c16 >> 1) ^ wswz<RBI>(r)) << 1) | (c16 & 1)) * 8;
+        // row fold: the gradient's input index covers `rows` kernel rows of fold_k contiguous elements each; this lane's
+        // chunk belongs to kernel row icol / fold_k (an extra input-row offset) and element icol % fold_k of the run
+        idh[j] = p.fold_k ? icol[j] / p.fold_k : 0;
+        ick[j] = p.fold_k ? icol[j] % p.fold_k : icol[j];
     }
 
     auto issue = [&](int s, int slot) {
@@ -260,10 +265,10 @@ __global__ __launch_bounds__(64 * WO * WI) void wgrad_ring_kernel(const WgradArg
             const int mi = m < m_end ? (int)m : 0;
             const int n = mi / hw, rem = mi - n * hw;
             const int a = rem / p.wo, b = rem - a * p.wo;
-            const int ih = a * p.sh + dh, iw = b * p.sw + dw;
+            const int ih = a * p.sh + dh + idh[j], iw = b * p.sw + dw;
             const bool ok = (int)(m < m_end) & (int)(icol[j] < p.k_run) & (int)((unsigned)ih < (unsigned)p.hi) &
                             (int)((unsigned)iw < (unsigned)p.wi);
-            const unsigned char* src = p.x + (((long)(n * p.hi + ih) * p.wi + iw) * p.in_pix_stride + icol[j]) * 2;
+            const unsigned char* src = p.x + (((long)(n * p.hi + ih) * p.wi + iw) * p.in_pix_stride + ick[j]) * 2;
             src = ok ? src : zero;
             if (!(LH_ABL & 4)) __builtin_amdgcn_global_load_lds((gbl_p)src, (lds_p)(st + KP * RBO + (NWAVE * j + wave) * 1024), 16, 0, 0);
         }
@@ -521,8 +526,8 @@ static int launch_wgrad(const WgradArgs& a, hipStream_t s) {
     return LH_OK;
 }
 
-extern "C" int lh_wgrad(const lh_igemm_desc* d, const void* x, const void* dy, int dy_pix_stride,
-                        int n_out, int n_in, float* slab, int dtype, void* stream) {
+static int wgrad_impl(const lh_igemm_desc* d, const void* x, const void* dy, int dy_pix_stride,
+                      int n_out, int n_in, float* slab, int dtype, void* stream, int fold_rows) {
     LH_REQUIRE(d && x && dy && slab, "lh_wgrad: null pointer");
     const int es = lh_dtype_size(dtype);
     LH_REQUIRE(es > 0, "lh_wgrad: bad dtype %d", dtype);
@@ -536,12 +541,18 @@ extern "C" int lh_wgrad(const lh_igemm_desc* d, const void* x, const void* dy, i
     a.ho = d->ho; a.wo = d->wo; a.M = d->n * d->ho * d->wo; a.sh = d->sh; a.sw = d->sw;
     a.dy_pix_stride = dy_pix_stride; a.n_out = n_out; a.n_in = n_in; a.ntaps = d->ntaps;
     for (int i = 0; i < 64; ++i) { a.dh[i] = d->dh[i]; a.dw[i] = d->dw[i]; }
+    a.fold_k = 0;
     int bo, bi;
     wgrad_plan(d, n_out, n_in, dtype, &bo, &bi, &a.nsplit, &a.steps_per_split);
     a.i_tiles = ceil_div(n_in, bi);
     hipStream_t s = (hipStream_t)stream;
     // 16-bit types with 16-byte aligned pixel rows take the LDS-DMA ring kernel
     const bool ring = wgrad_ring_ok(d, es);
+    if (fold_rows > 1) {
+        LH_REQUIRE(ring && d->ntaps == 1 && n_in % fold_rows == 0 && (n_in / fold_rows) % epc == 0,
+                   "lh_wgrad_rowfold: needs the LDS-DMA kernel, one tap and a run of whole 16-byte chunks per row");
+        a.fold_k = n_in / fold_rows;
+    }
 #define LH_WR(T)                                                                  \
     if (bo == 256 && bi == 256) return launch_wgrad_ring<T, 256, 256, 2, 4>(a, s); \
     if (bo == 128 && bi == 128) return launch_wgrad_ring<T, 128, 128, 2, 2>(a, s); \
@@ -564,6 +575,17 @@ extern "C" int lh_wgrad(const lh_igemm_desc* d, const void* x, const void* dy, i
 #undef LH_WT
     lh_set_error("lh_wgrad: unsupported dtype %d", dtype);
     return LH_ERR_ARG;
+}
+
+extern "C" int lh_wgrad(const lh_igemm_desc* d, const void* x, const void* dy, int dy_pix_stride,
+                        int n_out, int n_in, float* slab, int dtype, void* stream) {
+    return wgrad_impl(d, x, dy, dy_pix_stride, n_out, n_in, slab, dtype, stream, 0);
+}
+
+extern "C" int lh_wgrad_rowfold(const lh_igemm_desc* d, int rows, const void* x, const void* dy, int dy_pix_stride,
+                                int n_out, float* slab, int dtype, void* stream) {
+    LH_REQUIRE(d && rows >= 1, "lh_wgrad_rowfold: bad arguments");
+    return wgrad_impl(d, x, dy, dy_pix_stride, n_out, d->k_run, slab, dtype, stream, rows);
 }
 
 extern "C" int lh_wgrad_reduce(const lh_igemm_desc* d, const float* slab, float* grad, int n_out,

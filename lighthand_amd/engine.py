@@ -739,18 +739,31 @@ class Plan:
         self.profile_meta.append(("fwd", self.fwd[-1], self._kname(d), flops, (x.pixels * 4 + y.pixels * y.c) * self.es))
         if not self.with_bwd:
             return
-        slab_bytes = self.lib.lh_wgrad_slab_bytes(C.byref(d), y.c, kr, self.dt)
+        # 16-bit runs: all k kernel rows in ONE pass (lh_wgrad_rowfold: dy is read once per input tile, not once per row);
+        # the gradient index row*kr + j is gstage's [cout][k][kr] layout, so the fold is a plain sum over the splits
+        bo, bi, ns, ring = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+        self.lib.lh_wgrad_tile(C.byref(d), y.c, kr, self.dt, C.byref(bo), C.byref(bi), C.byref(ns), C.byref(ring))
+        fold = bool(ring.value) and not os.environ.get("LH_NO_ROWFOLD")
+        dw = _desc(x.n, hp, wp, 4, k * kr, y.h, y.w, s, s, y.c, y.h, y.w, 1, 1, 0, 0, y.c, [(0, 0)]) if fold else d
+        self.keep.append(dw)
+        n_in_w = k * kr if fold else kr
+        slab_bytes = self.lib.lh_wgrad_slab_bytes(C.byref(dw), y.c, n_in_w, self.dt)
         self._ws_wgrad = max(self._ws_wgrad, slab_bytes)
-        rs_arr = _taps_array(rows)
+        rs_arr = _taps_array([(0, 0)] if fold else rows)
         gstage = self._alloc(cout, k, kr // 4, 4, dtype=torch.float32)
         gw = self.grads[nd["w"] + ".weight"]
 
         def emit():
             dy = self._act_grad(y)
-            a = [C.byref(d), img.data_ptr(), dy.data_ptr(), y.c, y.c, kr, 0, self.dt]
-            b = [C.byref(d), 0, gstage.data_ptr(), cout, kr, k * kr, 1, kr, 0, rs_arr, 0, self.dt]
+            if fold:
+                a = [C.byref(dw), k, img.data_ptr(), dy.data_ptr(), y.c, y.c, 0, self.dt]
+                b = [C.byref(dw), 0, gstage.data_ptr(), cout, k * kr, k * kr, 1, 0, 0, rs_arr, 0, self.dt]
+            else:
+                a = [C.byref(d), img.data_ptr(), dy.data_ptr(), y.c, y.c, kr, 0, self.dt]
+                b = [C.byref(d), 0, gstage.data_ptr(), cout, kr, k * kr, 1, kr, 0, rs_arr, 0, self.dt]
             tail = 2 if self.own_slabs else 1
-            cw, cr = _Call(self.lib.lh_wgrad, None, "stem wgrad", lane=1), _Call(self.lib.lh_wgrad_reduce, None, "stem wgrad reduce", keep=rs_arr, lane=tail)
+            cw = _Call(self.lib.lh_wgrad_rowfold if fold else self.lib.lh_wgrad, None, "stem wgrad", lane=1)
+            cr = _Call(self.lib.lh_wgrad_reduce, None, "stem wgrad reduce", keep=rs_arr, lane=tail)
 
             def set_ws(ptr):
                 a[6] = ptr
@@ -759,7 +772,7 @@ class Plan:
             self._ws_note(set_ws, slab_bytes)
             wl = self._wl()
             wl.append(cw)
-            self.profile_meta.append(("bwd", wl[-1], self._kname(d, (y.c, kr)), flops, (x.pixels * 4 + y.pixels * y.c) * self.es))
+            self.profile_meta.append(("bwd", wl[-1], self._kname(dw, (y.c, n_in_w)), flops, (x.pixels * 4 + y.pixels * y.c) * self.es))
             wl.append(cr)
             wl.append(_TorchCall(lambda: gw.copy_(gstage[:, :, :k, :3].permute(0, 3, 1, 2)), "stem grad unstage", lane=tail))
         blk.append(emit)
