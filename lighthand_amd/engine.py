@@ -228,7 +228,11 @@ class Plan:
         # single-lane network: LH_WGRAD_GROUP layers per group; a branch lane of HRNet: its chain inside one module).
         # 0 = in place.  Groups alternate over LH_WGRAD_STREAMS side streams, each with its own split-K slab.
         self.own_slabs = bool(os.environ.get("LH_OWN_WGRAD_SLABS"))
-        self.wgrad_group = int(os.environ.get("LH_WGRAD_GROUP", "16")) if (self.with_bwd and not self.own_slabs) else 0
+        n_convs = sum(1 for k, _ in self.nodes if k in ("conv", "deconv"))
+        auto_group = max(4, -(-n_convs * 42 // 100))         # ~2.4 groups per backward pass: 24 layers for R50 (measured best)
+        if self.n_lanes > 1:
+            auto_group = 16                                   # branch lanes hand over at every module end; 16 on the main lane
+        self.wgrad_group = int(os.environ.get("LH_WGRAD_GROUP", str(auto_group))) if (self.with_bwd and not self.own_slabs) else 0
         if self.n_lanes > 1 and os.environ.get("LH_NO_WGRAD_DEFER_LANES"):
             self.wgrad_group = 0
         if self.wgrad_group > 0 and not os.environ.get("LH_NO_LANES"):
