@@ -128,6 +128,12 @@ typedef struct {
     int relu;                 /* apply max(.,0) before the store                     */
     signed char dh[64];
     signed char dw[64];
+    /* Kernel configuration chosen by the caller (all zero = the library's static default).  cfg[0..4] = convolution
+     * kernel: tile output channels, tile pixels, ring depth, K bytes per ring stage, reserved (0)
+     * -- one of lh_igemm_candidates().  cfg[5..7] = weight-gradient kernel (lh_wgrad*): tile output channels, tile
+     * input channels, pixel splits -- one of lh_wgrad_candidates().  Results do not depend on cfg[0..4]; the
+     * weight gradient's fp32 summation order depends on the split count (deterministic for a given cfg). */
+    int cfg[8];
 } lh_igemm_desc;
 
 /* out[pixel][co] = relu?( (sum_taps sum_k in[pix(tap)][k] * wpack[co][tap][k] + bias[co]) * scale[co] + shift[co]
@@ -147,28 +153,16 @@ int lh_igemm_phases_rows(const lh_igemm_desc* const* descs, int nphase, int dtyp
 int lh_igemm_phases(const lh_igemm_desc* const* descs, int nphase, const void* in, const void* const* wpacks,
                     void* out, const void* addend, const float* bias, const float* scale, const float* shift,
                     float* stats, int dtype, void* stream);
-/* Data gradient with the BatchNorm-backward reduction of the node that PRODUCED the differentiated activation fused
- * into its epilogue (loss.backward() through conv -> relu -> BN, e.g. pose_resnet.py:83-97 walked in reverse).
- * `out` receives the data gradient dA (+ addend: the launch must then be the LAST writer of dA, so that the stored
- * value is final); `partial` receives lh_igemm_stats_rows(d) rows [2][cout] of
- *   (sum g, sum g * (x - mean) * invstd),  g = dA masked by the activation's ReLU,
- * i.e. the per-strip sums lh_fuse_bwd's reduce pass would produce, so that pass (one read of dA, x and the mask) is
- * skipped via lh_fuse_bwd_desc.ext_partial.  The mask is (x*scale + shift > 0) for a = relu(BN(x)), or the relu_mask
- * bits lh_fuse_fwd stored for a = relu(BN(x) + other terms).  x has out's layout (same pixel stride and placement). */
-typedef struct lh_bn_tap {
-    const void* x;
-    const float* scale;        /* may be NULL when relu_mask is given */
-    const float* shift;
-    const float* mean;
-    const float* invstd;
-    const void* relu_mask;     /* optional: one byte per 16-byte chunk of the (dense) activation */
-} lh_bn_tap;
-int lh_igemm_bntap(const lh_igemm_desc* d, const void* in, const void* wpack, void* out, const void* addend,
-                   const lh_bn_tap* tap, float* partial, int dtype, void* stream);
 /* tile (output channels x pixels) the dispatcher picks for this descriptor: names the kernel
  * instantiation a launch uses -- igemm_ring_kernel<T, bm, bp, .., depth, kbytes> when *ring != 0 (LDS-DMA ring
  * path, 16-byte aligned pixel rows; *ring = kbytes*10 + depth) else igemm_kernel<T, bm, bp, ..>. */
 int lh_igemm_tile(const lh_igemm_desc* d, int dtype, int* bm, int* bp, int* ring);
+/* The configuration a launch of this descriptor runs with (cfg5 = tile channels, tile pixels, ring depth, K bytes per
+ * stage, 0; depth 0 = the register-staged kernel), and the configurations compiled in that fit it
+ * (5 ints each, returns the count; 0 when the form only runs on the register-staged kernel): the plan times them on
+ * the real buffers and writes the winner into lh_igemm_desc.cfg (lighthand_amd/engine.py, Plan._tune). */
+int lh_igemm_config(const lh_igemm_desc* d, int dtype, int* cfg5);
+int lh_igemm_candidates(const lh_igemm_desc* d, int dtype, int* cfgs, int max);
 /* Weight gradient of a convolution whose kernel rows are separate "row taps" (the C_in = 3 stem on NHWC4: a kernel row =
  * one contiguous run of k pixels x 4 channels, pose_resnet.py:152) with ALL rows in one pass: d describes ONE tap (the
  * first kernel row) and has k_run = rows * run; gradient input index i = row * run + k is read at input row ih + row,
@@ -177,6 +171,11 @@ int lh_igemm_tile(const lh_igemm_desc* d, int dtype, int* bm, int* bp, int* ring
 int lh_wgrad_rowfold(const lh_igemm_desc* d, int rows, const void* x, const void* dy, int dy_pix_stride,
                      int n_out, float* slab, int dtype, void* stream);
 int lh_wgrad_tile(const lh_igemm_desc* d, int n_out, int n_in, int dtype, int* bo, int* bi, int* nsplit, int* ring);
+/* Launch plans of the LDS-DMA weight-gradient kernel that fit this descriptor: 5 ints each = { tile output channels,
+ * tile input channels, cfg[7] encoding (splits | stage rows << 16 | ring depth << 24), workgroups, slab MiB }.  Writing
+ * the first three into lh_igemm_desc.cfg[5..7] selects the plan for lh_wgrad / lh_wgrad_slab_bytes / lh_wgrad_reduce
+ * (0 when only the register-staged kernel applies: fp32, unaligned pixel rows). */
+int lh_wgrad_candidates(const lh_igemm_desc* d, int n_out, int n_in, int dtype, int* out, int max);
 /* rows of the stats slab lh_igemm writes for this descriptor (= number of pixel tiles) */
 int lh_igemm_stats_rows(const lh_igemm_desc* d, int dtype);
 
@@ -249,8 +248,6 @@ typedef struct {
     int nterms;
     int relu;
     const void* relu_mask;      /* mask bits written by lh_fuse_fwd; when set, `out` is not read and may be NULL */
-    const float* ext_partial[4];   /* reduce sums already produced by lh_igemm_bntap (rows x [2][c]); NULL = run the reduce pass */
-    int ext_rows[4];
 } lh_fuse_bwd_desc;
 size_t lh_fuse_bwd_workspace_bytes(int n, int h, int w, int c);
 int lh_fuse_bwd(const lh_fuse_bwd_desc* d, int n, int h, int w, int c, void* workspace,

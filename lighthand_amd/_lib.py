@@ -21,7 +21,7 @@ class IgemmDesc(C.Structure):
                 ("k_run", C.c_int), ("ho", C.c_int), ("wo", C.c_int), ("sh", C.c_int), ("sw", C.c_int),
                 ("cout", C.c_int), ("OH", C.c_int), ("OW", C.c_int), ("osh", C.c_int), ("osw", C.c_int),
                 ("ooh", C.c_int), ("oow", C.c_int), ("out_pix_stride", C.c_int), ("ntaps", C.c_int),
-                ("relu", C.c_int), ("dh", C.c_byte * 64), ("dw", C.c_byte * 64)]
+                ("relu", C.c_int), ("dh", C.c_byte * 64), ("dw", C.c_byte * 64), ("cfg", C.c_int * 8)]
 
 
 class FuseDesc(C.Structure):
@@ -34,11 +34,6 @@ class FuseBwdDesc(C.Structure):
                 ("shift", C.c_void_p * 4), ("save_mean", C.c_void_p * 4), ("save_invstd", C.c_void_p * 4), ("dx", C.c_void_p * 4),
                 ("dgamma", C.c_void_p * 4), ("dbeta", C.c_void_p * 4), ("log2up", C.c_int * 4),
                 ("accumulate", C.c_int * 4), ("nterms", C.c_int), ("relu", C.c_int),
-                ("relu_mask", C.c_void_p), ("ext_partial", C.c_void_p * 4), ("ext_rows", C.c_int * 4)]
-
-
-class BnTap(C.Structure):
-    _fields_ = [("x", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p),
                 ("relu_mask", C.c_void_p)]
 
 
@@ -76,9 +71,11 @@ SIGNATURES = {
     "lh_igemm": (_I, [C.POINTER(IgemmDesc), _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "lh_igemm_phases_rows": (_I, [C.POINTER(C.POINTER(IgemmDesc)), _I, _I]),
     "lh_igemm_phases": (_I, [C.POINTER(C.POINTER(IgemmDesc)), _I, _P, C.POINTER(C.c_void_p), _P, _P, _P, _P, _P, _P, _I, _P]),
-    "lh_igemm_bntap": (_I, [C.POINTER(IgemmDesc), _P, _P, _P, _P, C.POINTER(BnTap), _P, _I, _P]),
     "lh_igemm_tile": (_I, [C.POINTER(IgemmDesc), _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
+    "lh_igemm_config": (_I, [C.POINTER(IgemmDesc), _I, C.POINTER(_I)]),
+    "lh_igemm_candidates": (_I, [C.POINTER(IgemmDesc), _I, C.POINTER(_I), _I]),
     "lh_wgrad_tile": (_I, [C.POINTER(IgemmDesc), _I, _I, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
+    "lh_wgrad_candidates": (_I, [C.POINTER(IgemmDesc), _I, _I, _I, C.POINTER(_I), _I]),
     "lh_igemm_stats_rows": (_I, [C.POINTER(IgemmDesc), _I]),
     "lh_wgrad_slab_bytes": (_SZ, [C.POINTER(IgemmDesc), _I, _I, _I]),
     "lh_wgrad": (_I, [C.POINTER(IgemmDesc), _P, _P, _I, _I, _I, _P, _I, _P]),

@@ -764,17 +764,11 @@ extern "C" int lh_fuse_bwd(const lh_fuse_bwd_desc* d, int n, int h, int w, int c
             LH_REQUIRE(workspace && a.scale && a.mean && a.invstd, "lh_fuse_bwd: BN term %d lacks workspace/statistics", t);
             long strips = fuse_bwd_strips(a.count, &a.rows_per_strip);
             a.partial = (float*)workspace;
-            const bool ext = d->ext_partial[t] != nullptr;
-            LH_REQUIRE(!ext || (flat && d->relu && d->ext_rows[t] > 0 && (a.mask_from_x || d->relu_mask)),
-                       "lh_fuse_bwd: ext_partial needs a flat BN term under ReLU (mask from x or from relu_mask bits)");
             const long slab_floats = strips * 2 * c;
             double* scratch = (double*)((float*)workspace + ((slab_floats + 3) & ~3L));
             double* totals = scratch + (long)ceil_div(strips, 256) * 2 * c;
             a.totals = totals;
-            if (ext) {               // the producing data-gradient kernel already reduced its tiles
-                a.partial = const_cast<float*>(d->ext_partial[t]);
-                strips = d->ext_rows[t];
-            } else if (flat && a.mask_from_x) {
+            if (flat && a.mask_from_x) {
                 LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((fuse_bwd_reduce_flat_kernel<T, true>), dim3((int)strips), dim3(256), 0, s, a));
             } else if (flat) {
                 LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((fuse_bwd_reduce_flat_kernel<T, false>), dim3((int)strips), dim3(256), 0, s, a));

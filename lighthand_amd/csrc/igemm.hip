@@ -195,15 +195,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
     float s1[EPC], s2[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) s1[e] = s2[e] = 0.f;
-    float tsc[EPC], tsh[EPC], tmn[EPC], tiv[EPC];
-    const bool use_bits = p.tap_bits != nullptr;
-    if (p.tap_x && col_ok) {
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) {
-            tsc[e] = p.tap_bits ? 0.f : p.tap_scale[col0 + e]; tsh[e] = p.tap_bits ? 0.f : p.tap_shift[col0 + e];
-            tmn[e] = p.tap_mean[col0 + e]; tiv[e] = p.tap_invstd[col0 + e];
-        }
-    }
 
     for (int pr = r0; pr < BP; pr += RPP) {
         const int m = pblk * BP + pr;
@@ -235,21 +226,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
         if (p.stats) {
             float sv[EPC];
             unpack16<T>(u, sv);
-            if (p.tap_x) {
-                float xv[EPC];
-                unpack16<T>(*reinterpret_cast<const uint4*>(p.tap_x + eoff * ES), xv);
-                const unsigned mbits = use_bits ? p.tap_bits[eoff / EPC] : 0u;
 #pragma unroll
-                for (int e = 0; e < EPC; ++e) {
-                    const bool on = use_bits ? ((mbits >> e) & 1u) != 0 : (xv[e] * tsc[e] + tsh[e]) > 0.f;
-                    const float g = on ? sv[e] : 0.f;
-                    s1[e] += g;
-                    s2[e] += g * (xv[e] - tmn[e]) * tiv[e];
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < EPC; ++e) { s1[e] += sv[e]; s2[e] += sv[e] * sv[e]; }
-            }
+            for (int e = 0; e < EPC; ++e) { s1[e] += sv[e]; s2[e] += sv[e] * sv[e]; }
         }
         *reinterpret_cast<uint4*>(p.out + eoff * ES) = u;
     }
@@ -291,7 +269,9 @@ static int launch_tile(const IgemmArgs& a, hipStream_t s) {
 
 static void pick_tile(const lh_igemm_desc* d, int dtype, int* bm, int* bp) {
     if (lh_ring_supported(d, dtype)) {
-        lh_ring_pick_tile(d, dtype, bm, bp);
+        RingCfg c;
+        if (lh_ring_resolve(d, dtype, &c) != LH_OK) lh_ring_default_cfg(d, dtype, &c);
+        *bm = c.bm; *bp = c.bp;
         return;
     }
     const long M = (long)d->n * d->ho * d->wo;
@@ -306,16 +286,31 @@ static void pick_tile(const lh_igemm_desc* d, int dtype, int* bm, int* bp) {
 
 extern "C" int lh_igemm_tile(const lh_igemm_desc* d, int dtype, int* bm, int* bp, int* ring) {
     LH_REQUIRE(d && bm && bp && ring, "lh_igemm_tile: null pointer");
-    pick_tile(d, dtype, bm, bp);
-    *ring = 0;
-    if (lh_ring_supported(d, dtype)) {          // encodes K bytes per stage and ring depth: kb * 10 + depth
-        const int es = lh_dtype_size(dtype), kb = lh_ring_kb();
-        const int steps = d->ntaps * ((d->k_run * es + kb - 1) / kb);
-        const char* e2 = getenv("LH_RING_T2"); const char* e3 = getenv("LH_RING_T3");
-        const int t2 = e2 ? atoi(e2) : 4, t3 = e3 ? atoi(e3) : 0;
-        *ring = kb * 10 + (kb != 64 ? 4 : steps <= t2 ? 2 : steps <= t3 ? 3 : 4);
-    }
+    int cfg[5];
+    const int rc = lh_igemm_config(d, dtype, cfg);
+    if (rc) return rc;
+    *bm = cfg[0]; *bp = cfg[1];
+    *ring = cfg[2] ? cfg[3] * 10 + cfg[2] : 0;          // K bytes per stage * 10 + ring depth; 0 = register-staged kernel
     return LH_OK;
+}
+
+extern "C" int lh_igemm_config(const lh_igemm_desc* d, int dtype, int* cfg5) {
+    LH_REQUIRE(d && cfg5, "lh_igemm_config: null pointer");
+    if (lh_ring_supported(d, dtype)) {
+        RingCfg c;
+        const int rc = lh_ring_resolve(d, dtype, &c);
+        if (rc) return rc;
+        cfg5[0] = c.bm; cfg5[1] = c.bp; cfg5[2] = c.depth; cfg5[3] = c.kb; cfg5[4] = 0;
+        return LH_OK;
+    }
+    pick_tile(d, dtype, &cfg5[0], &cfg5[1]);
+    cfg5[2] = cfg5[3] = cfg5[4] = 0;
+    return LH_OK;
+}
+
+extern "C" int lh_igemm_candidates(const lh_igemm_desc* d, int dtype, int* cfgs, int max) {
+    if (!d || !cfgs || max <= 0 || !lh_ring_supported(d, dtype)) return 0;
+    return lh_ring_candidates(d, dtype, cfgs, max);
 }
 
 extern "C" int lh_igemm_stats_rows(const lh_igemm_desc* d, int dtype) {
@@ -333,7 +328,7 @@ struct PhaseSet {                 // lh_igemm_phases: the other descriptors / pa
 
 static int igemm_impl(const lh_igemm_desc* d, const void* in, const void* wpack, void* out,
                       const void* addend, const float* bias, const float* scale, const float* shift, float* stats,
-                      const lh_bn_tap* tap, int dtype, void* stream, const PhaseSet* phases = nullptr) {
+                      int dtype, void* stream, const PhaseSet* phases = nullptr) {
     LH_REQUIRE(d && in && wpack && out, "lh_igemm: null pointer");
     const int es = lh_dtype_size(dtype);
     LH_REQUIRE(es > 0, "lh_igemm: bad dtype %d", dtype);
@@ -348,16 +343,8 @@ static int igemm_impl(const lh_igemm_desc* d, const void* in, const void* wpack,
                "lh_igemm: output placement exceeds the %dx%d image", d->OH, d->OW);
     IgemmArgs a;
     a.in = (const unsigned char*)in; a.w = (const unsigned char*)wpack; a.out = (unsigned char*)out;
-    a.addend = (const unsigned char*)addend; a.bias = bias; a.stats = stats;
+    a.addend = (const unsigned char*)addend; a.bias = bias; a.stats = stats; a.zero = nullptr;
     a.scale = scale; a.shift = shift;
-    a.tap_x = nullptr; a.tap_scale = a.tap_shift = a.tap_mean = a.tap_invstd = nullptr; a.tap_bits = nullptr;
-    if (tap) {
-        LH_REQUIRE(tap->x && tap->mean && tap->invstd && stats && (tap->relu_mask || (tap->scale && tap->shift)),
-                   "lh_igemm_bntap: incomplete tap");
-        LH_REQUIRE(!tap->relu_mask || d->out_pix_stride == d->cout, "lh_igemm_bntap: mask bits need a dense output");
-        a.tap_x = (const unsigned char*)tap->x; a.tap_scale = tap->scale; a.tap_shift = tap->shift;
-        a.tap_mean = tap->mean; a.tap_invstd = tap->invstd; a.tap_bits = (const unsigned char*)tap->relu_mask;
-    }
     LH_REQUIRE((scale == nullptr) == (shift == nullptr), "lh_igemm: scale and shift must come together");
     a.n = d->n; a.hi = d->hi; a.wi = d->wi; a.in_pix_stride = d->in_pix_stride; a.k_run = d->k_run;
     a.kspt = (d->k_run * es + 63) / 64;
@@ -367,15 +354,21 @@ static int igemm_impl(const lh_igemm_desc* d, const void* in, const void* wpack,
     a.out_pix_stride = d->out_pix_stride; a.ntaps = d->ntaps; a.relu = d->relu;
     for (int i = 0; i < 64; ++i) { a.dh[i] = d->dh[i]; a.dw[i] = d->dw[i]; }
     int bm, bp;
-    pick_tile(d, dtype, &bm, &bp);
+    RingCfg rc_;
+    const bool ring = lh_ring_supported(d, dtype);
+    if (ring) {
+        const int rc = lh_ring_resolve(d, dtype, &rc_);
+        if (rc) return rc;
+        bm = rc_.bm; bp = rc_.bp;
+    } else {
+        pick_tile(d, dtype, &bm, &bp);
+    }
     hipStream_t s = (hipStream_t)stream;
     a.tw = 1; a.dh0 = a.dhs = a.dw0 = a.dws = 0;
-    static int xcd = -1;
-    if (xcd < 0) xcd = getenv("LH_NO_XCD") ? 0 : 1;
-    a.xcd = xcd;
+    a.xcd = 1;
     a.nphase = 1; a.phase_blocks = 0;
     if (phases) {
-        LH_REQUIRE(lh_ring_supported(d, dtype), "lh_igemm_phases: the form is not supported by the LDS-DMA kernel");
+        LH_REQUIRE(ring, "lh_igemm_phases: the form is not supported by the LDS-DMA kernel");
         a.nphase = phases->n;
         a.phase_blocks = ceil_div(a.M, bp) * ceil_div(a.cout, bm);
         for (int i = 0; i < phases->n; ++i) {
@@ -389,10 +382,10 @@ static int igemm_impl(const lh_igemm_desc* d, const void* in, const void* wpack,
             a.ph_row0[i] = i * ceil_div(a.M, bp);
         }
     }
-    if (lh_ring_supported(d, dtype)) {
+    if (ring) {
         lh_tap_grid(d, &a.tw, &a.dh0, &a.dhs, &a.dw0, &a.dws);
-        a.kspt = (d->k_run * es + lh_ring_kb() - 1) / lh_ring_kb();
-        return lh_igemm_ring_launch(a, bm, bp, dtype, s);
+        a.kspt = (d->k_run * es + rc_.kb - 1) / rc_.kb;
+        return lh_igemm_ring_launch(a, rc_, dtype, s);
     }
 #define LH_TILE(T)                                                               \
     if (bm == 128 && bp == 128) return launch_tile<T, 128, 128, 2, 2>(a, s);     \
@@ -416,13 +409,7 @@ static int igemm_impl(const lh_igemm_desc* d, const void* in, const void* wpack,
 extern "C" int lh_igemm(const lh_igemm_desc* d, const void* in, const void* wpack, void* out,
                         const void* addend, const float* bias, const float* scale, const float* shift, float* stats,
                         int dtype, void* stream) {
-    return igemm_impl(d, in, wpack, out, addend, bias, scale, shift, stats, nullptr, dtype, stream);
-}
-
-extern "C" int lh_igemm_bntap(const lh_igemm_desc* d, const void* in, const void* wpack, void* out, const void* addend,
-                              const lh_bn_tap* tap, float* partial, int dtype, void* stream) {
-    LH_REQUIRE(tap && partial, "lh_igemm_bntap: null tap / partial slab");
-    return igemm_impl(d, in, wpack, out, addend, nullptr, nullptr, nullptr, partial, tap, dtype, stream);
+    return igemm_impl(d, in, wpack, out, addend, bias, scale, shift, stats, dtype, stream);
 }
 
 // ---- phase batching ------------------------------------------------------------------------------------------------
@@ -460,5 +447,5 @@ extern "C" int lh_igemm_phases(const lh_igemm_desc* const* descs, int nphase, co
     const int lead = phase_lead(descs, nphase);
     LH_REQUIRE(descs[lead]->ntaps > 0 && wpacks[lead], "lh_igemm_phases: no phase has taps");
     PhaseSet ps = {descs, wpacks, nphase};
-    return igemm_impl(descs[lead], in, wpacks[lead], out, addend, bias, scale, shift, stats, nullptr, dtype, stream, &ps);
+    return igemm_impl(descs[lead], in, wpacks[lead], out, addend, bias, scale, shift, stats, dtype, stream, &ps);
 }

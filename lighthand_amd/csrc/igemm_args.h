@@ -7,18 +7,11 @@ struct IgemmArgs {
     const unsigned char* w;
     unsigned char* out;
     const unsigned char* addend;
+    const unsigned char* zero;       // 16 zero bytes in device memory (LDS-DMA kernel: what masked lanes fetch)
     const float* bias;
     const float* scale;      // optional per-output-channel affine applied to the fp32 accumulator (eval-mode BN fold)
     const float* shift;
     float* stats;
-    // optional BN-backward reduction fused into a data-gradient epilogue (lh_igemm_bntap): with tap_x set, `stats`
-    // receives (sum g, sum g*xhat) of g = stored value masked by (x*scale+shift > 0) instead of (sum, sum of squares)
-    const unsigned char* tap_x;
-    const float* tap_scale;
-    const float* tap_shift;
-    const float* tap_mean;
-    const float* tap_invstd;
-    const unsigned char* tap_bits;   // ReLU mask bits of the activation (lh_fuse_fwd relu_mask): replace the x*scale+shift test
     int n, hi, wi, in_pix_stride, k_run, kspt, kpad;   // kpad: elements per (row, tap) of the weight pack
     int ho, wo, M, sh, sw, cout;
     int OH, OW, osh, osw, ooh, oow, out_pix_stride;
@@ -34,11 +27,16 @@ struct IgemmArgs {
     signed char dw[64];
 };
 
+// One configuration of the LDS-DMA kernel: tile (output channels x pixels), ring depth, K bytes per stage
+// (igemm_ring_kernel.h).
+struct RingCfg {
+    int bm, bp, depth, kb;
+};
+
 // igemm_ring.hip
 bool lh_ring_supported(const lh_igemm_desc* d, int dtype);
 bool lh_tap_grid(const lh_igemm_desc* d, int* tw, int* dh0, int* dhs, int* dw0, int* dws);
-void lh_ring_pick_tile(const lh_igemm_desc* d, int dtype, int* bm, int* bp);
-int lh_ring_kb();
-
-// igemm_patch.hip
-int lh_igemm_ring_launch(const IgemmArgs& a, int bm, int bp, int dtype, hipStream_t s);
+int lh_ring_resolve(const lh_igemm_desc* d, int dtype, RingCfg* out);
+void lh_ring_default_cfg(const lh_igemm_desc* d, int dtype, RingCfg* out);
+int lh_ring_candidates(const lh_igemm_desc* d, int dtype, int* out, int max);
+int lh_igemm_ring_launch(const IgemmArgs& a, const RingCfg& c, int dtype, hipStream_t s);

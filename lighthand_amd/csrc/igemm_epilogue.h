@@ -1,6 +1,6 @@
 // Epilogue of the LDS-DMA convolution kernel (igemm_ring.hip), kept apart from its K loop: accumulators -> LDS tile
 // [BP pixels][BM channels] (bias / per-channel affine applied on the fp32 accumulator), then full-line NHWC stores with
-// optional addend / ReLU and the BN partial sums (or the BN-backward tap sums) of the STORED values.
+// optional addend / ReLU and the BN partial sums of the STORED values.
 #pragma once
 #include "common.h"
 #include "igemm_args.h"
@@ -68,15 +68,6 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, unsigned char
     float s1[EPC], s2[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) s1[e] = s2[e] = 0.f;
-    float tsc[EPC], tsh[EPC], tmn[EPC], tiv[EPC];
-    const bool use_bits = p.tap_bits != nullptr;
-    if (p.tap_x && col_ok) {
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) {
-            tsc[e] = p.tap_bits ? 0.f : p.tap_scale[col0 + e]; tsh[e] = p.tap_bits ? 0.f : p.tap_shift[col0 + e];
-            tmn[e] = p.tap_mean[col0 + e]; tiv[e] = p.tap_invstd[col0 + e];
-        }
-    }
 
     for (int pr = r0; pr < BP; pr += RPP) {
         const int m = pblk * BP + pr;
@@ -107,21 +98,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, unsigned char
         if (stats) {
             float sv[EPC];
             unpack16<T>(u, sv);
-            if (p.tap_x) {
-                float xv[EPC];
-                unpack16<T>(*reinterpret_cast<const uint4*>(p.tap_x + eoff * ES), xv);
-                const unsigned mbits = use_bits ? p.tap_bits[eoff / EPC] : 0u;
 #pragma unroll
-                for (int e = 0; e < EPC; ++e) {
-                    const bool on = use_bits ? ((mbits >> e) & 1u) != 0 : (xv[e] * tsc[e] + tsh[e]) > 0.f;
-                    const float g = on ? sv[e] : 0.f;
-                    s1[e] += g;
-                    s2[e] += g * (xv[e] - tmn[e]) * tiv[e];
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < EPC; ++e) { s1[e] += sv[e]; s2[e] += sv[e] * sv[e]; }
-            }
+            for (int e = 0; e < EPC; ++e) { s1[e] += sv[e]; s2[e] += sv[e] * sv[e]; }
         }
         *reinterpret_cast<uint4*>(p.out + eoff * ES) = u;
     }

@@ -1,0 +1,5 @@
+// bf16 instantiations of the LDS-DMA convolution kernel, configuration part "big" (see igemm_ring_inst.h).
+#define LH_T bf16
+#define LH_FN lh_ring_launch_bf16_big
+#define LH_LIST LH_RING_CFGS_BIG
+#include "igemm_ring_inst.h"

@@ -1,0 +1,5 @@
+// fp16 instantiations of the LDS-DMA convolution kernel, configuration part "small" (see igemm_ring_inst.h).
+#define LH_T f16
+#define LH_FN lh_ring_launch_f16_small
+#define LH_LIST LH_RING_CFGS_SMALL
+#include "igemm_ring_inst.h"

@@ -1,0 +1,263 @@
+// Weight-gradient GEMM, LDS-DMA ring kernel (16-bit types; the production path on gfx950):
+//
+//   dW[tap][o][i] = sum_pixels dy[pixel][o] * x[pix(pixel, tap)][i]
+//
+// The contraction index (pixels) is the SLOW index of both NHWC operands, so the MFMA fragments (8 consecutive k per
+// lane) are formed with the CDNA4 transposing LDS read ds_read_b64_tr_b16 from row-major [pixel][channel] LDS images.
+//  * tile BO x BI of one tap, a stage = KPS pixel rows of both operands (KPS / 32 logical steps of one
+//    v_mfma_f32_16x16x32 K slice each), ring of D stages filled by global_load_lds_dwordx4, ONE raw s_barrier per
+//    stage and a counted s_waitcnt vmcnt that leaves D - 2 stages in flight (protocol of igemm_ring_kernel.h);
+//  * LDS image per operand: [KPS pixel rows][B * 2 bytes], unpadded (an LDS-DMA writes 1 KiB lane-linear), 32-byte
+//    granules XOR-swizzled by the row so the 8 pixel rows a half-wave touches per transposed read hit distinct banks;
+//    the swizzle is applied to the per-lane SOURCE address and to the read address;
+//  * the pixel a lane fetches advances by KPS per stage: its (image, row, column) is carried in registers and advanced
+//    by a mixed-radix add (no division in the loop); rows past the split's end or outside the image read a zero page;
+//  * fragment reads are retired by a ladder of counted s_waitcnt lgkmcnt: the MFMAs of output-channel tile i start as
+//    soon as its two reads are back;
+//  * split-K over pixels -> fp32 slabs [split][tap][o][i], folded (deterministically, in split order) into the
+//    reference-layout gradient by wgrad_reduce_kernel (wgrad.hip).
+#pragma once
+#include "common.h"
+
+#include <type_traits>
+
+#ifndef LH_ABL      // debug-only ablation builds, see igemm_ring_kernel.h / tools/ablate.sh
+#define LH_ABL 0
+#endif
+
+struct WgradArgs {
+    const unsigned char* x;
+    const unsigned char* dy;
+    const unsigned char* zero;   // 16 zero bytes in device memory (what masked lanes fetch)
+    float* slab;
+    int n, hi, wi, in_pix_stride, k_run;
+    int ho, wo, M, sh, sw;
+    int dy_pix_stride, n_out, n_in;
+    int ntaps, nsplit, steps_per_split, i_tiles;   // steps_per_split: ring stages (ring kernel) / K steps (wgrad_kernel)
+    int tiles, xcd;              // ring kernel: 1-D grid of tiles * ntaps * nsplit work items, XCD-aware order
+    int fold_k;                  // ring kernel, row fold (lh_wgrad_rowfold): input index i = row * fold_k + k, 0 = off
+    int adv_n, adv_a, adv_b;     // ring kernel: one stage of KPS pixels = adv_n images + adv_a rows + adv_b columns
+    signed char dh[64];
+    signed char dw[64];
+};
+
+template <int I> using wic = std::integral_constant<int, I>;
+template <int B, int E, typename F> __device__ __forceinline__ void wstatic_for(F&& f) {
+    if constexpr (B < E) {
+        f(wic<B>{});
+        wstatic_for<B + 1, E>(f);
+    }
+}
+
+template <int L, int MAXS> __device__ __forceinline__ void wwait_stages(int stages) {
+    static_assert(MAXS * L <= 63, "vmcnt is a 6-bit counter");
+    if constexpr (MAXS == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        if (stages >= MAXS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MAXS * L) : "memory");
+        else wwait_stages<L, MAXS - 1>(stages);
+    }
+}
+
+template <int ROWB> __device__ __forceinline__ int wswz(int row) {
+    return ROWB >= 256 ? (row & 7) : ((row >> 1) & 3);
+}
+
+template <typename T> struct WMma;
+template <> struct WMma<bf16> {
+    static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct WMma<f16> {
+    static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
+
+template <typename T, int BO, int BI, int WO, int WI, int D, int KPS>
+__global__ __launch_bounds__(64 * WO * WI, 2) void wgrad_ring_kernel(const WgradArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    static_assert(sizeof(T) == 2, "16-bit types only");
+    constexpr int KP = 32;                                    // pixels per logical step (one MFMA K slice)
+    constexpr int KSUB = KPS / KP;
+    constexpr int RBO = BO * 2, RBI = BI * 2;                 // bytes per pixel row
+    constexpr int RPO = 1024 / RBO, RPI = 1024 / RBI;         // pixel rows per LDS-DMA instruction
+    constexpr int NWAVE = WO * WI;                            // 4 waves, or 8 for the 256 x 256 tile
+    constexpr int NO = KPS / RPO / NWAVE, NI = KPS / RPI / NWAVE;   // instructions per wave and stage
+    constexpr int L = NO + NI;
+    constexpr int STAGE = KPS * (RBO + RBI);
+    constexpr int TO = BO / WO, TI = BI / WI, OT = TO / 16, IT = TI / 16;
+    static_assert((NWAVE == 4 || NWAVE == 8) && NO >= 1 && NI >= 1 && D >= 2 && D <= 8 && (KPS == 32 || KPS == 64), "bad tile");
+    typedef __attribute__((address_space(3))) void* lds_p;
+    typedef const __attribute__((address_space(1))) void* gbl_p;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wo_ = wave / WI, wi_ = wave % WI;
+    // work item w = (split, tap, tile), tile fastest: every XCD gets a contiguous range of pixel splits with all their
+    // taps and tiles, which re-read the same dy / x rows from that XCD's L2 instead of the Infinity Cache
+    const int w = p.xcd ? lh_xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int tile = w % p.tiles, tap = (w / p.tiles) % p.ntaps, split = w / (p.tiles * p.ntaps);
+    const int otile = tile / p.i_tiles, itile = tile % p.i_tiles;
+    const int dh = p.dh[tap], dw = p.dw[tap];
+    const int hw = p.ho * p.wo;
+    const long m_begin = (long)split * p.steps_per_split * KPS;
+    long m_end = m_begin + (long)p.steps_per_split * KPS;
+    if (m_end > p.M) m_end = p.M;
+    const int S = m_begin < m_end ? (int)((m_end - m_begin + KPS - 1) / KPS) : 0;
+    const int span = (int)(m_end - m_begin);                  // pixels of this split (<= 0: nothing to do)
+    const unsigned char* zero = p.zero;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+
+    // ---- per-lane source bookkeeping: instruction q = NWAVE*j + wave covers rows [q*RP, (q+1)*RP) of the stage
+    const unsigned char* osrc[NO];          // dy address of this lane's chunk in stage 0 (advances by KPS rows per stage)
+    int oleft[NO];                          // the chunk is live while (pixels done) < oleft
+#pragma unroll
+    for (int j = 0; j < NO; ++j) {
+        const int q = NWAVE * j + wave;
+        const int r = q * RPO + lane / (RBO / 16), c16 = lane % (RBO / 16);
+        const int ocol = otile * BO + ((((c16 >> 1) ^ wswz<RBO>(r)) << 1) | (c16 & 1)) * 8;
+        osrc[j] = p.dy + ((m_begin + r) * p.dy_pix_stride + ocol) * 2;
+        oleft[j] = ocol < p.n_out ? span - r : 0;
+    }
+    const unsigned char* xsrc[NI];          // x address of (image 0, row 0, column 0) + this lane's channel chunk
+    int xn[NI], xa[NI], xb[NI], xleft[NI];  // output pixel (image, row, column) this lane fetches for in the next stage
+    int xdh[NI];                            // input row offset of this lane's chunk: the tap's dh (+ the folded kernel row)
+    const int xpix = p.in_pix_stride * 2;   // bytes per input pixel
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int q = NWAVE * j + wave;
+        const int r = q * RPI + lane / (RBI / 16), c16 = lane % (RBI / 16);
+        const int icol = itile * BI + ((((c16 >> 1) ^ wswz<RBI>(r)) << 1) | (c16 & 1)) * 8;
+        // row fold: the gradient's input index covers `rows` kernel rows of fold_k contiguous elements each; this lane's
+        // chunk belongs to kernel row icol / fold_k (an extra input-row offset) and element icol % fold_k of the run
+        const int idh = p.fold_k ? icol / p.fold_k : 0;
+        const int ick = p.fold_k ? icol % p.fold_k : icol;
+        const long m = m_begin + r;
+        const int mi = m < p.M ? (int)m : 0;
+        xn[j] = mi / hw;
+        const int rem = mi - xn[j] * hw;
+        xa[j] = rem / p.wo;
+        xb[j] = rem - xa[j] * p.wo;
+        xleft[j] = icol < p.k_run ? span - r : 0;
+        xdh[j] = dh + idh;
+        xsrc[j] = p.x + (long)ick * 2;
+    }
+
+    int issued = 0, islot = 0, done = 0;    // done = pixels of the split covered by the stages issued so far
+    long oadv = 0;
+    auto issue = [&]() {
+        unsigned char* st = smem + islot * STAGE;
+#pragma unroll
+        for (int j = 0; j < NO; ++j) {
+            const unsigned char* src = done < oleft[j] ? osrc[j] + oadv : zero;
+            if (!(LH_ABL & 4)) __builtin_amdgcn_global_load_lds((gbl_p)src, (lds_p)(st + (NWAVE * j + wave) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int ih = xa[j] * p.sh + xdh[j], iw = xb[j] * p.sw + dw;
+            const bool ok = (int)(done < xleft[j]) & (int)((unsigned)ih < (unsigned)p.hi) & (int)((unsigned)iw < (unsigned)p.wi);
+            const int pix = (xn[j] * p.hi + ih) * p.wi + iw;            // input pixel index (any value when !ok)
+            const unsigned char* src = ok ? xsrc[j] + (long)pix * xpix : zero;
+            if (!(LH_ABL & 4)) __builtin_amdgcn_global_load_lds((gbl_p)src, (lds_p)(st + KPS * RBO + (NWAVE * j + wave) * 1024), 16, 0, 0);
+            // advance this lane's pixel by one stage (mixed-radix add: no division)
+            int b = xb[j] + p.adv_b, a = xa[j] + p.adv_a, n = xn[j] + p.adv_n;
+            if (b >= p.wo) { b -= p.wo; ++a; }
+            if (a >= p.ho) { a -= p.ho; ++n; }
+            xb[j] = b; xa[j] = a; xn[j] = n;
+        }
+        ++issued;
+        if (++islot == D) islot = 0;
+        done += KPS;
+        oadv += (long)KPS * p.dy_pix_stride * 2;
+    };
+
+    f32x4 acc[OT][IT];
+#pragma unroll
+    for (int i = 0; i < OT; ++i)
+#pragma unroll
+        for (int j = 0; j < IT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int s = 0; s < D - 1; ++s)
+        if (issued < S) issue();
+
+    // transposed-read addresses: lane (group g, q, pp) reads pixel row 4g+q (and +16), 4 channels at 4*pp of a 16-channel tile
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int row0 = 4 * g + q, row1 = row0 + 16;
+    unsigned ao[OT][2], ai[IT][2];
+#pragma unroll
+    for (int i = 0; i < OT; ++i) {
+        const int ct = wo_ * OT + i;                              // 32-byte granule index inside the row
+        ao[i][0] = lds_base + row0 * RBO + ((ct ^ wswz<RBO>(row0)) << 5) + pp * 8;
+        ao[i][1] = lds_base + row1 * RBO + ((ct ^ wswz<RBO>(row1)) << 5) + pp * 8;
+    }
+#pragma unroll
+    for (int j = 0; j < IT; ++j) {
+        const int ct = wi_ * IT + j;
+        ai[j][0] = lds_base + KPS * RBO + row0 * RBI + ((ct ^ wswz<RBI>(row0)) << 5) + pp * 8;
+        ai[j][1] = lds_base + KPS * RBO + row1 * RBI + ((ct ^ wswz<RBI>(row1)) << 5) + pp * 8;
+    }
+
+    auto rdtr = [](auto OFFc, uint2& dst, unsigned addr) {
+        if constexpr ((LH_ABL & 2) != 0) { dst = uint2{addr, addr}; return; }
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(decltype(OFFc)::value));
+    };
+    // one logical step: pixel rows [32*kk, 32*kk + 32) of the stage at byte offset `so` (the swizzle repeats every 8 rows)
+    auto step = [&](auto KKc, unsigned so) {
+        constexpr int kk = decltype(KKc)::value;
+        uint2 fi[IT][2], fo[OT][2];
+        wstatic_for<0, IT>([&](auto Jc) {
+            rdtr(wic<kk * KP * RBI>{}, fi[decltype(Jc)::value][0], ai[decltype(Jc)::value][0] + so);
+            rdtr(wic<kk * KP * RBI>{}, fi[decltype(Jc)::value][1], ai[decltype(Jc)::value][1] + so);
+        });
+        wstatic_for<0, OT>([&](auto Ic) {
+            rdtr(wic<kk * KP * RBO>{}, fo[decltype(Ic)::value][0], ao[decltype(Ic)::value][0] + so);
+            rdtr(wic<kk * KP * RBO>{}, fo[decltype(Ic)::value][1], ao[decltype(Ic)::value][1] + so);
+        });
+        wstatic_for<0, OT>([&](auto Ic) {
+            constexpr int i = decltype(Ic)::value;
+            // the reads younger than output-channel fragment i may stay in flight (LDS returns in order)
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (OT - 1 - i)) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            const uint4 a = uint4{fo[i][0].x, fo[i][0].y, fo[i][1].x, fo[i][1].y};
+#pragma unroll
+            for (int j = 0; j < IT; ++j) {
+                const uint4 b = uint4{fi[j][0].x, fi[j][0].y, fi[j][1].x, fi[j][1].y};
+                if (!(LH_ABL & 1)) WMma<T>::run(a, b, acc[i][j]);
+            }
+        });
+    };
+
+    // waves 4-7 of the 8-wave tile share their SIMDs with waves 0-3: they refill the ring half a stage later
+    const bool late = NWAVE == 8 && KSUB == 2 && wave >= NWAVE / 2;
+    int cslot = 0;
+    for (int s = 0; s < S; ++s) {
+        wwait_stages<L, D - 2>(issued - 1 - s);          // stage s has landed; later stages stay in flight
+        __builtin_amdgcn_s_barrier();
+        const unsigned so = cslot * STAGE;
+        if (++cslot == D) cslot = 0;
+        if (!late && issued < S) issue();                // into the slot of stage s - 1, retired by every wave
+        step(wic<0>{}, so);
+        if constexpr (KSUB == 2) {
+            if (late && issued < S) issue();
+            step(wic<1>{}, so);
+        }
+    }
+
+    if (LH_ABL & 8) { if (acc[0][0][0] == 123.456f) p.slab[0] = 1.f; return; }
+    float* slab = p.slab + ((long)split * p.ntaps + tap) * p.n_out * p.n_in;
+    const int qq = lane >> 4, cc = lane & 15;
+#pragma unroll
+    for (int i = 0; i < OT; ++i)
+#pragma unroll
+        for (int j = 0; j < IT; ++j) {
+            const int ci = itile * BI + wi_ * TI + j * 16 + cc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = otile * BO + wo_ * TO + i * 16 + qq * 4 + r;
+                if (o < p.n_out && ci < p.n_in) slab[(long)o * p.n_in + ci] = acc[i][j][r];
+            }
+        }
+}

@@ -14,7 +14,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import BnTap, FuseBwdDesc, FuseDesc, IgemmDesc, check
+from ._lib import FuseBwdDesc, FuseDesc, IgemmDesc, check
 
 PRECISIONS = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}
 BN_MOMENTUM = 0.1   # src/modeling/simplebaseline/pose_resnet.py:19, src/modeling/hrnet/pose_hrnet.py:18
@@ -28,7 +28,7 @@ def _ptr(t):
 class Act:
     """One NHWC activation (and, in training plans, its gradient)."""
     __slots__ = ("n", "h", "w", "c", "c_valid", "buf", "grad", "needs_grad", "stats", "stats_rows",
-                 "is_image", "name", "bn_tap")
+                 "is_image", "name")
 
     def __init__(self, n, h, w, c, c_valid=None, name=""):
         self.n, self.h, self.w, self.c = n, h, w, c
@@ -38,7 +38,6 @@ class Act:
         self.needs_grad = True
         self.is_image = False
         self.name = name
-        self.bn_tap = None       # set by a single-BN-term fuse node whose output feeds exactly one convolution
 
     @property
     def pixels(self):
@@ -262,7 +261,9 @@ class Plan:
         self._ws_users = []
         self._ws_users_fuse = []
         self.profile_meta = []             # (list name, call object, kernel name, flops, bytes)
+        self._tune_bufs = {}
         self._compile()
+        self._tune_bufs = {}               # scratch operands of the autotuner are only needed while compiling
 
     # ------------------------------------------------------------------ helpers
     def _alloc(self, *shape, dtype=None, zero=False):
@@ -333,6 +334,136 @@ class Plan:
         conv.npacks += 1
         return True
 
+    # ------------------------------------------------------------------ kernel autotuning
+    _TUNE_CACHE = {}        # launch signature -> (bm, bp, depth, kb): shared by every plan of the process
+    # test hooks: force_cfg(candidates) -> (bm, bp, depth, kb) | None and force_wgrad(candidates) -> (bo, bi, enc) | None
+    # replace the measurement for the plans built while they are set (tests walk every compiled-in configuration)
+    force_cfg = None
+    force_wgrad = None
+
+    @staticmethod
+    def _desc_key(d):
+        return (d.n, d.hi, d.wi, d.in_pix_stride, d.k_run, d.ho, d.wo, d.sh, d.sw, d.cout, d.OH, d.OW, d.osh, d.osw,
+                d.ooh, d.oow, d.out_pix_stride, d.ntaps, bytes(d.dh)[:d.ntaps], bytes(d.dw)[:d.ntaps])
+
+    def _scratch(self, name, nbytes):
+        t = self._tune_bufs.get(name)
+        if t is None or t.numel() < nbytes:
+            t = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
+            if name != "out":
+                # random bit patterns in every operand: all-zero operands let the chip clock higher and would rank the
+                # MFMA-heavy configurations too well (cdna guide, methodology rule 25)
+                t.view(torch.int16).random_(-16000, 16000) if self.es == 2 else t.view(torch.float32).normal_()
+            self._tune_bufs[name] = t
+        return t
+
+    def _tune(self, descs, with_stats=False):
+        """Measured kernel choice (cdna guide: measure, don't guess): time every compiled-in configuration that fits
+        this launch (lh_igemm_candidates) on scratch operands of the real size and write the fastest into the
+        descriptors' cfg.  One descriptor = lh_igemm; several = the phases of lh_igemm_phases (one shared choice).
+        Results do not depend on the choice (the K-loop order is the same for every tile).  LH_AUTOTUNE=0 keeps the
+        library's static default."""
+        if os.environ.get("LH_AUTOTUNE", "1") == "0":
+            return
+        lead = max(descs, key=lambda d: d.ntaps)
+        if lead.ntaps == 0:
+            return
+        key = (self.dt, with_stats) + tuple(self._desc_key(d) for d in descs)
+        hit = Plan._TUNE_CACHE.get(key) if Plan.force_cfg is None else None
+        if hit is None:
+            buf = (C.c_int * (5 * 64))()
+            n = self.lib.lh_igemm_candidates(C.byref(lead), self.dt, buf, 64)
+            cands = [tuple(buf[5 * i:5 * i + 4]) for i in range(n)]
+            if len(descs) > 1 and self._phase_rows(descs) <= 0:
+                cands = []                                      # phases that cannot be batched: keep the default
+            if Plan.force_cfg is not None:
+                forced = Plan.force_cfg(cands) if cands else None
+                for d in descs:
+                    d.cfg[0], d.cfg[1], d.cfg[2], d.cfg[3] = forced or (0, 0, 0, 0)
+                return
+            hit = (0, 0, 0, 0)
+            if len(cands) > 1:
+                es = self.es
+                kpad = (lead.k_run * es + 127) // 128 * 128
+                src = self._scratch("in", lead.n * lead.hi * lead.wi * lead.in_pix_stride * es + 256)
+                dst = self._scratch("out", lead.n * lead.OH * lead.OW * lead.out_pix_stride * es + 256)
+                packs = [self._scratch(f"pack{i}", (d.cout + 255) // 256 * 256 * max(d.ntaps, 1) * kpad + 256) for i, d in enumerate(descs)]
+                rows = (lead.n * lead.ho * lead.wo + 63) // 64 * len(descs)
+                stats = self._scratch("stats", rows * 2 * lead.cout * 4 + 256) if with_stats else None
+                stream = torch.cuda.current_stream()
+                sp = stream.cuda_stream
+                if len(descs) > 1:
+                    arr = (C.POINTER(IgemmDesc) * len(descs))(*[C.pointer(d) for d in descs])
+                    parr = (C.c_void_p * len(descs))(*[pk.data_ptr() for pk in packs])
+
+                    def run():
+                        check(self.lib.lh_igemm_phases(arr, len(descs), src.data_ptr(), parr, dst.data_ptr(), None, None, None, None,
+                                                       _ptr(stats), self.dt, sp), "autotune lh_igemm_phases")
+                else:
+                    def run():
+                        check(self.lib.lh_igemm(C.byref(lead), src.data_ptr(), packs[0].data_ptr(), dst.data_ptr(), None, None, None, None,
+                                                _ptr(stats), self.dt, sp), "autotune lh_igemm")
+                best = None
+                for cfg in cands:
+                    for d in descs:
+                        d.cfg[0], d.cfg[1], d.cfg[2], d.cfg[3] = cfg
+                    run()
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record(stream)
+                    for _ in range(4):
+                        run()
+                    b.record(stream)
+                    b.synchronize()
+                    t = a.elapsed_time(b)
+                    if best is None or t < best[0]:
+                        best = (t, cfg)
+                hit = best[1]
+            Plan._TUNE_CACHE[key] = hit
+        for d in descs:
+            d.cfg[0], d.cfg[1], d.cfg[2], d.cfg[3] = hit
+
+    def _tune_wgrad(self, d, n_out, n_in, dy_stride, launch, grad_floats, tag=()):
+        """Measured plan of one weight-gradient launch + its fold: (tile, stage rows, ring depth, pixel splits) from
+        lh_wgrad_candidates, timed on scratch operands; the winner goes into d.cfg[5..7].  The split count changes the
+        fp32 summation order (deterministically): the choice is cached per launch signature for the whole process so
+        that every plan of a process computes the same sums."""
+        if os.environ.get("LH_AUTOTUNE", "1") == "0":
+            return
+        key = ("w", self.dt, self._desc_key(d), n_out, n_in, dy_stride) + tuple(tag)
+        hit = Plan._TUNE_CACHE.get(key) if Plan.force_wgrad is None else None
+        if hit is None:
+            buf = (C.c_int * (5 * 128))()
+            n = self.lib.lh_wgrad_candidates(C.byref(d), n_out, n_in, self.dt, buf, 128)
+            cands = [tuple(buf[5 * i:5 * i + 5]) for i in range(n)]
+            if Plan.force_wgrad is not None:
+                d.cfg[5], d.cfg[6], d.cfg[7] = (Plan.force_wgrad(cands) if cands else None) or (0, 0, 0)
+                return
+            hit = (0, 0, 0)
+            if len(cands) > 1:
+                es = self.es
+                xs = self._scratch("in", d.n * d.hi * d.wi * d.in_pix_stride * es + 256)
+                dys = self._scratch("dy", d.n * d.ho * d.wo * dy_stride * es + 256)
+                slab = self._scratch("out", (max(c[4] for c in cands) + 1) << 20)
+                grad = self._scratch("stats", grad_floats * 4 + 256)
+                stream = torch.cuda.current_stream()
+                sp = stream.cuda_stream
+                best = None
+                for bo, bi, enc, _, _ in cands:
+                    d.cfg[5], d.cfg[6], d.cfg[7] = bo, bi, enc
+                    launch(xs.data_ptr(), dys.data_ptr(), slab.data_ptr(), grad.data_ptr(), sp)
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record(stream)
+                    for _ in range(3):
+                        launch(xs.data_ptr(), dys.data_ptr(), slab.data_ptr(), grad.data_ptr(), sp)
+                    b.record(stream)
+                    b.synchronize()
+                    t = a.elapsed_time(b)
+                    if best is None or t < best[0]:
+                        best = (t, (bo, bi, enc))
+                hit = best[1]
+            Plan._TUNE_CACHE[key] = hit
+        d.cfg[5], d.cfg[6], d.cfg[7] = hit
+
     def _igemm(self, lst, d, src, pack, dst, addend, bias, stats, what, flops=0, produces=None):
         self.keep.append(d)
         c = _Call(self.lib.lh_igemm, (C.byref(d), _ptr(src), _ptr(pack), _ptr(dst), _ptr(addend), _ptr(bias), 0, 0, _ptr(stats), self.dt), what)
@@ -343,46 +474,21 @@ class Plan:
         return c
 
     def _dgrad(self, descs, dy, packs, x, what):
-        """Data-gradient launches into x.grad.  When x is the output of a fuse node that registered a BN tap, and this
-        launch set writes the FINAL value of x.grad (sole consumer of a conv -> BN -> ReLU output, or last of the
-        writers of a residual tail's output), the launches also produce that node's BN-backward reduction
-        (lh_igemm_bntap) so the separate reduce pass over dA / x / mask disappears."""
+        """Data-gradient launches into x.grad (the first writer of a gradient buffer overwrites, later ones add)."""
         dx = self._act_grad(x)
-        n_before = self._nwrites.get(id(x), 0)
         first = self._first_write(x)
-
-        tap = x.bn_tap
-        if tap is not None and n_before != self._n_uses.get(id(x), 1) - 1:
-            tap = None                            # a later launch still adds to this gradient
-        if tap is None and not first and len(descs) > 1:      # accumulating: a phase without taps would add zeros -- drop
-            keep = [i for i, dd in enumerate(descs) if dd.ntaps > 0]       # it (a BN tap must visit every pixel, though)
+        if not first and len(descs) > 1:          # accumulating: a phase without taps would add zeros -- drop it
+            keep = [i for i, dd in enumerate(descs) if dd.ntaps > 0]
             descs, packs = [descs[i] for i in keep], [packs[i] for i in keep]
-        if tap is None and self._phase_rows(descs) > 0:
+        if self._phase_rows(descs) > 0:
+            self._tune(descs)
             self._igemm_phases(self.bwd, descs, dy, packs, dx, None if first else dx, None, None, what)
             yield max(descs, key=lambda d: d.ntaps), sum(d.ntaps for d in descs)
             return
-        if tap is None:
-            for dd, pk in zip(descs, packs):
-                self._igemm(self.bwd, dd, dy, pk, dx, None if first else dx, None, None, what)
-                yield dd, dd.ntaps
-            return
-        rows = [self.lib.lh_igemm_stats_rows(C.byref(dd), self.dt) for dd in descs]
-        slab = self._alloc(sum(rows) * 2 * x.c, dtype=torch.float32)
-        st, bits = tap["st"], tap.get("bits")
-        bt = BnTap(tap["x"].buf.data_ptr(), None if bits is not None else st["scale"].data_ptr(),
-                   None if bits is not None else st["shift"].data_ptr(), st["mean"].data_ptr(), st["invstd"].data_ptr(),
-                   None if bits is None else bits.data_ptr())
-        self.keep.append(bt)
-        off = 0
-        for dd, pk, r in zip(descs, packs, rows):
-            self.keep.append(dd)
-            c = _Call(self.lib.lh_igemm_bntap, (C.byref(dd), dy.data_ptr(), pk.data_ptr(), dx.data_ptr(), None if first else dx.data_ptr(),
-                                                C.byref(bt), slab.data_ptr() + off, self.dt), what + " (+BN-bwd reduce)")
-            c.keep = dd
-            self.bwd.append(c)
-            off += r * 2 * x.c * 4
+        for dd, pk in zip(descs, packs):
+            self._tune([dd])
+            self._igemm(self.bwd, dd, dy, pk, dx, None if first else dx, None, None, what)
             yield dd, dd.ntaps
-        tap["slab"] = (slab, sum(rows))
 
     def _patch(self, call, relu=None, **ptrs):
         a = list(call.args)
@@ -421,17 +527,18 @@ class Plan:
         t = {"fp32": "float", "bf16": "__bf16", "fp16": "_Float16"}[self.precision]
         a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
         if wgrad is None:
-            self.lib.lh_igemm_tile(C.byref(d), self.dt, C.byref(a), C.byref(b), C.byref(c))
-            wc, wp = {(256, 256): (2, 4), (128, 256): (2, 2), (128, 128): (2, 2), (128, 64): (4, 1), (64, 128): (1, 4), (64, 64): (2, 2)}[(a.value, b.value)]
-            if c.value:
-                depth = 3 if b.value == 256 else c.value % 10       # both 256-pixel tiles run a 3-stage ring
-                return f"igemm_ring_kernel<{t}, {a.value}, {b.value}, {wc}, {wp}, {depth}, {c.value // 10}>"
-            return f"igemm_kernel<{t}, {a.value}, {b.value}, {wc}, {wp}>"
+            cfg = (C.c_int * 5)()
+            check(self.lib.lh_igemm_config(C.byref(d), self.dt, cfg), "lh_igemm_config")
+            bm, bp, depth, kb = cfg[0], cfg[1], cfg[2], cfg[3]
+            wc, wp = {(256, 256): (2, 4), (128, 256): (2, 2), (128, 128): (2, 2), (128, 64): (4, 1), (64, 128): (1, 4), (64, 64): (2, 2)}[(bm, bp)]
+            if depth:
+                return f"igemm_ring_kernel<{t}, {bm}, {bp}, {wc}, {wp}, {depth}, {kb}>"
+            return f"igemm_kernel<{t}, {bm}, {bp}, {wc}, {wp}>"
         r = C.c_int(0)
-        self.lib.lh_wgrad_tile(C.byref(d), wgrad[0], wgrad[1], self.dt, C.byref(a), C.byref(b), C.byref(c), C.byref(r))
+        check(self.lib.lh_wgrad_tile(C.byref(d), wgrad[0], wgrad[1], self.dt, C.byref(a), C.byref(b), C.byref(c), C.byref(r)), "lh_wgrad_tile")
         wo, wi = {(256, 256): (2, 4), (128, 128): (2, 2), (128, 64): (4, 1), (64, 128): (1, 4), (64, 64): (2, 2)}[(a.value, b.value)]
         if r.value:
-            return f"wgrad_ring_kernel<{t}, {a.value}, {b.value}, {wo}, {wi}, {r.value}>"
+            return f"wgrad_ring_kernel<{t}, {a.value}, {b.value}, {wo}, {wi}, {r.value % 10}, {r.value // 10}>"
         return f"wgrad_kernel<{t}, {a.value}, {b.value}, {wo}, {wi}>"
 
     def _pending(self):
@@ -493,20 +600,6 @@ class Plan:
                     if bn is not None:
                         consumers_bn.add(id(a))
         self._bn_inputs = consumers_bn
-        # activations with exactly one consumer (a convolution): their data gradient is written once, by that
-        # consumer's dgrad, which can therefore carry the BN-backward reduction of the producing fuse node
-        uses = {}
-        for kind, nd in self.nodes:
-            if kind in ("conv", "deconv", "maxpool"):
-                uses.setdefault(id(nd["x"]), []).append(kind)
-            elif kind == "fuse":
-                for a, _, _ in nd["terms"]:
-                    uses.setdefault(id(a), []).append(kind)
-            elif kind == "output":
-                uses.setdefault(id(nd["y"]), []).append(kind)
-        self._sole_conv_input = {k for k, v in uses.items() if len(v) == 1 and v[0] in ("conv", "deconv")}
-        self._n_uses = {k: len(v) for k, v in uses.items()}       # gradient writers per activation
-        self._last_use_is_conv = {k for k, v in uses.items() if v[0] in ("conv", "deconv")}   # first consumer = last writer
         self._nwrites = {}
         bwd_blocks = []
         for (kind, nd), lane in zip(self.nodes, self.node_lanes):
@@ -653,6 +746,7 @@ class Plan:
         d = _desc(x.n, x.h, x.w, x.c, cin, y.h, y.w, s, s, y.c, y.h, y.w, 1, 1, 0, 0, y.c, taps)
         pack = self._pack(wt, cout, cin, (cin * k * k, k * k, k, 1), all_rs, nd["w"] + " fwd pack")
         stats_ptr = None
+        self._tune([d], with_stats=id(y) in self._bn_inputs and self.training)
         if id(y) in self._bn_inputs and self.training:
             self._stats_for(y, [d])
             stats_ptr = y.stats
@@ -662,12 +756,18 @@ class Plan:
         if not self.with_bwd:
             return
         # --- backward: weight gradient, then data gradient
-        slab_bytes = self.lib.lh_wgrad_slab_bytes(C.byref(d), y.c, cin, self.dt)
-        self._ws_wgrad = max(self._ws_wgrad, slab_bytes)
         rs_arr = _taps_array(all_rs)
         gw = self.grads[nd["w"] + ".weight"]
         pad_out = y.c != cout
         gtmp = self._alloc(y.c, cin, k, k, dtype=torch.float32) if pad_out else gw
+        n_out_r = y.c if pad_out else cout
+
+        def tune_launch(xp, dyp, slab, grad, sp):
+            check(self.lib.lh_wgrad(C.byref(d), xp, dyp, y.c, y.c, cin, slab, self.dt, sp), "autotune lh_wgrad")
+            check(self.lib.lh_wgrad_reduce(C.byref(d), slab, grad, n_out_r, cin, cin * k * k, k * k, k, 1, rs_arr, 0, self.dt, sp), "autotune lh_wgrad_reduce")
+        self._tune_wgrad(d, y.c, cin, y.c, tune_launch, y.c * cin * k * k)
+        slab_bytes = self.lib.lh_wgrad_slab_bytes(C.byref(d), y.c, cin, self.dt)
+        self._ws_wgrad = max(self._ws_wgrad, slab_bytes)
         dpacks, ddescs = [], []
         if x.needs_grad:
             for ph in range(s):
@@ -735,6 +835,7 @@ class Plan:
         d = _desc(x.n, hp, wp, 4, kr, y.h, y.w, s, s, y.c, y.h, y.w, 1, 1, 0, 0, y.c, rows)
         ybuf = self._act_buf(y)
         stats_ptr = None
+        self._tune([d], with_stats=id(y) in self._bn_inputs and self.training)
         if id(y) in self._bn_inputs and self.training:
             self._stats_for(y, [d])
             stats_ptr = y.stats
@@ -751,9 +852,18 @@ class Plan:
         dw = _desc(x.n, hp, wp, 4, k * kr, y.h, y.w, s, s, y.c, y.h, y.w, 1, 1, 0, 0, y.c, [(0, 0)]) if fold else d
         self.keep.append(dw)
         n_in_w = k * kr if fold else kr
+        rs_arr = _taps_array([(0, 0)] if fold else rows)
+
+        def tune_launch(xp, dyp, slab, grad, sp):
+            if fold:
+                check(self.lib.lh_wgrad_rowfold(C.byref(dw), k, xp, dyp, y.c, y.c, slab, self.dt, sp), "autotune lh_wgrad_rowfold")
+                check(self.lib.lh_wgrad_reduce(C.byref(dw), slab, grad, cout, k * kr, k * kr, 1, 0, 0, rs_arr, 0, self.dt, sp), "autotune lh_wgrad_reduce")
+            else:
+                check(self.lib.lh_wgrad(C.byref(d), xp, dyp, y.c, y.c, kr, slab, self.dt, sp), "autotune lh_wgrad")
+                check(self.lib.lh_wgrad_reduce(C.byref(d), slab, grad, cout, kr, k * kr, 1, kr, 0, rs_arr, 0, self.dt, sp), "autotune lh_wgrad_reduce")
+        self._tune_wgrad(dw, y.c, n_in_w, y.c, tune_launch, y.c * k * kr, tag=("fold", k if fold else 0))
         slab_bytes = self.lib.lh_wgrad_slab_bytes(C.byref(dw), y.c, n_in_w, self.dt)
         self._ws_wgrad = max(self._ws_wgrad, slab_bytes)
-        rs_arr = _taps_array([(0, 0)] if fold else rows)
         gstage = self._alloc(cout, k, kr // 4, 4, dtype=torch.float32)
         gw = self.grads[nd["w"] + ".weight"]
 
@@ -801,6 +911,12 @@ class Plan:
                 gh, gw_ = (y.h - ph + 1) // 2, (y.w - pw + 1) // 2
                 descs.append(_desc(x.n, x.h, x.w, x.c, cin, gh, gw_, 1, 1, cout, y.h, y.w, 2, 2, ph, pw, y.c, tp))
                 packs.append(self._pack(wt, cout, cin, (k * k, cout * k * k, k, 1), sub, nd["w"] + " deconv pack"))
+        with_stats = id(y) in self._bn_inputs and self.training
+        if self._phase_rows(descs) > 0:
+            self._tune(descs, with_stats=with_stats)
+        else:
+            for dd in descs:
+                self._tune([dd], with_stats=with_stats)
         prow = self._phase_rows(descs)
         if prow > 0:                          # the four sub-pixel phases as ONE launch
             stats = None
@@ -828,9 +944,14 @@ class Plan:
         dg = _desc(y.n, y.h, y.w, y.c, cout, x.h, x.w, 2, 2, x.c, x.h, x.w, 1, 1, 0, 0, x.c, taps)
         self.keep.append(dg)
         gpack = self._pack(wt, cin, cout, (cout * k * k, k * k, k, 1), all_rs, nd["w"] + " deconv dgrad pack")
+        rs_arr = _taps_array(all_rs)
+
+        def tune_launch(xp, dyp, slab, grad, sp):          # dy is the gathered operand here, x the dense one
+            check(self.lib.lh_wgrad(C.byref(dg), xp, dyp, x.c, cin, cout, slab, self.dt, sp), "autotune lh_wgrad")
+            check(self.lib.lh_wgrad_reduce(C.byref(dg), slab, grad, cin, cout, cout * k * k, k * k, k, 1, rs_arr, 0, self.dt, sp), "autotune lh_wgrad_reduce")
+        self._tune_wgrad(dg, cin, cout, x.c, tune_launch, cin * cout * k * k)
         slab_bytes = self.lib.lh_wgrad_slab_bytes(C.byref(dg), cin, cout, self.dt)
         self._ws_wgrad = max(self._ws_wgrad, slab_bytes)
-        rs_arr = _taps_array(all_rs)
         gw = self.grads[nd["w"] + ".weight"]
         flops = 2.0 * x.pixels * cin * cout * k * k
 
@@ -902,21 +1023,6 @@ class Plan:
         if not self.with_bwd:
             return
         self._ws_fuse = max(self._ws_fuse, self.lib.lh_fuse_bwd_workspace_bytes(out.n, out.h, out.w, c))
-        # BN-backward reduction inside the consumer's data-gradient epilogue (lh_igemm_bntap): opt-in (LH_BNTAP=1).
-        # Measured on R50 bs64 after the ring kernel's load path was fixed: 13.41 ms with the taps vs 13.20 ms without --
-        # the epilogue is the one phase of the convolution that nothing overlaps, and lengthening it by a read of x
-        # costs more than the streaming reduce pass (two reads at HBM rate) it replaces.
-        nchunk = c // (16 // self.es)
-        flat = nchunk & (nchunk - 1) == 0 and nchunk <= 256         # lh_fuse_bwd's flat kernels (the ones that take ext_partial)
-        can_tap = flat and relu and terms[0][1] is not None and terms[0][0].needs_grad and bool(os.environ.get("LH_BNTAP"))
-        if can_tap and len(terms) == 1 and terms[0][2] == 0 and id(out) in self._sole_conv_input:
-            out.bn_tap = {"x": terms[0][0], "st": bn_state[0], "slab": None}
-        elif (can_tap and len(terms) == 2 and terms[0][2] == 0 and terms[1][2] == 0 and relu_bits is not None
-              and id(out) in self._last_use_is_conv and not os.environ.get("LH_NO_TAILTAP")):
-            # residual tail relu(BN(conv3) + shortcut): its output's gradient is finished by the first consumer's dgrad
-            # (the last writer in backward order), which then carries the reduction of the main BN term
-            out.bn_tap = {"x": terms[0][0], "st": bn_state[0], "slab": None, "bits": relu_bits}
-
         def emit():
             bd = FuseBwdDesc()
             bd.dout = self._act_grad(out).data_ptr()
@@ -936,9 +1042,6 @@ class Plan:
                     bd.shift[i] = st["shift"].data_ptr()
                     bd.dgamma[i] = self.grads[bn + ".weight"].data_ptr()
                     bd.dbeta[i] = self.grads[bn + ".bias"].data_ptr()
-                    if i == 0 and out.bn_tap is not None and out.bn_tap["slab"] is not None:     # reduced by a consumer's dgrad
-                        bd.ext_partial[i] = out.bn_tap["slab"][0].data_ptr()
-                        bd.ext_rows[i] = out.bn_tap["slab"][1]
             self.keep.append(bd)
             args = [C.byref(bd), out.n, out.h, out.w, c, 0, self.dt]
             call = _Call(self.lib.lh_fuse_bwd, None, "fuse bwd")

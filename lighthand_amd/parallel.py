@@ -35,6 +35,14 @@ def init_distributed(backend=None):
     return rank, world, local
 
 
+def all_reduce_sum_(t, group=None):
+    """Sum a small tensor over the ranks in place (no-op for a single process).  Used wherever ranks must take the
+    SAME host-side decision from per-rank numbers (validation loss -> best checkpoint / early stop)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
 def plan_buckets(marks, offsets, total, bucket_bytes=32 << 20):
     """Cut the backward list into segments whose finished gradients form contiguous arena slices.
 

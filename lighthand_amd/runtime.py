@@ -93,7 +93,6 @@ class TrainStep:
             self._enqueue_all() if self.grad_sync is None else self._eager_synced()
         torch.cuda.current_stream().wait_stream(warm)
         torch.cuda.synchronize()
-        self.optimizer_reset()
         self.graphs = []
         if self.grad_sync is None:
             g = torch.cuda.CUDAGraph()
@@ -125,15 +124,23 @@ class TrainStep:
         self.grad_sync.wait_all()
         self.optimizer.step(grad_scale=self.grad_scale)
 
-    def optimizer_reset(self):
-        """Undo the warm-up iteration: restore Adam state / step counter (weights are restored by the caller
-        through the snapshot taken in ``__call__``)."""
+    def _optimizer_snapshot(self):
+        """Adam moments and device step counters as they are BEFORE the warm-up / capture iterations: a resumed run
+        (optimizer.load_state_dict before the first step, src/tools/train.py:50) must keep them."""
         st = self.optimizer.state.get("flat")
-        if st:
-            st["exp_avg"].zero_()
-            st["exp_avg_sq"].zero_()
-        for d in self.optimizer._dev.values():
-            d["step"].zero_()
+        moments = {k: st[k].clone() for k in ("exp_avg", "exp_avg_sq")} if st and "exp_avg" in st else None
+        steps = {gi: d["step"].clone() for gi, d in self.optimizer._dev.items()}
+        return moments, steps
+
+    def _optimizer_restore(self, snap):
+        """Undo the warm-up iteration on the optimizer side (weights / BN buffers are restored by ``__call__``)."""
+        moments, steps = snap
+        st = self.optimizer.state.get("flat")
+        if st and "exp_avg" in st:
+            for k in ("exp_avg", "exp_avg_sq"):
+                st[k].copy_(moments[k]) if moments is not None else st[k].zero_()
+        for gi, d in self.optimizer._dev.items():
+            d["step"].copy_(steps[gi]) if gi in steps else d["step"].zero_()
 
     def sync_hyper(self):
         """Push lr / betas / eps changes (e.g. CosineAnnealingLR.step()) to the device-side Adam state."""
@@ -157,7 +164,9 @@ class TrainStep:
             if self.graphs is None:
                 snap = self.arena.flat.clone()
                 bufs = {k: v.clone() for k, v in self.model.named_buffers()}
+                opt_snap = self._optimizer_snapshot()
                 self._capture()
+                self._optimizer_restore(opt_snap)
                 self.arena.flat.copy_(snap)                       # warm-up / capture must not train
                 for k, v in self.model.named_buffers():
                     v.copy_(bufs[k])

@@ -128,8 +128,31 @@ def validate(model, loader, args):
             pck, esum, ecnt = device_pck_epe(kp, joints, T=0.2)
             acc += torch.stack([loss * b, torch.tensor(float(b), device="cuda"), pck * b, esum, ecnt])
     model.train()
-    a = acc.tolist()                               # the only host read of the validation pass
+    return reduce_validation(acc)
+
+
+def reduce_validation(acc):
+    """acc = [loss*b, b, pck*b, epe sum, epe count] of THIS rank's validation shard.  Summed over the data-parallel
+    ranks first, so every rank derives the same (loss, pck, epe) and therefore the same best-checkpoint / early-stop
+    decision: a rank leaving the epoch loop alone would leave the others inside the next bucketed all-reduce."""
+    from lighthand_amd import parallel
+    a = parallel.all_reduce_sum_(acc).tolist()     # the only host read of the validation pass
     return a[0] / max(a[1], 1), 100.0 * a[2] / max(a[1], 1), a[3] / max(a[4], 1)
+
+
+class EarlyStop:
+    """best-loss / patience bookkeeping of the reference loop (src/tools/train.py:84-112)."""
+
+    def __init__(self, best_loss, count, patience):
+        self.best_loss, self.count, self.patience = best_loss, count, patience
+
+    def update(self, val_loss):
+        """Returns (improved, stop)."""
+        if self.best_loss > val_loss:
+            self.best_loss, self.count = val_loss, 0
+            return True, False
+        self.count += 1
+        return False, self.count == self.patience
 
 
 def main(args):
@@ -165,6 +188,7 @@ def main(args):
     if opt_state and not args.optim:                      # src/tools/train.py:50
         optimizer.load_state_dict(opt_state)
 
+    stopper = EarlyStop(best_loss, count, args.count)
     for epoch in range(epo, args.epoch):
         t0, seen, running = time.time(), 0, None
         for it, (images, joints) in enumerate(train_loader):
@@ -178,15 +202,13 @@ def main(args):
         val_loss, pck, epe = validate(model, val_loader, args)
         if rank == 0:
             print(f"epoch {epoch} valid loss {val_loss:.6f} pck {pck:.2f}% epe {epe * 0.26:.2f} mm")     # method.py:131
-        if best_loss > val_loss:
-            best_loss, count = val_loss, 0
-            save_checkpoint(model, args, epoch, optimizer, best_loss, count, "good")
-        else:
-            count += 1
-            if count == args.count:
-                break
+        improved, stop = stopper.update(val_loss)     # val_loss is rank-invariant (reduce_validation): collective decision
+        if improved:
+            save_checkpoint(model, args, epoch, optimizer, stopper.best_loss, stopper.count, "good")
+        if stop:
+            break
         scheduler.step()
-    return best_loss
+    return stopper.best_loss
 
 
 if __name__ == "__main__":

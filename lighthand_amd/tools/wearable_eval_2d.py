@@ -43,16 +43,29 @@ class SyntheticEvalSet(torch.utils.data.Dataset):
         return self.images[i], self.joints[i], self.cats[i]
 
 
+class _Steps:
+    """One captured InferStep per batch size met: the last, short batch runs AS IS like in the reference loop
+    (argparser.py:258-262) -- padding it would put foreign samples into the BatchNorm batch statistics that
+    ``pred_store``'s train-mode forward uses, and into the running-statistics update."""
+
+    def __init__(self, model, size, bn_train):
+        self.model, self.size, self.bn_train, self.steps = model, size, bn_train, {}
+
+    def __call__(self, images):
+        from lighthand_amd.runtime import InferStep
+        n = images.shape[0]
+        step = self.steps.get(n)
+        if step is None:
+            step = self.steps[n] = InferStep(self.model, n, self.size, self.size, bn_train=self.bn_train)
+        return step(images.cuda(non_blocking=True))
+
+
 def pred_store(model, loader, out_json, batch, size, bn_train=True):
     """src/utils/argparser.py:246-281 with the forward + arg-max decode on the device."""
-    from lighthand_amd.runtime import InferStep
     meta = {c: {"bb": [], "pred": [], "gt": []} for c in CATEGORIES}
-    step = InferStep(model, batch, size, size, bn_train=bn_train)
+    step = _Steps(model, size, bn_train)
     for images, joints_v, cats in loader:
-        n = images.shape[0]
-        if n != batch:                                   # static-shape graph: pad the last batch
-            images = torch.cat([images, images[:1].expand(batch - n, -1, -1, -1)])
-        preds = step(images.cuda(non_blocking=True)).cpu()[:n]              # already x4 (method.py:157)
+        preds = step(images).cpu()                       # already x4 (method.py:157)
         gt = joints_v[:, :, :2]
         w = gt[..., 0].max(1).values - gt[..., 0].min(1).values
         h = gt[..., 1].max(1).values - gt[..., 1].min(1).values
@@ -73,14 +86,10 @@ def device_eval(model, loader, batch, size, bn_train=True):
     the host once.  Returns {(type, T1): [auc, epe_mm, curve]}; the AUC equals pred_eval's 'mean_auc' AUC (whose EPE is
     diluted by the reference's zeros quirk; the EPE here is the plain mean)."""
     from lighthand_amd.metrics import auc_from_counts, device_pck_curve
-    from lighthand_amd.runtime import InferStep
-    step = InferStep(model, batch, size, size, bn_train=bn_train)
+    step = _Steps(model, size, bn_train)
     acc = {(t, tuple(T)): None for t, T in THRESHOLDS}
     for images, joints_v, _ in loader:
-        n = images.shape[0]
-        if n != batch:
-            images = torch.cat([images, images[:1].expand(batch - n, -1, -1, -1)])
-        preds = step(images.cuda(non_blocking=True))[:n]
+        preds = step(images)
         gt = joints_v.cuda(non_blocking=True)
         w = gt[..., 0].max(1).values - gt[..., 0].min(1).values
         h = gt[..., 1].max(1).values - gt[..., 1].min(1).values

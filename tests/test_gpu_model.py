@@ -199,52 +199,6 @@ def test_reduced_precision_trains_like_fp32(precision):
     assert abs(b[-1] - a[-1]) < 0.25 * a[-1]
 
 
-def _grads_with_env(tag, precision, env, monkeypatch, expect_fused):
-    from lighthand_amd.heatmap import JointsMSELoss
-    for k in ("LH_BNTAP", "LH_NO_TAILTAP", "LH_NO_FLAT"):
-        monkeypatch.delenv(k, raising=False)
-    for k in env:
-        monkeypatch.setenv(k, "1")
-    rng = np.random.RandomState(3)
-    x = torch.from_numpy(rng.randn(4, 3, 64, 64).astype(np.float32)).cuda()
-    torch.manual_seed(0)
-    model, _ = _build(tag)
-    model = model.cuda().train().set_precision(precision)
-    out = model(x)
-    JointsMSELoss(False)(out, torch.zeros_like(out), None).backward()
-    plan = next(iter(model._lh_plans.values()))
-    fused_calls = sum(1 for c in plan.bwd if "BN-bwd reduce" in c.what)
-    assert (fused_calls > 0) == expect_fused
-    return {k: p.grad.detach().double().cpu().numpy().copy() for k, p in model.named_parameters()}
-
-
-def _tensor_diffs(a, b):
-    return np.array([np.abs(a[k] - b[k]).max() / (np.abs(b[k]).max() + 1e-20) for k in b])
-
-
-@pytest.mark.parametrize("tag", ["r18", "r50", "hrnet_w32"])
-def test_fused_bn_backward_reduce_matches_separate_pass(tag, monkeypatch):
-    """Opt-in path (LH_BNTAP=1).  conv -> BN -> ReLU -> conv chains and residual tails: the data-gradient kernel that
-    finishes an activation's gradient also produces the BN-backward sums (lh_igemm_bntap).  Same arithmetic as lh_fuse_bwd's own reduce pass up to the fp32 summation order inside a tile:
-    in fp32 every parameter gradient agrees to 1e-4 of its tensor's scale (measured <= 1e-5)."""
-    fused = _grads_with_env(tag, "fp32", ["LH_BNTAP"], monkeypatch, True)
-    separate = _grads_with_env(tag, "fp32", [], monkeypatch, False)
-    d = _tensor_diffs(fused, separate)
-    print(tag, "worst rel diff", d.max())
-    assert d.max() < 1e-4
-
-
-def test_fused_bn_backward_reduce_bf16_within_summation_noise(monkeypatch):
-    """In bf16 a 1e-7 change of a BN-backward coefficient flips the rounding of a few stored gradients, and the
-    backward chain of a random-init network amplifies that to percents in the first layers -- for ANY reordering of the
-    sums.  Yardstick: the separate pass with its generic (LH_NO_FLAT) reduce kernel, which also only reorders sums."""
-    separate = _grads_with_env("r50", "bf16", [], monkeypatch, False)
-    fused = _tensor_diffs(_grads_with_env("r50", "bf16", ["LH_BNTAP"], monkeypatch, True), separate)
-    yard = _tensor_diffs(_grads_with_env("r50", "bf16", ["LH_NO_FLAT"], monkeypatch, False), separate)
-    print("bf16 fused-vs-separate median/max", np.median(fused), fused.max(), "| reorder yardstick", np.median(yard), yard.max())
-    assert np.median(fused) < 3 * np.median(yard) + 1e-4 and fused.max() < 3 * yard.max() + 1e-3
-
-
 @pytest.mark.parametrize("tag,shape", [("r18", (3, 3, 96, 160)), ("r34", (1, 3, 64, 64)), ("r50", (5, 3, 128, 96)),
                                        ("r50caffe", (2, 3, 192, 64)), ("hrnet_w32", (3, 3, 64, 96)), ("hrnet_w48", (1, 3, 128, 128))])
 def test_forward_odd_shapes_match_oracle(tag, shape):
@@ -269,3 +223,58 @@ def test_forward_odd_shapes_match_oracle(tag, shape):
     assert got_tr.shape == want_tr.shape == (shape[0], 21, shape[2] // 4, shape[3] // 4)
     assert rel(got_tr, want_tr) < FP32_REL and rel(got_ev, want_ev) < FP32_REL
     assert rel(got_bf, want_ev) < 5e-2
+
+
+def _trained_like(sd, g=0.05, seed=3):
+    """Weights in the regime of a TRAINED residual network: BN gains random in [0.5, 1.5] except the last BN of every
+    residual branch (x g: the branch is a small correction of its shortcut), BN offsets ~ 0.2 N(0,1).  Gradients of such a
+    network are well conditioned (CPU fp32 vs fp64: global rel-L2 2.6e-4 for R50, 4.6e-4 for HRNet-W32), unlike the
+    default random init, whose train-mode BN stack amplifies rounding noise to percents."""
+    rng = np.random.RandomState(seed)
+    out = {}
+    for k, v in sd.items():
+        v = v.detach().clone()
+        if v.dim() == 1 and k.endswith(".weight"):
+            last = k.endswith("bn3.weight") or (".bn2.weight" in k and (k[:-len("bn2.weight")] + "bn3.weight") not in sd)
+            v = torch.from_numpy(((g if last else 1.0) * (0.5 + rng.rand(v.numel()))).astype(np.float32))
+        elif v.dim() == 1 and k.endswith(".bias") and k.replace(".bias", ".running_mean") in sd:
+            v = torch.from_numpy((0.2 * rng.randn(v.numel())).astype(np.float32))
+        out[k] = v
+    return out
+
+
+@pytest.mark.parametrize("tag", ["r50", "r50caffe", "hrnet_w32"])
+def test_gradients_well_conditioned_case_at_1e3(tag):
+    """Whole-model dL/dtheta at the north-star tolerance: on trained-like weights (see _trained_like) the HIP fp32
+    gradients agree with the fp64 oracle to 1e-3 in global relative L2 (every parameter tensor of the model in one
+    vector), and per tensor they are as accurate as the CPU fp32 oracle (median within 2x)."""
+    from oracle import models as omod
+    from lighthand_amd.heatmap import JointsMSELoss
+    torch.manual_seed(11)
+    model, fwd = _build(tag)
+    model.load_state_dict(_trained_like(model.state_dict()))
+    rng = np.random.RandomState(5)
+    b, h, w = 4, 128, 128
+    x = torch.from_numpy(rng.randn(b, 3, h, w).astype(np.float32))
+    tgt = torch.from_numpy(rng.rand(b, 21, h // 4, w // 4).astype(np.float32))
+    sd = omod.clone_state(model.state_dict())
+    loss_ref, pred_ref, g32 = omod.loss_and_grads(sd, lambda s, xx: fwd(s, xx, True), x, tgt)
+    sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in model.state_dict().items()}
+    _, _, g64 = omod.loss_and_grads(sd64, lambda s, xx: fwd(s, xx, True), x.double(), tgt.double())
+    model = model.cuda().train()
+    pred = model(x.cuda())
+    loss = JointsMSELoss(False)(pred, tgt.cuda(), None)
+    loss.backward()
+    assert abs(float(loss.detach()) - loss_ref) < 1e-4 * abs(loss_ref)
+    assert rel(pred.detach().cpu().numpy(), pred_ref.numpy()) < FP32_REL
+    num_h = num_c = den = 0.0
+    eh, ec = [], []
+    for k, p in model.named_parameters():
+        gh, gc, gt = p.grad.cpu().double().numpy(), g32[k].double().numpy(), g64[k].numpy()
+        eh.append(rel(gh, gt)); ec.append(rel(gc, gt))
+        num_h += ((gh - gt) ** 2).sum(); num_c += ((gc - gt) ** 2).sum(); den += (gt ** 2).sum()
+    l2_h, l2_c = (num_h / den) ** 0.5, (num_c / den) ** 0.5
+    print(f"{tag} (trained-like weights): grad error vs fp64 oracle: global rel-L2 HIP fp32 {l2_h:.3e} / CPU fp32 {l2_c:.3e}; "
+          f"per-tensor median {np.median(eh):.3e} / {np.median(ec):.3e}, max {max(eh):.3e} / {max(ec):.3e}")
+    assert l2_h < FP32_REL
+    assert np.median(eh) <= 2 * np.median(ec) + 1e-5

@@ -16,6 +16,15 @@ def rel_err(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-12))
 
 
+_QT = {"bf16": torch.bfloat16, "fp16": torch.float16}
+
+
+def quant(t, precision):
+    """Round a fp32 tensor to the run precision's grid (identity for fp32): the reference side of a 16-bit case sees the
+    same stored operands as the HIP side, so the tolerance covers accumulation and output rounding only."""
+    return t.to(_QT[precision]).float() if precision in _QT else t
+
+
 def _mods():
     from lighthand_amd.module import HipModule
 
@@ -111,7 +120,7 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_fwd_bwd(case, precision):
     ConvNet, _ = _mods()
@@ -119,17 +128,16 @@ def test_conv_fwd_bwd(case, precision):
     torch.manual_seed(1)
     m = ConvNet(cin, cout, k, s, p, bias=(cout == 21))
     x = torch.randn(n, cin, h, w)
-    xq = x.to(torch.bfloat16).float() if precision == "bf16" else x
+    xq = quant(x, precision)
     ref_m = nn.Conv2d(cin, cout, k, s, p, bias=(cout == 21))
     ref_m.load_state_dict(m.conv.state_dict())
-    if precision == "bf16":
-        with torch.no_grad():
-            ref_m.weight.copy_(ref_m.weight.to(torch.bfloat16).float())
+    with torch.no_grad():
+        ref_m.weight.copy_(quant(ref_m.weight, precision))
     xr = xq.clone().requires_grad_(True)
     ref = ref_m(xr)
     torch.manual_seed(2)
     dy = torch.randn_like(ref)
-    dyq = dy.to(torch.bfloat16).float() if precision == "bf16" else dy
+    dyq = quant(dy, precision)
     ref.backward(dyq)
     out, dx, grads = _run_plan(m, xq, lambda o: dy, precision)
     tol = TOL[precision]
@@ -140,56 +148,86 @@ def test_conv_fwd_bwd(case, precision):
         assert rel_err(grads["conv.bias"], ref_m.bias.grad) < tol
 
 
-@pytest.mark.parametrize("case", [(256, 256, 3, 1, 1, 2, 16, 16), (512, 256, 1, 1, 0, 3, 12, 20), (256, 512, 3, 2, 1, 2, 16, 16)])
-def test_conv_256_tile_matches_torch(case, monkeypatch):
-    """The 256 x 256 (8-wave) convolution tile, forced on small layers (LH_TILE_MIN_256=1): forward, data gradient and
-    BN statistics path against PyTorch, and against the default tiles on the same inputs."""
+@pytest.fixture
+def forced_plans():
+    """Lets a test pick the kernel configuration of every launch of the plans it builds (engine.Plan.force_cfg /
+    force_wgrad: the autotuner's measurement is replaced by the test's choice)."""
+    from lighthand_amd.engine import Plan
+    yield Plan
+    Plan.force_cfg = Plan.force_wgrad = None
+
+
+CFG_CASES = [(256, 256, 3, 1, 1, 2, 16, 16), (512, 256, 1, 1, 0, 3, 12, 20), (256, 512, 3, 2, 1, 2, 16, 16), (64, 128, 3, 1, 1, 2, 20, 12)]
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+@pytest.mark.parametrize("case", CFG_CASES)
+def test_every_conv_kernel_configuration(case, precision, forced_plans):
+    """Every compiled-in configuration of the LDS-DMA convolution kernel (tile 64..256, ring depth, 64- / 128-byte
+    stages: lh_igemm_candidates) that fits the launch, forced in turn on forward and data gradient: each must match
+    PyTorch, and all must agree BIT FOR BIT with one another (the K-loop order does not depend on the tile)."""
     ConvNet, _ = _mods()
     cin, cout, k, s_, p, n, h, w = case
     torch.manual_seed(5)
-    x = torch.randn(n, cin, h, w).to(torch.bfloat16).float()
+    x = quant(torch.randn(n, cin, h, w), precision)
     ref_m = nn.Conv2d(cin, cout, k, s_, p, bias=False)
     with torch.no_grad():
-        ref_m.weight.copy_(ref_m.weight.to(torch.bfloat16).float())
+        ref_m.weight.copy_(quant(ref_m.weight, precision))
     xr = x.clone().requires_grad_(True)
     ref = ref_m(xr)
-    dy = torch.randn_like(ref).to(torch.bfloat16).float()
+    dy = quant(torch.randn_like(ref), precision)
     ref.backward(dy)
-    res = {}
-    for mode in ("1", "0"):
-        monkeypatch.setenv("LH_TILE_MIN_256", mode)
+    seen, first = [], None
+    idx = 0
+    while True:
+        chosen = []
+
+        def pick(cands, idx=idx, chosen=chosen):
+            c = cands[idx % len(cands)]
+            chosen.append((c, len(cands)))
+            return c
+        forced_plans.force_cfg = pick
         m = ConvNet(cin, cout, k, s_, p, bias=False)
         m.conv.load_state_dict(ref_m.state_dict())
-        res[mode] = _run_plan(m, x, lambda o: dy, "bf16")
-        plan = next(iter(m._lh_plans.values()))
-        names = [meta[2] for meta in plan.profile_meta if meta[2].startswith("igemm")]
-        assert any("256, 256" in nm for nm in names) == (mode == "1"), names
-    out, dx, _ = res["1"]
-    assert rel_err(out, ref.detach()) < TOL["bf16"] and rel_err(dx, xr.grad) < TOL["bf16"]
-    assert rel_err(out, res["0"][0]) < 1e-2 and rel_err(dx, res["0"][1]) < 1e-2
+        out, dx, _ = _run_plan(m, x, lambda o: dy, precision)
+        assert chosen, "no launch of this plan offered candidates"
+        seen.append(tuple(c for c, _ in chosen))
+        assert rel_err(out, ref.detach()) < TOL[precision] and rel_err(dx, xr.grad) < TOL[precision], chosen
+        if first is None:
+            first = (out, dx)
+        else:
+            assert torch.equal(out, first[0]) and torch.equal(dx, first[1]), chosen
+        idx += 1
+        if idx >= max(nc for _, nc in chosen):
+            break
+    tiles = {c[0][:2] for c in seen}
+    print(case, precision, len(seen), "configurations, forward tiles", sorted(tiles))
+    assert len(seen) >= 3
+    if precision == "bf16" and cout % 256 == 0:
+        assert (256, 256) in tiles
 
 
-def test_conv_256_tile_bn_statistics(monkeypatch):
-    """conv -> BN -> ReLU (+ residual) with the 256 x 256 tile forced: the tile's epilogue writes the BN partial sums, so
-    running statistics, BN parameter gradients and the data gradient must equal the default tiles' (bf16: same stored
-    activations, fp32 folds) and PyTorch's within the 16-bit tolerance."""
+def test_conv_tile_bn_statistics(forced_plans):
+    """conv -> BN -> ReLU (+ residual) with the largest and the smallest tile forced: the tile's epilogue writes the BN
+    partial sums (one slab row per pixel tile), so running statistics, BN parameter gradients and the data gradient must
+    agree between the two (bf16: same stored activations, fp32 folds) and with PyTorch within the 16-bit tolerance."""
     import copy
     _, BnNet = _mods()
     for mode in ("plain", "residual"):
         torch.manual_seed(7)
         proto = BnNet(256, mode)
         x = torch.randn(2, 256, 16, 16).to(torch.bfloat16).float()
-        dy = None
         res = {}
-        for tile in ("1", "0"):
-            monkeypatch.setenv("LH_TILE_MIN_256", tile)
+        for which in ("big", "small"):
+            forced_plans.force_cfg = (lambda cands: max(cands, key=lambda c: (c[0] * c[1], c[3]))) if which == "big" else \
+                (lambda cands: min(cands, key=lambda c: (c[0] * c[1], c[3])))
             m = copy.deepcopy(proto)
             torch.manual_seed(8)
             out, dx, grads = _run_plan(m, x, lambda o: torch.randn_like(o), "bf16")
-            res[tile] = (out, dx, grads, {k: v.cpu().clone() for k, v in m.state_dict().items() if "running" in k})
+            res[which] = (out, dx, grads, {k: v.cpu().clone() for k, v in m.state_dict().items() if "running" in k})
             plan = next(iter(m._lh_plans.values()))
-            assert any("256, 256" in meta[2] for meta in plan.profile_meta if meta[2].startswith("igemm")) == (tile == "1")
-        a, b = res["1"], res["0"]
+            assert any("256, 256" in meta[2] for meta in plan.profile_meta if meta[2].startswith("igemm")) == (which == "big")
+        a, b = res["big"], res["small"]
         assert rel_err(a[0], b[0]) < 1e-2 and rel_err(a[1], b[1]) < 2e-2
         for k in a[3]:
             assert rel_err(a[3][k], b[3][k]) < 1e-5, k
@@ -200,34 +238,49 @@ def test_conv_256_tile_bn_statistics(monkeypatch):
         assert rel_err(a[0], y.detach()) < TOL["bf16"]
 
 
-def test_wgrad_big_tile_matches_small_tile(monkeypatch):
-    """The 256 x 256 (8-wave) weight-gradient tile is chosen by a cost model only for large layers; forced on a small
-    256->256 3x3 layer (LH_WGRAD_BIG=2) it must give the gradient of the 128 x 128 tile (LH_WGRAD_BIG=0) up to the fp32
-    summation order of the pixel splits, and both must match PyTorch."""
+@pytest.mark.parametrize("case", [(256, 256, 3, 1, 1, 2, 16, 16), (64, 128, 3, 2, 1, 3, 20, 12), (512, 256, 1, 1, 0, 2, 8, 8)])
+def test_every_wgrad_kernel_plan(case, forced_plans):
+    """Every launch plan of the LDS-DMA weight-gradient kernel (tile, 32- / 64-row stages, ring depth, pixel splits:
+    lh_wgrad_candidates) forced in turn: each matches PyTorch, all agree up to the fp32 summation order of the pixel
+    splits, and a plan run twice gives the same bits."""
     ConvNet, _ = _mods()
+    cin, cout, k, s_, p, n, h, w = case
     torch.manual_seed(3)
-    x = torch.randn(2, 256, 16, 16).to(torch.bfloat16).float()
-    ref_m = nn.Conv2d(256, 256, 3, 1, 1, bias=False)
+    x = torch.randn(n, cin, h, w).to(torch.bfloat16).float()
+    ref_m = nn.Conv2d(cin, cout, k, s_, p, bias=False)
     with torch.no_grad():
         ref_m.weight.copy_(ref_m.weight.to(torch.bfloat16).float())
     ref = ref_m(x)
     dy = torch.randn_like(ref).to(torch.bfloat16).float()
     ref.backward(dy)
-    grads = {}
-    for mode in ("2", "0"):
-        monkeypatch.setenv("LH_WGRAD_BIG", mode)
-        m = ConvNet(256, 256, 3, 1, 1, bias=False)
-        m.conv.load_state_dict(ref_m.state_dict())
-        _, _, g = _run_plan(m, x, lambda o: dy, "bf16")
-        grads[mode] = g["conv.weight"]
-        plan = next(iter(m._lh_plans.values()))
-        names = [meta[2] for meta in plan.profile_meta if "wgrad" in meta[2]]
-        assert any("256, 256" in n for n in names) == (mode == "2"), names
-    assert rel_err(grads["2"], grads["0"]) < 1e-5
-    assert rel_err(grads["2"], ref_m.weight.grad) < TOL["bf16"]
+    grads, idx, ncand = [], 0, 1
+    while idx < ncand:
+        chosen = []
+
+        def pick(cands, idx=idx, chosen=chosen):
+            chosen.append((cands[idx % len(cands)], len(cands)))
+            return cands[idx % len(cands)][:3]
+        forced_plans.force_wgrad = pick
+        both = []
+        for _ in range(2):
+            m = ConvNet(cin, cout, k, s_, p, bias=False)
+            m.conv.load_state_dict(ref_m.state_dict())
+            both.append(_run_plan(m, x, lambda o: dy, "bf16")[2]["conv.weight"])
+        assert torch.equal(both[0], both[1]), chosen[0]
+        assert rel_err(both[0], ref_m.weight.grad) < TOL["bf16"], chosen[0]
+        grads.append((chosen[0][0], both[0]))
+        ncand = chosen[0][1]
+        idx += 1
+    for cfg, g in grads[1:]:
+        assert rel_err(g, grads[0][1]) < 1e-5, cfg
+    tiles = {c[:2] for c, _ in grads}
+    print(case, len(grads), "plans, tiles", sorted(tiles))
+    assert len(grads) >= 6
+    if cin % 256 == 0 and cout % 256 == 0:
+        assert (256, 256) in tiles
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("case", [(64, 32, 4, 2, 8, 8), (128, 64, 4, 1, 6, 10), (32, 32, 3, 1, 4, 4), (32, 16, 2, 1, 4, 4)])
 def test_deconv_fwd_bwd(case, precision):
     ConvNet, _ = _mods()
@@ -235,17 +288,15 @@ def test_deconv_fwd_bwd(case, precision):
     torch.manual_seed(3)
     m = ConvNet(cin, cout, k, 2, 1, transposed=True)
     x = torch.randn(n, cin, h, w)
-    xq = x.to(torch.bfloat16).float() if precision == "bf16" else x
-    wt = m.conv.weight.detach().clone()
-    if precision == "bf16":
-        wt = wt.to(torch.bfloat16).float()
+    xq = quant(x, precision)
+    wt = quant(m.conv.weight.detach().clone(), precision)
     wt.requires_grad_(True)
     xr = xq.clone().requires_grad_(True)
     pad, opad = {4: (1, 0), 3: (1, 1), 2: (0, 0)}[k]
     ref = F.conv_transpose2d(xr, wt, None, 2, pad, opad)
     torch.manual_seed(4)
     dy = torch.randn_like(ref)
-    dyq = dy.to(torch.bfloat16).float() if precision == "bf16" else dy
+    dyq = quant(dy, precision)
     ref.backward(dyq)
     out, dx, grads = _run_plan(m, xq, lambda o: dy, precision)
     tol = TOL[precision]

@@ -74,3 +74,45 @@ def test_init_distributed_single_process_is_noop(monkeypatch):
         monkeypatch.delenv(k, raising=False)
     assert parallel.init_distributed() == (0, 1, 0)
     assert not dist.is_initialized()
+
+
+def _val_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from lighthand_amd import parallel
+    from lighthand_amd.tools import train as T
+    parallel.init_distributed(backend="gloo")
+    stopper = T.EarlyStop(float("inf"), 0, patience=2)
+    # per-rank validation sums that would rank the epochs DIFFERENTLY on the two ranks (per-rank BN statistics):
+    # rank 0 sees losses 1.0, 0.8, 0.9, 0.95 ; rank 1 sees 1.0, 1.1, 0.7, 1.2  ->  joint 1.0, 0.95, 0.8, 1.075, ...
+    local = {0: [1.0, 0.8, 0.9, 0.95, 0.96], 1: [1.0, 1.1, 0.7, 1.2, 1.3]}[rank]
+    trace = []
+    for epoch, l in enumerate(local):
+        acc = torch.tensor([l * 8, 8.0, 4.0, 10.0, 19.0 * 8])
+        val_loss, pck, epe = T.reduce_validation(acc)
+        improved, stop = stopper.update(val_loss)
+        trace.append((round(val_loss, 6), improved, stop))
+        # a real loop would now enter the next epoch's bucketed all-reduce: every rank must still be here
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        assert int(t) == world
+        if stop:
+            break
+    q.put((rank, trace))
+    dist.destroy_process_group()
+
+
+def test_validation_decisions_are_collective_gloo_world2():
+    """Early stop / best-checkpoint decisions come from the all-reduced validation sums, so the ranks leave the epoch
+    loop together (a rank leaving alone would deadlock the others' gradient all-reduce)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_val_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0] == res[1]
+    assert [t[0] for t in res[0]] == [1.0, 0.95, 0.8, 1.075, 1.13] and res[0][-1][2] is True
