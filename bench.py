@@ -24,11 +24,46 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 METRIC = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
-# conv/deconv FLOPs per image (x2 per MAC), R50 @ 256x256
+# SURVEY.md section 8(d) / BASELINE.md section 3: algorithmic work per image -- conv/deconv FLOPs (x2 per MAC) and
+# ideal-fusion activation traffic at 2 bytes per element: (fwd GFLOP, train GFLOP, fwd MB, train MB)
+WORK = {
+    ("r18", 256): (7.734, 22.895, 17.9, 53.8),
+    ("r50", 256): (14.479, 43.128, 62.8, 188.5),
+    ("r50", 384): (32.577, 97.038, 141.4, 424.1),
+    ("hrnet32", 256): (20.388, 61.107, 107.2, 321.5),
+    ("hrnet48", 256): (41.846, 125.483, 142.9, 428.7),
+}
 TRAIN_GFLOP_PER_IMG = 43.128
 FWD_GFLOP_PER_IMG = 14.479
-PEAK_BF16_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA
+PEAK_BF16_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA
 PEAK_HBM_GBS = 8000.0
+
+
+def step_roofline(key, train, images_per_s, es=2):
+    """Whole-step roofline fractions: algorithmic FLOPs vs the dense MFMA peak, algorithmic bytes vs the
+    HBM peak, and the measured time against the governing (larger) of the two lower bounds."""
+    w = WORK.get(key)
+    if w is None or images_per_s <= 0:
+        return None
+    gflop, mb = (w[1], w[3]) if train else (w[0], w[2])
+    mb = mb * es / 2
+    t = 1.0 / images_per_s                                  # seconds per image
+    t_mfma, t_hbm = gflop * 1e9 / (PEAK_BF16_TFLOPS * 1e12), mb * 1e6 / (PEAK_HBM_GBS * 1e9)
+    return {"mfma_frac": round(t_mfma / t, 4), "hbm_frac": round(t_hbm / t, 4),
+            "governing": "hbm" if t_hbm >= t_mfma else "mfma", "frac": round(max(t_mfma, t_hbm) / t, 4),
+            "achieved_tflops": round(gflop * images_per_s / 1e3, 1), "achieved_gbs": round(mb * images_per_s / 1e3, 1),
+            "gflop_per_image": gflop, "mb_per_image": mb}
+
+
+def timed_replays(fn, warmup, steps):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
 
 
 def build_model(depth=50, precision="bf16", hrnet_width=0):
@@ -94,7 +129,7 @@ def profile_kernels(step, iters=3, plan=None, fwd_only=False):
     return agg
 
 
-def cpu_baseline(depth, size, batch, seconds_budget=25.0):
+def cpu_baseline(depth, size, batch, seconds_budget=25.0, cores=None):
     """The oracle (plain PyTorch fp32 on the host cores) running the same training step on a
     bounded sample of the workload."""
     from oracle import heatmap as oh
@@ -106,7 +141,7 @@ def cpu_baseline(depth, size, batch, seconds_budget=25.0):
                NUM_DECONV_KERNELS=[4] * 3, FINAL_CONV_KERNEL=1)
     torch.manual_seed(9001)
     sd = omod.clone_state(get_pose_net(ns(MODEL=ns(EXTRA=extra, STYLE="pytorch")), True).state_dict())
-    cores = min(16, len(os.sched_getaffinity(0)))          # the GPU box gives one GPU a 16-core CPU share
+    cores = cores or min(16, len(os.sched_getaffinity(0)))   # the GPU box gives one GPU a 16-core CPU share
     torch.set_num_threads(cores)
     rng = np.random.RandomState(9001)
     x = torch.from_numpy(rng.randn(batch, 3, size, size).astype(np.float32))
@@ -125,7 +160,7 @@ def cpu_baseline(depth, size, batch, seconds_budget=25.0):
     while True:
         one()
         n += 1
-        if time.time() - t0 > seconds_budget * 0.6 or n >= 3:
+        if time.time() - t0 > seconds_budget * 0.6 or n >= (3 if batch >= 16 else 10):
             break
     dt = (time.time() - t0) / n
     return dict(value=round(batch / dt, 2), unit="images/s", cores=cores, kind="port",
@@ -146,6 +181,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra configurations (HRNet-W32 training, R50 384x384 fp16 inference)")
     args = ap.parse_args()
 
     from lighthand_amd import parallel
@@ -171,11 +207,13 @@ def main():
             inf()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        key = (f"hrnet{args.hrnet_width}" if args.hrnet_width else f"r{args.depth}", args.size)
         print(json.dumps({"metric": METRIC, "value": round(args.batch * args.steps / dt, 1), "unit": "images/s", "n_gpus": 1,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
                           "config": {"workload": f"{name} {args.size}x{args.size} inference (eval-mode forward, BN folded, + argmax decode), "
-                                                 f"batch {args.batch}, hipGraph replay"}}))
+                                                 f"batch {args.batch}, hipGraph replay"},
+                          "step_roofline": step_roofline(key, False, args.batch * args.steps / dt, 4 if args.precision == "fp32" else 2)}))
         return
     sync = parallel.GradSync(world) if world > 1 else None
     step = TrainStep(model, args.batch, args.size, args.size, lr=1e-3, use_graph=not args.no_graph, grad_sync=sync)
@@ -215,6 +253,11 @@ def main():
         "loss_after": round(loss_val, 6),
         "train_tflops": round(value * (TRAIN_GFLOP_PER_IMG if (args.depth, args.size) == (50, 256) else 0) / 1e3, 1),
     }
+    wkey = (f"hrnet{args.hrnet_width}" if args.hrnet_width else f"r{args.depth}", args.size)
+    es = 4 if args.precision == "fp32" else 2
+    # whole-step roofline: per-GPU rate against the per-GPU peaks (2.760 TFLOP / 12.06 GB per R50 bs64 step)
+    out["step_roofline"] = step_roofline(wkey, True, value / world, es)
+    out["c_abi_calls_per_step"] = sum(1 for c in step.plan.packs + step.plan.fwd + step.plan.bwd if hasattr(c, "fn")) + 4
 
     if rank == 0 and world == 1:
         # eval-mode forward + decode throughput (the "infer" half of the metric)
@@ -229,6 +272,7 @@ def main():
             inf()
         torch.cuda.synchronize()
         out["infer_images_per_s"] = round(args.batch * args.steps / (time.perf_counter() - t1), 1)
+        out["infer_step_roofline"] = step_roofline(wkey, False, out["infer_images_per_s"], es)
 
         if not args.no_roofline:
             agg = profile_kernels(step)
@@ -262,11 +306,11 @@ def main():
             # HBM bytes per launch of that kernel from the committed PMC passes of this same command
             # (profiles/README.md; tools/pmc_traffic.py applies the guide's KiB unit and gfx950 FETCH_SIZE x2 correction)
             try:
-                pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")))
+                pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")))
                 if name in pmc and args.depth == 50 and args.batch == 64 and args.size == 256 and args.precision == "bf16":
                     out["roofline"]["traffic"] = pmc[name]["read_bytes_per_launch"] + pmc[name]["write_bytes_per_launch"]
                     out["roofline"]["traffic_note"] = ("bytes per launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, corrected per the "
-                                                       "MI355X guide), profiles/r01_pmc_hbm_traffic.txt; algorithmic bytes per launch = "
+                                                       "MI355X guide), profiles/r02_pmc_hbm_traffic.txt; algorithmic bytes per launch = "
                                                        f"{int(d['bytes'] / d['launches'])}")
             except (OSError, ValueError, KeyError):
                 pass
@@ -277,8 +321,34 @@ def main():
             out["kernel_breakdown_ms"] = {k: [round(v["ms"], 3), v["launches"],
                                               round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] else None]
                                           for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
+        if not args.no_extra and (args.depth, args.size, args.batch, args.hrnet_width) == (50, 256, 64, 0):
+            # the other single-GPU configurations of BASELINE.json, timed the same way (hipGraph replays, inputs resident)
+            extra = {}
+            del inf
+            m4 = build_model(precision=args.precision, hrnet_width=32)                      # configs[3], one GPU's share
+            s4 = TrainStep(m4, 32, 256, 256, lr=1e-3)
+            im4, j4 = synthetic_batch(32, 256, dev)
+            s4.images.copy_(im4); s4.joints.copy_(j4)
+            dt4 = timed_replays(s4, 5, 20)
+            extra["hrnet_w32_train_bs32"] = {
+                "images_per_s": round(32 / dt4, 1), "ms_per_step": round(dt4 * 1e3, 3), "dtype": args.precision,
+                "c_abi_calls_per_step": sum(1 for c in s4.plan.packs + s4.plan.fwd + s4.plan.bwd if hasattr(c, "fn")) + 4,
+                "step_roofline": step_roofline(("hrnet32", 256), True, 32 / dt4, es)}
+            del s4, m4
+            m5 = build_model(50, "fp16").eval()                                             # configs[4]
+            i5 = InferStep(m5, 256, 384, 384)
+            i5.images.copy_(synthetic_batch(256, 384, dev)[0])
+            dt5 = timed_replays(i5, 3, 10)
+            extra["r50_infer_384_bs256_fp16"] = {"images_per_s": round(256 / dt5, 1), "ms_per_step": round(dt5 * 1e3, 3), "dtype": "fp16",
+                                                 "step_roofline": step_roofline(("r50", 384), False, 256 / dt5, 2)}
+            del i5, m5
+            out["extra"] = extra
         if not args.no_cpu_baseline:
+            # the oracle on the host cores: the headline workload on a bounded sample, and BASELINE.json configs[0]
+            # (R18, 256x256, bs 8) at 8 threads (comparable with BASELINE.md section 2) and at the box's core share
             out["cpu_baseline"] = cpu_baseline(args.depth, args.size, batch=16)
+            ncore = min(16, len(os.sched_getaffinity(0)))
+            out["cpu_baseline_c1"] = [cpu_baseline(18, 256, batch=8, seconds_budget=12.0, cores=c) for c in sorted({min(8, ncore), ncore})]
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

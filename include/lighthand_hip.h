@@ -55,6 +55,15 @@ int lh_image_to_nhwc4(const float* nchw, void* out, int n, int h, int w, int pad
  * float[3] arrays) -> zero-padded NHWC4 in the run dtype, i.e. the stem's input format. */
 int lh_image_u8_to_nhwc4(const unsigned char* hwc, void* out, int n, int hs, int ws, int h, int w, int pad, int wp,
                          const float* mean3, const float* std3, int dtype, void* stream);
+/* The same with torchvision's ColorJitter(brightness, contrast, saturation, hue) between Resize and Normalize -- the
+ * training transform of src/tools/dataset.py:134-146.  The random draw (ColorJitter.get_params) stays with the caller:
+ * factors_dev fp32 [n][4] = per-image brightness / contrast / saturation / hue factors, order_dev int32 [n][4] = the op
+ * order (op ids 0..3, a negative id skips: the reference jitters only a fraction of its samples).  workspace (device,
+ * lh_image_jitter_workspace_bytes(n)) holds the fp64 strip sums of the per-image grey mean the contrast op needs. */
+size_t lh_image_jitter_workspace_bytes(int n);
+int lh_image_u8_jitter_to_nhwc4(const unsigned char* hwc, void* out, int n, int hs, int ws, int h, int w, int pad, int wp,
+                                const float* mean3, const float* std3, const float* factors_dev, const int* order_dev,
+                                void* workspace, int dtype, void* stream);
 /* NHWC (run dtype) -> NCHW fp32 heatmaps (what model(images) returns, pose_resnet.py:246)
  * and the inverse for the incoming gradient. c_stride = channel stride of the NHWC side. */
 int lh_nhwc_to_nchw_f32(const void* nhwc, float* nchw, int n, int h, int w, int c, int c_stride,

@@ -62,6 +62,8 @@ SIGNATURES = {
     "lh_dtype_size": (_I, [_I]),
     "lh_image_to_nhwc4": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "lh_image_u8_to_nhwc4": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _I, _P]),
+    "lh_image_jitter_workspace_bytes": (_SZ, [_I]),
+    "lh_image_u8_jitter_to_nhwc4": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _P, _P, _P, _I, _P]),
     "lh_nhwc_to_nchw_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "lh_nchw_f32_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "lh_pack_weight": (_I, [_P, _P, C.POINTER(_SZ), _I, _I, _L, _L, _L, _L, _I, C.POINTER(_I), _I, _P]),

@@ -111,6 +111,150 @@ extern "C" int lh_image_u8_to_nhwc4(const unsigned char* hwc, void* out, int n, 
     return LH_OK;
 }
 
+// ---- the same pipeline with torchvision's ColorJitter between Resize and Normalize (src/tools/dataset.py:134-146).
+// The random draw stays on the host (ColorJitter.get_params): per image four factors (brightness, contrast,
+// saturation, hue) and the op order (four op ids 0..3, negative = skip) arrive as device arrays.  Contrast blends
+// with the mean grey level of the WHOLE image as it is when the op runs, so a first kernel reduces that mean (of the
+// image after the ops that precede contrast) into fp64 strip sums, and the second kernel applies everything.
+__device__ __forceinline__ float cj_clamp01(float v) { return fminf(fmaxf(v, 0.f), 1.f); }
+__device__ __forceinline__ float cj_gray(const float* c) { return 0.2989f * c[0] + 0.587f * c[1] + 0.114f * c[2]; }
+__device__ __forceinline__ void cj_blend(float* c, float o0, float o1, float o2, float r) {
+    c[0] = cj_clamp01(r * c[0] + (1.f - r) * o0);
+    c[1] = cj_clamp01(r * c[1] + (1.f - r) * o1);
+    c[2] = cj_clamp01(r * c[2] + (1.f - r) * o2);
+}
+__device__ __forceinline__ void cj_hue(float* c, float f) {
+    const float r = c[0], g = c[1], b = c[2];
+    const float maxc = fmaxf(r, fmaxf(g, b)), minc = fminf(r, fminf(g, b));
+    const bool eq = maxc == minc;
+    const float cr = maxc - minc;
+    const float s = cr / (eq ? 1.f : maxc);
+    const float div = eq ? 1.f : cr;
+    const float rc = (maxc - r) / div, gc = (maxc - g) / div, bc = (maxc - b) / div;
+    float h = 0.f;
+    if (maxc == r) h = bc - gc;
+    else if (maxc == g) h = 2.f + rc - bc;
+    else h = 4.f + gc - rc;
+    h = fmodf(h / 6.f + 1.f, 1.f);
+    h = fmodf(h + f, 1.f);
+    if (h < 0.f) h += 1.f;
+    const float h6 = h * 6.f;
+    const float fl = floorf(h6);
+    const float fr = h6 - fl;
+    int i = (int)fl % 6;
+    if (i < 0) i += 6;
+    const float v = maxc;
+    const float p = cj_clamp01(v * (1.f - s)), q = cj_clamp01(v * (1.f - s * fr)), t = cj_clamp01(v * (1.f - s * (1.f - fr)));
+    switch (i) {
+        case 0: c[0] = v; c[1] = t; c[2] = p; break;
+        case 1: c[0] = q; c[1] = v; c[2] = p; break;
+        case 2: c[0] = p; c[1] = v; c[2] = t; break;
+        case 3: c[0] = p; c[1] = q; c[2] = v; break;
+        case 4: c[0] = t; c[1] = p; c[2] = v; break;
+        default: c[0] = v; c[1] = p; c[2] = q; break;
+    }
+}
+// ops order[first .. last) on one pixel; `mean` = the image's grey mean for the contrast op
+__device__ __forceinline__ void cj_apply(float* c, const float* f, const int* order, int first, int last, float mean) {
+    for (int k = first; k < last; ++k) {
+        const int op = order[k];
+        if (op == 0) cj_blend(c, 0.f, 0.f, 0.f, f[0]);
+        else if (op == 1) cj_blend(c, mean, mean, mean, f[1]);
+        else if (op == 2) { const float g = cj_gray(c); cj_blend(c, g, g, g, f[2]); }
+        else if (op == 3) cj_hue(c, f[3]);
+    }
+}
+__device__ __forceinline__ void u8_bilinear(const U8Args& p, int b, int oy, int ox, float* c) {
+    const float sy = (float)p.hs / p.h, sx = (float)p.ws / p.w;
+    float fy = (oy + 0.5f) * sy - 0.5f, fx = (ox + 0.5f) * sx - 0.5f;
+    fy = fy < 0.f ? 0.f : fy;
+    fx = fx < 0.f ? 0.f : fx;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + 1 < p.hs ? y0 + 1 : p.hs - 1, x1 = x0 + 1 < p.ws ? x0 + 1 : p.ws - 1;
+    const float wy = fy - y0, wx = fx - x0;
+    const unsigned char* base = p.src + (long)b * p.hs * p.ws * 3;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        const float a00 = base[((long)y0 * p.ws + x0) * 3 + ch], a01 = base[((long)y0 * p.ws + x1) * 3 + ch];
+        const float a10 = base[((long)y1 * p.ws + x0) * 3 + ch], a11 = base[((long)y1 * p.ws + x1) * 3 + ch];
+        const float top = a00 + (a01 - a00) * wx, bot = a10 + (a11 - a10) * wx;
+        c[ch] = (top + (bot - top) * wy) * (1.f / 255.f);
+    }
+}
+
+constexpr int CJ_STRIPS = 32;
+
+__global__ __launch_bounds__(256) void jitter_mean_kernel(const U8Args p, const float* factors, const int* order, double* partial) {
+    __shared__ double red[256];
+    const int b = blockIdx.y, strip = blockIdx.x;
+    const float* f = factors + b * 4;
+    const int* ord = order + b * 4;
+    int kc = 4;                                         // position of the contrast op (4 = absent)
+    for (int k = 3; k >= 0; --k)
+        if (ord[k] == 1) kc = k;
+    double acc = 0.0;
+    const int rows = (p.h + CJ_STRIPS - 1) / CJ_STRIPS;
+    const int y0 = strip * rows, y1 = min(p.h, y0 + rows);
+    if (kc < 4)
+        for (int i = threadIdx.x; i < (y1 - y0) * p.w; i += 256) {
+            float c[3];
+            u8_bilinear(p, b, y0 + i / p.w, i % p.w, c);
+            cj_apply(c, f, ord, 0, kc, 0.f);
+            acc += (double)cj_gray(c);
+        }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[b * CJ_STRIPS + strip] = red[0];
+}
+
+template <typename T>
+__global__ void image_u8_jitter_to_nhwc4_kernel(const U8Args p, const float* factors, const int* order, const double* partial) {
+    const long total = (long)p.n * p.hp * p.wp;
+    T* dst = (T*)p.dst;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % p.wp);
+        const long t = i / p.wp;
+        const int y = (int)(t % p.hp), b = (int)(t / p.hp);
+        const int oy = y - p.pad, ox = x - p.pad;
+        float v[3] = {0.f, 0.f, 0.f};
+        if ((unsigned)oy < (unsigned)p.h && (unsigned)ox < (unsigned)p.w) {
+            double m = 0.0;
+            for (int k = 0; k < CJ_STRIPS; ++k) m += partial[b * CJ_STRIPS + k];
+            const float mean = (float)(m / ((double)p.h * p.w));
+            float c[3];
+            u8_bilinear(p, b, oy, ox, c);
+            cj_apply(c, factors + b * 4, order + b * 4, 0, 4, mean);
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) v[ch] = (c[ch] - p.mean[ch]) * p.istd[ch];
+        }
+        T* o = dst + i * 4;
+        o[0] = from_f<T>(v[0]); o[1] = from_f<T>(v[1]); o[2] = from_f<T>(v[2]); o[3] = from_f<T>(0.f);
+    }
+}
+
+extern "C" size_t lh_image_jitter_workspace_bytes(int n) { return (size_t)n * CJ_STRIPS * sizeof(double); }
+
+extern "C" int lh_image_u8_jitter_to_nhwc4(const unsigned char* hwc, void* out, int n, int hs, int ws, int h, int w, int pad, int wp,
+                                           const float* mean3, const float* std3, const float* factors_dev, const int* order_dev,
+                                           void* workspace, int dtype, void* stream) {
+    LH_REQUIRE(hwc && out && mean3 && std3 && factors_dev && order_dev && workspace && n > 0 && hs > 0 && ws > 0 && h > 0 && w > 0 &&
+               pad >= 0 && wp >= w + 2 * pad, "lh_image_u8_jitter_to_nhwc4: bad arguments");
+    U8Args a;
+    a.src = hwc; a.dst = out; a.n = n; a.hs = hs; a.ws = ws; a.h = h; a.w = w; a.pad = pad; a.hp = h + 2 * pad; a.wp = wp;
+    for (int c = 0; c < 3; ++c) { a.mean[c] = mean3[c]; a.istd[c] = 1.f / std3[c]; }
+    hipLaunchKernelGGL(jitter_mean_kernel, dim3(CJ_STRIPS, n), dim3(256), 0, (hipStream_t)stream, a, factors_dev, order_dev, (double*)workspace);
+    const long total = (long)n * a.hp * wp;
+    const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((image_u8_jitter_to_nhwc4_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a,
+                                                   factors_dev, order_dev, (const double*)workspace));
+    LH_LAUNCH_CHECK("image_u8_jitter_to_nhwc4 launch");
+    return LH_OK;
+}
+
 template <typename T>
 __global__ void nhwc_to_nchw_kernel(const T* src, float* dst, int n, int hw, int c, int cs) {
     const long total = (long)n * hw;

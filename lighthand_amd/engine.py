@@ -1106,13 +1106,27 @@ class Plan:
             self.bwd.append(_Call(self.lib.lh_maxpool3x3s2_bwd, (dy.data_ptr(), idx.data_ptr(), dx.data_ptr(), x.n, x.h, x.w, x.c, self.dt), "maxpool bwd"))
         blk.append(emit)
 
-    def use_uint8_input(self, hs, ws, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
-        """Switch the plan's input to raw uint8 HWC images [n][hs][ws][3]: ToTensor + bilinear Resize + Normalize
-        (the reference's CPU transform chain, src/tools/dataset.py:128-159, defaults = its ImageNet constants) run in
-        ONE kernel that writes the stem's padded NHWC4 input.  Returns the static uint8 input buffer."""
+    def use_uint8_input(self, hs, ws, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225), jitter=False):
+        """Switch the plan's input to raw uint8 HWC images [n][hs][ws][3]: ToTensor + bilinear Resize [+ ColorJitter] +
+        Normalize (the reference's CPU transform chain, src/tools/dataset.py:128-159, defaults = its ImageNet
+        constants) run fused on the device and write the stem's padded NHWC4 input.  With ``jitter`` the plan owns
+        ``jitter_factors`` (fp32 [n][4]: brightness, contrast, saturation, hue) and ``jitter_order`` (int32 [n][4]: op
+        ids, negative = skip) that the caller fills per batch (``sample_color_jitter``).  Returns the static uint8
+        input buffer."""
         self.img_u8 = self._alloc(self.n, hs, ws, 3, dtype=torch.uint8, zero=True)
         m3, s3 = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
         self.keep += [m3, s3]
+        if jitter:
+            self.jitter_factors = self._alloc(self.n, 4, dtype=torch.float32, zero=True)
+            self.jitter_factors[:, :3] = 1.0                                    # identity until the caller draws
+            self.jitter_order = torch.full((self.n, 4), -1, dtype=torch.int32, device=self.device)
+            ws_j = self._alloc(self.lib.lh_image_jitter_workspace_bytes(self.n), dtype=torch.uint8)
+            self.keep.append(self.jitter_order)
+            self.fwd[self._image_call_index] = _Call(self.lib.lh_image_u8_jitter_to_nhwc4, (
+                self.img_u8.data_ptr(), self.img_nhwc4.data_ptr(), self.n, hs, ws, self.h, self.w, self.img_pad, self.img_wp,
+                m3, s3, self.jitter_factors.data_ptr(), self.jitter_order.data_ptr(), ws_j.data_ptr(), self.dt),
+                "uint8 input pipeline + ColorJitter")
+            return self.img_u8
         self.fwd[self._image_call_index] = _Call(self.lib.lh_image_u8_to_nhwc4, (
             self.img_u8.data_ptr(), self.img_nhwc4.data_ptr(), self.n, hs, ws, self.h, self.w, self.img_pad, self.img_wp,
             m3, s3, self.dt), "uint8 input pipeline")

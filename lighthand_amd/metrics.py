@@ -8,6 +8,8 @@ import sys
 
 import numpy as np
 
+_trapz = getattr(np, "trapezoid", None) or np.trapz      # np.trapz is deprecated (removed in newer NumPy)
+
 PX_PER_MM_EVAL = 3.7795275591
 PX_PER_MM_THRESH = 2.83464567
 
@@ -47,7 +49,7 @@ def pred_eval(meta, T_list, method):
         thr = np.linspace(T_list[0], T_list[-1], 100)
     else:
         assert 0, "this method is the wrong"
-    norm = np.trapz(np.ones_like(thr), thr)
+    norm = _trapz(np.ones_like(thr), thr)
     out, vis_all, diff_all = {}, [], [np.zeros([971, 21])]
     for cat, d in meta.items():
         bb, pred, gt = np.array(d["bb"]), np.array(d["pred"]), np.array(d["gt"])
@@ -57,10 +59,10 @@ def pred_eval(meta, T_list, method):
         diff_all.append(diff)
         vis_all.insert(0, vis)
         curve = np.array([(vis < t).sum() / len(vis) * 100 for t in thr])
-        out[cat] = [float(np.trapz(curve, thr) / (norm + sys.float_info.epsilon)), float(diff.mean() / PX_PER_MM_EVAL), curve]
+        out[cat] = [float(_trapz(curve, thr) / (norm + sys.float_info.epsilon)), float(diff.mean() / PX_PER_MM_EVAL), curve]
     vis = np.concatenate(vis_all)
     curve = np.array([(vis < t).sum() / len(vis) * 100 for t in thr])
-    out["mean_auc"] = [float(np.trapz(curve, thr) / (norm + sys.float_info.epsilon)),
+    out["mean_auc"] = [float(_trapz(curve, thr) / (norm + sys.float_info.epsilon)),
                        float(np.concatenate(diff_all, 0).mean() / PX_PER_MM_EVAL), curve]
     return out
 
@@ -123,7 +125,7 @@ def device_pck_curve(pred_2d, gt_3, bb, T_list, method, out=None):
 def auc_from_counts(counts, nvis, diff_sum, n_all, T_list, method):
     """[auc, epe_mm, pck_curve] exactly as pred_eval reports one category (src/utils/argparser.py:362-375)."""
     thr = eval_thresholds(T_list, method)
-    norm = np.trapz(np.ones_like(thr), thr)
+    norm = _trapz(np.ones_like(thr), thr)
     curve = np.asarray(counts, dtype=np.float64) / float(nvis) * 100
-    return [float(np.trapz(curve, thr) / (norm + sys.float_info.epsilon)), float(diff_sum) / float(n_all) / PX_PER_MM_EVAL, curve]
+    return [float(_trapz(curve, thr) / (norm + sys.float_info.epsilon)), float(diff_sum) / float(n_all) / PX_PER_MM_EVAL, curve]
 

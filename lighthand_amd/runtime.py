@@ -17,10 +17,25 @@ from ._lib import check
 from .optim import Adam
 
 
+def sample_color_jitter(n, brightness=0.5, contrast=0.5, saturation=0.5, hue=0.5, ratio=1.0, generator=None):
+    """torchvision ColorJitter.get_params per image (host side): factor ~ U[max(0, 1 - v), 1 + v] for brightness /
+    contrast / saturation, hue ~ U[-h, h], op order = randperm(4).  ``ratio`` = fraction of the samples that are
+    jittered at all (the reference's --ratio_of_aug, src/tools/dataset.py:133); the others get order -1 (skip).
+    Returns (factors fp32 [n][4], order int32 [n][4]) CPU tensors for Plan.jitter_factors / jitter_order."""
+    g = generator
+    u = torch.rand(n, 4, generator=g)
+    lo = torch.tensor([max(0.0, 1 - brightness), max(0.0, 1 - contrast), max(0.0, 1 - saturation), -hue])
+    hi = torch.tensor([1 + brightness, 1 + contrast, 1 + saturation, hue])
+    factors = (lo + (hi - lo) * u).to(torch.float32)
+    order = torch.stack([torch.randperm(4, generator=g) for _ in range(n)]).to(torch.int32)
+    order[torch.rand(n, generator=g) >= ratio] = -1
+    return factors, order
+
+
 class TrainStep:
     def __init__(self, model, batch, height, width, lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
                  optimizer=None, decode=True, use_graph=True, grad_sync=None, targets_from_joints=True,
-                 overlap_wgrad=False, input_u8=None):
+                 overlap_wgrad=False, input_u8=None, color_jitter=None):
         self.lib = _lib.load()
         self.model = model
         model.train()
@@ -30,7 +45,10 @@ class TrainStep:
         out = self.plan.out_nchw
         self.images = self.plan.img_nchw                               # static input: fp32 NCHW
         # input_u8=(hs, ws): feed raw uint8 HWC frames instead; ToTensor/Resize/Normalize run fused on the device
-        self.images_u8 = self.plan.use_uint8_input(*input_u8) if input_u8 else None
+        # color_jitter=(brightness, contrast, saturation, hue): torchvision ColorJitter ranges (reference: 0.5 each,
+        # src/tools/dataset.py:139-141) applied inside the fused input kernel; factors are drawn per batch on the host
+        self.color_jitter = color_jitter
+        self.images_u8 = self.plan.use_uint8_input(*input_u8, jitter=color_jitter is not None) if input_u8 else None
         self.joints = torch.zeros(batch, out.shape[1], 2, dtype=torch.float32, device=dev)
         self.target = torch.zeros_like(out)
         self.targets_from_joints = targets_from_joints
@@ -154,6 +172,10 @@ class TrainStep:
             self.sync_hyper()
         if images is not None:
             (self.images_u8 if images.dtype == torch.uint8 and self.images_u8 is not None else self.images).copy_(images, non_blocking=True)
+        if self.color_jitter is not None and self.images_u8 is not None:
+            f, o = sample_color_jitter(self.joints.shape[0], *self.color_jitter)
+            self.plan.jitter_factors.copy_(f, non_blocking=True)
+            self.plan.jitter_order.copy_(o, non_blocking=True)
         if joints is not None:
             self.joints.copy_(joints[..., :2], non_blocking=True)
         if target is not None:

@@ -6,6 +6,8 @@ import sys
 
 import numpy as np
 
+_trapz = getattr(np, "trapezoid", None) or np.trapz      # np.trapz is deprecated (removed in newer NumPy)
+
 PX_PER_MM_EVAL = 3.7795275591     # src/utils/argparser.py:374,385
 PX_PER_MM_THRESH = 2.83464567     # src/utils/argparser.py:336
 PX_TO_MM_LOG = 0.26               # src/utils/method.py:131
@@ -65,7 +67,7 @@ def pred_eval(meta, T_list, method):
         thr = np.linspace(T_list[0], T_list[-1], 100)
     else:
         raise AssertionError("this method is the wrong")
-    norm = np.trapz(np.ones_like(thr), thr)
+    norm = _trapz(np.ones_like(thr), thr)
     out = {}
     all_vis = []
     all_diff = [np.zeros((971, 21))]
@@ -79,10 +81,10 @@ def pred_eval(meta, T_list, method):
         all_diff.append(diff)
         all_vis.insert(0, vis)
         curve = np.array([(vis < t).sum() / len(vis) * 100 for t in thr])
-        auc = np.trapz(curve, thr) / (norm + sys.float_info.epsilon)
+        auc = _trapz(curve, thr) / (norm + sys.float_info.epsilon)
         out[cat] = [float(auc), float(diff.mean() / PX_PER_MM_EVAL), curve]
     vis = np.concatenate(all_vis)
     curve = np.array([(vis < t).sum() / len(vis) * 100 for t in thr])
-    auc = np.trapz(curve, thr) / (norm + sys.float_info.epsilon)
+    auc = _trapz(curve, thr) / (norm + sys.float_info.epsilon)
     out["mean_auc"] = [float(auc), float(np.concatenate(all_diff, 0).mean() / PX_PER_MM_EVAL), curve]
     return out

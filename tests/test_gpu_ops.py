@@ -203,7 +203,7 @@ def test_every_conv_kernel_configuration(case, precision, forced_plans):
     tiles = {c[0][:2] for c in seen}
     print(case, precision, len(seen), "configurations, forward tiles", sorted(tiles))
     assert len(seen) >= 3
-    if precision == "bf16" and cout % 256 == 0:
+    if precision == "bf16" and cout % 256 == 0 and out.shape[0] * out.shape[2] * out.shape[3] > 128:
         assert (256, 256) in tiles
 
 
@@ -489,6 +489,53 @@ def test_uint8_input_pipeline_matches_torch_transform_chain(src):
     a = plan.out_nchw.clone()
     m2_out = m.eval()(want.permute(0, 3, 1, 2).contiguous().cuda())
     assert torch.allclose(a, m2_out, atol=1e-4, rtol=1e-3)
+
+
+def test_color_jitter_input_pipeline_matches_oracle():
+    """The training transform chain with ColorJitter (dataset.py:134-146) fused on the device: per-image factors and
+    op orders (all 24 permutations, skipped images, factors at the ends of the reference's 0.5 ranges) against the
+    numpy restatement of torchvision's published tensor algorithm (oracle/color.py)."""
+    import itertools
+    from conftest import resnet_cfg
+    from lighthand_amd.modeling.simplebaseline.pose_resnet import get_pose_net
+    from lighthand_amd.runtime import sample_color_jitter
+    from oracle import color as oc
+    torch.manual_seed(0)
+    perms = list(itertools.permutations(range(4)))
+    n, hs, ws = len(perms) + 4, 56, 40
+    m = get_pose_net(resnet_cfg(18), True).cuda()
+    plan = m.plan(n, 64, 64, training=False, backward=False)
+    rng = np.random.RandomState(3)
+    u8 = rng.randint(0, 256, size=(n, hs, ws, 3)).astype(np.uint8)
+    u8[1] = (u8[1] // 4) * 4 // 4 * 4                              # an image with many equal channels (grey pixels: hue no-op)
+    u8[1][..., 1] = u8[1][..., 0]
+    u8[1][..., 2] = u8[1][..., 0]
+    factors, order = sample_color_jitter(n, generator=torch.Generator().manual_seed(5))
+    for i, p in enumerate(perms):
+        order[i] = torch.tensor(p, dtype=torch.int32)
+    order[len(perms)] = torch.tensor([-1, -1, -1, -1], dtype=torch.int32)                 # not jittered at all
+    order[len(perms) + 1] = torch.tensor([3, -1, 1, -1], dtype=torch.int32)               # a subset of the ops
+    factors[len(perms) + 2] = torch.tensor([0.5, 0.5, 0.5, -0.5])                          # range ends
+    factors[len(perms) + 3] = torch.tensor([1.5, 1.5, 1.5, 0.5])
+    buf = plan.use_uint8_input(hs, ws, jitter=True)
+    buf.copy_(torch.from_numpy(u8))
+    plan.jitter_factors.copy_(factors)
+    plan.jitter_order.copy_(order)
+    s = torch.cuda.current_stream().cuda_stream
+    plan.fwd[plan._image_call_index](s)
+    torch.cuda.synchronize()
+    got = plan.img_nhwc4.float().cpu().numpy()
+    p = plan.img_pad
+    worst = 0.0
+    for i in range(n):
+        want = oc.input_pipeline(u8[i], 64, 64, factors[i].numpy(), [int(v) for v in order[i]])
+        g = np.transpose(got[i, p:p + 64, p:p + 64, :3], (2, 0, 1))
+        d = np.abs(g - want)
+        # a pixel on a hue-sector / clamp boundary may take the other branch after fp32 reassociation: allow a handful
+        assert (d > 1e-4).mean() < 1e-3, (i, order[i], float(d.max()))
+        worst = max(worst, float(np.median(d)))
+    assert worst < 1e-6
+    assert float(np.abs(got[:, :p]).max()) == 0 and float(np.abs(got[..., 3]).max()) == 0
 
 
 def test_device_metrics_match_host_metrics(golden_dir):

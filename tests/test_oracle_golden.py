@@ -121,3 +121,35 @@ def test_g7_metrics(golden_dir):
     s, c = om.epe_train(pred, gt)
     assert c == g["epe_cnt"] == 19 * 4
     assert abs(s - g["epe_sum"]) < 1e-4 * g["epe_sum"]
+
+
+def test_color_jitter_oracle_known_answers():
+    """oracle/color.py restates torchvision's published ColorJitter tensor algorithm (torchvision is absent from this
+    image, so no fixture can be generated from it): closed-form known answers pin it."""
+    from oracle import color as oc
+    rng = np.random.RandomState(0)
+    img = rng.rand(3, 6, 5).astype(np.float32)
+    # identity factors in any order leave the image unchanged
+    assert np.allclose(oc.color_jitter(img, (1.0, 1.0, 1.0, 0.0), (2, 0, 3, 1)), img, atol=2e-6)
+    # brightness scales and clamps
+    assert np.allclose(oc.adjust_brightness(img, 0.5), img * 0.5, atol=1e-7)
+    assert oc.adjust_brightness(img, 1.5).max() <= 1.0
+    # contrast 0 -> the grey mean everywhere; saturation 0 -> grey-scale image (0.2989 R + 0.587 G + 0.114 B)
+    gray = 0.2989 * img[0] + 0.587 * img[1] + 0.114 * img[2]
+    assert np.allclose(oc.adjust_contrast(img, 0.0), gray.mean(), atol=1e-6)
+    assert np.allclose(oc.adjust_saturation(img, 0.0), np.broadcast_to(gray, img.shape), atol=1e-6)
+    # hue: rotating pure red by +1/3 gives green, by -1/3 blue; a full turn is the identity; grey pixels do not move
+    red = np.zeros((3, 2, 2), np.float32)
+    red[0] = 1.0
+    assert np.allclose(oc.adjust_hue(red, 1 / 3)[:, 0, 0], [0, 1, 0], atol=1e-6)
+    assert np.allclose(oc.adjust_hue(red, -1 / 3)[:, 0, 0], [0, 0, 1], atol=1e-6)
+    assert np.allclose(oc.adjust_hue(img, 0.5), oc.adjust_hue(img, -0.5), atol=1e-5)
+    grey = np.full((3, 2, 2), 0.37, np.float32)
+    assert np.allclose(oc.adjust_hue(grey, 0.4), grey, atol=1e-7)
+    # HSV round trip
+    assert np.allclose(oc.hsv2rgb(oc.rgb2hsv(img)), img, atol=2e-6)
+    # the whole chain without jitter = ToTensor / Resize / Normalize (identity resize here)
+    u8 = rng.randint(0, 256, size=(4, 4, 3)).astype(np.uint8)
+    want = (np.transpose(u8, (2, 0, 1)).astype(np.float32) / 255.0 - np.array([0.485, 0.456, 0.406], np.float32)[:, None, None]) \
+        / np.array([0.229, 0.224, 0.225], np.float32)[:, None, None]
+    assert np.allclose(oc.input_pipeline(u8, 4, 4), want, atol=1e-6)
