@@ -365,7 +365,7 @@ extern "C" int lh_fuse_fwd(const lh_fuse_desc* d, void* out, int n, int h, int w
     const long total = (long)n * h * w * (c / (16 / es));
     const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     const int nchunk = c / (16 / es);
-    bool flat = d->nterms <= 2 && (nchunk & (nchunk - 1)) == 0 && nchunk <= 256 && !getenv("LH_NO_FLAT");
+    bool flat = d->nterms <= 2 && (nchunk & (nchunk - 1)) == 0 && nchunk <= 256;
     for (int t = 0; t < d->nterms; ++t) flat = flat && a.log2up[t] == 0;
     if (flat) {
         const int grid = (int)((total + 1023) / 1024 > 2048 ? 2048 : (total + 1023) / 1024);      // >= 4 chunks per thread
@@ -732,7 +732,7 @@ extern "C" int lh_fuse_bwd(const lh_fuse_bwd_desc* d, int n, int h, int w, int c
     hipStream_t s = (hipStream_t)stream;
     const int nchunk0 = c / (16 / es);
     const bool merge2 = d->nterms == 2 && d->log2up[0] == 0 && d->log2up[1] == 0 && (nchunk0 & (nchunk0 - 1)) == 0 &&
-                        nchunk0 <= 256 && (d->dx[0] || d->dx[1]) && !getenv("LH_NO_FLAT") && !getenv("LH_NO_MERGE2");
+                        nchunk0 <= 256 && (d->dx[0] || d->dx[1]);
     FuseBwd2Args m2;
     if (merge2) {
         m2.dout = (const unsigned char*)d->dout; m2.out = (const unsigned char*)d->out; m2.c = c; m2.relu = d->relu;
@@ -756,7 +756,7 @@ extern "C" int lh_fuse_bwd(const lh_fuse_bwd_desc* d, int n, int h, int w, int c
         a.partial = nullptr; a.totals = nullptr; a.coef = nullptr; a.rows_per_strip = 0;
         a.shift = nullptr;
         const int nchunk = c / (16 / es);
-        const bool flat = a.l == 0 && (nchunk & (nchunk - 1)) == 0 && nchunk <= 256 && !getenv("LH_NO_FLAT");
+        const bool flat = a.l == 0 && (nchunk & (nchunk - 1)) == 0 && nchunk <= 256;
         // single BN term under the ReLU: the mask is sign(x*scale+shift), no need to read the stored activation
         a.mask_from_x = (flat && d->relu && d->nterms == 1 && a.x && d->shift[t]) ? 1 : 0;
         if (a.mask_from_x) a.shift = d->shift[t];

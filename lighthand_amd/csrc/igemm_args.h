@@ -21,7 +21,7 @@ struct IgemmArgs {
     int nphase, phase_blocks;
     const unsigned char* ph_w[4];
     int ph_ntaps[4], ph_tw[4], ph_dh0[4], ph_dhs[4], ph_dw0[4], ph_dws[4], ph_ooh[4], ph_oow[4], ph_row0[4];
-    int xcd;                         // ring kernel: XCD-aware work-item order (LH_NO_XCD=1 disables)
+    int xcd;                         // ring kernel: XCD-aware work-item order (always on: speed only)
     int tw, dh0, dhs, dw0, dws;      // regular tap grid (ring kernel): tap t = (t / tw, t % tw)
     signed char dh[64];
     signed char dw[64];

@@ -191,7 +191,7 @@ class _TorchCall:
 class Plan:
     """Everything needed to run one model at one static shape."""
 
-    def __init__(self, model, n, h, w, precision="fp32", training=True, backward=None, device=None):
+    def __init__(self, model, n, h, w, precision="fp32", training=True, backward=None, device=None, wgrad_bucket_bytes=None):
         self.lib = _lib.load()
         self.precision = precision
         self.tdtype = PRECISIONS[precision]
@@ -219,28 +219,26 @@ class Plan:
         self.nodes = gb.nodes
         self.node_lanes = gb.node_lanes
         self.n_lanes = max(gb.node_lanes) + 1 if gb.node_lanes else 1
-        self.use_lanes = self.n_lanes > 1 and not os.environ.get("LH_NO_LANES")
+        self.use_lanes = self.n_lanes > 1
         self._lane_streams = {L: torch.cuda.Stream(device=self.device) for L in range(1, self.n_lanes)} if self.use_lanes else {}
         self._cur_lane = 0
         # Deferred weight gradients: the weight-gradient launches (+ folds) of a GROUP of layers are appended behind one
         # event and run on a side stream while the stream that produced their dy walks on (the main stream of a
-        # single-lane network: LH_WGRAD_GROUP layers per group; a branch lane of HRNet: its chain inside one module).
-        # 0 = in place.  Groups alternate over LH_WGRAD_STREAMS side streams, each with its own split-K slab.
-        self.own_slabs = bool(os.environ.get("LH_OWN_WGRAD_SLABS"))
+        # single-lane network; a branch lane of HRNet: its chain inside one module).  Groups alternate over the side
+        # streams, each with its own split-K slab.  LH_WGRAD_GROUP = layers per group (0 = weight gradients in place).
         n_convs = sum(1 for k, _ in self.nodes if k in ("conv", "deconv"))
         auto_group = max(4, -(-n_convs * 42 // 100))         # ~2.4 groups per backward pass: 24 layers for R50 (measured best)
         if self.n_lanes > 1:
             auto_group = 16                                   # branch lanes hand over at every module end; 16 on the main lane
-        self.wgrad_group = int(os.environ.get("LH_WGRAD_GROUP", str(auto_group))) if (self.with_bwd and not self.own_slabs) else 0
-        if self.n_lanes > 1 and os.environ.get("LH_NO_WGRAD_DEFER_LANES"):
-            self.wgrad_group = 0
-        if self.wgrad_group > 0 and not os.environ.get("LH_NO_LANES"):
+        self.wgrad_group = int(os.environ.get("LH_WGRAD_GROUP", str(auto_group))) if self.with_bwd else 0
+        # data-parallel plans: a deferred group ALSO ends as soon as its layers hold one gradient bucket's worth of
+        # parameters, so the first bucket's all-reduce starts early in the backward pass (parallel.wgrad_group_cuts)
+        self.wgrad_bucket_bytes = wgrad_bucket_bytes
+        if self.wgrad_group > 0:
             self.use_lanes = True
-            self._w_lanes = max(1, int(os.environ.get("LH_WGRAD_STREAMS", "2" if self.n_lanes == 1 else "4")))
+            self._w_lanes = 2 if self.n_lanes == 1 else 4
             for i in range(self._w_lanes):
                 self._lane_streams[-1 - i] = torch.cuda.Stream(device=self.device)
-        else:
-            self.wgrad_group = 0
         self._pend = {}                    # source lane -> dict(calls, names, layers, ws)
         self._w_flushes = 0
         self._ready = {}
@@ -251,19 +249,17 @@ class Plan:
         self._producers = {}               # id(raw conv output Act) -> the igemm calls that write it (eval-mode BN folding)
         self.keep = []                     # ctypes objects / tensors referenced by raw pointer
         self._ws_wgrad = 0
-        # LH_OWN_WGRAD_SLABS=1: every convolution keeps its own split-K slab, so its fold kernel (and the other small
-        # gradient tails, lane 2) may run on a side stream beside the next layer.  Measured on R50 bs64 inside the
-        # captured step: 14.16 ms with the tails on a side stream vs 13.22 ms in order on one stream with ONE shared,
-        # cache-resident slab -- every cross-stream edge of the hipGraph costs more than the 5-8 us kernel it hides,
-        # so the default is the shared slab and a single stream.
-        self.own_slabs = bool(os.environ.get("LH_OWN_WGRAD_SLABS"))
         self._ws_fuse = 0
         self._ws_users = []
         self._ws_users_fuse = []
         self.profile_meta = []             # (list name, call object, kernel name, flops, bytes)
         self._tune_bufs = {}
+        Plan._tune_cache_io()
+        n_tuned = len(Plan._TUNE_CACHE)
         self._compile()
         self._tune_bufs = {}               # scratch operands of the autotuner are only needed while compiling
+        if len(Plan._TUNE_CACHE) != n_tuned:
+            Plan._tune_cache_io(save=True)
 
     # ------------------------------------------------------------------ helpers
     def _alloc(self, *shape, dtype=None, zero=False):
@@ -340,6 +336,28 @@ class Plan:
     # replace the measurement for the plans built while they are set (tests walk every compiled-in configuration)
     force_cfg = None
     force_wgrad = None
+    _tune_file_loaded = False
+
+    @classmethod
+    def _tune_cache_io(cls, save=False):
+        """LH_TUNE_CACHE=<file>: measured choices persist across processes (a restarted job, or a profiling run that
+        should not contain the tuner's own launches, starts from the file; new measurements are written back)."""
+        path = os.environ.get("LH_TUNE_CACHE")
+        if not path:
+            return
+        import ast
+        if save:
+            tmp = path + ".tmp%d" % os.getpid()
+            with open(tmp, "w") as f:
+                for k, v in cls._TUNE_CACHE.items():
+                    f.write(repr((k, v)) + "\n")
+            os.replace(tmp, path)
+        elif not cls._tune_file_loaded:
+            cls._tune_file_loaded = True
+            if os.path.isfile(path):
+                for line in open(path):
+                    k, v = ast.literal_eval(line)
+                    cls._TUNE_CACHE.setdefault(k, tuple(v))
 
     @staticmethod
     def _desc_key(d):
@@ -504,7 +522,7 @@ class Plan:
 
     def _phase_rows(self, descs):
         """Rows of the stats slab ONE phase of a batched launch writes, or -1 when the phases cannot be batched."""
-        if len(descs) < 2 or len(descs) > 4 or os.environ.get("LH_NO_PHASES"):
+        if len(descs) < 2 or len(descs) > 4:
             return -1
         arr = (C.POINTER(IgemmDesc) * len(descs))(*[C.pointer(d) for d in descs])
         return self.lib.lh_igemm_phases_rows(arr, len(descs), self.dt)
@@ -542,7 +560,7 @@ class Plan:
         return f"wgrad_kernel<{t}, {a.value}, {b.value}, {wo}, {wi}>"
 
     def _pending(self):
-        return self._pend.setdefault(self._cur_lane, dict(calls=[], names=[], layers=0, ws=[]))
+        return self._pend.setdefault(self._cur_lane, dict(calls=[], names=[], layers=0, ws=[], bytes=0))
 
     def _ws_note(self, setter, nbytes):
         ent = [setter, nbytes, self._cur_lane]
@@ -571,7 +589,7 @@ class Plan:
         self.bwd += p["calls"]
         if p["names"]:
             self.bwd_marks.append((len(self.bwd), p["names"]))
-        self._pend[src] = dict(calls=[], names=[], layers=0, ws=[])
+        self._pend[src] = dict(calls=[], names=[], layers=0, ws=[], bytes=0)
 
     def _first_write(self, a):
         """True the first time a gradient buffer is produced in the backward list (every writer calls this once)."""
@@ -661,7 +679,9 @@ class Plan:
                         p = self._pending()
                         p["names"] += wnames
                         p["layers"] += 1
-                        if p["layers"] >= self.wgrad_group:
+                        p["bytes"] += sum(self.params[k].numel() * 4 for k in wnames)
+                        # same rule as parallel.wgrad_group_cuts (tested on the CPU with the real parameter sizes)
+                        if p["layers"] >= self.wgrad_group or (self.wgrad_bucket_bytes and p["bytes"] >= self.wgrad_bucket_bytes):
                             self._flush_wgrads(lane)
                     else:
                         names += wnames
@@ -678,11 +698,11 @@ class Plan:
             # (stream lanes run concurrently: each lane has its own pair)
             lanes = list(range(self.n_lanes if self.use_lanes else 1)) + ([-1 - i for i in range(self._w_lanes)] if self.wgrad_group > 0 else [])
             need_w = {L: max([nb for _, nb, l in self._ws_users if (l if self.use_lanes else 0) == L] + [256]) for L in lanes}
-            ws_w = {L: None if self.own_slabs else self._alloc(need_w[L], dtype=torch.uint8) for L in lanes}
+            ws_w = {L: self._alloc(need_w[L], dtype=torch.uint8) for L in lanes}      # ONE shared, cache-resident slab per stream
             ws_f = {L: self._alloc(max(self._ws_fuse, 256), dtype=torch.uint8) for L in lanes}
             for setter, nbytes, lane in self._ws_users:
                 L = lane if self.use_lanes else 0
-                setter((self._alloc(max(nbytes, 256), dtype=torch.uint8) if ws_w[L] is None else ws_w[L]).data_ptr())
+                setter(ws_w[L].data_ptr())
             for setter, lane in self._ws_users_fuse:
                 setter(ws_f[lane if self.use_lanes else 0].data_ptr())
 
@@ -783,7 +803,7 @@ class Plan:
             dy = self._act_grad(y)
             call_w = [self.lib.lh_wgrad, [C.byref(d), xbuf.data_ptr(), dy.data_ptr(), y.c, y.c, cin, 0, self.dt], nd["w"] + " wgrad"]
             call_r = [self.lib.lh_wgrad_reduce, [C.byref(d), 0, gtmp.data_ptr(), y.c if pad_out else cout, cin, cin * k * k, k * k, k, 1, rs_arr, 0, self.dt], nd["w"] + " wgrad reduce"]
-            tail = 2 if self.own_slabs else 1
+            tail = 1
             cw, cr = _Call(call_w[0], None, call_w[2], lane=1), _Call(call_r[0], None, call_r[2], keep=rs_arr, lane=tail)
 
             def set_ws(ptr, cw=cw, cr=cr, a=call_w[1], b=call_r[1]):
@@ -848,7 +868,7 @@ class Plan:
         # the gradient index row*kr + j is gstage's [cout][k][kr] layout, so the fold is a plain sum over the splits
         bo, bi, ns, ring = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
         self.lib.lh_wgrad_tile(C.byref(d), y.c, kr, self.dt, C.byref(bo), C.byref(bi), C.byref(ns), C.byref(ring))
-        fold = bool(ring.value) and not os.environ.get("LH_NO_ROWFOLD")
+        fold = bool(ring.value)
         dw = _desc(x.n, hp, wp, 4, k * kr, y.h, y.w, s, s, y.c, y.h, y.w, 1, 1, 0, 0, y.c, [(0, 0)]) if fold else d
         self.keep.append(dw)
         n_in_w = k * kr if fold else kr
@@ -875,7 +895,7 @@ class Plan:
             else:
                 a = [C.byref(d), img.data_ptr(), dy.data_ptr(), y.c, y.c, kr, 0, self.dt]
                 b = [C.byref(d), 0, gstage.data_ptr(), cout, kr, k * kr, 1, kr, 0, rs_arr, 0, self.dt]
-            tail = 2 if self.own_slabs else 1
+            tail = 1
             cw = _Call(self.lib.lh_wgrad_rowfold if fold else self.lib.lh_wgrad, None, "stem wgrad", lane=1)
             cr = _Call(self.lib.lh_wgrad_reduce, None, "stem wgrad reduce", keep=rs_arr, lane=tail)
 
@@ -959,7 +979,7 @@ class Plan:
             dy = self._act_grad(y)
             a = [C.byref(dg), dy.data_ptr(), xbuf.data_ptr(), x.c, cin, cout, 0, self.dt]
             b = [C.byref(dg), 0, gw.data_ptr(), cin, cout, cout * k * k, k * k, k, 1, rs_arr, 0, self.dt]
-            tail = 2 if self.own_slabs else 1
+            tail = 1
             cw, cr = _Call(self.lib.lh_wgrad, None, nd["w"] + " wgrad", lane=1), _Call(self.lib.lh_wgrad_reduce, None, nd["w"] + " wgrad reduce", keep=rs_arr, lane=tail)
 
             def set_ws(ptr):
@@ -1015,7 +1035,7 @@ class Plan:
         # backward pass reads n*h*w*c/8 bytes instead of the stored activation (single-BN-term nodes recompute the
         # mask from x*scale+shift and need neither)
         relu_bits = None
-        if relu and self.with_bwd and len(terms) > 1 and not os.environ.get("LH_NO_RELU_BITS"):
+        if relu and self.with_bwd and len(terms) > 1:
             relu_bits = self._alloc(out.pixels * c // (16 // self.es), dtype=torch.uint8)
             fd.relu_mask = relu_bits.data_ptr()
         self.fwd.append(_Call(self.lib.lh_fuse_fwd, (C.byref(fd), obuf.data_ptr(), out.n, out.h, out.w, c, self.dt), "fuse fwd"))
@@ -1201,36 +1221,14 @@ class Plan:
             if not isinstance(c, _Marker):
                 c(stream)
 
-    def run_backward(self, stream, lo=0, hi=None, side=None, side_lanes=(1, 2)):
-        """Run bwd[lo:hi].  With ``side`` (a torch stream) the launches whose lane is in ``side_lanes`` go to that
-        stream (lane 1: weight-gradient kernels, lane 2: their small tails -- split-K fold, crops): each waits for the
-        main-stream work enqueued before it and the main stream joins at the end, so they overlap the data-gradient
-        chain (also inside a captured hipGraph)."""
+    def run_backward(self, stream, lo=0, hi=None):
+        """Run bwd[lo:hi] (a segment of the backward list: data-parallel plans replay it bucket by bucket)."""
         calls = self.bwd[lo:hi]
         if self.use_lanes:
             return self._run_lanes(calls, stream)
-        calls = [c for c in calls if not isinstance(c, _Marker)]
-        if side is None or not side_lanes:
-            for c in calls:
-                c(stream)
-            return
-        main = torch.cuda.current_stream()
-        sptr = side.cuda_stream
-        pending = False
         for c in calls:
-            if c.lane in side_lanes:
-                if not pending:                 # first side launch after main-stream work: order it behind that work
-                    side.wait_stream(main)
-                    pending = True
-                if isinstance(c, _TorchCall):
-                    with torch.cuda.stream(side):
-                        c(sptr)
-                else:
-                    c(sptr)
-            else:
+            if not isinstance(c, _Marker):
                 c(stream)
-                pending = False
-        main.wait_stream(side)
 
     def forward(self, images, repack=True):
         """images: fp32 NCHW on the device.  Returns the plan's fp32 NCHW heatmap buffer."""

@@ -123,14 +123,14 @@ class HipModule(nn.Module):
             self._lh_arena = ParamArena(self)
         return self._lh_arena
 
-    def plan(self, n, h, w, training=None, backward=None):
+    def plan(self, n, h, w, training=None, backward=None, wgrad_bucket_bytes=None):
         training = self.training if training is None else training
         backward = training if backward is None else backward
         self.arena()
-        key = (n, h, w, self._lh_precision, training, backward)
+        key = (n, h, w, self._lh_precision, training, backward, wgrad_bucket_bytes)
         p = self._lh_plans.get(key)
         if p is None:
-            p = Plan(self, n, h, w, self._lh_precision, training=training, backward=backward)
+            p = Plan(self, n, h, w, self._lh_precision, training=training, backward=backward, wgrad_bucket_bytes=wgrad_bucket_bytes)
             p.generation = 0
             self._lh_plans[key] = p
         return p

@@ -43,6 +43,23 @@ def all_reduce_sum_(t, group=None):
     return t
 
 
+def wgrad_group_cuts(layer_bytes, max_layers, bucket_bytes=None):
+    """Where the backward pass hands its deferred weight-gradient groups over to the side streams.
+
+    layer_bytes: fp32 parameter bytes of every convolution in BACKWARD order (last layer first).  A group ends after
+    ``max_layers`` layers, and -- in data-parallel plans (``bucket_bytes``) -- as soon as it holds one gradient bucket's
+    worth of parameters, so that the bucket's all-reduce can start while most of the backward pass is still ahead
+    (the groups' ends are where ``plan_buckets`` may cut).  Returns the indices AFTER which a group is flushed."""
+    cuts, n, b = [], 0, 0
+    for i, nb in enumerate(layer_bytes):
+        n += 1
+        b += nb
+        if n >= max_layers or (bucket_bytes and b >= bucket_bytes):
+            cuts.append(i)
+            n = b = 0
+    return cuts
+
+
 def plan_buckets(marks, offsets, total, bucket_bytes=32 << 20):
     """Cut the backward list into segments whose finished gradients form contiguous arena slices.
 
@@ -78,10 +95,16 @@ def plan_buckets(marks, offsets, total, bucket_bytes=32 << 20):
 class GradSync:
     """Launches one all-reduce per gradient bucket on a side stream and lets Adam wait for all."""
 
-    def __init__(self, world_size=None, bucket_bytes=32 << 20, group=None):
+    def __init__(self, world_size=None, bucket_bytes=32 << 20, group=None, compress=None):
+        """compress='bf16': every bucket travels as bfloat16 (half the bytes per xGMI link; the sum is formed in bf16 by
+        the collective, the fp32 arena slice receives the result).  Default: fp32 buckets, exact sums."""
         self.world_size = world_size or (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.bucket_bytes = bucket_bytes
         self.group = group
+        if compress not in (None, "bf16"):
+            raise ValueError("compress must be None or 'bf16'")
+        self.compress = compress
+        self._staging = {}
         self.cuda = torch.cuda.is_available()
         self.stream = torch.cuda.Stream() if self.cuda else None
         self._pending = []
@@ -103,10 +126,22 @@ class GradSync:
             ev.record(torch.cuda.current_stream())
             self.stream.wait_event(ev)
             with torch.cuda.stream(self.stream):
-                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+                if self.compress == "bf16":
+                    half = self._staging.get(bucket)
+                    if half is None:
+                        half = self._staging[bucket] = torch.empty(stop - start, dtype=torch.bfloat16, device=view.device)
+                    half.copy_(view)
+                    dist.all_reduce(half, op=dist.ReduceOp.SUM, group=self.group)
+                    view.copy_(half)
+                else:
+                    dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
                 done = torch.cuda.Event()
                 done.record(self.stream)
             self._pending.append(done)
+        elif self.compress == "bf16":
+            half = view.to(torch.bfloat16)
+            dist.all_reduce(half, op=dist.ReduceOp.SUM, group=self.group)
+            view.copy_(half)
         else:
             self._pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 

@@ -35,11 +35,12 @@ def sample_color_jitter(n, brightness=0.5, contrast=0.5, saturation=0.5, hue=0.5
 class TrainStep:
     def __init__(self, model, batch, height, width, lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
                  optimizer=None, decode=True, use_graph=True, grad_sync=None, targets_from_joints=True,
-                 overlap_wgrad=False, input_u8=None, color_jitter=None):
+                 input_u8=None, color_jitter=None):
         self.lib = _lib.load()
         self.model = model
         model.train()
-        self.plan = model.plan(batch, height, width, training=True, backward=True)
+        self.plan = model.plan(batch, height, width, training=True, backward=True,
+                               wgrad_bucket_bytes=grad_sync.bucket_bytes if grad_sync is not None else None)
         self.arena = model.arena()
         dev = self.arena.device
         out = self.plan.out_nchw
@@ -66,15 +67,6 @@ class TrainStep:
         self.use_graph = use_graph
         self.heat_scale = float(height // out.shape[2])               # x4 of method.py:157
         self.steps = 0
-        # measured on R50 bs64: running the weight-gradient chain beside the data-gradient chain is ~3 % SLOWER
-        # (every kernel already fills the CUs' LDS), so the overlap is opt-in (LH_OVERLAP_WGRAD=1 or the argument)
-        if os.environ.get("LH_OVERLAP_WGRAD"):
-            overlap_wgrad = True
-        # lane 2 (split-K folds and other small gradient tails) can also go to the side stream when the plan keeps one
-        # slab per layer (LH_OWN_WGRAD_SLABS=1); measured slower as well (see Plan.__init__), so off by default
-        tails = self.plan.own_slabs
-        self.side = torch.cuda.Stream() if (overlap_wgrad or tails) else None
-        self.side_lanes = (1, 2) if overlap_wgrad else (2,)
 
     # ---- the work of one iteration, enqueued on the current stream --------------------------------
     def _fwd_loss(self, stream):
@@ -98,7 +90,7 @@ class TrainStep:
     def _enqueue_all(self):
         stream = torch.cuda.current_stream().cuda_stream
         self._fwd_loss(stream)
-        self.plan.run_backward(stream, side=self.side, side_lanes=self.side_lanes)
+        self.plan.run_backward(stream)
         self.optimizer.step(grad_scale=self.grad_scale)
 
     def _capture(self):
@@ -125,7 +117,7 @@ class TrainStep:
                 stream = torch.cuda.current_stream().cuda_stream
                 if i == 0:
                     self._fwd_loss(stream)
-                self.plan.run_backward(stream, lo, hi, side=self.side, side_lanes=self.side_lanes)
+                self.plan.run_backward(stream, lo, hi)
             self.graphs.append((g, bucket))
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
@@ -136,7 +128,7 @@ class TrainStep:
         stream = torch.cuda.current_stream().cuda_stream
         self._fwd_loss(stream)
         for lo, hi, bucket in self.grad_sync.segments(self.plan):
-            self.plan.run_backward(stream, lo, hi, side=self.side, side_lanes=self.side_lanes)
+            self.plan.run_backward(stream, lo, hi)
             if bucket is not None:
                 self.grad_sync.launch(self.arena.flat_grad, bucket)
         self.grad_sync.wait_all()

@@ -321,3 +321,76 @@ def test_eval_tail_batch_runs_unpadded(tmp_path):
             total += 21
     print("tail-batch eval: arg-max agreement with the oracle", agree / total)
     assert agree / total >= 0.99
+
+
+def _dp_rank(rank, world, port, compress, q):
+    """One data-parallel rank (spawned fresh: the parent's GPU context is never re-used or re-exec'ed)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      LH_DIST_BACKEND="gloo")
+    import torch.distributed as dist
+    from lighthand_amd import parallel
+    from lighthand_amd.runtime import TrainStep
+    parallel.init_distributed()
+    m = _model(18)
+    x, j = _batch(4, 64, 11 + rank)
+    sync = parallel.GradSync(world, bucket_bytes=2 << 20, compress=compress)
+    step = TrainStep(m, 4, 64, 64, lr=1e-3, use_graph=True, grad_sync=sync)
+    losses = [float(step(x, j)) for _ in range(2)]
+    torch.cuda.synchronize()
+    segs = sync.segments(step.plan)
+    q.put((rank, m.arena().flat.cpu(), losses, len(segs), [b for _, _, b in segs]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("compress", [None, "bf16"])
+def test_two_process_data_parallel_step_with_real_collective(compress):
+    """The per-segment hipGraph path with a REAL collective between two processes (gloo through the host, both ranks on
+    this GPU; on a multi-GPU node the same code runs over RCCL): after two steps both ranks hold identical weights,
+    equal to the single-process emulation -- two micro-batches with their own BatchNorm statistics, gradients averaged,
+    one Adam step each (SURVEY 8e oracle)."""
+    import socket
+    import torch.multiprocessing as mp
+    from lighthand_amd.heatmap import JointsMSELoss, render_targets
+    from lighthand_amd.optim import Adam
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_rank, args=(r, 2, port, compress, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in procs:
+        r = q.get(timeout=300)
+        res[r[0]] = r
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert torch.equal(res[0][1], res[1][1]), "ranks diverged"
+    assert res[0][3] >= 2 and res[0][4] == res[1][4]                 # several segments, same buckets on both ranks
+    # single-process emulation of the two ranks
+    crit = JointsMSELoss(False)
+    m = _model(18)
+    opt = Adam(m.parameters(), lr=1e-3).bind_arena(m.arena())
+    batches = [_batch(4, 64, 11), _batch(4, 64, 12)]
+    for _ in range(2):            # (train-mode BN normalises with batch statistics: the running buffers do not enter the gradients)
+        grads = []
+        for x, j in batches:
+            loss = crit(m(x), render_targets(j)[:, :, :16, :16].contiguous(), None)
+            opt.zero_grad()
+            loss.backward()
+            grads.append(m.arena().flat_grad.clone())
+        m.arena().flat_grad.copy_((grads[0] + grads[1]) / 2)
+        opt.step()
+    want = m.arena().flat.cpu()
+    diff = (res[0][1] - want).abs()
+    if compress is None:
+        assert torch.allclose(res[0][1], want, rtol=2e-4, atol=2e-6), float(diff.max())
+    else:
+        # bf16 buckets round every rank's gradient to 8 significant bits before the sum: where the two ranks' values
+        # nearly cancel the sign of the sum can flip, and Adam's first steps move such an element by +-lr either way
+        print("bf16 buckets: max |dw|", float(diff.max()), "share of elements off by > 1e-4:", float((diff > 1e-4).float().mean()))
+        assert float(diff.max()) <= 2 * 2 * 1e-3 * 1.05 and float((diff > 1e-4).float().mean()) < 0.02
