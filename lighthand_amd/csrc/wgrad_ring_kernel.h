@@ -204,17 +204,22 @@ __global__ __launch_bounds__(64 * WO * WI, 2) void wgrad_ring_kernel(const Wgrad
         if constexpr ((LH_ABL & 2) != 0) { dst = uint2{addr, addr}; return; }
         asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(decltype(OFFc)::value));
     };
-    // one logical step: pixel rows [32*kk, 32*kk + 32) of the stage at byte offset `so` (the swizzle repeats every 8 rows)
-    auto step = [&](auto KKc, unsigned so) {
-        constexpr int kk = decltype(KKc)::value;
+    // one logical step: pixel rows [32*kk, 32*kk + 32) of ring slot SLOT (the swizzle repeats every 8 rows).  Slot and
+    // step offsets are compile-time: they ride in the reads' immediate offset fields, the address registers never change
+    // (the 8-wave tile's second slot lies beyond the 16-bit immediate range and takes one add per read instead).
+    auto step = [&](auto KKc, auto SLOTc) {
+        constexpr int kk = decltype(KKc)::value, slot = decltype(SLOTc)::value;
+        constexpr bool imm = (D - 1) * STAGE + KPS * RBO + KP * RBI * (KSUB - 1) < 65536;
+        constexpr int so_imm = imm ? slot * STAGE : 0;
+        const unsigned so_reg = imm ? 0u : (unsigned)(slot * STAGE);
         uint2 fi[IT][2], fo[OT][2];
         wstatic_for<0, IT>([&](auto Jc) {
-            rdtr(wic<kk * KP * RBI>{}, fi[decltype(Jc)::value][0], ai[decltype(Jc)::value][0] + so);
-            rdtr(wic<kk * KP * RBI>{}, fi[decltype(Jc)::value][1], ai[decltype(Jc)::value][1] + so);
+            rdtr(wic<so_imm + kk * KP * RBI>{}, fi[decltype(Jc)::value][0], ai[decltype(Jc)::value][0] + so_reg);
+            rdtr(wic<so_imm + kk * KP * RBI>{}, fi[decltype(Jc)::value][1], ai[decltype(Jc)::value][1] + so_reg);
         });
         wstatic_for<0, OT>([&](auto Ic) {
-            rdtr(wic<kk * KP * RBO>{}, fo[decltype(Ic)::value][0], ao[decltype(Ic)::value][0] + so);
-            rdtr(wic<kk * KP * RBO>{}, fo[decltype(Ic)::value][1], ao[decltype(Ic)::value][1] + so);
+            rdtr(wic<so_imm + kk * KP * RBO>{}, fo[decltype(Ic)::value][0], ao[decltype(Ic)::value][0] + so_reg);
+            rdtr(wic<so_imm + kk * KP * RBO>{}, fo[decltype(Ic)::value][1], ao[decltype(Ic)::value][1] + so_reg);
         });
         wstatic_for<0, OT>([&](auto Ic) {
             constexpr int i = decltype(Ic)::value;
@@ -225,39 +230,43 @@ __global__ __launch_bounds__(64 * WO * WI, 2) void wgrad_ring_kernel(const Wgrad
 #pragma unroll
             for (int j = 0; j < IT; ++j) {
                 const uint4 b = uint4{fi[j][0].x, fi[j][0].y, fi[j][1].x, fi[j][1].y};
-                if (!(LH_ABL & 1)) WMma<T>::run(a, b, acc[i][j]);
+                // D[input channel][output channel]: a lane ends up with 4 CONSECUTIVE input channels of one output
+                // channel, i.e. one 16-byte store into the [o][i] slab
+                if (!(LH_ABL & 1)) WMma<T>::run(b, a, acc[i][j]);
             }
         });
     };
 
     // waves 4-7 of the 8-wave tile share their SIMDs with waves 0-3: they refill the ring half a stage later
     const bool late = NWAVE == 8 && KSUB == 2 && wave >= NWAVE / 2;
-    int cslot = 0;
-    for (int s = 0; s < S; ++s) {
+    auto stage = [&](auto SLOTc, int s) {
         wwait_stages<L, D - 2>(issued - 1 - s);          // stage s has landed; later stages stay in flight
         __builtin_amdgcn_s_barrier();
-        const unsigned so = cslot * STAGE;
-        if (++cslot == D) cslot = 0;
         if (!late && issued < S) issue();                // into the slot of stage s - 1, retired by every wave
-        step(wic<0>{}, so);
+        step(wic<0>{}, SLOTc);
         if constexpr (KSUB == 2) {
             if (late && issued < S) issue();
-            step(wic<1>{}, so);
+            step(wic<1>{}, SLOTc);
         }
-    }
+    };
+    // D stages per trip, so that the slot of every stage is a compile-time constant
+    int s = 0;
+    for (; s + D <= S; s += D) wstatic_for<0, D>([&](auto Kc) { stage(Kc, s + decltype(Kc)::value); });
+    wstatic_for<0, D - 1>([&](auto Kc) {
+        if (s + decltype(Kc)::value < S) stage(Kc, s + decltype(Kc)::value);
+    });
 
     if (LH_ABL & 8) { if (acc[0][0][0] == 123.456f) p.slab[0] = 1.f; return; }
     float* slab = p.slab + ((long)split * p.ntaps + tap) * p.n_out * p.n_in;
     const int qq = lane >> 4, cc = lane & 15;
 #pragma unroll
-    for (int i = 0; i < OT; ++i)
+    for (int i = 0; i < OT; ++i) {
+        const int o = otile * BO + wo_ * TO + i * 16 + cc;
 #pragma unroll
         for (int j = 0; j < IT; ++j) {
-            const int ci = itile * BI + wi_ * TI + j * 16 + cc;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int o = otile * BO + wo_ * TO + i * 16 + qq * 4 + r;
-                if (o < p.n_out && ci < p.n_in) slab[(long)o * p.n_in + ci] = acc[i][j][r];
-            }
+            const int ci = itile * BI + wi_ * TI + j * 16 + qq * 4;            // n_in % 8 == 0: whole 16-byte groups
+            if (o < p.n_out && ci < p.n_in)
+                *reinterpret_cast<float4*>(slab + (long)o * p.n_in + ci) = float4{acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
         }
+    }
 }
