@@ -148,11 +148,15 @@ typedef struct {
 /* out[pixel][co] = relu?( (sum_taps sum_k in[pix(tap)][k] * wpack[co][tap][k] + bias[co]) * scale[co] + shift[co]
  *                          + addend[pixel][co] )      (bias / scale+shift / addend optional; relu from the descriptor).
  * scale/shift fold an eval-mode BatchNorm (and with addend + relu a whole residual-unit tail) into the epilogue.
+ * addend_mask (optional, dense outputs only): the relu_mask bits lh_fuse_fwd stored for an activation; element e of a
+ * 16-byte chunk of the addend is added only where its bit is set.  Lets a data-gradient launch add the identity-shortcut
+ * gradient of a residual tail, dout * (out > 0), straight from dout (loss.backward() through `out += residual; relu`,
+ * pose_resnet.py:96-97) instead of reading a copy lh_fuse_bwd would have to write first.
  * stats (optional): fp32 [gridM][2][cout] per-block column sums / sums of squares of the stored values,
  * consumed by lh_bn_finalize.  addend may alias out. */
 int lh_igemm(const lh_igemm_desc* d, const void* in, const void* wpack, void* out,
-             const void* addend, const float* bias, const float* scale, const float* shift, float* stats,
-             int dtype, void* stream);
+             const void* addend, const void* addend_mask, const float* bias, const float* scale, const float* shift,
+             float* stats, int dtype, void* stream);
 /* Phase batching: 2..4 lh_igemm launches that share input, output tensor, sizes and epilogue and differ only in weight
  * pack, tap list and output placement (ooh, oow) -- the sub-pixel phases of a 4x4/s2 transposed convolution
  * (pose_resnet.py:194-232) or of a stride-2 convolution's data gradient -- as ONE grid.  Phases may have zero taps
@@ -160,8 +164,8 @@ int lh_igemm(const lh_igemm_desc* d, const void* in, const void* wpack, void* ou
  * Requires the LDS-DMA kernel (16-byte aligned rows, regular tap grids); returns LH_ERR_* otherwise. */
 int lh_igemm_phases_rows(const lh_igemm_desc* const* descs, int nphase, int dtype);
 int lh_igemm_phases(const lh_igemm_desc* const* descs, int nphase, const void* in, const void* const* wpacks,
-                    void* out, const void* addend, const float* bias, const float* scale, const float* shift,
-                    float* stats, int dtype, void* stream);
+                    void* out, const void* addend, const void* addend_mask, const float* bias, const float* scale,
+                    const float* shift, float* stats, int dtype, void* stream);
 /* tile (output channels x pixels) the dispatcher picks for this descriptor: names the kernel
  * instantiation a launch uses -- igemm_ring_kernel<T, bm, bp, .., depth, kbytes> when *ring != 0 (LDS-DMA ring
  * path, 16-byte aligned pixel rows; *ring = kbytes*10 + depth) else igemm_kernel<T, bm, bp, ..>. */

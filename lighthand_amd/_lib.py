@@ -70,9 +70,9 @@ SIGNATURES = {
     "lh_pack_chunk_elems": (_I, []),
     "lh_pack_weights_multi": (_I, [_P, _P, _P, _I, _I, _P]),
     "lh_pack_weights_tiled": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
-    "lh_igemm": (_I, [C.POINTER(IgemmDesc), _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "lh_igemm": (_I, [C.POINTER(IgemmDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "lh_igemm_phases_rows": (_I, [C.POINTER(C.POINTER(IgemmDesc)), _I, _I]),
-    "lh_igemm_phases": (_I, [C.POINTER(C.POINTER(IgemmDesc)), _I, _P, C.POINTER(C.c_void_p), _P, _P, _P, _P, _P, _P, _I, _P]),
+    "lh_igemm_phases": (_I, [C.POINTER(C.POINTER(IgemmDesc)), _I, _P, C.POINTER(C.c_void_p), _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "lh_igemm_tile": (_I, [C.POINTER(IgemmDesc), _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "lh_igemm_config": (_I, [C.POINTER(IgemmDesc), _I, C.POINTER(_I)]),
     "lh_igemm_candidates": (_I, [C.POINTER(IgemmDesc), _I, C.POINTER(_I), _I]),

@@ -215,6 +215,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
         if (p.addend) {
             float av[EPC];
             unpack16<T>(*reinterpret_cast<const uint4*>(p.addend + eoff * ES), av);
+            if (p.addend_mask) {
+                const unsigned mb = p.addend_mask[eoff / EPC];
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) av[e] = ((mb >> e) & 1u) ? av[e] : 0.f;
+            }
 #pragma unroll
             for (int e = 0; e < EPC; ++e) v[e] += av[e];
         }
@@ -327,7 +332,7 @@ struct PhaseSet {                 // lh_igemm_phases: the other descriptors / pa
 };
 
 static int igemm_impl(const lh_igemm_desc* d, const void* in, const void* wpack, void* out,
-                      const void* addend, const float* bias, const float* scale, const float* shift, float* stats,
+                      const void* addend, const void* addend_mask, const float* bias, const float* scale, const float* shift, float* stats,
                       int dtype, void* stream, const PhaseSet* phases = nullptr) {
     LH_REQUIRE(d && in && wpack && out, "lh_igemm: null pointer");
     const int es = lh_dtype_size(dtype);
@@ -344,6 +349,8 @@ static int igemm_impl(const lh_igemm_desc* d, const void* in, const void* wpack,
     IgemmArgs a;
     a.in = (const unsigned char*)in; a.w = (const unsigned char*)wpack; a.out = (unsigned char*)out;
     a.addend = (const unsigned char*)addend; a.bias = bias; a.stats = stats; a.zero = nullptr;
+    a.addend_mask = (const unsigned char*)addend_mask;
+    LH_REQUIRE(!addend_mask || (addend && d->out_pix_stride == d->cout), "lh_igemm: addend_mask needs an addend and a dense output (mask bits index 16-byte chunks)");
     a.scale = scale; a.shift = shift;
     LH_REQUIRE((scale == nullptr) == (shift == nullptr), "lh_igemm: scale and shift must come together");
     a.n = d->n; a.hi = d->hi; a.wi = d->wi; a.in_pix_stride = d->in_pix_stride; a.k_run = d->k_run;
@@ -407,9 +414,9 @@ static int igemm_impl(const lh_igemm_desc* d, const void* in, const void* wpack,
 }
 
 extern "C" int lh_igemm(const lh_igemm_desc* d, const void* in, const void* wpack, void* out,
-                        const void* addend, const float* bias, const float* scale, const float* shift, float* stats,
-                        int dtype, void* stream) {
-    return igemm_impl(d, in, wpack, out, addend, bias, scale, shift, stats, dtype, stream);
+                        const void* addend, const void* addend_mask, const float* bias, const float* scale, const float* shift,
+                        float* stats, int dtype, void* stream) {
+    return igemm_impl(d, in, wpack, out, addend, addend_mask, bias, scale, shift, stats, dtype, stream);
 }
 
 // ---- phase batching ------------------------------------------------------------------------------------------------
@@ -441,11 +448,11 @@ extern "C" int lh_igemm_phases_rows(const lh_igemm_desc* const* descs, int nphas
 }
 
 extern "C" int lh_igemm_phases(const lh_igemm_desc* const* descs, int nphase, const void* in, const void* const* wpacks,
-                               void* out, const void* addend, const float* bias, const float* scale, const float* shift,
-                               float* stats, int dtype, void* stream) {
+                               void* out, const void* addend, const void* addend_mask, const float* bias, const float* scale,
+                               const float* shift, float* stats, int dtype, void* stream) {
     LH_REQUIRE(phases_ok(descs, nphase) && wpacks, "lh_igemm_phases: 2..4 descriptors that differ only in taps / placement are required");
     const int lead = phase_lead(descs, nphase);
     LH_REQUIRE(descs[lead]->ntaps > 0 && wpacks[lead], "lh_igemm_phases: no phase has taps");
     PhaseSet ps = {descs, wpacks, nphase};
-    return igemm_impl(descs[lead], in, wpacks[lead], out, addend, bias, scale, shift, stats, dtype, stream, &ps);
+    return igemm_impl(descs[lead], in, wpacks[lead], out, addend, addend_mask, bias, scale, shift, stats, dtype, stream, &ps);
 }

@@ -7,6 +7,7 @@ struct IgemmArgs {
     const unsigned char* w;
     unsigned char* out;
     const unsigned char* addend;
+    const unsigned char* addend_mask; // optional: ReLU mask bits (lh_fuse_fwd relu_mask) gating the addend element-wise
     const unsigned char* zero;       // 16 zero bytes in device memory (LDS-DMA kernel: what masked lanes fetch)
     const float* bias;
     const float* scale;      // optional per-output-channel affine applied to the fp32 accumulator (eval-mode BN fold)

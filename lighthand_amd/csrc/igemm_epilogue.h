@@ -86,6 +86,11 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, unsigned char
             if (p.addend) {
                 float av[EPC];
                 unpack16<T>(*reinterpret_cast<const uint4*>(p.addend + eoff * ES), av);
+                if (p.addend_mask) {                    // addend = upstream gradient, gated by the activation's ReLU mask
+                    const unsigned mb = p.addend_mask[eoff / EPC];
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) av[e] = ((mb >> e) & 1u) ? av[e] : 0.f;
+                }
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) v[e] += av[e];
             }

@@ -297,7 +297,7 @@ class Plan:
         return buf
 
     # positions of lh_igemm's arguments inside a _Call.args tuple
-    _IG = dict(desc=0, src=1, pack=2, dst=3, addend=4, bias=5, scale=6, shift=7, stats=8)
+    _IG = dict(desc=0, src=1, pack=2, dst=3, addend=4, addend_mask=5, bias=6, scale=7, shift=8, stats=9)
 
     def _pack_regular(self, wt, buf, n_out, n_in, strides, taps_rs):
         """Queue a pack of a plain [d0][d1][kH][kW] weight tensor for the LDS-tiled transposing pack kernel.
@@ -342,10 +342,20 @@ class Plan:
     def _tune_cache_io(cls, save=False):
         """LH_TUNE_CACHE=<file>: measured choices persist across processes (a restarted job, or a profiling run that
         should not contain the tuner's own launches, starts from the file; new measurements are written back)."""
+        import ast
+        if not save and not cls._tune_file_loaded:
+            # the shipped database: choices measured on MI355X for the benchmark configurations (tools/make_tune_db.sh);
+            # entries are validated against the compiled-in configurations when used, anything else is measured on the fly
+            db = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tune_db_gfx950.txt")
+            if os.path.isfile(db) and os.environ.get("LH_TUNE_DB", "1") != "0":
+                for line in open(db):
+                    if line.strip() and not line.startswith("#"):
+                        k, v = ast.literal_eval(line)
+                        cls._TUNE_CACHE.setdefault(k, tuple(v))
         path = os.environ.get("LH_TUNE_CACHE")
         if not path:
+            cls._tune_file_loaded = True
             return
-        import ast
         if save:
             tmp = path + ".tmp%d" % os.getpid()
             with open(tmp, "w") as f:
@@ -388,12 +398,14 @@ class Plan:
             return
         key = (self.dt, with_stats) + tuple(self._desc_key(d) for d in descs)
         hit = Plan._TUNE_CACHE.get(key) if Plan.force_cfg is None else None
+        buf = (C.c_int * (5 * 64))()
+        n = self.lib.lh_igemm_candidates(C.byref(lead), self.dt, buf, 64)
+        cands = [tuple(buf[5 * i:5 * i + 4]) for i in range(n)]
+        if len(descs) > 1 and self._phase_rows(descs) <= 0:
+            cands = []                                          # phases that cannot be batched: keep the default
+        if hit is not None and hit != (0, 0, 0, 0) and hit not in cands:
+            hit = None                                          # stale entry (configuration no longer compiled in): measure again
         if hit is None:
-            buf = (C.c_int * (5 * 64))()
-            n = self.lib.lh_igemm_candidates(C.byref(lead), self.dt, buf, 64)
-            cands = [tuple(buf[5 * i:5 * i + 4]) for i in range(n)]
-            if len(descs) > 1 and self._phase_rows(descs) <= 0:
-                cands = []                                      # phases that cannot be batched: keep the default
             if Plan.force_cfg is not None:
                 forced = Plan.force_cfg(cands) if cands else None
                 for d in descs:
@@ -415,11 +427,11 @@ class Plan:
                     parr = (C.c_void_p * len(descs))(*[pk.data_ptr() for pk in packs])
 
                     def run():
-                        check(self.lib.lh_igemm_phases(arr, len(descs), src.data_ptr(), parr, dst.data_ptr(), None, None, None, None,
+                        check(self.lib.lh_igemm_phases(arr, len(descs), src.data_ptr(), parr, dst.data_ptr(), None, None, None, None, None,
                                                        _ptr(stats), self.dt, sp), "autotune lh_igemm_phases")
                 else:
                     def run():
-                        check(self.lib.lh_igemm(C.byref(lead), src.data_ptr(), packs[0].data_ptr(), dst.data_ptr(), None, None, None, None,
+                        check(self.lib.lh_igemm(C.byref(lead), src.data_ptr(), packs[0].data_ptr(), dst.data_ptr(), None, None, None, None, None,
                                                 _ptr(stats), self.dt, sp), "autotune lh_igemm")
                 best = None
                 for cfg in cands:
@@ -449,10 +461,12 @@ class Plan:
             return
         key = ("w", self.dt, self._desc_key(d), n_out, n_in, dy_stride) + tuple(tag)
         hit = Plan._TUNE_CACHE.get(key) if Plan.force_wgrad is None else None
+        buf = (C.c_int * (5 * 128))()
+        n = self.lib.lh_wgrad_candidates(C.byref(d), n_out, n_in, self.dt, buf, 128)
+        cands = [tuple(buf[5 * i:5 * i + 5]) for i in range(n)]
+        if hit is not None and hit != (0, 0, 0) and hit not in [c[:3] for c in cands]:
+            hit = None
         if hit is None:
-            buf = (C.c_int * (5 * 128))()
-            n = self.lib.lh_wgrad_candidates(C.byref(d), n_out, n_in, self.dt, buf, 128)
-            cands = [tuple(buf[5 * i:5 * i + 5]) for i in range(n)]
             if Plan.force_wgrad is not None:
                 d.cfg[5], d.cfg[6], d.cfg[7] = (Plan.force_wgrad(cands) if cands else None) or (0, 0, 0)
                 return
@@ -482,9 +496,10 @@ class Plan:
             Plan._TUNE_CACHE[key] = hit
         d.cfg[5], d.cfg[6], d.cfg[7] = hit
 
-    def _igemm(self, lst, d, src, pack, dst, addend, bias, stats, what, flops=0, produces=None):
+    def _igemm(self, lst, d, src, pack, dst, addend, bias, stats, what, flops=0, produces=None, addend_mask=None):
         self.keep.append(d)
-        c = _Call(self.lib.lh_igemm, (C.byref(d), _ptr(src), _ptr(pack), _ptr(dst), _ptr(addend), _ptr(bias), 0, 0, _ptr(stats), self.dt), what)
+        c = _Call(self.lib.lh_igemm, (C.byref(d), _ptr(src), _ptr(pack), _ptr(dst), _ptr(addend), _ptr(addend_mask), _ptr(bias), 0, 0,
+                                      _ptr(stats), self.dt), what)
         c.keep = d
         lst.append(c)
         if produces is not None:
@@ -498,14 +513,21 @@ class Plan:
         if not first and len(descs) > 1:          # accumulating: a phase without taps would add zeros -- drop it
             keep = [i for i, dd in enumerate(descs) if dd.ntaps > 0]
             descs, packs = [descs[i] for i in keep], [packs[i] for i in keep]
+        addend, amask = (None if first else dx), None
+        pend = self._masked_addend.pop(id(x), None)
+        if pend is not None:
+            # the identity-shortcut gradient of a residual tail, dout * mask, was NOT written by that tail's lh_fuse_bwd:
+            # this first writer of dx adds it straight from dout (one tensor write and one read less per block)
+            assert first
+            addend, amask = pend
         if self._phase_rows(descs) > 0:
             self._tune(descs)
-            self._igemm_phases(self.bwd, descs, dy, packs, dx, None if first else dx, None, None, what)
+            self._igemm_phases(self.bwd, descs, dy, packs, dx, addend, None, None, what, addend_mask=amask)
             yield max(descs, key=lambda d: d.ntaps), sum(d.ntaps for d in descs)
             return
         for dd, pk in zip(descs, packs):
             self._tune([dd])
-            self._igemm(self.bwd, dd, dy, pk, dx, None if first else dx, None, None, what)
+            self._igemm(self.bwd, dd, dy, pk, dx, addend, None, None, what, addend_mask=amask)
             yield dd, dd.ntaps
 
     def _patch(self, call, relu=None, **ptrs):
@@ -518,7 +540,7 @@ class Plan:
             for d in (call.keep if isinstance(call.keep, list) else [call.keep]):
                 d.relu = int(relu)
 
-    _IGP = dict(src=2, dst=4, addend=5, bias=6, scale=7, shift=8, stats=9)      # lh_igemm_phases argument positions
+    _IGP = dict(src=2, dst=4, addend=5, addend_mask=6, bias=7, scale=8, shift=9, stats=10)      # lh_igemm_phases argument positions
 
     def _phase_rows(self, descs):
         """Rows of the stats slab ONE phase of a batched launch writes, or -1 when the phases cannot be batched."""
@@ -527,12 +549,12 @@ class Plan:
         arr = (C.POINTER(IgemmDesc) * len(descs))(*[C.pointer(d) for d in descs])
         return self.lib.lh_igemm_phases_rows(arr, len(descs), self.dt)
 
-    def _igemm_phases(self, lst, descs, src, packs, dst, addend, bias, stats, what, produces=None):
+    def _igemm_phases(self, lst, descs, src, packs, dst, addend, bias, stats, what, produces=None, addend_mask=None):
         """The sub-pixel phases of a stride-2 transposed form as one launch (lh_igemm_phases)."""
         arr = (C.POINTER(IgemmDesc) * len(descs))(*[C.pointer(d) for d in descs])
         parr = (C.c_void_p * len(descs))(*[pk.data_ptr() if pk is not None else None for pk in packs])
         self.keep += [arr, parr] + list(descs)
-        c = _Call(self.lib.lh_igemm_phases, (arr, len(descs), _ptr(src), parr, _ptr(dst), _ptr(addend), _ptr(bias), 0, 0,
+        c = _Call(self.lib.lh_igemm_phases, (arr, len(descs), _ptr(src), parr, _ptr(dst), _ptr(addend), _ptr(addend_mask), _ptr(bias), 0, 0,
                                              _ptr(stats), self.dt), what + f" ({len(descs)} phases)")
         c.keep, c.ig = list(descs), self._IGP
         lst.append(c)
@@ -619,6 +641,17 @@ class Plan:
                         consumers_bn.add(id(a))
         self._bn_inputs = consumers_bn
         self._nwrites = {}
+        self._masked_addend = {}           # id(activation) -> (dout, relu mask bits) a later data-gradient launch adds
+        # consumers of every activation in forward order: (kind, node) -- backward visits them in reverse
+        self._uses = {}
+        for kind, nd in self.nodes:
+            if kind in ("conv", "deconv", "maxpool"):
+                self._uses.setdefault(id(nd["x"]), []).append((kind, nd))
+            elif kind == "fuse":
+                for a, _, _ in nd["terms"]:
+                    self._uses.setdefault(id(a), []).append((kind, nd))
+            elif kind == "output":
+                self._uses.setdefault(id(nd["y"]), []).append((kind, nd))
         bwd_blocks = []
         for (kind, nd), lane in zip(self.nodes, self.node_lanes):
             blk = []
@@ -1053,6 +1086,12 @@ class Plan:
                 bd.log2up[i] = l
                 if not a.needs_grad:
                     continue
+                if (bn is None and l == 0 and len(terms) == 2 and relu_bits is not None and a.c == out.c
+                        and self._nwrites.get(id(a), 0) == 0 and self._next_writer_is_conv(a, nd)):
+                    # identity shortcut whose gradient dout * mask would be the first write of a.grad, followed by a
+                    # convolution's data gradient: that launch adds it from dout itself (lh_igemm addend_mask)
+                    self._masked_addend[id(a)] = (self._act_grad(out), relu_bits)
+                    continue
                 bd.dx[i] = self._act_grad(a).data_ptr()
                 bd.accumulate[i] = 0 if self._first_write(a) else 1
                 if bn is not None:
@@ -1073,6 +1112,16 @@ class Plan:
             self.bwd.append(call)
             self.profile_meta.append(("bwd", self.bwd[-1], "fuse_bwd(all kernels)", 0.0, 0.0))
         blk.append(emit)
+
+    def _next_writer_is_conv(self, a, nd):
+        """True when, walking backward from fuse node `nd`, the next writer of a.grad is a stride-1-output convolution /
+        transposed convolution data gradient over a dense tensor (it can take a masked addend)."""
+        uses = self._uses.get(id(a), [])
+        idx = [i for i, (_, n) in enumerate(uses) if n is nd]
+        if len(idx) != 1 or idx[0] == 0:
+            return False
+        kind, nxt = uses[idx[0] - 1]
+        return kind in ("conv", "deconv") and a.c == a.c_valid
 
     def _fold_eval_bn(self, terms, bn_state, out, relu):
         """Inference plans: BatchNorm uses running statistics, so `relu(BN(conv) [+ residual | + BN(conv_ds)])` is folded

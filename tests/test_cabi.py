@@ -30,7 +30,7 @@ def test_argument_validation_sets_error_text():
     from lighthand_amd import _lib
     lib = _lib.load()
     d = _lib.IgemmDesc()
-    rc = lib.lh_igemm(C.byref(d), None, None, None, None, None, None, None, None, _lib.LH_BF16, None)
+    rc = lib.lh_igemm(C.byref(d), None, None, None, None, None, None, None, None, None, _lib.LH_BF16, None)
     assert rc == -1 and b"null" in lib.lh_last_error()
     try:
         _lib.check(rc, "lh_igemm")
