@@ -204,6 +204,13 @@ int lh_wgrad(const lh_igemm_desc* d, const void* x, const void* dy, int dy_pix_s
 int lh_wgrad_reduce(const lh_igemm_desc* d, const float* slab, float* grad, int n_out, int n_in,
                     long so, long si, long sr, long ss, const int* taps_rs, int accumulate,
                     int dtype, void* stream);
+/* Both steps as one call: lh_wgrad (rows <= 1) or lh_wgrad_rowfold (rows > 1) into `workspace`
+ * (lh_wgrad_workspace_bytes, device; launches that run one after another on a stream may share it), then lh_wgrad_reduce
+ * into `grad`. */
+size_t lh_wgrad_workspace_bytes(const lh_igemm_desc* d, int n_out, int n_in, int dtype);
+int lh_wgrad_fused(const lh_igemm_desc* d, int rows, const void* x, const void* dy, int dy_pix_stride, int n_out, int n_in,
+                   void* workspace, float* grad, long so, long si, long sr, long ss, const int* taps_rs, int accumulate,
+                   int dtype, void* stream);
 
 /* ------------------------------------------------------------------ BatchNorm / fused elementwise
  * nn.BatchNorm2d(C, momentum=0.1): pose_resnet.py:19,35,... ; nn.ReLU / residual add:
@@ -330,6 +337,19 @@ int lh_channel_sum_nchw(const float* x, int n, int c, int hw, float* out, void* 
  * all-reduce.  AUC = trapz(100*counts/nvis, thr) / trapz(1, thr) on the host (lighthand_amd.metrics.auc_from_counts). */
 int lh_pck_curve(const float* pred, const float* gt, int gt_stride, const float* bb, int n, int j, const double* thr,
                  int nthr, unsigned long long* counts, unsigned long long* nvis, double* diff_row, void* stream);
+
+/* ------------------------------------------------------------------ data-parallel gradient exchange
+ * The reference trains on one device (no DistributedDataParallel anywhere: src/utils/comm.py:15-32 only queries rank /
+ * world size for logging and checkpoint gating); the data-parallel path is this engine's addition.  One
+ * communicator per process (= per GPU) over RCCL / xGMI: rank 0 creates a 128-byte id (lh_comm_unique_id) that the host
+ * side hands to every rank (any channel: torch.distributed's store, a file); lh_comm_allreduce_sum sums one gradient
+ * bucket in place across the ranks, asynchronously on `stream` (legal inside hipGraph capture).  dtype: LH_F32 for exact
+ * sums, LH_BF16 for half the bytes per link.  The library binds to the RCCL already loaded in the process. */
+typedef struct lh_comm lh_comm;
+int lh_comm_unique_id(void* id128);
+int lh_comm_init(lh_comm** comm, int rank, int nranks, const void* id128);
+int lh_comm_allreduce_sum(lh_comm* comm, void* buf, size_t count, int dtype, void* stream);
+int lh_comm_destroy(lh_comm* comm);
 
 #ifdef __cplusplus
 }

@@ -82,6 +82,8 @@ SIGNATURES = {
     "lh_wgrad_slab_bytes": (_SZ, [C.POINTER(IgemmDesc), _I, _I, _I]),
     "lh_wgrad": (_I, [C.POINTER(IgemmDesc), _P, _P, _I, _I, _I, _P, _I, _P]),
     "lh_wgrad_rowfold": (_I, [C.POINTER(IgemmDesc), _I, _P, _P, _I, _I, _P, _I, _P]),
+    "lh_wgrad_workspace_bytes": (_SZ, [C.POINTER(IgemmDesc), _I, _I, _I]),
+    "lh_wgrad_fused": (_I, [C.POINTER(IgemmDesc), _I, _P, _P, _I, _I, _I, _P, _P, _L, _L, _L, _L, C.POINTER(_I), _I, _I, _P]),
     "lh_wgrad_reduce": (_I, [C.POINTER(IgemmDesc), _P, _P, _I, _I, _L, _L, _L, _L, C.POINTER(_I), _I, _I, _P]),
     "lh_bn_stats": (_I, [_P, _I, _I, _P, C.POINTER(_I), _I, _P]),
     "lh_bn_stats_rows": (_I, [_I, _I]),
@@ -103,6 +105,10 @@ SIGNATURES = {
     "lh_heatmap_soft_argmax": (_I, [_P, _I, _I, _I, _F, _F, _P, _P]),
     "lh_heatmap_refine": (_I, [_P, _P, _P, _I, _I, _I, _F, _P, _P]),
     "lh_keypoint_metrics": (_I, [_P, _P, _I, _I, _I, _F, _P, _P, _P]),
+    "lh_comm_unique_id": (_I, [_P]),
+    "lh_comm_init": (_I, [C.POINTER(_P), _I, _I, _P]),
+    "lh_comm_allreduce_sum": (_I, [_P, _P, _SZ, _I, _P]),
+    "lh_comm_destroy": (_I, [_P]),
     "lh_adam_step": (_I, [_P, _P, _P, _P, _L, _P, _P, _P, _F, _P]),
 }
 

@@ -451,6 +451,19 @@ extern "C" int lh_wgrad_rowfold(const lh_igemm_desc* d, int rows, const void* x,
     return wgrad_impl(d, x, dy, dy_pix_stride, n_out, d->k_run, slab, dtype, stream, rows);
 }
 
+extern "C" size_t lh_wgrad_workspace_bytes(const lh_igemm_desc* d, int n_out, int n_in, int dtype) {
+    return lh_wgrad_slab_bytes(d, n_out, n_in, dtype);
+}
+
+extern "C" int lh_wgrad_fused(const lh_igemm_desc* d, int rows, const void* x, const void* dy, int dy_pix_stride, int n_out,
+                              int n_in, void* workspace, float* grad, long so, long si, long sr, long ss, const int* taps_rs,
+                              int accumulate, int dtype, void* stream) {
+    LH_REQUIRE(d && workspace && grad && taps_rs, "lh_wgrad_fused: null pointer");
+    const int rc = wgrad_impl(d, x, dy, dy_pix_stride, n_out, n_in, (float*)workspace, dtype, stream, rows);
+    if (rc) return rc;
+    return lh_wgrad_reduce(d, (const float*)workspace, grad, n_out, n_in, so, si, sr, ss, taps_rs, accumulate, dtype, stream);
+}
+
 extern "C" int lh_wgrad_reduce(const lh_igemm_desc* d, const float* slab, float* grad, int n_out,
                                int n_in, long so, long si, long sr, long ss, const int* taps_rs,
                                int accumulate, int dtype, void* stream) {

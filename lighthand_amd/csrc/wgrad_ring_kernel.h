@@ -14,8 +14,12 @@
 //    by a mixed-radix add (no division in the loop); rows past the split's end or outside the image read a zero page;
 //  * fragment reads are retired by a ladder of counted s_waitcnt lgkmcnt: the MFMAs of output-channel tile i start as
 //    soon as its two reads are back;
-//  * split-K over pixels -> fp32 slabs [split][tap][o][i], folded (deterministically, in split order) into the
-//    reference-layout gradient by wgrad_reduce_kernel (wgrad.hip).
+//  * split-K over pixels -> fp32 slabs [split][tap][o][i] (16-byte stores: the MFMA operands are swapped so that a lane
+//    holds four consecutive input channels), folded deterministically, in split order, into the reference-layout
+//    gradient by wgrad_reduce_kernel (wgrad.hip).  A fold INSIDE this launch by the last-arriving workgroup of every
+//    (tile, tap) -- write-through partial tiles, agent-scope arrival counter, acquire, sum -- was built and measured:
+//    the serial tail of one workgroup reading nsplit tiles costs more than the 5-8 us reduce launch it replaces at
+//    every split count this network uses, and its registers slowed the large tiles; removed.
 #pragma once
 #include "common.h"
 

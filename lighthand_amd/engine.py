@@ -378,7 +378,7 @@ class Plan:
         t = self._tune_bufs.get(name)
         if t is None or t.numel() < nbytes:
             t = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
-            if name != "out":
+            if name not in ("out", "wws"):
                 # random bit patterns in every operand: all-zero operands let the chip clock higher and would rank the
                 # MFMA-heavy configurations too well (cdna guide, methodology rule 25)
                 t.view(torch.int16).random_(-16000, 16000) if self.es == 2 else t.view(torch.float32).normal_()
@@ -475,7 +475,7 @@ class Plan:
                 es = self.es
                 xs = self._scratch("in", d.n * d.hi * d.wi * d.in_pix_stride * es + 256)
                 dys = self._scratch("dy", d.n * d.ho * d.wo * dy_stride * es + 256)
-                slab = self._scratch("out", (max(c[4] for c in cands) + 1) << 20)
+                slab = self._scratch("wws", (max(c[4] for c in cands) + 1) << 20)
                 grad = self._scratch("stats", grad_floats * 4 + 256)
                 stream = torch.cuda.current_stream()
                 sp = stream.cuda_stream
@@ -815,11 +815,11 @@ class Plan:
         gtmp = self._alloc(y.c, cin, k, k, dtype=torch.float32) if pad_out else gw
         n_out_r = y.c if pad_out else cout
 
-        def tune_launch(xp, dyp, slab, grad, sp):
-            check(self.lib.lh_wgrad(C.byref(d), xp, dyp, y.c, y.c, cin, slab, self.dt, sp), "autotune lh_wgrad")
-            check(self.lib.lh_wgrad_reduce(C.byref(d), slab, grad, n_out_r, cin, cin * k * k, k * k, k, 1, rs_arr, 0, self.dt, sp), "autotune lh_wgrad_reduce")
+        def tune_launch(xp, dyp, ws, grad, sp):
+            check(self.lib.lh_wgrad_fused(C.byref(d), 0, xp, dyp, y.c, y.c, cin, ws, grad, cin * k * k, k * k, k, 1, rs_arr, 0, self.dt, sp),
+                  "autotune lh_wgrad_fused")
         self._tune_wgrad(d, y.c, cin, y.c, tune_launch, y.c * cin * k * k)
-        slab_bytes = self.lib.lh_wgrad_slab_bytes(C.byref(d), y.c, cin, self.dt)
+        slab_bytes = self.lib.lh_wgrad_workspace_bytes(C.byref(d), y.c, cin, self.dt)
         self._ws_wgrad = max(self._ws_wgrad, slab_bytes)
         dpacks, ddescs = [], []
         if x.needs_grad:
@@ -834,20 +834,18 @@ class Plan:
 
         def emit():
             dy = self._act_grad(y)
-            call_w = [self.lib.lh_wgrad, [C.byref(d), xbuf.data_ptr(), dy.data_ptr(), y.c, y.c, cin, 0, self.dt], nd["w"] + " wgrad"]
-            call_r = [self.lib.lh_wgrad_reduce, [C.byref(d), 0, gtmp.data_ptr(), y.c if pad_out else cout, cin, cin * k * k, k * k, k, 1, rs_arr, 0, self.dt], nd["w"] + " wgrad reduce"]
+            # weight gradient + fold of the pixel splits as ONE C-ABI call (wgrad kernel, then reduce kernel)
+            a = [C.byref(d), 0, xbuf.data_ptr(), dy.data_ptr(), y.c, y.c, cin, 0, gtmp.data_ptr(), cin * k * k, k * k, k, 1, rs_arr, 0, self.dt]
             tail = 1
-            cw, cr = _Call(call_w[0], None, call_w[2], lane=1), _Call(call_r[0], None, call_r[2], keep=rs_arr, lane=tail)
+            cw = _Call(self.lib.lh_wgrad_fused, None, nd["w"] + " wgrad", keep=rs_arr, lane=1)
 
-            def set_ws(ptr, cw=cw, cr=cr, a=call_w[1], b=call_r[1]):
-                a[6] = ptr
-                b[1] = ptr
-                cw.args, cr.args = tuple(a), tuple(b)
+            def set_ws(ptr, cw=cw, a=a):
+                a[7] = ptr
+                cw.args = tuple(a)
             self._ws_note(set_ws, slab_bytes)
             wl = self._wl()
             wl.append(cw)
             self.profile_meta.append(("bwd", wl[-1], self._kname(d, (y.c, cin)), flops, (x.pixels * x.c + y.pixels * y.c) * self.es))
-            wl.append(cr)
             if pad_out:
                 wl.append(_TorchCall(lambda: gw.copy_(gtmp[:cout]), "head grad crop", lane=tail))
             if nd["bias"]:
@@ -907,15 +905,15 @@ class Plan:
         n_in_w = k * kr if fold else kr
         rs_arr = _taps_array([(0, 0)] if fold else rows)
 
-        def tune_launch(xp, dyp, slab, grad, sp):
+        def tune_launch(xp, dyp, ws, grad, sp):
             if fold:
-                check(self.lib.lh_wgrad_rowfold(C.byref(dw), k, xp, dyp, y.c, y.c, slab, self.dt, sp), "autotune lh_wgrad_rowfold")
-                check(self.lib.lh_wgrad_reduce(C.byref(dw), slab, grad, cout, k * kr, k * kr, 1, 0, 0, rs_arr, 0, self.dt, sp), "autotune lh_wgrad_reduce")
+                check(self.lib.lh_wgrad_fused(C.byref(dw), k, xp, dyp, y.c, y.c, k * kr, ws, grad, k * kr, 1, 0, 0, rs_arr, 0, self.dt, sp),
+                      "autotune lh_wgrad_fused")
             else:
-                check(self.lib.lh_wgrad(C.byref(d), xp, dyp, y.c, y.c, kr, slab, self.dt, sp), "autotune lh_wgrad")
-                check(self.lib.lh_wgrad_reduce(C.byref(d), slab, grad, cout, kr, k * kr, 1, kr, 0, rs_arr, 0, self.dt, sp), "autotune lh_wgrad_reduce")
+                check(self.lib.lh_wgrad_fused(C.byref(d), 0, xp, dyp, y.c, y.c, kr, ws, grad, k * kr, 1, kr, 0, rs_arr, 0, self.dt, sp),
+                      "autotune lh_wgrad_fused")
         self._tune_wgrad(dw, y.c, n_in_w, y.c, tune_launch, y.c * k * kr, tag=("fold", k if fold else 0))
-        slab_bytes = self.lib.lh_wgrad_slab_bytes(C.byref(dw), y.c, n_in_w, self.dt)
+        slab_bytes = self.lib.lh_wgrad_workspace_bytes(C.byref(dw), y.c, n_in_w, self.dt)
         self._ws_wgrad = max(self._ws_wgrad, slab_bytes)
         gstage = self._alloc(cout, k, kr // 4, 4, dtype=torch.float32)
         gw = self.grads[nd["w"] + ".weight"]
@@ -923,24 +921,19 @@ class Plan:
         def emit():
             dy = self._act_grad(y)
             if fold:
-                a = [C.byref(dw), k, img.data_ptr(), dy.data_ptr(), y.c, y.c, 0, self.dt]
-                b = [C.byref(dw), 0, gstage.data_ptr(), cout, k * kr, k * kr, 1, 0, 0, rs_arr, 0, self.dt]
+                a = [C.byref(dw), k, img.data_ptr(), dy.data_ptr(), y.c, y.c, k * kr, 0, gstage.data_ptr(), k * kr, 1, 0, 0, rs_arr, 0, self.dt]
             else:
-                a = [C.byref(d), img.data_ptr(), dy.data_ptr(), y.c, y.c, kr, 0, self.dt]
-                b = [C.byref(d), 0, gstage.data_ptr(), cout, kr, k * kr, 1, kr, 0, rs_arr, 0, self.dt]
+                a = [C.byref(d), 0, img.data_ptr(), dy.data_ptr(), y.c, y.c, kr, 0, gstage.data_ptr(), k * kr, 1, kr, 0, rs_arr, 0, self.dt]
             tail = 1
-            cw = _Call(self.lib.lh_wgrad_rowfold if fold else self.lib.lh_wgrad, None, "stem wgrad", lane=1)
-            cr = _Call(self.lib.lh_wgrad_reduce, None, "stem wgrad reduce", keep=rs_arr, lane=tail)
+            cw = _Call(self.lib.lh_wgrad_fused, None, "stem wgrad", keep=rs_arr, lane=1)
 
             def set_ws(ptr):
-                a[6] = ptr
-                b[1] = ptr
-                cw.args, cr.args = tuple(a), tuple(b)
+                a[7] = ptr
+                cw.args = tuple(a)
             self._ws_note(set_ws, slab_bytes)
             wl = self._wl()
             wl.append(cw)
             self.profile_meta.append(("bwd", wl[-1], self._kname(dw, (y.c, n_in_w)), flops, (x.pixels * 4 + y.pixels * y.c) * self.es))
-            wl.append(cr)
             wl.append(_TorchCall(lambda: gw.copy_(gstage[:, :, :k, :3].permute(0, 3, 1, 2)), "stem grad unstage", lane=tail))
         blk.append(emit)
 
@@ -999,31 +992,27 @@ class Plan:
         gpack = self._pack(wt, cin, cout, (cout * k * k, k * k, k, 1), all_rs, nd["w"] + " deconv dgrad pack")
         rs_arr = _taps_array(all_rs)
 
-        def tune_launch(xp, dyp, slab, grad, sp):          # dy is the gathered operand here, x the dense one
-            check(self.lib.lh_wgrad(C.byref(dg), xp, dyp, x.c, cin, cout, slab, self.dt, sp), "autotune lh_wgrad")
-            check(self.lib.lh_wgrad_reduce(C.byref(dg), slab, grad, cin, cout, cout * k * k, k * k, k, 1, rs_arr, 0, self.dt, sp), "autotune lh_wgrad_reduce")
+        def tune_launch(xp, dyp, ws, grad, sp):            # dy is the gathered operand here, x the dense one
+            check(self.lib.lh_wgrad_fused(C.byref(dg), 0, xp, dyp, x.c, cin, cout, ws, grad, cout * k * k, k * k, k, 1, rs_arr, 0, self.dt, sp),
+                  "autotune lh_wgrad_fused")
         self._tune_wgrad(dg, cin, cout, x.c, tune_launch, cin * cout * k * k)
-        slab_bytes = self.lib.lh_wgrad_slab_bytes(C.byref(dg), cin, cout, self.dt)
+        slab_bytes = self.lib.lh_wgrad_workspace_bytes(C.byref(dg), cin, cout, self.dt)
         self._ws_wgrad = max(self._ws_wgrad, slab_bytes)
         gw = self.grads[nd["w"] + ".weight"]
         flops = 2.0 * x.pixels * cin * cout * k * k
 
         def emit():
             dy = self._act_grad(y)
-            a = [C.byref(dg), dy.data_ptr(), xbuf.data_ptr(), x.c, cin, cout, 0, self.dt]
-            b = [C.byref(dg), 0, gw.data_ptr(), cin, cout, cout * k * k, k * k, k, 1, rs_arr, 0, self.dt]
-            tail = 1
-            cw, cr = _Call(self.lib.lh_wgrad, None, nd["w"] + " wgrad", lane=1), _Call(self.lib.lh_wgrad_reduce, None, nd["w"] + " wgrad reduce", keep=rs_arr, lane=tail)
+            a = [C.byref(dg), 0, dy.data_ptr(), xbuf.data_ptr(), x.c, cin, cout, 0, gw.data_ptr(), cout * k * k, k * k, k, 1, rs_arr, 0, self.dt]
+            cw = _Call(self.lib.lh_wgrad_fused, None, nd["w"] + " wgrad", keep=rs_arr, lane=1)
 
             def set_ws(ptr):
-                a[6] = ptr
-                b[1] = ptr
-                cw.args, cr.args = tuple(a), tuple(b)
+                a[7] = ptr
+                cw.args = tuple(a)
             self._ws_note(set_ws, slab_bytes)
             wl = self._wl()
             wl.append(cw)
             self.profile_meta.append(("bwd", wl[-1], self._kname(dg, (cin, cout)), flops, (x.pixels * x.c + y.pixels * y.c) * self.es))
-            wl.append(cr)
             if nd["bias"]:
                 gb_ = self.grads[nd["bias"]]
                 wl.append(_TorchCall(lambda: gb_.copy_(dy.view(-1, y.c)[:, :cout].sum(0, dtype=torch.float32)), "bias grad"))

@@ -35,6 +35,40 @@ def init_distributed(backend=None):
     return rank, world, local
 
 
+class LhComm:
+    """The C-ABI communicator (lh_comm_*: RCCL underneath, include/lighthand_hip.h).  Rank 0 creates the 128-byte id,
+    torch.distributed (already initialised by ``init_distributed``; any backend) carries it to the other ranks."""
+
+    def __init__(self, rank=None, world_size=None):
+        import ctypes as C
+        from . import _lib
+        self.lib, self._C = _lib.load(), C
+        self.rank = dist.get_rank() if rank is None else rank
+        self.world_size = dist.get_world_size() if world_size is None else world_size
+        uid = (C.c_char * 128)()
+        if self.rank == 0:
+            _lib.check(self.lib.lh_comm_unique_id(uid), "lh_comm_unique_id")
+        if self.world_size > 1:
+            box = [bytes(uid)]
+            dist.broadcast_object_list(box, src=0)
+            uid = (C.c_char * 128).from_buffer_copy(box[0])
+        self.handle = C.c_void_p()
+        _lib.check(self.lib.lh_comm_init(C.byref(self.handle), self.rank, self.world_size, uid), "lh_comm_init")
+
+    def all_reduce_sum_(self, t, stream=None):
+        """In-place sum of a contiguous fp32 / bf16 / fp16 device tensor on `stream` (default: the current one)."""
+        from . import _lib
+        assert t.is_cuda and t.is_contiguous()
+        s = (stream or torch.cuda.current_stream()).cuda_stream
+        _lib.check(self.lib.lh_comm_allreduce_sum(self.handle, t.data_ptr(), t.numel(), _lib.dtype_code(t.dtype), s), "lh_comm_allreduce_sum")
+        return t
+
+    def close(self):
+        if self.handle:
+            self.lib.lh_comm_destroy(self.handle)
+            self.handle = None
+
+
 def all_reduce_sum_(t, group=None):
     """Sum a small tensor over the ranks in place (no-op for a single process).  Used wherever ranks must take the
     SAME host-side decision from per-rank numbers (validation loss -> best checkpoint / early stop)."""
@@ -95,9 +129,12 @@ def plan_buckets(marks, offsets, total, bucket_bytes=32 << 20):
 class GradSync:
     """Launches one all-reduce per gradient bucket on a side stream and lets Adam wait for all."""
 
-    def __init__(self, world_size=None, bucket_bytes=32 << 20, group=None, compress=None):
+    def __init__(self, world_size=None, bucket_bytes=32 << 20, group=None, compress=None, comm=None):
         """compress='bf16': every bucket travels as bfloat16 (half the bytes per xGMI link; the sum is formed in bf16 by
-        the collective, the fp32 arena slice receives the result).  Default: fp32 buckets, exact sums."""
+        the collective, the fp32 arena slice receives the result).  Default: fp32 buckets, exact sums.
+        comm: an ``LhComm`` -- the buckets then go through the C-ABI communicator (lh_comm_allreduce_sum) instead of
+        torch.distributed's all_reduce (same RCCL underneath)."""
+        self.comm = comm
         self.world_size = world_size or (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.bucket_bytes = bucket_bytes
         self.group = group
@@ -126,15 +163,17 @@ class GradSync:
             ev.record(torch.cuda.current_stream())
             self.stream.wait_event(ev)
             with torch.cuda.stream(self.stream):
+                reduce_ = self.comm.all_reduce_sum_ if self.comm is not None else \
+                    (lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group))
                 if self.compress == "bf16":
                     half = self._staging.get(bucket)
                     if half is None:
                         half = self._staging[bucket] = torch.empty(stop - start, dtype=torch.bfloat16, device=view.device)
                     half.copy_(view)
-                    dist.all_reduce(half, op=dist.ReduceOp.SUM, group=self.group)
+                    reduce_(half)
                     view.copy_(half)
                 else:
-                    dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+                    reduce_(view)
                 done = torch.cuda.Event()
                 done.record(self.stream)
             self._pending.append(done)

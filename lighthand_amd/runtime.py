@@ -94,9 +94,9 @@ class TrainStep:
         self.optimizer.step(grad_scale=self.grad_scale)
 
     def _capture(self):
-        """One graph for the whole step, or -- with gradient synchronisation -- one graph per
-        backward segment so each gradient bucket's all-reduce (eager RCCL call on the side stream)
-        starts as soon as its segment has been replayed."""
+        """One graph for the whole step; with gradient synchronisation through torch.distributed one graph per backward
+        segment, so that each gradient bucket's all-reduce (an eager call on the side stream) starts as soon as its
+        segment has been replayed; with the C-ABI communicator again one graph, collectives included."""
         warm = torch.cuda.Stream()
         warm.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(warm):          # warm-up outside capture (allocations, lazy state)
@@ -108,6 +108,15 @@ class TrainStep:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self._enqueue_all()
+            self.graphs.append((g, None))
+            return
+        if getattr(self.grad_sync, "comm", None) is not None:
+            # C-ABI communicator (lh_comm_*): the bucket all-reduces are stream-ordered RCCL launches that a hipGraph can
+            # hold, so the whole data-parallel step -- backward segments, the all-reduces on the side stream, Adam -- is
+            # ONE captured graph (no host work between segments)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._eager_synced()
             self.graphs.append((g, None))
             return
         segs = self.grad_sync.segments(self.plan)

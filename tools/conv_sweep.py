@@ -133,33 +133,27 @@ for name, cin, cout, k, s, n, h, w, tr in SHAPES:
               + "  ".join(f"{r[1]} {r[0]:.1f}" for r in res[:4]) + (f" | worst {res[-1][1]} {res[-1][0]:.1f}" if res else "")
               + (f" | MISMATCH {[r[1] for r in bad]}" if bad else ""))
     # ---- weight gradient: every launch plan (tile, stage rows, ring depth, pixel splits), wgrad + fold timed together
-    wcalls = [c for c in plan.bwd if getattr(c, "fn", None) in (lib.lh_wgrad, lib.lh_wgrad_rowfold)]
-    rcalls = [c for c in plan.bwd if getattr(c, "fn", None) == lib.lh_wgrad_reduce]
-    for cw, cr in zip(wcalls, rcalls):
+    wcalls = [c for c in plan.bwd if getattr(c, "fn", None) == lib.lh_wgrad_fused]
+    for cw in wcalls:
         d = cw.args[0]._obj
-        n_out, n_in = cw.args[4], cw.args[5]
+        n_out, n_in = cw.args[5], cw.args[6]
         buf = (C.c_int * (5 * 128))()
         nc = lib.lh_wgrad_candidates(C.byref(d), n_out, n_in, plan.dt, buf, 128)
         cands = [tuple(buf[5 * i:5 * i + 5]) for i in range(nc)]
-        slab = torch.empty(((max([c[4] for c in cands] + [0]) + 2) << 20), dtype=torch.uint8, device="cuda")
-        wa, ra = list(cw.args), list(cr.args)
-        wa[6] = slab.data_ptr(); ra[1] = slab.data_ptr()
-        cw.args, cr.args = tuple(wa), tuple(ra)
-
-        class Both:
-            def __call__(self, sp_):
-                cw(sp_); cr(sp_)
-        both = Both()
+        ws = torch.zeros((max([c[4] for c in cands] + [0]) + 2) << 20, dtype=torch.uint8, device="cuda")
+        wa = list(cw.args)
+        wa[7] = ws.data_ptr()
+        cw.args = tuple(wa)
         for i in range(5, 8):
             d.cfg[i] = 0
-        t_def = timed(both, iters)
+        t_def = timed(cw, iters)
         gref = plan.grads["conv.weight"].clone()
         a, b, c_, r = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
         lib.lh_wgrad_tile(C.byref(d), n_out, n_in, plan.dt, C.byref(a), C.byref(b), C.byref(c_), C.byref(r))
         res = []
         for bo, bi, enc, wgs, mib in cands:
             d.cfg[5], d.cfg[6], d.cfg[7] = bo, bi, enc
-            t = timed(both, iters)
+            t = timed(cw, iters)
             err = float((plan.grads["conv.weight"] - gref).abs().max() / (gref.abs().max() + 1e-20))
             res.append((t, (bo, bi, (enc >> 16) & 255, enc >> 24, enc & 0xffff), err))
         for i in range(5, 8):
