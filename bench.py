@@ -179,6 +179,10 @@ def main():
     ap.add_argument("--hrnet-width", type=int, default=0, help="benchmark HRNet-W<width> instead of SimpleBaseline (configs[3])")
     ap.add_argument("--infer-only", action="store_true", help="inference graph only (configs[4]: --size 384 --batch 256 --precision fp16)")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--comm", default="torch", choices=["torch", "lh"],
+                    help="gradient transport for --gpus > 1: torch.distributed all-reduce between per-segment graphs (default) or "
+                         "the C-ABI communicator lh_comm_* (RCCL inside ONE captured graph per step)")
+    ap.add_argument("--grad-buckets", default="fp32", choices=["fp32", "bf16"], help="dtype the gradient buckets travel in")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra configurations (HRNet-W32 training, R50 384x384 fp16 inference)")
@@ -215,7 +219,10 @@ def main():
                                                  f"batch {args.batch}, hipGraph replay"},
                           "step_roofline": step_roofline(key, False, args.batch * args.steps / dt, 4 if args.precision == "fp32" else 2)}))
         return
-    sync = parallel.GradSync(world) if world > 1 else None
+    sync = None
+    if world > 1:
+        sync = parallel.GradSync(world, compress="bf16" if args.grad_buckets == "bf16" else None,
+                                 comm=parallel.LhComm() if args.comm == "lh" else None)
     step = TrainStep(model, args.batch, args.size, args.size, lr=1e-3, use_graph=not args.no_graph, grad_sync=sync)
     images, joints = synthetic_batch(args.batch, args.size, dev, seed=9001 + rank)
     step.images.copy_(images)
@@ -248,7 +255,7 @@ def main():
         "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
         "config": {"workload": f"{name} {args.size}x{args.size} training step "
                                f"(fwd + JointsMSELoss + argmax decode + bwd + Adam), batch {args.batch}/GPU, 21 joints, "
-                               f"random init (seed 9001), hipGraph replay" + (f", dp{world} RCCL all-reduce" if world > 1 else ""),
+                               f"random init (seed 9001), hipGraph replay" + (f", dp{world} RCCL all-reduce ({args.comm}, {args.grad_buckets} buckets)" if world > 1 else ""),
                    "global_batch": world * args.batch, "parallelism": f"dp{world}"},
         "loss_after": round(loss_val, 6),
         "train_tflops": round(value * (TRAIN_GFLOP_PER_IMG if (args.depth, args.size) == (50, 256) else 0) / 1e3, 1),

@@ -13,5 +13,6 @@ tail -c 600 $O/bench.json
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o r02 -- python3 bench.py --no-cpu-baseline --no-extra > $O/stats.log 2>&1
 timeout -k 10 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-extra > $O/pmc_fetch.log 2>&1
 timeout -k 10 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-extra > $O/pmc_write.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --output-format csv -d $O/pmc_mfma -o m -- python3 tools/conv_bench.py 256 256 3 1 64 64 64 bf16 3 > $O/pmc_mfma.log 2>&1
 timeout -k 10 300 python tools/layer_profile.py > $O/layers.txt 2>&1
 find $O -name "*.csv" | head -20

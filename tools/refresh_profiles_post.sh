@@ -8,4 +8,5 @@ cp "$(find $O/stats -name '*kernel_stats.csv' | head -1)" profiles/r02_bench_ker
 cp $O/layers.txt profiles/r02_layers.txt
 python tools/pmc_traffic.py "$(find $O/pmc_fetch -name '*counter_collection.csv' | head -1)" \
     "$(find $O/pmc_write -name '*counter_collection.csv' | head -1)" profiles/r02_pmc_hbm_traffic.txt profiles/r02_pmc_traffic.json
+python tools/pmc_mfma.py "$(find $O/pmc_mfma -name '*counter_collection.csv' | head -1)" profiles/r02_pmc_mfma.txt > /dev/null
 ls -la profiles/
