@@ -69,13 +69,30 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, unsigned char
 #pragma unroll
     for (int e = 0; e < EPC; ++e) s1[e] = s2[e] = 0.f;
 
-    for (int pr = r0; pr < BP; pr += RPP) {
-        const int m = pblk * BP + pr;
+    // Output pixel of row pr: m = pblk * BP + pr -> (image, row, column) -> placement in the (possibly strided / phased)
+    // output.  A dense output (the common case) has opix == m; otherwise the decomposition is done ONCE per thread and
+    // advanced by RPP rows per iteration with two conditional subtracts (integer divisions per row were most of the
+    // epilogue's instruction count).
+    const bool dense = p.osh == 1 && p.osw == 1 && p.OH == p.ho && p.OW == p.wo && ooh == 0 && oow == 0;
+    int m = pblk * BP + r0;
+    int pn = 0, pa = 0, pb = 0;
+    const int qa = RPP / p.wo, step_b = RPP - qa * p.wo, step_n = qa / p.ho, step_a = qa - step_n * p.ho;   // wave-uniform
+    if (!dense) {
+        pn = m / hw;
+        const int rem = m - pn * hw;
+        pa = rem / p.wo;
+        pb = rem - pa * p.wo;
+    }
+    for (int pr = r0; pr < BP; pr += RPP, m += RPP) {
+        int opix = m;
+        if (!dense) {
+            opix = (pn * p.OH + pa * p.osh + ooh) * p.OW + pb * p.osw + oow;
+            pb += step_b; pa += step_a; pn += step_n;
+            if (pb >= p.wo) { pb -= p.wo; ++pa; }
+            if (pa >= p.ho) { pa -= p.ho; ++pn; }
+        }
         if (m >= p.M || !col_ok) continue;
-        const int n = m / hw, rem = m - n * hw;
-        const int a = rem / p.wo, b = rem - a * p.wo;
-        const long opix = ((long)n * p.OH + a * p.osh + ooh) * p.OW + b * p.osw + oow;
-        const long eoff = opix * p.out_pix_stride + col0;
+        const long eoff = (long)((unsigned long)(unsigned)opix * (unsigned)p.out_pix_stride) + col0;
         const unsigned char* src = smem + pr * RS + chunk * 16;
         const uint2 lo = *reinterpret_cast<const uint2*>(src);
         const uint2 hi = *reinterpret_cast<const uint2*>(src + 8);
@@ -106,7 +123,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, unsigned char
 #pragma unroll
             for (int e = 0; e < EPC; ++e) { s1[e] += sv[e]; s2[e] += sv[e] * sv[e]; }
         }
-        *reinterpret_cast<uint4*>(p.out + eoff * ES) = u;
+        if (!(LH_ABL & 16) || u.x == 0x12345678u) *reinterpret_cast<uint4*>(p.out + eoff * ES) = u;
     }
 
     if (stats) {

@@ -331,14 +331,28 @@ extern "C" int lh_wgrad_candidates(const lh_igemm_desc* d, int n_out, int n_in, 
     for (int i = 0; i < kNWCfg; ++i) {
         const WgradCfg& c = kWCfg[i];
         if (!wcfg_fits(c, n_out, n_in)) continue;
-        int last = -1;
+        const long tiles = (long)((n_out + c.bo - 1) / c.bo) * ((n_in + c.bi - 1) / c.bi) * d->ntaps;
+        const long stages = ((long)d->n * d->ho * d->wo + c.kps - 1) / c.kps;
+        int seen[8], nseen = 0;
         const long targets[5] = {256, 512, 1024, 2048, 4096};
-        for (int t = 0; t < 5 && k < max; ++t) {
+        for (int t = 0; t < 8 && k < max; ++t) {
             int ns, sps;
-            wgrad_splits(d, n_out, n_in, c.bo, c.bi, c.kps, targets[t], &ns, &sps);
-            if (ns == last || ns > 0xffff) continue;
-            last = ns;
-            const long tiles = (long)((n_out + c.bo - 1) / c.bo) * ((n_in + c.bi - 1) / c.bi) * d->ntaps;
+            if (t < 5) {
+                wgrad_splits(d, n_out, n_in, c.bo, c.bi, c.kps, targets[t], &ns, &sps);
+            } else {
+                // the 8-wave tile runs one workgroup per CU: also offer the split counts that fill the 256 CUs exactly
+                // once, twice, three times (a 257th workgroup would run alone in a second round)
+                if (c.bo * c.bi < 256 * 256) break;
+                const long fill = 256L * (t - 4) / tiles;
+                if (fill < 1 || fill > 0xffff) continue;
+                sps = (int)((stages + fill - 1) / fill);
+                ns = (int)((stages + sps - 1) / sps);
+                if (sps * c.kps < 256) continue;
+            }
+            bool dup = ns > 0xffff;
+            for (int q = 0; q < nseen; ++q) dup = dup || seen[q] == ns;
+            if (dup) continue;
+            seen[nseen++] = ns;
             out[5 * k] = c.bo; out[5 * k + 1] = c.bi; out[5 * k + 2] = ns | (c.kps << 16) | (c.depth << 24);
             out[5 * k + 3] = (int)(tiles * ns);
             out[5 * k + 4] = (int)(((long)ns * d->ntaps * n_out * n_in * 4) >> 20);

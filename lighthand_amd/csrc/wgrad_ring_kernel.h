@@ -63,7 +63,7 @@ template <int L, int MAXS> __device__ __forceinline__ void wwait_stages(int stag
     }
 }
 
-template <int ROWB> __device__ __forceinline__ int wswz(int row) {
+template <int ROWB> __device__ __forceinline__ constexpr int wswz(int row) {
     return ROWB >= 256 ? (row & 7) : ((row >> 1) & 3);
 }
 
@@ -114,62 +114,64 @@ __global__ __launch_bounds__(64 * WO * WI, 2) void wgrad_ring_kernel(const Wgrad
     const unsigned char* zero = p.zero;
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
 
-    // ---- per-lane source bookkeeping: instruction q = NWAVE*j + wave covers rows [q*RP, (q+1)*RP) of the stage
-    const unsigned char* osrc[NO];          // dy address of this lane's chunk in stage 0 (advances by KPS rows per stage)
-    int oleft[NO];                          // the chunk is live while (pixels done) < oleft
-#pragma unroll
-    for (int j = 0; j < NO; ++j) {
-        const int q = NWAVE * j + wave;
-        const int r = q * RPO + lane / (RBO / 16), c16 = lane % (RBO / 16);
-        const int ocol = otile * BO + ((((c16 >> 1) ^ wswz<RBO>(r)) << 1) | (c16 & 1)) * 8;
-        osrc[j] = p.dy + ((m_begin + r) * p.dy_pix_stride + ocol) * 2;
-        oleft[j] = ocol < p.n_out ? span - r : 0;
-    }
-    const unsigned char* xsrc[NI];          // x address of (image 0, row 0, column 0) + this lane's channel chunk
-    int xn[NI], xa[NI], xb[NI], xleft[NI];  // output pixel (image, row, column) this lane fetches for in the next stage
-    int xdh[NI];                            // input row offset of this lane's chunk: the tap's dh (+ the folded kernel row)
+    // ---- per-lane source bookkeeping: instruction q = NWAVE*j + wave covers rows [q*RP, (q+1)*RP) of the stage.
+    // Instruction j of a wave lies j * NWAVE * RP rows below instruction 0, a multiple of 8 rows: same swizzle, same
+    // channel chunk, so one address / one limit per operand serves all j (the row offset of j is wave-uniform).
+    static_assert((NWAVE * RPO) % 8 == 0 && (NWAVE * RPI) % 8 == 0, "instructions of a wave must share the swizzle phase");
+    const int ro0 = wave * RPO + lane / (RBO / 16), oc16 = lane % (RBO / 16);
+    const int ocol = otile * BO + ((((oc16 >> 1) ^ wswz<RBO>(ro0)) << 1) | (oc16 & 1)) * 8;
+    const unsigned char* osrc = p.dy + ((m_begin + ro0) * p.dy_pix_stride + ocol) * 2;   // dy address of this lane's chunk, instruction 0, stage 0
+    const int oleft = ocol < p.n_out ? span - ro0 : 0;       // chunk j is live while (pixels done) + j * NWAVE * RPO < oleft
+    const long ostep = (long)NWAVE * RPO * p.dy_pix_stride * 2;
+    const int ri0 = wave * RPI + lane / (RBI / 16), ic16 = lane % (RBI / 16);
+    const int icol = itile * BI + ((((ic16 >> 1) ^ wswz<RBI>(ri0)) << 1) | (ic16 & 1)) * 8;
+    // row fold: the gradient's input index covers `rows` kernel rows of fold_k contiguous elements each; this lane's
+    // chunk belongs to kernel row icol / fold_k (an extra input-row offset) and element icol % fold_k of the run
+    const int xdh = dh + (p.fold_k ? icol / p.fold_k : 0);   // input row offset of this lane's chunk
+    const unsigned char* xsrc = p.x + (long)(p.fold_k ? icol % p.fold_k : icol) * 2;     // (image 0, row 0, column 0) + channel chunk
+    const int xleft = icol < p.k_run ? span - ri0 : 0;
+    // output pixel (image, row, column) instruction 0 fetches for in the next stage; instruction j's lies j * NWAVE * RPI
+    // pixels further on: (jn, ja, jb) is that distance as a mixed-radix number (wave-uniform)
+    int xn, xa, xb;
     const int xpix = p.in_pix_stride * 2;   // bytes per input pixel
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        const int q = NWAVE * j + wave;
-        const int r = q * RPI + lane / (RBI / 16), c16 = lane % (RBI / 16);
-        const int icol = itile * BI + ((((c16 >> 1) ^ wswz<RBI>(r)) << 1) | (c16 & 1)) * 8;
-        // row fold: the gradient's input index covers `rows` kernel rows of fold_k contiguous elements each; this lane's
-        // chunk belongs to kernel row icol / fold_k (an extra input-row offset) and element icol % fold_k of the run
-        const int idh = p.fold_k ? icol / p.fold_k : 0;
-        const int ick = p.fold_k ? icol % p.fold_k : icol;
-        const long m = m_begin + r;
+    {
+        const long m = m_begin + ri0;
         const int mi = m < p.M ? (int)m : 0;
-        xn[j] = mi / hw;
-        const int rem = mi - xn[j] * hw;
-        xa[j] = rem / p.wo;
-        xb[j] = rem - xa[j] * p.wo;
-        xleft[j] = icol < p.k_run ? span - r : 0;
-        xdh[j] = dh + idh;
-        xsrc[j] = p.x + (long)ick * 2;
+        xn = mi / hw;
+        const int rem = mi - xn * hw;
+        xa = rem / p.wo;
+        xb = rem - xa * p.wo;
     }
+    const int jq = (NWAVE * RPI) / p.wo, jb = NWAVE * RPI - jq * p.wo, jn = jq / p.ho, ja = jq - jn * p.ho;
 
     int issued = 0, islot = 0, done = 0;    // done = pixels of the split covered by the stages issued so far
     long oadv = 0;
-    auto issue = [&]() {
+    auto issue = [&]() __attribute__((always_inline)) {
         unsigned char* st = smem + islot * STAGE;
 #pragma unroll
         for (int j = 0; j < NO; ++j) {
-            const unsigned char* src = done < oleft[j] ? osrc[j] + oadv : zero;
+            const unsigned char* src = done + j * NWAVE * RPO < oleft ? osrc + (oadv + j * ostep) : zero;
             if (!(LH_ABL & 4)) __builtin_amdgcn_global_load_lds((gbl_p)src, (lds_p)(st + (NWAVE * j + wave) * 1024), 16, 0, 0);
         }
+        int cn = xn, ca = xa, cb = xb;
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-            const int ih = xa[j] * p.sh + xdh[j], iw = xb[j] * p.sw + dw;
-            const bool ok = (int)(done < xleft[j]) & (int)((unsigned)ih < (unsigned)p.hi) & (int)((unsigned)iw < (unsigned)p.wi);
-            const int pix = (xn[j] * p.hi + ih) * p.wi + iw;            // input pixel index (any value when !ok)
-            const unsigned char* src = ok ? xsrc[j] + (long)pix * xpix : zero;
+            const int ih = ca * p.sh + xdh, iw = cb * p.sw + dw;
+            const bool ok = (int)(done + j * NWAVE * RPI < xleft) & (int)((unsigned)ih < (unsigned)p.hi) & (int)((unsigned)iw < (unsigned)p.wi);
+            const int pix = (cn * p.hi + ih) * p.wi + iw;               // input pixel index (any value when !ok)
+            const unsigned char* src = ok ? xsrc + (long)pix * xpix : zero;
             if (!(LH_ABL & 4)) __builtin_amdgcn_global_load_lds((gbl_p)src, (lds_p)(st + KPS * RBO + (NWAVE * j + wave) * 1024), 16, 0, 0);
-            // advance this lane's pixel by one stage (mixed-radix add: no division)
-            int b = xb[j] + p.adv_b, a = xa[j] + p.adv_a, n = xn[j] + p.adv_n;
+            if (j + 1 < NI) {                                           // on to instruction j + 1 (mixed-radix add: no division)
+                cb += jb; ca += ja; cn += jn;
+                if (cb >= p.wo) { cb -= p.wo; ++ca; }
+                if (ca >= p.ho) { ca -= p.ho; ++cn; }
+            }
+        }
+        {                                                               // this lane's pixel one stage on
+            int b = xb + p.adv_b, a = xa + p.adv_a, n = xn + p.adv_n;
             if (b >= p.wo) { b -= p.wo; ++a; }
             if (a >= p.ho) { a -= p.ho; ++n; }
-            xb[j] = b; xa[j] = a; xn[j] = n;
+            xb = b; xa = a; xn = n;
         }
         ++issued;
         if (++islot == D) islot = 0;
@@ -189,48 +191,58 @@ __global__ __launch_bounds__(64 * WO * WI, 2) void wgrad_ring_kernel(const Wgrad
 
     // transposed-read addresses: lane (group g, q, pp) reads pixel row 4g+q (and +16), 4 channels at 4*pp of a 16-channel tile
     const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
-    const int row0 = 4 * g + q, row1 = row0 + 16;
-    unsigned ao[OT][2], ai[IT][2];
+    const int row0 = 4 * g + q;
+    // (the second read of a fragment, pixel rows +16, has the same swizzle: it is the first address + 16 rows, an immediate)
+    unsigned ao[OT], ai[IT];
 #pragma unroll
     for (int i = 0; i < OT; ++i) {
         const int ct = wo_ * OT + i;                              // 32-byte granule index inside the row
-        ao[i][0] = lds_base + row0 * RBO + ((ct ^ wswz<RBO>(row0)) << 5) + pp * 8;
-        ao[i][1] = lds_base + row1 * RBO + ((ct ^ wswz<RBO>(row1)) << 5) + pp * 8;
+        ao[i] = lds_base + row0 * RBO + ((ct ^ wswz<RBO>(row0)) << 5) + pp * 8;
     }
 #pragma unroll
     for (int j = 0; j < IT; ++j) {
         const int ct = wi_ * IT + j;
-        ai[j][0] = lds_base + KPS * RBO + row0 * RBI + ((ct ^ wswz<RBI>(row0)) << 5) + pp * 8;
-        ai[j][1] = lds_base + KPS * RBO + row1 * RBI + ((ct ^ wswz<RBI>(row1)) << 5) + pp * 8;
+        ai[j] = lds_base + KPS * RBO + row0 * RBI + ((ct ^ wswz<RBI>(row0)) << 5) + pp * 8;
     }
+    static_assert(wswz<RBO>(3) == wswz<RBO>(19) && wswz<RBI>(5) == wswz<RBI>(21), "the swizzle must repeat every 16 rows");
 
-    auto rdtr = [](auto OFFc, uint2& dst, unsigned addr) {
+    auto rdtr = [](auto OFFc, uint2& dst, unsigned addr) __attribute__((always_inline)) {
         if constexpr ((LH_ABL & 2) != 0) { dst = uint2{addr, addr}; return; }
         asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(decltype(OFFc)::value));
     };
     // one logical step: pixel rows [32*kk, 32*kk + 32) of ring slot SLOT (the swizzle repeats every 8 rows).  Slot and
     // step offsets are compile-time: they ride in the reads' immediate offset fields, the address registers never change
     // (the 8-wave tile's second slot lies beyond the 16-bit immediate range and takes one add per read instead).
-    auto step = [&](auto KKc, auto SLOTc) {
+    auto step = [&](auto KKc, auto SLOTc) __attribute__((always_inline)) {
         constexpr int kk = decltype(KKc)::value, slot = decltype(SLOTc)::value;
-        constexpr bool imm = (D - 1) * STAGE + KPS * RBO + KP * RBI * (KSUB - 1) < 65536;
+        constexpr bool imm = (D - 1) * STAGE + KPS * RBO + KP * RBI * (KSUB - 1) + 16 * (RBO > RBI ? RBO : RBI) < 65536;
         constexpr int so_imm = imm ? slot * STAGE : 0;
         const unsigned so_reg = imm ? 0u : (unsigned)(slot * STAGE);
-        uint2 fi[IT][2], fo[OT][2];
+        // Output-channel fragments live in OW register slots and ROLL: once the MFMAs of fragment i are issued, its slot
+        // takes the read of fragment i + OW (the large tiles would not fit their 8 fragments beside 128 accumulators).
+        constexpr int OW = OT > 4 ? 4 : OT;
+        uint2 fi[IT][2], fo[OW][2];
+        auto rd_o = [&](auto Ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(Ic)::value;
+            rdtr(wic<so_imm + kk * KP * RBO>{}, fo[i % OW][0], ao[i] + so_reg);
+            rdtr(wic<so_imm + kk * KP * RBO + 16 * RBO>{}, fo[i % OW][1], ao[i] + so_reg);
+        };
         wstatic_for<0, IT>([&](auto Jc) {
-            rdtr(wic<so_imm + kk * KP * RBI>{}, fi[decltype(Jc)::value][0], ai[decltype(Jc)::value][0] + so_reg);
-            rdtr(wic<so_imm + kk * KP * RBI>{}, fi[decltype(Jc)::value][1], ai[decltype(Jc)::value][1] + so_reg);
+            rdtr(wic<so_imm + kk * KP * RBI>{}, fi[decltype(Jc)::value][0], ai[decltype(Jc)::value] + so_reg);
+            rdtr(wic<so_imm + kk * KP * RBI + 16 * RBI>{}, fi[decltype(Jc)::value][1], ai[decltype(Jc)::value] + so_reg);
         });
-        wstatic_for<0, OT>([&](auto Ic) {
-            rdtr(wic<so_imm + kk * KP * RBO>{}, fo[decltype(Ic)::value][0], ao[decltype(Ic)::value][0] + so_reg);
-            rdtr(wic<so_imm + kk * KP * RBO>{}, fo[decltype(Ic)::value][1], ao[decltype(Ic)::value][1] + so_reg);
-        });
+        wstatic_for<0, OW>(rd_o);
         wstatic_for<0, OT>([&](auto Ic) {
             constexpr int i = decltype(Ic)::value;
-            // the reads younger than output-channel fragment i may stay in flight (LDS returns in order)
-            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (OT - 1 - i)) : "memory");
+            // reads younger than fragment i's may stay in flight (LDS returns in order): the rest of the first OW, plus
+            // the rolled reads issued since (one per earlier fragment k with k + OW < OT, issued after k's MFMAs)
+            constexpr int first = i < OW ? OW - 1 - i : 0;
+            constexpr int lo = i < OW ? 0 : i - OW + 1;
+            constexpr int hi = i < OT - OW ? i : OT - OW;                 // rolled reads come from k in [lo, hi)
+            constexpr int younger = first + (hi > lo ? hi - lo : 0);
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * younger) : "memory");
             __builtin_amdgcn_sched_barrier(0);
-            const uint4 a = uint4{fo[i][0].x, fo[i][0].y, fo[i][1].x, fo[i][1].y};
+            const uint4 a = uint4{fo[i % OW][0].x, fo[i % OW][0].y, fo[i % OW][1].x, fo[i % OW][1].y};
 #pragma unroll
             for (int j = 0; j < IT; ++j) {
                 const uint4 b = uint4{fi[j][0].x, fi[j][0].y, fi[j][1].x, fi[j][1].y};
@@ -238,12 +250,16 @@ __global__ __launch_bounds__(64 * WO * WI, 2) void wgrad_ring_kernel(const Wgrad
                 // channel, i.e. one 16-byte store into the [o][i] slab
                 if (!(LH_ABL & 1)) WMma<T>::run(b, a, acc[i][j]);
             }
+            if constexpr (i + OW < OT) {
+                __builtin_amdgcn_sched_barrier(0);
+                rd_o(wic<i + OW>{});
+            }
         });
     };
 
     // waves 4-7 of the 8-wave tile share their SIMDs with waves 0-3: they refill the ring half a stage later
     const bool late = NWAVE == 8 && KSUB == 2 && wave >= NWAVE / 2;
-    auto stage = [&](auto SLOTc, int s) {
+    auto stage = [&](auto SLOTc, int s) __attribute__((always_inline)) {
         wwait_stages<L, D - 2>(issued - 1 - s);          // stage s has landed; later stages stay in flight
         __builtin_amdgcn_s_barrier();
         if (!late && issued < S) issue();                // into the slot of stage s - 1, retired by every wave

@@ -1,12 +1,17 @@
 #!/bin/bash
-# Builds debug variants of the library with parts of the igemm ring kernel's K loop removed (see LH_ABL in
-# igemm_ring.hip) into tools/abl/, for timing experiments only:  LH_LIB_PATH=tools/abl/lib_abl1.so python ...
+# Builds debug variants of the library with parts of the convolution kernels removed (LH_ABL bits, see
+# igemm_ring_kernel.h) into tools/abl/, for timing experiments only:  LH_LIB_PATH=tools/abl/lib_abl8.so python ...
+# usage: tools/ablate.sh 4 8 16 ...   (bf16 kernels only; the other objects are taken from the normal build)
 set -e
 cd "$(dirname "$0")/../lighthand_amd/csrc"
+make -j8 > /dev/null
 mkdir -p ../../tools/abl
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -ffp-contract=off"
+UNITS="igemm_ring_bf16_big igemm_ring_bf16_mid igemm_ring_bf16_small wgrad_ring_bf16"
 for v in "$@"; do
-  /opt/rocm/bin/hipcc $FLAGS -DLH_ABL=$v -c igemm_ring.hip -o /tmp/igemm_ring_abl$v.o
-  /opt/rocm/bin/hipcc $FLAGS -DLH_ABL=$v -c wgrad.hip -o /tmp/wgrad_abl$v.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC igemm.o /tmp/igemm_ring_abl$v.o /tmp/wgrad_abl$v.o bn.o misc.o -o ../../tools/abl/lib_abl$v.so
+  for u in $UNITS; do /opt/rocm/bin/hipcc $FLAGS -DLH_ABL=$v -c $u.hip -o /tmp/${u}_abl$v.o & done
+  wait
+  OTHERS=$(ls *.o | grep -v -E "^($(echo $UNITS | tr ' ' '|'))\.o$")
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OTHERS $(for u in $UNITS; do echo /tmp/${u}_abl$v.o; done) -ldl -o ../../tools/abl/lib_abl$v.so
 done
+ls -la ../../tools/abl/
