@@ -530,24 +530,47 @@ __global__ __launch_bounds__(256) void fuse_bwd_reduce_flat_kernel(const FuseBwd
     fill_vec<EPC>(s1, 0.f);
     fill_vec<EPC>(s2, 0.f);
     const long rowb = (long)p.c * sizeof(T);
-    for (long r = r0 + rl; r < r1; r += lanes) {
-        const long off = r * rowb + chunk * 16;
+    // one row of this thread's channel chunk: gate the gradient, accumulate (rows in ascending order: the sums do not
+    // depend on how many rows are fetched ahead)
+    auto row = [&](const uint4& gd, const uint4& xd, unsigned mbits, const uint4& od) __attribute__((always_inline)) {
         float g[EPC], xv[EPC];
-        unpack16<T>(*reinterpret_cast<const uint4*>(p.dout + off), g);
-        unpack16<T>(*reinterpret_cast<const uint4*>(p.x + off), xv);
+        unpack16<T>(gd, g);
+        unpack16<T>(xd, xv);
         if (MASK_X) {
 #pragma unroll
             for (int e = 0; e < EPC; ++e) g[e] = (xv[e] * sc[e] + sh[e]) > 0.f ? g[e] : 0.f;
         } else if (p.relu && p.mask) {
-            mask_by_bits<EPC>(p.mask[off >> 4], g);
+            mask_by_bits<EPC>(mbits, g);
         } else if (p.relu) {
             float o[EPC];
-            unpack16<T>(*reinterpret_cast<const uint4*>(p.out + off), o);
+            unpack16<T>(od, o);
 #pragma unroll
             for (int e = 0; e < EPC; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
         }
 #pragma unroll
         for (int e = 0; e < EPC; ++e) { s1[e] += g[e]; s2[e] += g[e] * (xv[e] - mean[e]) * inv[e]; }
+    };
+    const bool bits = !MASK_X && p.relu && p.mask, outs = !MASK_X && p.relu && !p.mask;
+    constexpr int UN = MASK_X ? 1 : 4;      // rows fetched ahead per thread (measured: the mask-from-x form, with 16 more registers, is faster without)
+    long r = r0 + rl;
+    for (; r + (UN - 1) * (long)lanes < r1; r += UN * (long)lanes) {
+        uint4 gd[UN], xd[UN], od[UN];
+        unsigned mb[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const long off = (r + u * (long)lanes) * rowb + chunk * 16;
+            gd[u] = *reinterpret_cast<const uint4*>(p.dout + off);
+            xd[u] = *reinterpret_cast<const uint4*>(p.x + off);
+            mb[u] = bits ? p.mask[off >> 4] : 0u;
+            od[u] = outs ? *reinterpret_cast<const uint4*>(p.out + off) : uint4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) row(gd[u], xd[u], mb[u], od[u]);
+    }
+    for (; r < r1; r += lanes) {
+        const long off = r * rowb + chunk * 16;
+        row(*reinterpret_cast<const uint4*>(p.dout + off), *reinterpret_cast<const uint4*>(p.x + off), bits ? p.mask[off >> 4] : 0u,
+            outs ? *reinterpret_cast<const uint4*>(p.out + off) : uint4{0u, 0u, 0u, 0u});
     }
 #pragma unroll
     for (int e = 0; e < EPC; ++e) { red[(threadIdx.x * EPC + e) * 2] = s1[e]; red[(threadIdx.x * EPC + e) * 2 + 1] = s2[e]; }
