@@ -19,6 +19,15 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, unsigned char
     constexpr int CT = TC / 16, PT = TP / 16;
     constexpr int RS = BM * ES + 8;
     if (LH_ABL & 8) { if (acc[0][0][0] == 123.456f) p.out[0] = 1; return; }
+    if (LH_ABL & 32) {                  // no epilogue, but every accumulator stays live (the K loop is not pruned)
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < BM / WC / 16; ++i)
+#pragma unroll
+            for (int j = 0; j < BP / WP / 16; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (t == 123.456f) p.out[0] = 1;
+        return;
+    }
     __syncthreads();
     {
         const int q = lane >> 4, pl = lane & 15;

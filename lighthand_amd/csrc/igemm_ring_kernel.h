@@ -53,7 +53,8 @@ template <> struct MmaR<float> {
 };
 
 // Debug-only ablation builds (tools/ablate.sh): -DLH_ABL=<bits>  1 = drop the MFMAs, 2 = drop the fragment reads,
-// 4 = drop the LDS-DMA loads, 8 = drop the epilogue, 16 = keep the epilogue but drop its global stores.  Results are garbage; only the timing is of interest.  Never set in the product build.
+// 4 = drop the LDS-DMA loads, 8 = drop the epilogue (the K loop is pruned with it), 16 = keep the epilogue but drop its
+// global stores, 32 = drop the epilogue but keep every accumulator live.  Results are garbage; only the timing is of interest.  Never set in the product build.
 #ifndef LH_ABL
 #define LH_ABL 0
 #endif
