@@ -351,6 +351,12 @@ int lh_comm_init(lh_comm** comm, int rank, int nranks, const void* id128);
 int lh_comm_allreduce_sum(lh_comm* comm, void* buf, size_t count, int dtype, void* stream);
 int lh_comm_destroy(lh_comm* comm);
 
+/* dst[i0][i1][i2][i3] = src[i0][i1][i2][i3], fp32, element strides on both sides (shape4 / strides are HOST arrays read at
+ * call time).  The layout shuffles of a step that the reference leaves to tensor views: the stem weight and its gradient
+ * between [O][3][k][k] (pose_resnet.py:151) and the padded NHWC4 staging, the head-gradient crop, bias padding. */
+int lh_copy_strided_f32(float* dst, const float* src, const int* shape4, const long* dst_strides4, const long* src_strides4,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

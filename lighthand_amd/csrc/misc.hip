@@ -853,3 +853,31 @@ extern "C" int lh_pck_curve(const float* pred, const float* gt, int gt_stride, c
     return LH_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ strided fp32 copy
+// dst[i0][i1][i2][i3] = src[i0][i1][i2][i3] with arbitrary element strides on both sides: the small layout shuffles of a
+// step (stem weight [O][3][k][k] <-> [O][k][k'][4] staging, head-gradient crop, bias padding) without a framework op.
+__global__ void copy_strided_f32_kernel(float* dst, const float* src, int n0, int n1, int n2, int n3, long d0, long d1, long d2,
+                                        long d3, long s0, long s1, long s2, long s3) {
+    const long total = (long)n0 * n1 * n2 * n3;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int i3 = (int)(i % n3);
+        long t = i / n3;
+        const int i2 = (int)(t % n2);
+        t /= n2;
+        const int i1 = (int)(t % n1), i0 = (int)(t / n1);
+        dst[i0 * d0 + i1 * d1 + i2 * d2 + i3 * d3] = src[i0 * s0 + i1 * s1 + i2 * s2 + i3 * s3];
+    }
+}
+
+extern "C" int lh_copy_strided_f32(float* dst, const float* src, const int* shape4, const long* dst_strides4, const long* src_strides4,
+                                   void* stream) {
+    LH_REQUIRE(dst && src && shape4 && dst_strides4 && src_strides4, "lh_copy_strided_f32: null pointer");
+    const long total = (long)shape4[0] * shape4[1] * shape4[2] * shape4[3];
+    LH_REQUIRE(shape4[0] > 0 && shape4[1] > 0 && shape4[2] > 0 && shape4[3] > 0, "lh_copy_strided_f32: empty shape");
+    const int grid = (int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
+    hipLaunchKernelGGL(copy_strided_f32_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dst, src, shape4[0], shape4[1], shape4[2],
+                       shape4[3], dst_strides4[0], dst_strides4[1], dst_strides4[2], dst_strides4[3], src_strides4[0], src_strides4[1],
+                       src_strides4[2], src_strides4[3]);
+    LH_LAUNCH_CHECK("copy_strided_f32 launch");
+    return LH_OK;
+}

@@ -562,6 +562,15 @@ class Plan:
             self._producers.setdefault(id(produces), []).append(c)
         return c
 
+    def _copy4(self, dst, src, what, lane=0):
+        """dst.copy_(src) for two fp32 views of equal shape (<= 4 dims, any strides) as one C-ABI launch."""
+        assert dst.dtype == src.dtype == torch.float32 and tuple(dst.shape) == tuple(src.shape) and dst.dim() <= 4
+        pad = 4 - dst.dim()
+        shape = (C.c_int * 4)(*([1] * pad + list(dst.shape)))
+        ds = (C.c_long * 4)(*([0] * pad + list(dst.stride())))
+        ss = (C.c_long * 4)(*([0] * pad + list(src.stride())))
+        return _Call(self.lib.lh_copy_strided_f32, (dst.data_ptr(), src.data_ptr(), shape, ds, ss), what, keep=(shape, ds, ss, dst, src), lane=lane)
+
     def _kname(self, d, wgrad=None):
         """Kernel instantiation name as rocprofv3 prints it (for roofline attribution)."""
         t = {"fp32": "float", "bf16": "__bf16", "fp16": "_Float16"}[self.precision]
@@ -789,7 +798,7 @@ class Plan:
         if nd["bias"]:
             bias = self._alloc(y.c, dtype=torch.float32, zero=True)
             bsrc = self.params[nd["bias"]]
-            self.packs.append(_TorchCall(lambda: bias[:cout].copy_(bsrc.detach()), "bias pad"))
+            self.packs.append(self._copy4(bias[:cout], bsrc.detach(), "bias pad"))
         all_rs = [(r, q) for r in range(k) for q in range(k)]
         if x.is_image:
             self._c_stem(nd, blk, bias)
@@ -847,7 +856,7 @@ class Plan:
             wl.append(cw)
             self.profile_meta.append(("bwd", wl[-1], self._kname(d, (y.c, cin)), flops, (x.pixels * x.c + y.pixels * y.c) * self.es))
             if pad_out:
-                wl.append(_TorchCall(lambda: gw.copy_(gtmp[:cout]), "head grad crop", lane=tail))
+                wl.append(self._copy4(gw, gtmp[:cout].view_as(gw), "head grad crop", lane=tail))
             if nd["bias"]:
                 gb_ = self.grads[nd["bias"]]
                 if y is self.out_act:      # the head: reduce the contiguous fp32 NCHW gradient instead of strided bf16
@@ -880,7 +889,7 @@ class Plan:
         self.fwd.append(_Call(self.lib.lh_image_to_nhwc4, (self.img_nchw.data_ptr(), img.data_ptr(), x.n, x.h, x.w, p, wp, self.dt), "image transform"))
         self._image_call_index = len(self.fwd) - 1
         stage = self._alloc(cout, k, kr // 4, 4, dtype=torch.float32, zero=True)
-        self.packs.append(_TorchCall(lambda: stage[:, :, :k, :3].copy_(wt.detach().permute(0, 2, 3, 1)), "stem weight staging"))
+        self.packs.append(self._copy4(stage[:, :, :k, :3], wt.detach().permute(0, 2, 3, 1), "stem weight staging"))
         rows = [(r, 0) for r in range(k)]
         pack = self._pack(stage, cout, kr, (k * kr, 1, kr, 0), rows, nd["w"] + " stem pack")
         d = _desc(x.n, hp, wp, 4, kr, y.h, y.w, s, s, y.c, y.h, y.w, 1, 1, 0, 0, y.c, rows)
@@ -934,7 +943,7 @@ class Plan:
             wl = self._wl()
             wl.append(cw)
             self.profile_meta.append(("bwd", wl[-1], self._kname(dw, (y.c, n_in_w)), flops, (x.pixels * 4 + y.pixels * y.c) * self.es))
-            wl.append(_TorchCall(lambda: gw.copy_(gstage[:, :, :k, :3].permute(0, 3, 1, 2)), "stem grad unstage", lane=tail))
+            wl.append(self._copy4(gw, gstage[:, :, :k, :3].permute(0, 3, 1, 2), "stem grad unstage", lane=tail))
         blk.append(emit)
 
     # ---- transposed convolution ------------------------------------------------------------------
@@ -948,7 +957,7 @@ class Plan:
         if nd["bias"]:
             bias = self._alloc(y.c, dtype=torch.float32, zero=True)
             bsrc = self.params[nd["bias"]]
-            self.packs.append(_TorchCall(lambda: bias[:cout].copy_(bsrc.detach()), "bias pad"))
+            self.packs.append(self._copy4(bias[:cout], bsrc.detach(), "bias pad"))
         descs, packs = [], []
         for ph in range(2):
             for pw in range(2):

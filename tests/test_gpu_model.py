@@ -27,7 +27,7 @@ def _build(tag):
         pr.resnet_spec[-1] = (kind, [1, 1, 1, 1])
         return (get_pose_net(resnet_cfg(-1), True),
                 lambda sd, x, tr: omod.pose_resnet_forward(sd, x, training=tr, spec=(kind, [1, 1, 1, 1])))
-    depth = {"r18": 18, "r34": 34, "r50": 50, "r50caffe": 50}[tag]
+    depth = {"r18": 18, "r34": 34, "r50": 50, "r50caffe": 50, "r101": 101, "r152": 152}[tag]
     style = "caffe" if tag.endswith("caffe") else "pytorch"
     return (get_pose_net(resnet_cfg(depth, style), True),
             lambda sd, x, tr: omod.pose_resnet_forward(sd, x, depth, style, training=tr))
@@ -200,7 +200,8 @@ def test_reduced_precision_trains_like_fp32(precision):
 
 
 @pytest.mark.parametrize("tag,shape", [("r18", (3, 3, 96, 160)), ("r34", (1, 3, 64, 64)), ("r50", (5, 3, 128, 96)),
-                                       ("r50caffe", (2, 3, 192, 64)), ("hrnet_w32", (3, 3, 64, 96)), ("hrnet_w48", (1, 3, 128, 128))])
+                                       ("r50caffe", (2, 3, 192, 64)), ("r101", (2, 3, 64, 96)), ("r152", (3, 3, 128, 96)),
+                                       ("hrnet_w32", (3, 3, 64, 96)), ("hrnet_w48", (1, 3, 128, 128))])
 def test_forward_odd_shapes_match_oracle(tag, shape):
     """Ragged cases the fixed goldens do not hold: odd batch sizes (pixel-tile tails), batch 1, non-square and
     non-power-of-two maps, every block kind -- train- and eval-mode forward in fp32 vs the CPU oracle on the same
@@ -221,7 +222,16 @@ def test_forward_odd_shapes_match_oracle(tag, shape):
         got_ev = model(x.cuda()).cpu().numpy()
         got_bf = model.set_precision("bf16")(x.cuda()).cpu().numpy()
     assert got_tr.shape == want_tr.shape == (shape[0], 21, shape[2] // 4, shape[3] // 4)
-    assert rel(got_tr, want_tr) < FP32_REL and rel(got_ev, want_ev) < FP32_REL
+    if tag in ("r101", "r152"):
+        # 100+ train-mode BN layers at random init amplify fp32 rounding itself: the CPU fp32 oracle sits 1e-3 .. 3e-3 from
+        # an fp64 evaluation of the same network.  Yardstick: as close to fp64 as the CPU fp32 oracle is (x3), eval at 1e-3.
+        with torch.no_grad():
+            sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+            want64 = oracle_fwd(sd64, x.double(), True).numpy()
+        assert rel(got_tr, want64) < max(FP32_REL, 3 * rel(want_tr, want64)), (rel(got_tr, want64), rel(want_tr, want64))
+        assert rel(got_ev, want_ev) < FP32_REL
+    else:
+        assert rel(got_tr, want_tr) < FP32_REL and rel(got_ev, want_ev) < FP32_REL
     assert rel(got_bf, want_ev) < 5e-2
 
 
