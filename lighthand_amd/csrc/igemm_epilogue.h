@@ -92,7 +92,16 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, unsigned char
         pa = rem / p.wo;
         pb = rem - pa * p.wo;
     }
-    for (int pr = r0; pr < BP; pr += RPP, m += RPP) {
+    // Pass 1: where every row of this thread goes, and -- when an addend rides in -- ALL its addend chunks and mask bytes
+    // requested at once (one row's load at a time left the epilogue latency-bound at ~3.6 TB/s on the data gradients
+    // that carry the identity-shortcut gradient); the accumulators are dead by now, the registers are free.
+    constexpr int NR = BP / RPP;
+    static_assert(BP % RPP == 0, "rows per thread");
+    int opx[NR];                                      // output pixel of row k, -1: nothing to store
+    uint4 ad[NR];
+    unsigned mbits[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k, m += RPP) {
         int opix = m;
         if (!dense) {
             opix = (pn * p.OH + pa * p.osh + ooh) * p.OW + pb * p.osw + oow;
@@ -100,8 +109,20 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, unsigned char
             if (pb >= p.wo) { pb -= p.wo; ++pa; }
             if (pa >= p.ho) { pa -= p.ho; ++pn; }
         }
-        if (m >= p.M || !col_ok) continue;
-        const long eoff = (long)((unsigned long)(unsigned)opix * (unsigned)p.out_pix_stride) + col0;
+        opx[k] = (m < p.M && col_ok) ? opix : -1;
+        ad[k] = uint4{0u, 0u, 0u, 0u};
+        mbits[k] = 0xffu;
+        if (p.addend && opx[k] >= 0) {
+            const long eoff = (long)((unsigned long)(unsigned)opx[k] * (unsigned)p.out_pix_stride) + col0;
+            ad[k] = *reinterpret_cast<const uint4*>(p.addend + eoff * ES);
+            if (p.addend_mask) mbits[k] = p.addend_mask[eoff / EPC];    // addend = upstream gradient, gated by the activation's ReLU mask
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        if (opx[k] < 0) continue;
+        const int pr = r0 + k * RPP;
+        const long eoff = (long)((unsigned long)(unsigned)opx[k] * (unsigned)p.out_pix_stride) + col0;
         const unsigned char* src = smem + pr * RS + chunk * 16;
         const uint2 lo = *reinterpret_cast<const uint2*>(src);
         const uint2 hi = *reinterpret_cast<const uint2*>(src + 8);
@@ -111,11 +132,10 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, unsigned char
             unpack16<T>(u, v);
             if (p.addend) {
                 float av[EPC];
-                unpack16<T>(*reinterpret_cast<const uint4*>(p.addend + eoff * ES), av);
-                if (p.addend_mask) {                    // addend = upstream gradient, gated by the activation's ReLU mask
-                    const unsigned mb = p.addend_mask[eoff / EPC];
+                unpack16<T>(ad[k], av);
+                if (p.addend_mask) {
 #pragma unroll
-                    for (int e = 0; e < EPC; ++e) av[e] = ((mb >> e) & 1u) ? av[e] : 0.f;
+                    for (int e = 0; e < EPC; ++e) av[e] = ((mbits[k] >> e) & 1u) ? av[e] : 0.f;
                 }
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) v[e] += av[e];
