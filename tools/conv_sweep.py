@@ -46,6 +46,11 @@ SHAPES = [
     ("deconv1 256->256 @16", 256, 256, 4, 2, B, 16, 16, 1),
     ("deconv2 256->256 @32", 256, 256, 4, 2, B, 32, 32, 1),
     ("head 1x1 256->21 @64", 256, 21, 1, 1, B, 64, 64, 0),
+    # split-K stand-ins: K / 4 with 4x the pixels = the main kernel of a 4-way split of the layer-4 / layer-3 3x3 convolutions
+    ("emu l4 3x3 512 @8 split4", 128, 512, 3, 1, 4 * B, 8, 8, 0),
+    ("emu l4 3x3 512 @8 split2", 256, 512, 3, 1, 2 * B, 8, 8, 0),
+    ("emu l3 3x3 256 @16 split2", 128, 256, 3, 1, 2 * B, 16, 16, 0),
+    ("emu l4 1x1 2048->512 @8 split4", 512, 512, 1, 1, 4 * B, 8, 8, 0),
 ]
 
 
