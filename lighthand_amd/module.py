@@ -79,6 +79,7 @@ class HipModule(nn.Module):
         self._lh_precision = "fp32"
         self._lh_plans = {}
         self._lh_arena = None
+        self._lh_generation = 0          # bumped whenever the parameter storages are re-created (plans / steps built before are stale)
 
     # -- configuration --------------------------------------------------------------------------
     def set_precision(self, precision):
@@ -94,10 +95,18 @@ class HipModule(nn.Module):
         return self._lh_precision
 
     def _apply(self, fn, *args, **kwargs):
-        # .to() / .cuda() / .float() re-create the parameter storages: drop arena and plans
-        self._lh_plans.clear()
-        self._lh_arena = None
-        return super()._apply(fn, *args, **kwargs)
+        # .to() / .cuda() / .float() may re-create the parameter storages: drop arena and plans -- but only when a storage,
+        # device or dtype really changed (model.cuda() on a model that already lives there is a no-op and must leave a live
+        # TrainStep / optimizer, which hold raw pointers into the arena, intact)
+        def sig():
+            return [(t.data_ptr(), t.device, t.dtype) for t in list(self.parameters()) + list(self.buffers())]
+        before = sig()
+        out = super()._apply(fn, *args, **kwargs)
+        if sig() != before:
+            self._lh_plans.clear()
+            self._lh_arena = None
+            self._lh_generation = getattr(self, "_lh_generation", 0) + 1
+        return out
 
     def __getstate__(self):
         # plans hold raw device pointers / ctypes descriptors: never copied or pickled with the module

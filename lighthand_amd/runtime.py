@@ -13,7 +13,7 @@ import os
 import torch
 
 from . import _lib, heatmap
-from ._lib import check
+from ._lib import LightHandError, check
 from .optim import Adam
 
 
@@ -38,6 +38,7 @@ class TrainStep:
                  input_u8=None, color_jitter=None):
         self.lib = _lib.load()
         self.model = model
+        self._model_generation = getattr(model, "_lh_generation", 0)
         model.train()
         self.plan = model.plan(batch, height, width, training=True, backward=True,
                                wgrad_bucket_bytes=grad_sync.bucket_bytes if grad_sync is not None else None)
@@ -169,6 +170,9 @@ class TrainStep:
                 self.optimizer._sync_hyper(st, group)
 
     def __call__(self, images=None, joints=None, target=None):
+        if getattr(self.model, "_lh_generation", 0) != self._model_generation:
+            raise LightHandError("the model's parameter storages were re-created (.to() / .cuda() / .float()) after this TrainStep "
+                                 "was built: its graph still trains the old buffers -- build a new TrainStep")
         if self.graphs is not None:
             self.sync_hyper()
         if images is not None:

@@ -441,3 +441,27 @@ def test_lh_comm_c_abi_single_rank():
             assert len(step.graphs) == 1
     assert torch.allclose(got[0], got[1], rtol=1e-5, atol=1e-7), float((got[0] - got[1]).abs().max())
     comm.close()
+
+
+def test_noop_device_move_keeps_a_live_step_and_a_real_move_invalidates_it():
+    """model.cuda() on a model that already lives on the device leaves its arena (and the raw pointers a captured step
+    holds) alone; a move that re-creates the parameter storages makes the stale step refuse to run instead of training
+    buffers state_dict() no longer sees."""
+    from lighthand_amd._lib import LightHandError
+    from lighthand_amd.runtime import TrainStep
+    m = _model(18)
+    x, j = _batch(2, 64, 5)
+    step = TrainStep(m, 2, 64, 64, lr=1e-3, use_graph=True)
+    step(x, j)
+    flat = m.arena().flat
+    m.cuda()                                            # no-op: same storages
+    assert m.arena().flat.data_ptr() == flat.data_ptr()
+    before = flat.clone()
+    step(x, j)
+    torch.cuda.synchronize()
+    assert not torch.equal(m.arena().flat, before)      # the live step still trains what state_dict() sees
+    off, numel, _ = step.plan.arena_offsets["conv1.weight"]
+    assert torch.equal(m.state_dict()["conv1.weight"].flatten(), m.arena().flat[off:off + numel])
+    m.double().float()                                  # re-creates every storage
+    with pytest.raises(LightHandError, match="re-created"):
+        step(x, j)
