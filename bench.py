@@ -170,8 +170,8 @@ def cpu_baseline(depth, size, batch, seconds_budget=25.0, cores=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--depth", type=int, default=50)
@@ -236,11 +236,18 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    # the K timed steps (wall clock between barriers = the contract's number); every step is also bracketed by HIP events on
+    # the launch stream for the per-step median SURVEY 8d asks for
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    evs[0].record()
+    for i in range(args.steps):
         step()
+        evs[i + 1].record()
     barrier()
     elapsed = time.perf_counter() - t0
+    per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
+    median_ms = per_step[len(per_step) // 2]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -257,6 +264,7 @@ def main():
                                f"(fwd + JointsMSELoss + argmax decode + bwd + Adam), batch {args.batch}/GPU, 21 joints, "
                                f"random init (seed 9001), hipGraph replay" + (f", dp{world} RCCL all-reduce ({args.comm}, {args.grad_buckets} buckets)" if world > 1 else ""),
                    "global_batch": world * args.batch, "parallelism": f"dp{world}"},
+        "ms_per_step_median": round(median_ms, 3),
         "loss_after": round(loss_val, 6),
         "train_tflops": round(value * (TRAIN_GFLOP_PER_IMG if (args.depth, args.size) == (50, 256) else 0) / 1e3, 1),
     }
