@@ -129,3 +129,21 @@ def auc_from_counts(counts, nvis, diff_sum, n_all, T_list, method):
     curve = np.asarray(counts, dtype=np.float64) / float(nvis) * 100
     return [float(_trapz(curve, thr) / (norm + sys.float_info.epsilon)), float(diff_sum) / float(n_all) / PX_PER_MM_EVAL, curve]
 
+
+def pred_test(meta, T_list, method):
+    """src/utils/argparser.py:391-438 -- the category-less evaluation (``pred_store_test`` output: lists of per-batch
+    predictions, ground truth and bounding-box diagonals): AUC of the PCK curve over ALL joints (no visibility flag) and
+    the mean error in PIXELS (the reference does not convert this one to mm).  Unlike the reference under NumPy >= 1.24
+    a short last batch is accepted.  Returns (auc, mean_error_px)."""
+    if method == "mm":          # this variant converts its mm thresholds with 3.7795 px/mm (argparser.py:400), pred_eval with 2.8346
+        thr = np.linspace(T_list[0], T_list[-1], 101)[1:] * PX_PER_MM_EVAL
+    else:
+        thr = eval_thresholds(T_list, method)
+    norm = _trapz(np.ones_like(thr), thr)
+    bb = np.concatenate([np.asarray(b, dtype=np.float64).reshape(-1) for b in meta["bb"]])
+    gt = np.concatenate([np.asarray(g, dtype=np.float64) for g in meta["gt"]])
+    pred = np.concatenate([np.asarray(q, dtype=np.float64) for q in meta["pred"]])
+    diff = np.sqrt(np.sum(np.square(gt[..., :2] - pred[..., :2]), axis=-1))
+    nd = (diff / bb[:, None] if method == "pckb" else diff).flatten()
+    curve = np.array([(nd < t).sum() / len(nd) * 100 for t in thr])
+    return float(_trapz(curve, thr) / (norm + sys.float_info.epsilon)), float(diff.mean())

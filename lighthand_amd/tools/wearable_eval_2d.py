@@ -80,6 +80,26 @@ def pred_store(model, loader, out_json, batch, size, bn_train=True):
     return meta
 
 
+def pred_store_test(model, loader, out_json, batch, size, bn_train=True):
+    """src/utils/argparser.py:284-323 -- the category-less variant: one entry per BATCH of predictions (x4, 256-px frame),
+    ground truth and bounding-box diagonals; read back by ``lighthand_amd.metrics.pred_test``.  The loader yields
+    (images, gt_2d_joints[, ...])."""
+    meta = {"pred": [], "gt": [], "bb": []}
+    step = _Steps(model, size, bn_train)
+    for item in loader:
+        images, gt = item[0], item[1][:, :, :2]
+        preds = step(images).cpu()
+        w = gt[..., 0].max(1).values - gt[..., 0].min(1).values
+        h = gt[..., 1].max(1).values - gt[..., 1].min(1).values
+        meta["pred"].append(preds.tolist())
+        meta["gt"].append(gt.tolist())
+        meta["bb"].append(torch.sqrt(w ** 2 + h ** 2).tolist())
+    os.makedirs(os.path.dirname(out_json), exist_ok=True)
+    with open(out_json, "w") as f:
+        json.dump([meta], f)
+    return meta
+
+
 def device_eval(model, loader, batch, size, bn_train=True):
     """Same evaluation reduced ON THE DEVICE: per threshold set the PCK-curve counts of all visible
     joints are accumulated by lh_pck_curve, summed across data-parallel ranks with one small all-reduce, and read by

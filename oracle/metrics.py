@@ -88,3 +88,23 @@ def pred_eval(meta, T_list, method):
     auc = _trapz(curve, thr) / (norm + sys.float_info.epsilon)
     out["mean_auc"] = [float(auc), float(np.concatenate(all_diff, 0).mean() / PX_PER_MM_EVAL), curve]
     return out
+
+
+def pred_test(meta, T_list, method):
+    """argparser.py:391-438 restated: flatten the per-batch lists, PCK curve over every joint (normalised by the
+    bounding-box diagonal for 'pckb'), AUC by the trapezoid rule normalised to the threshold span, mean error in pixels."""
+    if method == "mm":
+        thr = np.linspace(T_list[0], T_list[-1], 101)[1:] * PX_PER_MM_EVAL      # argparser.py:400 (pred_eval uses 2.8346)
+    elif method == "pckb":
+        thr = np.linspace(T_list[0], T_list[-1], 100)
+    else:
+        raise AssertionError("this method is the wrong")
+    norm = _trapz(np.ones_like(thr), thr)
+    bbox = np.array([b for batch in meta["bb"] for b in batch])
+    gt = np.array([g for batch in meta["gt"] for g in batch])
+    pred = np.array([q for batch in meta["pred"] for q in batch])
+    diff = np.sqrt(np.sum(np.square(gt - pred), axis=-1))
+    nd = diff / bbox[:, None].repeat(gt.shape[1], axis=1) if method == "pckb" else diff
+    nd = nd.flatten()
+    pck = np.array([(len(nd[nd < t]) / len(nd)) * 100 for t in thr])
+    return float(_trapz(pck, thr) / (norm + sys.float_info.epsilon)), float(diff.mean())

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generate the golden fixtures G1..G7 from the reference.
+"""Generate the golden fixtures G1..G8 (G8 = the pred_store_test / pred_test variant) from the reference.
 
 Runs ONLY in the build container, where the read-only reference tree is mounted
 at /root/reference.  It imports the reference's own Python (with inert stand-ins
@@ -9,6 +9,7 @@ inputs + outputs as data under tests/golden/.  Nothing from the reference's
 source text is stored; the GPU box never sees the reference.
 
     python tests/golden/make_golden.py            # rewrites tests/golden/*.npz|json
+    python tests/golden/make_golden.py g8         # only the named fixtures
 """
 import hashlib
 import json
@@ -307,17 +308,51 @@ def g7_metrics():
     print("G7", pck, float(esum), float(ecnt), out["pckb"]["mean_auc"][:2])
 
 
+def g8_pred_test():
+    """pred_store_test / pred_test (argparser.py:284-323, 391-438): the category-less evaluation file (batches of
+    predictions, ground truth and bounding-box diagonals) and its AUC / mean pixel error."""
+    from src.utils import argparser as ref_ap
+
+    rng = np.random.RandomState(8)
+    meta = {"pred": [], "gt": [], "bb": []}
+    for n in (8, 8, 8):                     # three equal batches (np.array() of ragged batches raises under NumPy >= 1.24)
+        gt = rng.uniform(20, 236, size=(n, 21, 2))
+        pred = gt + rng.randn(n, 21, 2) * rng.choice([2.0, 8.0, 30.0], size=(n, 1, 1))
+        bb = np.sqrt((gt[..., 0].max(1) - gt[..., 0].min(1)) ** 2 + (gt[..., 1].max(1) - gt[..., 1].min(1)) ** 2)
+        meta["pred"].append(pred.tolist()); meta["gt"].append(gt.tolist()); meta["bb"].append(bb.tolist())
+
+    class _Bar:
+        def update(self, n):
+            pass
+
+    out = {}
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as d:
+        os.makedirs(os.path.join(d, "final_model", "fx"))
+        with open(os.path.join(d, "final_model", "fx", "test.json"), "w") as f:
+            json.dump([meta], f)
+        os.chdir(d)
+        try:
+            args = types.SimpleNamespace(name="fx")
+            for key, T, method in (("pckb", [0.1, 0.3], "pckb"), ("mm30", [0, 30], "mm"), ("mm50", [0, 50], "mm")):
+                auc, epe, _ = ref_ap.pred_test(args, T, _Bar(), method)
+                out[key] = [float(auc), float(epe)]
+        finally:
+            os.chdir(cwd)
+    with open(os.path.join(OUT, "g8_pred_test.json"), "w") as f:
+        json.dump({"test": [meta], "pred_test": out}, f)
+    print("G8", out)
+
+
 def main():
     install_standins()
     sys.path.insert(0, REF)
     sys.path.insert(0, os.path.join(REF, "src", "tools"))
     torch.set_num_threads(8)
-    g1_targets()
-    g2_loss()
-    g3_decode()
-    g5_models()
-    g6_trajectory()
-    g7_metrics()
+    steps = {"g1": g1_targets, "g2": g2_loss, "g3": g3_decode, "g5": g5_models, "g6": g6_trajectory, "g7": g7_metrics,
+             "g8": g8_pred_test}
+    for name in (sys.argv[1:] or list(steps)):
+        steps[name]()
 
 
 if __name__ == "__main__":

@@ -465,3 +465,22 @@ def test_noop_device_move_keeps_a_live_step_and_a_real_move_invalidates_it():
     m.double().float()                                  # re-creates every storage
     with pytest.raises(LightHandError, match="re-created"):
         step(x, j)
+
+
+def test_pred_store_test_file_feeds_pred_test(tmp_path):
+    """The category-less evaluation file (argparser.py:284-323): one entry per batch, coordinates in the 256-pixel frame,
+    and pred_test on it equals the oracle's pred_test on the same file."""
+    import json
+    from lighthand_amd import metrics as M
+    from lighthand_amd.tools import wearable_eval_2d as E
+    from oracle import metrics as om
+    m = _model(18)
+    data = E.SyntheticEvalSet(16, 64)
+    loader = torch.utils.data.DataLoader(data, batch_size=8, shuffle=False)
+    path = str(tmp_path / "final_model" / "fx" / "test.json")
+    meta = E.pred_store_test(m.train(), loader, path, 8, 64)
+    on_disk = json.load(open(path))
+    assert isinstance(on_disk, list) and set(on_disk[0]) == {"pred", "gt", "bb"} and len(on_disk[0]["pred"]) == 2
+    assert np.asarray(on_disk[0]["pred"][0]).shape == (8, 21, 2) and len(on_disk[0]["bb"][1]) == 8
+    for T, method in (([0.1, 0.3], "pckb"), ([0, 30], "mm")):
+        assert M.pred_test(meta, T, method) == om.pred_test(on_disk[0], T, method)

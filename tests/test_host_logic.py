@@ -57,6 +57,16 @@ def test_metrics_match_oracle_and_golden(golden_dir):
     assert c == g["epe_cnt"] and abs(s - g["epe_sum"]) < 1e-4 * g["epe_sum"] and len(dist) == 20
     with pytest.raises(AssertionError):
         M.PCK_2d_loss(pred, gt, threshold="bogus")
+    # the category-less variant (pred_store_test -> pred_test): golden, oracle, and a short last batch
+    g8 = json.load(open(os.path.join(golden_dir, "g8_pred_test.json")))
+    meta = g8["test"][0]
+    for key, T, method in (("pckb", [0.1, 0.3], "pckb"), ("mm30", [0, 30], "mm"), ("mm50", [0, 50], "mm")):
+        auc, epe = M.pred_test(meta, T, method)
+        assert abs(auc - g8["pred_test"][key][0]) < 1e-9 * auc and abs(epe - g8["pred_test"][key][1]) < 1e-9 * epe
+        assert (auc, epe) == om.pred_test(meta, T, method)
+    ragged = {k: [v[0], v[1], v[2][:5]] for k, v in meta.items()}
+    flat = {k: [[x for b in ragged[k] for x in b]] for k in ragged}
+    assert M.pred_test(ragged, [0, 30], "mm") == M.pred_test(flat, [0, 30], "mm")
 
 
 @pytest.mark.parametrize("tag,nodes", [("r18", None), ("r50", None), ("hrnet_w32", None)])

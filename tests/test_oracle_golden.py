@@ -123,6 +123,16 @@ def test_g7_metrics(golden_dir):
     assert abs(s - g["epe_sum"]) < 1e-4 * g["epe_sum"]
 
 
+def test_g8_pred_test(golden_dir):
+    """The category-less evaluation (pred_store_test -> pred_test, argparser.py:284-323, 391-438) against the reference's
+    own output on a seeded evaluation file."""
+    g = json.load(open(os.path.join(golden_dir, "g8_pred_test.json")))
+    meta = g["test"][0]
+    for key, T, method in (("pckb", [0.1, 0.3], "pckb"), ("mm30", [0, 30], "mm"), ("mm50", [0, 50], "mm")):
+        auc, epe = om.pred_test(meta, T, method)
+        assert abs(auc - g["pred_test"][key][0]) < 1e-9 * max(1, abs(auc)) and abs(epe - g["pred_test"][key][1]) < 1e-9 * epe
+
+
 def test_color_jitter_oracle_known_answers():
     """oracle/color.py restates torchvision's published ColorJitter tensor algorithm (torchvision is absent from this
     image, so no fixture can be generated from it): closed-form known answers pin it."""
