@@ -46,6 +46,11 @@ SHAPES = [
     ("deconv1 256->256 @16", 256, 256, 4, 2, B, 16, 16, 1),
     ("deconv2 256->256 @32", 256, 256, 4, 2, B, 32, 32, 1),
     ("head 1x1 256->21 @64", 256, 21, 1, 1, B, 64, 64, 0),
+    # HRNet-W32 branch convolutions at batch 32
+    ("hr b0 3x3 32 @64", 32, 32, 3, 1, 32, 64, 64, 0),
+    ("hr b1 3x3 64 @32", 64, 64, 3, 1, 32, 32, 32, 0),
+    ("hr b2 3x3 128 @16", 128, 128, 3, 1, 32, 16, 16, 0),
+    ("hr b3 3x3 256 @8", 256, 256, 3, 1, 32, 8, 8, 0),
     # split-K stand-ins: K / 4 with 4x the pixels = the main kernel of a 4-way split of the layer-4 / layer-3 3x3 convolutions
     ("emu l4 3x3 512 @8 split4", 128, 512, 3, 1, 4 * B, 8, 8, 0),
     ("emu l4 3x3 512 @8 split2", 256, 512, 3, 1, 2 * B, 8, 8, 0),
@@ -169,6 +174,7 @@ for name, cin, cout, k, s, n, h, w, tr in SHAPES:
         bad = [r_ for r_ in res if r_[2] > 1e-4]
         print(f"{name:24s} {'wgrad + fold':26s} default ({a.value}, {b.value}, {r.value // 10}, {r.value % 10}, {c_.value}) {t_def:7.1f} us ({flops / t_def / 1e6:6.0f} TF/s) | best "
               + "  ".join(f"{r_[1]} {r_[0]:.1f}" for r_ in res[:4]) + (f" | worst {res[-1][1]} {res[-1][0]:.1f}" if res else "")
-              + (f" | MISMATCH {[r_[1] for r_ in bad]}" if bad else ""))
+              + (f" | MISMATCH {[r_[1] for r_ in bad]}" if bad else "")
+              + (" | tap-sharing: " + "  ".join(f"{r_[1][4]} splits {r_[0]:.1f}" for r_ in res if r_[1][2] == 1) if any(r_[1][2] == 1 for r_ in res) else ""))
     del plan, m
 print(f"sum of defaults {grand_def:.0f} us, sum of best {grand_best:.0f} us")

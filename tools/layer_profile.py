@@ -12,10 +12,11 @@ ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--size", type=int, default=256)
 ap.add_argument("--depth", type=int, default=50)
 ap.add_argument("--precision", default="bf16")
+ap.add_argument("--hrnet-width", type=int, default=0)
 ap.add_argument("--all", action="store_true", help="time every launch, not only the conv-family ones")
 args = ap.parse_args()
 from lighthand_amd.runtime import TrainStep
-model = bench.build_model(args.depth, args.precision)
+model = bench.build_model(args.depth, args.precision, args.hrnet_width)
 step = TrainStep(model, args.batch, args.size, args.size, use_graph=False)
 images, joints = bench.synthetic_batch(args.batch, args.size, "cuda")
 step.images.copy_(images); step.joints.copy_(joints)
