@@ -166,6 +166,21 @@ int lh_igemm_phases_rows(const lh_igemm_desc* const* descs, int nphase, int dtyp
 int lh_igemm_phases(const lh_igemm_desc* const* descs, int nphase, const void* in, const void* const* wpacks,
                     void* out, const void* addend, const void* addend_mask, const float* bias, const float* scale,
                     const float* shift, float* stats, int dtype, void* stream);
+/* Inference head (pose_resnet.py:245-246 with eval-mode BatchNorm: x = relu(bn(deconv(x))); x = final_layer(x)): the
+ * sub-pixel phases of the LAST transposed convolution with the folded BatchNorm affine and ReLU, and the 1x1 final layer
+ * applied to every output tile while it is still in LDS -- the C-channel activation never reaches HBM, only the fp32
+ * NCHW heat-map [n][n_out][OH][OW] is written.  Needs the 256 x 256 tile (descs[*]->cfg), cout <= 256, a 16-bit type.
+ * head.w: K-major rows [>= 32][w_row_bytes] of the 1x1 weight in the run precision (rows >= n_out zero: the pack
+ * lh_pack_weight makes for that convolution), head.bias: fp32 [n_out] or NULL. */
+typedef struct {
+    const void* w;
+    size_t w_row_bytes;
+    const float* bias;
+    float* out;
+    int n_out;
+} lh_head;
+int lh_igemm_phases_head(const lh_igemm_desc* const* descs, int nphase, const void* in, const void* const* wpacks,
+                         const float* scale, const float* shift, const lh_head* head, int dtype, void* stream);
 /* tile (output channels x pixels) the dispatcher picks for this descriptor: names the kernel
  * instantiation a launch uses -- igemm_ring_kernel<T, bm, bp, .., depth, kbytes> when *ring != 0 (LDS-DMA ring
  * path, 16-byte aligned pixel rows; *ring = kbytes*10 + depth) else igemm_kernel<T, bm, bp, ..>. */

@@ -37,6 +37,10 @@ class FuseBwdDesc(C.Structure):
                 ("relu_mask", C.c_void_p)]
 
 
+class Head(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("w_row_bytes", C.c_size_t), ("bias", C.c_void_p), ("out", C.c_void_p), ("n_out", C.c_int)]
+
+
 class PackItem(C.Structure):
     _fields_ = [("w", C.c_void_p), ("out", C.c_void_p), ("n_out", C.c_int), ("n_in", C.c_int), ("ntaps", C.c_int),
                 ("pad_", C.c_int), ("so", C.c_long), ("si", C.c_long), ("sr", C.c_long), ("ss", C.c_long),
@@ -73,6 +77,7 @@ SIGNATURES = {
     "lh_igemm": (_I, [C.POINTER(IgemmDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "lh_igemm_phases_rows": (_I, [C.POINTER(C.POINTER(IgemmDesc)), _I, _I]),
     "lh_igemm_phases": (_I, [C.POINTER(C.POINTER(IgemmDesc)), _I, _P, C.POINTER(C.c_void_p), _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "lh_igemm_phases_head": (_I, [C.POINTER(C.POINTER(IgemmDesc)), _I, _P, C.POINTER(C.c_void_p), _P, _P, C.POINTER(Head), _I, _P]),
     "lh_igemm_tile": (_I, [C.POINTER(IgemmDesc), _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "lh_igemm_config": (_I, [C.POINTER(IgemmDesc), _I, C.POINTER(_I)]),
     "lh_igemm_candidates": (_I, [C.POINTER(IgemmDesc), _I, C.POINTER(_I), _I]),

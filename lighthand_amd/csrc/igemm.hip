@@ -333,8 +333,8 @@ struct PhaseSet {                 // lh_igemm_phases: the other descriptors / pa
 
 static int igemm_impl(const lh_igemm_desc* d, const void* in, const void* wpack, void* out,
                       const void* addend, const void* addend_mask, const float* bias, const float* scale, const float* shift, float* stats,
-                      int dtype, void* stream, const PhaseSet* phases = nullptr) {
-    LH_REQUIRE(d && in && wpack && out, "lh_igemm: null pointer");
+                      int dtype, void* stream, const PhaseSet* phases = nullptr, const lh_head* head = nullptr) {
+    LH_REQUIRE(d && in && wpack && (out || head), "lh_igemm: null pointer");
     const int es = lh_dtype_size(dtype);
     LH_REQUIRE(es > 0, "lh_igemm: bad dtype %d", dtype);
     const int epc = 16 / es;
@@ -353,6 +353,7 @@ static int igemm_impl(const lh_igemm_desc* d, const void* in, const void* wpack,
     LH_REQUIRE(!addend_mask || (addend && d->out_pix_stride == d->cout), "lh_igemm: addend_mask needs an addend and a dense output (mask bits index 16-byte chunks)");
     a.scale = scale; a.shift = shift;
     LH_REQUIRE((scale == nullptr) == (shift == nullptr), "lh_igemm: scale and shift must come together");
+    a.head_w = nullptr; a.head_bias = nullptr; a.head_out = nullptr; a.head_j = 0; a.head_wstride = 0;
     a.n = d->n; a.hi = d->hi; a.wi = d->wi; a.in_pix_stride = d->in_pix_stride; a.k_run = d->k_run;
     a.kspt = (d->k_run * es + 63) / 64;
     a.kpad = (d->k_run * es + 127) / 128 * (128 / es);
@@ -388,6 +389,14 @@ static int igemm_impl(const lh_igemm_desc* d, const void* in, const void* wpack,
             a.ph_ooh[i] = q->ooh; a.ph_oow[i] = q->oow;
             a.ph_row0[i] = i * ceil_div(a.M, bp);
         }
+    }
+    if (head) {
+        LH_REQUIRE(head->w && head->out && head->n_out >= 1 && head->n_out <= 32 && head->w_row_bytes >= d->cout * es,
+                   "lh_igemm_phases_head: bad head (1..32 output channels, K-major weight rows)");
+        LH_REQUIRE(ring && es == 2 && bm == 256 && bp == 256 && d->cout <= 256 && !addend && !stats,
+                   "lh_igemm_phases_head: needs the 256 x 256 tile of the LDS-DMA kernel (cfg), a 16-bit type, <= 256 channels, no addend / statistics");
+        a.head_w = (const unsigned char*)head->w; a.head_bias = head->bias; a.head_out = head->out;
+        a.head_j = head->n_out; a.head_wstride = (int)head->w_row_bytes;
     }
     if (ring) {
         lh_tap_grid(d, &a.tw, &a.dh0, &a.dhs, &a.dw0, &a.dws);
@@ -455,4 +464,14 @@ extern "C" int lh_igemm_phases(const lh_igemm_desc* const* descs, int nphase, co
     LH_REQUIRE(descs[lead]->ntaps > 0 && wpacks[lead], "lh_igemm_phases: no phase has taps");
     PhaseSet ps = {descs, wpacks, nphase};
     return igemm_impl(descs[lead], in, wpacks[lead], out, addend, addend_mask, bias, scale, shift, stats, dtype, stream, &ps);
+}
+
+// The phases of a transposed convolution + per-channel affine + ReLU + a 1x1 head in ONE launch (include/lighthand_hip.h).
+extern "C" int lh_igemm_phases_head(const lh_igemm_desc* const* descs, int nphase, const void* in, const void* const* wpacks,
+                                    const float* scale, const float* shift, const lh_head* head, int dtype, void* stream) {
+    LH_REQUIRE(phases_ok(descs, nphase) && wpacks && head, "lh_igemm_phases_head: 2..4 descriptors that differ only in taps / placement are required");
+    const int lead = phase_lead(descs, nphase);
+    LH_REQUIRE(descs[lead]->ntaps > 0 && wpacks[lead], "lh_igemm_phases_head: no phase has taps");
+    PhaseSet ps = {descs, wpacks, nphase};
+    return igemm_impl(descs[lead], in, wpacks[lead], nullptr, nullptr, nullptr, nullptr, scale, shift, nullptr, dtype, stream, &ps, head);
 }

@@ -13,6 +13,13 @@ struct IgemmArgs {
     const float* scale;      // optional per-output-channel affine applied to the fp32 accumulator (eval-mode BN fold)
     const float* shift;
     float* stats;
+    // Fused 1x1 head (lh_igemm_phases_head, 256 x 256 tile only): the tile -- after affine + ReLU -- is multiplied by
+    // head_w [>= 32 rows][cout] (K-major pack rows of the 1x1 convolution, rows >= head_j zero) inside the epilogue and
+    // only head_out[n][j][OH][OW] (fp32) is written; `out` is not touched
+    const unsigned char* head_w;
+    const float* head_bias;
+    float* head_out;
+    int head_j, head_wstride;       // valid head channels (<= 32), bytes between head_w rows
     int n, hi, wi, in_pix_stride, k_run, kspt, kpad;   // kpad: elements per (row, tap) of the weight pack
     int ho, wo, M, sh, sw, cout;
     int OH, OW, osh, osw, ooh, oow, out_pix_stride;

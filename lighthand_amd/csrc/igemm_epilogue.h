@@ -174,3 +174,96 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, unsigned char
         }
     }
 }
+
+// Epilogue with the 1x1 head fused (C5: deconv + BN + ReLU + final_layer, pose_resnet.py:245-246): the [BP][BM] tile never
+// leaves the CU.  Phase 1 as above plus the ReLU; then D[j][pixel] = sum_c head_w[j][c] * tile[pixel][c] on the MFMA
+// (32 head rows x 32 pixels per wave, K = BM), bias, and fp32 stores straight into the NCHW heat-map.
+template <typename T, int BM, int BP, int WC, int WP, typename MMA>
+__device__ __forceinline__ void igemm_epilogue_head(const IgemmArgs& p, unsigned char* smem, f32x4 (&acc)[BM / WC / 16][BP / WP / 16],
+                                                    int pblk, int tid, int lane, int wave, int wc, int wp, int hw, int ooh, int oow) {
+    constexpr int ES = sizeof(T);
+    constexpr int TC = BM / WC, TP = BP / WP;
+    constexpr int CT = TC / 16, PT = TP / 16;
+    constexpr int RS = BM * ES + 8;
+    constexpr int HS = BM * ES + 16;                  // head-weight row pitch in LDS (16-byte aligned, banks shifted per row)
+    constexpr int NT = 64 * WC * WP, NW = WC * WP;
+    static_assert(ES == 2 && BP % (16 * NW) == 0 && BM % 32 == 0, "head epilogue: 16-bit types, whole pixel tiles per wave");
+    unsigned char* hw_lds = smem + BP * RS;
+    __syncthreads();
+    {
+        const int q = lane >> 4, pl = lane & 15;
+#pragma unroll
+        for (int i = 0; i < CT; ++i) {
+            const int col = wc * TC + i * 16 + q * 4;
+            float bv[4], sv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gc = col + r;
+                const bool ok = gc < p.cout;
+                sv[r] = (p.scale && ok) ? p.scale[gc] : 1.f;
+                bv[r] = ((p.bias && ok) ? p.bias[gc] : 0.f) * sv[r] + ((p.scale && ok) ? p.shift[gc] : 0.f);
+            }
+#pragma unroll
+            for (int j = 0; j < PT; ++j) {
+                const int pr = wp * TP + j * 16 + pl;
+                union { uint2 u; T e[4]; } pk;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[i][j][r] * sv[r] + bv[r];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    pk.e[r] = from_f<T>(col + r < p.cout ? v : 0.f);
+                }
+                *reinterpret_cast<uint2*>(smem + pr * RS + col * ES) = pk.u;
+            }
+        }
+        // head weights: 32 rows of BM elements
+        for (int c = tid; c < 32 * (BM * ES / 16); c += NT) {
+            const int row = c / (BM * ES / 16), ch = c % (BM * ES / 16);
+            uint4 v = uint4{0u, 0u, 0u, 0u};
+            if (ch * (16 / ES) < p.cout) v = *reinterpret_cast<const uint4*>(p.head_w + (long)row * p.head_wstride + ch * 16);
+            *reinterpret_cast<uint4*>(hw_lds + row * HS + ch * 16) = v;
+        }
+    }
+    __syncthreads();
+    constexpr int PW = BP / NW;                       // pixels of the tile per wave
+    constexpr int NPT = PW / 16;
+    f32x4 hacc[2][NPT];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < NPT; ++b) hacc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int l15 = lane & 15, kg = lane >> 4;
+#pragma unroll 2
+    for (int ks = 0; ks < BM / 32; ++ks) {
+        uint4 fa[2], fb[NPT];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) fa[a] = *reinterpret_cast<const uint4*>(hw_lds + (a * 16 + l15) * HS + (ks * 32 + kg * 8) * ES);
+#pragma unroll
+        for (int b = 0; b < NPT; ++b) {
+            const unsigned char* src = smem + (wave * PW + b * 16 + l15) * RS + (ks * 32 + kg * 8) * ES;
+            const uint2 lo = *reinterpret_cast<const uint2*>(src), hi = *reinterpret_cast<const uint2*>(src + 8);
+            fb[b] = uint4{lo.x, lo.y, hi.x, hi.y};
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < NPT; ++b) MMA::run(fa[a], fb[b], hacc[a][b]);
+    }
+    // lane (q = lane >> 4, pl = lane & 15) holds head rows a * 16 + q * 4 + r of pixel b * 16 + pl
+    const long plane = (long)p.OH * p.OW;
+#pragma unroll
+    for (int b = 0; b < NPT; ++b) {
+        const int m = pblk * BP + wave * PW + b * 16 + l15;
+        if (m >= p.M) continue;
+        const int n = m / hw, rem = m - n * hw;
+        const int ya = rem / p.wo, xb = rem - ya * p.wo;
+        const long opix = (long)(ya * p.osh + ooh) * p.OW + xb * p.osw + oow;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = a * 16 + kg * 4 + r;
+                if (j < p.head_j) p.head_out[((long)n * p.head_j + j) * plane + opix] = hacc[a][b][r] + (p.head_bias ? p.head_bias[j] : 0.f);
+            }
+    }
+}

@@ -260,6 +260,12 @@ __global__ __launch_bounds__(64 * WC * WP, 2) void igemm_ring_kernel(const Igemm
             step(ic<1>{}, so);
         }
     }
+    if constexpr (BM == 256 && BP == 256 && sizeof(T) == 2) {
+        if (p.head_w) {
+            igemm_epilogue_head<T, BM, BP, WC, WP, MmaR<T>>(p, smem, acc, pblk, tid, lane, wave, wc, wp, hw, ooh, oow);
+            return;
+        }
+    }
     igemm_epilogue<T, BM, BP, WC, WP>(p, smem, acc, pblk, cblk, tid, lane, wc, wp, hw, ooh, oow, stats);
 }
 
@@ -267,7 +273,7 @@ template <typename T, int BM, int BP, int WC, int WP, int D, int KB>
 static int launch_ring(const IgemmArgs& a, hipStream_t s) {
     constexpr int ES = sizeof(T);
     constexpr int ring = D * (BM + BP) * KB;
-    constexpr int epi = BP * (BM * ES + 8);
+    constexpr int epi = BP * (BM * ES + 8) + ((BM == 256 && BP == 256 && ES == 2) ? 32 * (BM * ES + 16) : 0);   // + the fused head's weights
     constexpr int lds = ring > epi ? ring : epi;
     static_assert(lds <= 160 * 1024, "LDS budget");
     if (lds > 64 * 1024) {

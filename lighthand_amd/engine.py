@@ -336,6 +336,7 @@ class Plan:
     # replace the measurement for the plans built while they are set (tests walk every compiled-in configuration)
     force_cfg = None
     force_wgrad = None
+    fuse_head = True             # test hook: False keeps the inference head as separate launches (A/B against _fuse_head)
     _tune_file_loaded = False
 
     @classmethod
@@ -777,6 +778,8 @@ class Plan:
 
     def _c_output(self, nd, blk):
         y = nd["y"]
+        if getattr(self, "_head_fused", False):           # the fused head wrote the fp32 NCHW heat-map itself (_fuse_head)
+            return
         self.out_nchw = self._alloc(y.n, y.c_valid, y.h, y.w, dtype=torch.float32)
         self.fwd.append(_Call(self.lib.lh_nhwc_to_nchw_f32, (y.buf.data_ptr(), self.out_nchw.data_ptr(), y.n, y.h, y.w, y.c_valid, y.c, self.dt), "output transform"))
         if self.with_bwd:
@@ -787,6 +790,51 @@ class Plan:
                 self._first_write(y)
                 self.bwd.append(_Call(self.lib.lh_nchw_f32_to_nhwc, (self.dout_nchw.data_ptr(), g.data_ptr(), y.n, y.h, y.w, y.c_valid, y.c, self.dt), "dheat transform"))
             blk.append(emit)
+
+    def _fuse_head(self, nd, pack, bias):
+        """Inference plans: `final_layer(relu(bn(deconv(x))))` (pose_resnet.py:245-246) as ONE launch.  When this 1x1
+        convolution produces the network output and its only input is the output of a transposed convolution whose
+        BatchNorm + ReLU were folded into its epilogue, the head is applied to every tile of that launch while it is in
+        LDS (lh_igemm_phases_head): the C-channel activation is never written.  Returns False when the pattern does not
+        apply (training plans, HRNet's head, more than 256 channels, a tile other than 256 x 256 on offer)."""
+        x, y, k, s, p = nd["x"], nd["y"], nd["k"], nd["s"], nd["p"]
+        if not Plan.fuse_head or self.with_bwd or self.es != 2 or k != 1 or s != 1 or p != 0 or y.c_valid > 32 or x.c > 256:
+            return False
+        if not any(kind == "output" and n["y"] is y for kind, n in self.nodes):
+            return False
+        users = sum(1 for kind, n in self.nodes
+                    if (kind in ("conv", "deconv", "maxpool") and n["x"] is x) or (kind == "fuse" and any(a is x for a, _, _ in n["terms"])))
+        prods = self._producers.get(id(x)) or []
+        if users != 1 or len(prods) != 1 or prods[0].fn is not self.lib.lh_igemm_phases or prods[0] not in self.fwd:
+            return False
+        call = prods[0]
+        a = call.args
+        ig = self._IGP
+        if a[ig["dst"]] != x.buf.data_ptr() or a[ig["addend"]] or a[ig["bias"]] or a[ig["stats"]] or not a[ig["scale"]]:
+            return False
+        descs = call.keep
+        lead = max(descs, key=lambda dd: dd.ntaps)
+        if (lead.cfg[0], lead.cfg[1]) != (256, 256):           # the head lives in the 256 x 256 tile's epilogue
+            buf = (C.c_int * (5 * 64))()
+            n = self.lib.lh_igemm_candidates(C.byref(lead), self.dt, buf, 64)
+            big = [tuple(buf[5 * i:5 * i + 4]) for i in range(n) if (buf[5 * i], buf[5 * i + 1]) == (256, 256)]
+            if not big:
+                return False
+            best = min(big, key=lambda c: (c[3] != 128, c[2]))
+            for dd in descs:
+                dd.cfg[0], dd.cfg[1], dd.cfg[2], dd.cfg[3] = best
+        if not all(dd.relu == lead.relu for dd in descs):
+            return False
+        self.out_nchw = self._alloc(y.n, y.c_valid, y.h, y.w, dtype=torch.float32)
+        kstep = 128 // self.es
+        head = _lib.Head(pack.data_ptr(), ((x.c + kstep - 1) // kstep * kstep) * self.es, _ptr(bias), self.out_nchw.data_ptr(), y.c_valid)
+        fused = _Call(self.lib.lh_igemm_phases_head, (a[0], a[1], a[ig["src"]], a[3], a[ig["scale"]], a[ig["shift"]], C.byref(head), self.dt),
+                      call.what.replace("fwd", "fwd + head"), keep=call.keep)
+        fused.slane = call.slane
+        self.keep += [head, call]
+        self.fwd[self.fwd.index(call)] = fused
+        self._head_fused = True
+        return True
 
     # ---- convolution ---------------------------------------------------------------------------
     def _c_conv(self, nd, blk):
@@ -807,6 +855,8 @@ class Plan:
         taps = [(r - p, q - p) for r, q in all_rs]
         d = _desc(x.n, x.h, x.w, x.c, cin, y.h, y.w, s, s, y.c, y.h, y.w, 1, 1, 0, 0, y.c, taps)
         pack = self._pack(wt, cout, cin, (cin * k * k, k * k, k, 1), all_rs, nd["w"] + " fwd pack")
+        if self._fuse_head(nd, pack, bias):
+            return
         stats_ptr = None
         self._tune([d], with_stats=id(y) in self._bn_inputs and self.training)
         if id(y) in self._bn_inputs and self.training:
@@ -1157,6 +1207,7 @@ class Plan:
                         self.fwd.insert(last_res, self.fwd.pop(i))
         for c in main:
             self._patch(c, relu=relu, dst=obuf, addend=addend, scale=st0["scale"].data_ptr(), shift=st0["shift"].data_ptr())
+        self._producers.setdefault(id(out), []).extend(main)       # `out` is now written by these launches (see _fuse_head)
         return True
 
     def _c_maxpool(self, nd, blk):

@@ -484,3 +484,33 @@ def test_pred_store_test_file_feeds_pred_test(tmp_path):
     assert np.asarray(on_disk[0]["pred"][0]).shape == (8, 21, 2) and len(on_disk[0]["bb"][1]) == 8
     for T, method in (([0.1, 0.3], "pckb"), ([0, 30], "mm")):
         assert M.pred_test(meta, T, method) == om.pred_test(on_disk[0], T, method)
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_fused_inference_head_matches_separate_launches(precision):
+    """Inference plans run `final_layer(relu(bn(deconv(x))))` as ONE launch (lh_igemm_phases_head: the 256-channel
+    activation never reaches HBM).  Against the same plan with the head as separate launches (Plan.fuse_head = False):
+    two launches fewer, heat-maps equal up to the 16-bit rounding the separate path applies to its NHWC heat-map before
+    the fp32 conversion (the fused path writes fp32 directly), decode of each path bit-equal to the oracle's decode."""
+    from lighthand_amd.engine import Plan
+    from lighthand_amd.runtime import InferStep
+    from oracle.heatmap import get_max_preds
+    x, _ = _batch(3, 96, 21)
+    out = {}
+    try:
+        for fused in (True, False):
+            Plan.fuse_head = fused
+            m = _model(18, precision).eval()
+            st = InferStep(m, 3, 96, 96)
+            preds = st(x).clone()
+            torch.cuda.synchronize()
+            hm = st.heatmaps.clone()
+            assert bool(getattr(st.plan, "_head_fused", False)) == fused
+            want = get_max_preds(hm.cpu().numpy())[0] * 4
+            assert np.array_equal(preds.cpu().numpy(), want)
+            out[fused] = (hm, sum(1 for c in st.plan.fwd if hasattr(c, "fn")))
+    finally:
+        Plan.fuse_head = True
+    assert out[True][1] == out[False][1] - 2
+    scale = float(out[False][0].abs().max())
+    assert float((out[True][0] - out[False][0]).abs().max()) <= scale * 2.0 ** (-8 if precision == "bf16" else -10)
