@@ -386,7 +386,7 @@ class Plan:
             self._tune_bufs[name] = t
         return t
 
-    def _tune(self, descs, with_stats=False):
+    def _tune(self, descs, with_stats=False, addend=None):
         """Measured kernel choice (cdna guide: measure, don't guess): time every compiled-in configuration that fits
         this launch (lh_igemm_candidates) on scratch operands of the real size and write the fastest into the
         descriptors' cfg.  One descriptor = lh_igemm; several = the phases of lh_igemm_phases (one shared choice).
@@ -397,7 +397,9 @@ class Plan:
         lead = max(descs, key=lambda d: d.ntaps)
         if lead.ntaps == 0:
             return
-        key = (self.dt, with_stats) + tuple(self._desc_key(d) for d in descs)
+        # addend: None | 'plain' | 'masked' -- the epilogue of an accumulating / masked-addend data gradient moves up to three
+        # times the bytes of a plain one, which shifts the best tile
+        key = (self.dt, with_stats) + tuple(self._desc_key(d) for d in descs) + ((addend,) if addend else ())
         hit = Plan._TUNE_CACHE.get(key) if Plan.force_cfg is None else None
         buf = (C.c_int * (5 * 64))()
         n = self.lib.lh_igemm_candidates(C.byref(lead), self.dt, buf, 64)
@@ -421,6 +423,9 @@ class Plan:
                 packs = [self._scratch(f"pack{i}", (d.cout + 255) // 256 * 256 * max(d.ntaps, 1) * kpad + 256) for i, d in enumerate(descs)]
                 rows = (lead.n * lead.ho * lead.wo + 63) // 64 * len(descs)
                 stats = self._scratch("stats", rows * 2 * lead.cout * 4 + 256) if with_stats else None
+                dense = lead.out_pix_stride == lead.cout
+                add = self._scratch("addend", lead.n * lead.OH * lead.OW * lead.out_pix_stride * es + 256) if addend else None
+                amask = self._scratch("amask", lead.n * lead.OH * lead.OW * lead.out_pix_stride * es // 16 + 256) if addend == "masked" and dense else None
                 stream = torch.cuda.current_stream()
                 sp = stream.cuda_stream
                 if len(descs) > 1:
@@ -428,11 +433,11 @@ class Plan:
                     parr = (C.c_void_p * len(descs))(*[pk.data_ptr() for pk in packs])
 
                     def run():
-                        check(self.lib.lh_igemm_phases(arr, len(descs), src.data_ptr(), parr, dst.data_ptr(), None, None, None, None, None,
+                        check(self.lib.lh_igemm_phases(arr, len(descs), src.data_ptr(), parr, dst.data_ptr(), _ptr(add), _ptr(amask), None, None, None,
                                                        _ptr(stats), self.dt, sp), "autotune lh_igemm_phases")
                 else:
                     def run():
-                        check(self.lib.lh_igemm(C.byref(lead), src.data_ptr(), packs[0].data_ptr(), dst.data_ptr(), None, None, None, None, None,
+                        check(self.lib.lh_igemm(C.byref(lead), src.data_ptr(), packs[0].data_ptr(), dst.data_ptr(), _ptr(add), _ptr(amask), None, None, None,
                                                 _ptr(stats), self.dt, sp), "autotune lh_igemm")
                 best = None
                 for cfg in cands:
@@ -521,13 +526,14 @@ class Plan:
             # this first writer of dx adds it straight from dout (one tensor write and one read less per block)
             assert first
             addend, amask = pend
+        kind = "masked" if amask is not None else ("plain" if addend is not None else None)
         if self._phase_rows(descs) > 0:
-            self._tune(descs)
+            self._tune(descs, addend=kind)
             self._igemm_phases(self.bwd, descs, dy, packs, dx, addend, None, None, what, addend_mask=amask)
             yield max(descs, key=lambda d: d.ntaps), sum(d.ntaps for d in descs)
             return
         for dd, pk in zip(descs, packs):
-            self._tune([dd])
+            self._tune([dd], addend=kind)
             self._igemm(self.bwd, dd, dy, pk, dx, addend, None, None, what, addend_mask=amask)
             yield dd, dd.ntaps
 
