@@ -375,6 +375,12 @@ class Plan:
         return (d.n, d.hi, d.wi, d.in_pix_stride, d.k_run, d.ho, d.wo, d.sh, d.sw, d.cout, d.OH, d.OW, d.osh, d.osw,
                 d.ooh, d.oow, d.out_pix_stride, d.ntaps, bytes(d.dh)[:d.ntaps], bytes(d.dw)[:d.ntaps])
 
+    @staticmethod
+    def tune_iters():
+        """Timed launches per candidate configuration: 4 at plan build (tuning must stay cheap), more when the shipped
+        database is generated (LH_TUNE_ITERS, tools/make_tune_db.sh: a 20-launch average ranks near-ties reliably)."""
+        return max(1, int(os.environ.get("LH_TUNE_ITERS", "4")))
+
     def _scratch(self, name, nbytes):
         t = self._tune_bufs.get(name)
         if t is None or t.numel() < nbytes:
@@ -446,7 +452,7 @@ class Plan:
                     run()
                     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     a.record(stream)
-                    for _ in range(4):
+                    for _ in range(Plan.tune_iters()):
                         run()
                     b.record(stream)
                     b.synchronize()
@@ -491,7 +497,7 @@ class Plan:
                     launch(xs.data_ptr(), dys.data_ptr(), slab.data_ptr(), grad.data_ptr(), sp)
                     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     a.record(stream)
-                    for _ in range(3):
+                    for _ in range(Plan.tune_iters()):
                         launch(xs.data_ptr(), dys.data_ptr(), slab.data_ptr(), grad.data_ptr(), sp)
                     b.record(stream)
                     b.synchronize()

@@ -4,5 +4,5 @@
 set -e
 cd "$GRAFT_REPO_ROOT"
 rm -f gpurun_out/tune_db.txt
-LH_TUNE_DB=0 LH_TUNE_CACHE=$PWD/gpurun_out/tune_db.txt python bench.py --no-cpu-baseline --steps 5 > /dev/null
+LH_TUNE_ITERS=20 LH_TUNE_DB=0 LH_TUNE_CACHE=$PWD/gpurun_out/tune_db.txt python bench.py --no-cpu-baseline --steps 5 > /dev/null
 wc -l gpurun_out/tune_db.txt
