@@ -734,7 +734,7 @@ __global__ __launch_bounds__(256) void fuse_bwd_coef_fused_kernel(const TI* slab
 
 static long fuse_bwd_strips(long count, int* rows_per_strip) {
     long rps = (count + 1023) / 1024;        // <= 1024 strips keep the streaming reduce at >= 4 workgroups per CU
-    if (rps < 32) rps = 32;
+    if (rps < 16) rps = 16;
     *rows_per_strip = (int)rps;
     return (count + rps - 1) / rps;
 }
