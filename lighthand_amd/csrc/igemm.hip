@@ -320,6 +320,10 @@ extern "C" int lh_igemm_candidates(const lh_igemm_desc* d, int dtype, int* cfgs,
 
 extern "C" int lh_igemm_stats_rows(const lh_igemm_desc* d, int dtype) {
     int bm, bp;
+    if (d->cfg[2] == 1 && lh_ring_supported(d, dtype)) {          // persistent pointwise kernel: one row per workgroup
+        RingCfg c;
+        if (lh_ring_resolve(d, dtype, &c) == LH_OK && c.depth == 1) return lh_pw_rows(d, c, dtype);
+    }
     pick_tile(d, dtype, &bm, &bp);
     const long M = (long)d->n * d->ho * d->wo;
     return (int)((M + bp - 1) / bp);
@@ -375,6 +379,7 @@ static int igemm_impl(const lh_igemm_desc* d, const void* in, const void* wpack,
     a.tw = 1; a.dh0 = a.dhs = a.dw0 = a.dws = 0;
     a.xcd = 1;
     a.nphase = 1; a.phase_blocks = 0;
+    LH_REQUIRE(!(ring && rc_.depth == 1 && (phases || head)), "lh_igemm_phases: the pointwise kernel takes single launches only");
     if (phases) {
         LH_REQUIRE(ring, "lh_igemm_phases: the form is not supported by the LDS-DMA kernel");
         a.nphase = phases->n;

@@ -30,16 +30,34 @@ struct IgemmArgs {
     const unsigned char* ph_w[4];
     int ph_ntaps[4], ph_tw[4], ph_dh0[4], ph_dhs[4], ph_dw0[4], ph_dws[4], ph_ooh[4], ph_oow[4], ph_row0[4];
     int xcd;                         // ring kernel: XCD-aware work-item order (always on: speed only)
+    int pw_g, pw_cb;                 // pointwise kernel (igemm_pw_kernel.h): workgroups per channel block, channel blocks
     int tw, dh0, dhs, dw0, dws;      // regular tap grid (ring kernel): tap t = (t / tw, t % tw)
     signed char dh[64];
     signed char dw[64];
 };
 
 // One configuration of the LDS-DMA kernel: tile (output channels x pixels), ring depth, K bytes per stage
-// (igemm_ring_kernel.h).
+// (igemm_ring_kernel.h).  depth == 1 selects the persistent pointwise kernel (igemm_pw_kernel.h): bm = channels of the
+// resident weight panel, bp = pixels a wave takes per step (16 * PT), kb = padded K of the panel in elements.
 struct RingCfg {
     int bm, bp, depth, kb;
 };
+
+// workgroups per channel block of a pointwise launch: every CU holds `occ` workgroups for the whole launch (occ = what the
+// occupancy query reports for the instantiation, 1..4: lh_pw_occupancy)
+static inline int lh_pw_lds_bytes(int bm, int kc, int pt) { return bm * kc * 2 + 4 * pt * 16 * (64 * 2 + 8) + 2 * bm * 4; }
+
+static inline void lh_pw_grid(int bm, int kc, int pt, long M, int cout, int occ, int* G, int* CB) {
+    const int cb = (cout + bm - 1) / bm;
+    const long ntile = (M + pt * 16 - 1) / (pt * 16);
+    long g = 256L * occ / cb / 8 * 8;
+    const long need = ((ntile + 3) / 4 + 7) / 8 * 8;           // no more workgroups than there are wave tiles
+    if (g > need) g = need;
+    if (g < 8) g = 8;
+    *G = (int)g;
+    *CB = cb;
+}
+
 
 // igemm_ring.hip
 bool lh_ring_supported(const lh_igemm_desc* d, int dtype);
@@ -48,3 +66,6 @@ int lh_ring_resolve(const lh_igemm_desc* d, int dtype, RingCfg* out);
 void lh_ring_default_cfg(const lh_igemm_desc* d, int dtype, RingCfg* out);
 int lh_ring_candidates(const lh_igemm_desc* d, int dtype, int* out, int max);
 int lh_igemm_ring_launch(const IgemmArgs& a, const RingCfg& c, int dtype, hipStream_t s);
+bool lh_pw_supported(const lh_igemm_desc* d, int dtype);
+int lh_pw_rows(const lh_igemm_desc* d, const RingCfg& c, int dtype);
+int lh_pw_occupancy(const RingCfg& c, int dtype, bool stats);

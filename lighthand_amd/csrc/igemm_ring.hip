@@ -4,6 +4,7 @@
 
 #include "igemm_args.h"
 #include "igemm_ring_cfgs.h"
+#include "igemm_pw_cfgs.h"
 #include <stdlib.h>
 #include <mutex>
 
@@ -14,6 +15,10 @@ int lh_ring_launch_f16_big(const IgemmArgs& a, const RingCfg& c, hipStream_t s);
 int lh_ring_launch_f16_mid(const IgemmArgs& a, const RingCfg& c, hipStream_t s);
 int lh_ring_launch_f16_small(const IgemmArgs& a, const RingCfg& c, hipStream_t s);
 int lh_ring_launch_f32(const IgemmArgs& a, const RingCfg& c, hipStream_t s);
+int lh_pw_launch_bf16(const IgemmArgs& a, const RingCfg& c, hipStream_t s);
+int lh_pw_launch_f16(const IgemmArgs& a, const RingCfg& c, hipStream_t s);
+int lh_pw_occ_bf16(const RingCfg& c, bool stats);
+int lh_pw_occ_f16(const RingCfg& c, bool stats);
 
 static const RingCfg kCfg16[] = {
 #define X(BM, BP, WC, WP, D, KB) {BM, BP, D, KB},
@@ -23,6 +28,13 @@ static const RingCfg kCfg16[] = {
 static const RingCfg kCfg32[] = {
 #define X(BM, BP, WC, WP, D, KB) {BM, BP, D, KB},
     LH_RING_CFGS_F32(X)
+#undef X
+};
+
+struct PwCfg { int bm, kc, pt; };
+static const PwCfg kCfgPw[] = {
+#define X(BM, KC, PT) {BM, KC, PT},
+    LH_PW_CFGS(X)
 #undef X
 };
 
@@ -69,16 +81,53 @@ bool lh_ring_supported(const lh_igemm_desc* d, int dtype) {
 
 // A configuration fits a launch when its tile is not wider than the problem rounded up to the smallest tile
 // (a 128-channel tile on <= 64 output channels only multiplies zeros) and its ring is not deeper than the K loop.
+// Hard rules (an explicit lh_igemm_desc.cfg is refused when it breaks one): what the kernel's loads assume about the pack.
+static bool cfg_safe(const lh_igemm_desc* d, int dtype, const RingCfg& c) {
+    const int es = lh_dtype_size(dtype);
+    if (c.bm == 256 && ((d->cout + 127) / 128) % 2 != 0) return false;   // weight packs are padded to 128 rows, not 256
+    if (c.kb == 128 && d->k_run * es <= 64) return false;            // the second K slice would be all padding
+    return true;
+}
+
 static bool cfg_fits(const lh_igemm_desc* d, int dtype, const RingCfg& c) {
     const int es = lh_dtype_size(dtype);
     const long M = (long)d->n * d->ho * d->wo;
     const int stages = d->ntaps * ((d->k_run * es + c.kb - 1) / c.kb);
-    if (c.bm > 64 && d->cout <= c.bm / 2) return false;
-    if (c.bm == 256 && ((d->cout + 127) / 128) % 2 != 0) return false;   // weight packs are padded to 128 rows, not 256
+    if (!cfg_safe(d, dtype, c)) return false;
+    if (c.bm > 64 && d->cout <= c.bm / 2) return false;               // (these three only multiply zeros / repeat a shallower ring)
     if (c.bp > 64 && M <= c.bp / 2) return false;
-    if (c.kb == 128 && d->k_run * es <= 64) return false;            // the second K slice would be all padding
-    if (c.depth > 2 && c.depth - 1 > stages) return false;            // deeper than the loop: same behaviour as a shallower ring
+    if (c.depth > 2 && c.depth - 1 > stages) return false;
     return true;
+}
+
+// ---- persistent pointwise kernel (igemm_pw_kernel.h): one tap at (0, 0), dense output, K <= 512, 16-bit types
+bool lh_pw_supported(const lh_igemm_desc* d, int dtype) {
+    if (lh_dtype_size(dtype) != 2) return false;
+    if (d->ntaps != 1 || d->dh[0] != 0 || d->dw[0] != 0) return false;
+    if (d->osh != 1 || d->osw != 1 || d->OH != d->ho || d->OW != d->wo || d->ooh != 0 || d->oow != 0) return false;
+    if (d->k_run > 512 || d->k_run % 8 != 0 || (d->in_pix_stride * 2) % 16 != 0) return false;
+    return true;
+}
+
+static int pw_kc(const lh_igemm_desc* d) { return d->k_run <= 64 ? 64 : d->k_run <= 128 ? 128 : d->k_run <= 256 ? 256 : 512; }
+
+static bool pw_fits(const lh_igemm_desc* d, int dtype, const RingCfg& c) {
+    if (!lh_pw_supported(d, dtype) || c.kb != pw_kc(d)) return false;
+    if (c.bm > 64 && d->cout <= c.bm / 2) return false;
+    for (const PwCfg& k : kCfgPw)
+        if (k.bm == c.bm && k.kc == c.kb && 16 * k.pt == c.bp) return true;
+    return false;
+}
+
+int lh_pw_occupancy(const RingCfg& c, int dtype, bool stats) {
+    return dtype == LH_BF16 ? lh_pw_occ_bf16(c, stats) : lh_pw_occ_f16(c, stats);
+}
+
+// rows of the statistics slab a pointwise launch writes: one per workgroup of a channel block
+int lh_pw_rows(const lh_igemm_desc* d, const RingCfg& c, int dtype) {
+    int g, cb;
+    lh_pw_grid(c.bm, c.kb, c.bp / 16, (long)d->n * d->ho * d->wo, d->cout, lh_pw_occupancy(c, dtype, true), &g, &cb);
+    return g;
 }
 
 // Static default (cfg all zero): the largest tile that still gives >= 2 workgroups per CU, a 2-stage ring for K loops
@@ -115,9 +164,26 @@ int lh_ring_resolve(const lh_igemm_desc* d, int dtype, RingCfg* out) {
         return LH_OK;
     }
     const RingCfg c = {d->cfg[0], d->cfg[1], d->cfg[2], d->cfg[3]};
+    if (c.depth == 1) {                                  // persistent pointwise kernel
+        if (!pw_fits(d, dtype, c)) {
+            lh_set_error("igemm: pointwise configuration panel %d x K %d, %d pixels per wave does not exist or does not fit this launch",
+                         c.bm, c.kb, c.bp);
+            return LH_ERR_ARG;
+        }
+        *out = c;
+        return LH_OK;
+    }
     if (!cfg_exists(dtype, c)) {
         lh_set_error("igemm: configuration tile %dx%d depth %d kb %d is not compiled in for dtype %d", c.bm, c.bp, c.depth, c.kb, dtype);
         return LH_ERR_UNSUPPORTED;
+    }
+    // an explicit choice must pass the hard rules of the candidate list: weight packs are padded to 128 rows, so e.g. a
+    // 256-row tile on a pack with an odd number of 128-row blocks would fetch past its end (the phases of a batched
+    // launch share the lead's choice, so the soft rules -- tile wider than the problem, ring deeper than the loop -- stay legal)
+    if (!cfg_safe(d, dtype, c)) {
+        lh_set_error("igemm: configuration tile %dx%d depth %d kb %d does not fit this launch (cout %d, k_run %d, %d taps)",
+                     c.bm, c.bp, c.depth, c.kb, d->cout, d->k_run, d->ntaps);
+        return LH_ERR_ARG;
     }
     *out = c;
     return LH_OK;
@@ -129,6 +195,12 @@ int lh_ring_candidates(const lh_igemm_desc* d, int dtype, int* out, int max) {
     for (int i = 0; i < n && k < max; ++i) {
         if (!cfg_fits(d, dtype, t[i])) continue;
         out[5 * k] = t[i].bm; out[5 * k + 1] = t[i].bp; out[5 * k + 2] = t[i].depth; out[5 * k + 3] = t[i].kb; out[5 * k + 4] = 0;
+        ++k;
+    }
+    for (const PwCfg& c : kCfgPw) {                      // pointwise configurations: depth = 1
+        const RingCfg r = {c.bm, 16 * c.pt, 1, c.kc};
+        if (k >= max || !pw_fits(d, dtype, r)) continue;
+        out[5 * k] = r.bm; out[5 * k + 1] = r.bp; out[5 * k + 2] = 1; out[5 * k + 3] = r.kb; out[5 * k + 4] = 0;
         ++k;
     }
     return k;
@@ -160,6 +232,15 @@ int lh_igemm_ring_launch(const IgemmArgs& a0, const RingCfg& c, int dtype, hipSt
         return LH_ERR_HIP;
     }
     int rc = 1;
+    if (c.depth == 1) {
+        if (dtype == LH_BF16) rc = lh_pw_launch_bf16(a, c, s);
+        else if (dtype == LH_F16) rc = lh_pw_launch_f16(a, c, s);
+        if (rc == 1) {
+            lh_set_error("igemm_pw: no kernel for panel %d x K %d, %d pixels per wave, dtype %d", c.bm, c.kb, c.bp, dtype);
+            return LH_ERR_UNSUPPORTED;
+        }
+        return rc;
+    }
     switch (dtype) {
         case LH_BF16:
             rc = lh_ring_launch_bf16_big(a, c, s);

@@ -297,6 +297,11 @@ static int wgrad_plan(const lh_igemm_desc* d, int n_out, int n_in, int dtype, Wg
             lh_set_error("lh_wgrad: configuration tile %dx%d stage %d depth %d splits %d is not available for this launch", c.bo, c.bi, c.kps, c.depth, c.nsplit);
             return LH_ERR_UNSUPPORTED;
         }
+        const WgradCfg wc = {c.bo, c.bi, c.depth, c.kps};
+        if (!wcfg_fits(wc, n_out, n_in)) {          // same rule as lh_wgrad_candidates: an explicit choice must fit the gradient
+            lh_set_error("lh_wgrad: tile %dx%d does not fit a %d x %d gradient", c.bo, c.bi, n_out, n_in);
+            return LH_ERR_ARG;
+        }
         const long stages = (M + c.kps - 1) / c.kps;
         c.sps = (int)((stages + c.nsplit - 1) / c.nsplit);
         c.nsplit = (int)((stages + c.sps - 1) / c.sps);

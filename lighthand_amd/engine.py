@@ -410,6 +410,8 @@ class Plan:
         buf = (C.c_int * (5 * 64))()
         n = self.lib.lh_igemm_candidates(C.byref(lead), self.dt, buf, 64)
         cands = [tuple(buf[5 * i:5 * i + 4]) for i in range(n)]
+        if len(descs) > 1:
+            cands = [c for c in cands if c[2] != 1]             # the persistent pointwise kernel takes single launches only
         if len(descs) > 1 and self._phase_rows(descs) <= 0:
             cands = []                                          # phases that cannot be batched: keep the default
         if hit is not None and hit != (0, 0, 0, 0) and hit not in cands:
@@ -427,7 +429,7 @@ class Plan:
                 src = self._scratch("in", lead.n * lead.hi * lead.wi * lead.in_pix_stride * es + 256)
                 dst = self._scratch("out", lead.n * lead.OH * lead.OW * lead.out_pix_stride * es + 256)
                 packs = [self._scratch(f"pack{i}", (d.cout + 255) // 256 * 256 * max(d.ntaps, 1) * kpad + 256) for i, d in enumerate(descs)]
-                rows = (lead.n * lead.ho * lead.wo + 63) // 64 * len(descs)
+                rows = max((lead.n * lead.ho * lead.wo + 63) // 64, 1024) * len(descs)     # pointwise candidates: one row per workgroup
                 stats = self._scratch("stats", rows * 2 * lead.cout * 4 + 256) if with_stats else None
                 dense = lead.out_pix_stride == lead.cout
                 add = self._scratch("addend", lead.n * lead.OH * lead.OW * lead.out_pix_stride * es + 256) if addend else None
@@ -584,7 +586,7 @@ class Plan:
         ss = (C.c_long * 4)(*([0] * pad + list(src.stride())))
         return _Call(self.lib.lh_copy_strided_f32, (dst.data_ptr(), src.data_ptr(), shape, ds, ss), what, keep=(shape, ds, ss, dst, src), lane=lane)
 
-    def _kname(self, d, wgrad=None):
+    def _kname(self, d, wgrad=None, stats=False):
         """Kernel instantiation name as rocprofv3 prints it (for roofline attribution)."""
         t = {"fp32": "float", "bf16": "__bf16", "fp16": "_Float16"}[self.precision]
         a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
@@ -592,6 +594,8 @@ class Plan:
             cfg = (C.c_int * 5)()
             check(self.lib.lh_igemm_config(C.byref(d), self.dt, cfg), "lh_igemm_config")
             bm, bp, depth, kb = cfg[0], cfg[1], cfg[2], cfg[3]
+            if depth == 1:
+                return f"igemm_pw_kernel<{t}, {bm}, {kb}, {bp // 16}, {'true' if stats else 'false'}>"
             wc, wp = {(256, 256): (2, 4), (128, 256): (2, 2), (128, 128): (2, 2), (128, 64): (4, 1), (64, 128): (1, 4), (64, 64): (2, 2)}[(bm, bp)]
             if depth:
                 return f"igemm_ring_kernel<{t}, {bm}, {bp}, {wc}, {wp}, {depth}, {kb}>"
@@ -876,7 +880,7 @@ class Plan:
             stats_ptr = y.stats
         flops = 2.0 * y.pixels * cout * cin * k * k
         self._igemm(self.fwd, d, xbuf, pack, ybuf, None, bias, stats_ptr, nd["w"] + " fwd", produces=y)
-        self.profile_meta.append(("fwd", self.fwd[-1], self._kname(d), flops, (x.pixels * x.c + y.pixels * y.c) * self.es))
+        self.profile_meta.append(("fwd", self.fwd[-1], self._kname(d, stats=stats_ptr is not None), flops, (x.pixels * x.c + y.pixels * y.c) * self.es))
         if not self.with_bwd:
             return
         # --- backward: weight gradient, then data gradient

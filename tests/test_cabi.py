@@ -54,3 +54,68 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
         assert "no CPU fallback" in str(e)
     else:
         raise AssertionError("load() must fail when the extension is missing")
+
+
+def _conv_desc(cin, cout, hw=16, k=1):
+    from lighthand_amd import _lib
+    d = _lib.IgemmDesc()
+    d.n, d.hi, d.wi, d.in_pix_stride, d.k_run = 1, hw, hw, cin, cin
+    d.ho, d.wo, d.sh, d.sw, d.cout = hw, hw, 1, 1, cout
+    d.OH, d.OW, d.osh, d.osw, d.ooh, d.oow, d.out_pix_stride = hw, hw, 1, 1, 0, 0, cout
+    d.ntaps = k * k
+    for t in range(k * k):
+        d.dh[t], d.dw[t] = t // k - k // 2, t % k - k // 2
+    return d
+
+
+def test_explicit_conv_configuration_must_fit():
+    """An explicit lh_igemm_desc.cfg that does not pass the rules of lh_igemm_candidates is refused with LH_ERR_ARG
+    instead of launching (a 256-row tile on a weight pack with an odd number of 128-row blocks would read past it)."""
+    from lighthand_amd import _lib
+    lib = _lib.load()
+    d = _conv_desc(256, 128)
+    cfg = (C.c_int * 5)()
+    d.cfg[0], d.cfg[1], d.cfg[2], d.cfg[3] = 256, 256, 3, 64          # compiled in, but cout = 128 is ONE 128-row block
+    assert lib.lh_igemm_config(C.byref(d), _lib.LH_BF16, cfg) == -1 and b"does not fit" in lib.lh_last_error()
+    d.cfg[0], d.cfg[1], d.cfg[2], d.cfg[3] = 128, 128, 2, 128
+    assert lib.lh_igemm_config(C.byref(d), _lib.LH_BF16, cfg) == 0 and tuple(cfg[:4]) == (128, 128, 2, 128)
+    d.cfg[0], d.cfg[1], d.cfg[2], d.cfg[3] = 256, 16, 1, 512          # pointwise panel with the wrong K padding
+    assert lib.lh_igemm_config(C.byref(d), _lib.LH_BF16, cfg) == -1
+    d.cfg[0], d.cfg[1], d.cfg[2], d.cfg[3] = 128, 16, 1, 256
+    assert lib.lh_igemm_config(C.byref(d), _lib.LH_BF16, cfg) == 0 and cfg[2] == 1
+    assert lib.lh_igemm_config(C.byref(d), _lib.LH_F32, cfg) == -1    # 16-bit types only
+    d3 = _conv_desc(256, 128, k=3)
+    d3.cfg[0], d3.cfg[1], d3.cfg[2], d3.cfg[3] = 128, 16, 1, 256      # not a 1x1 form
+    assert lib.lh_igemm_config(C.byref(d3), _lib.LH_BF16, cfg) == -1
+    # every candidate the library offers resolves, and the pointwise ones report their slab rows
+    buf = (C.c_int * (5 * 64))()
+    d = _conv_desc(64, 256, hw=64)
+    n = lib.lh_igemm_candidates(C.byref(d), _lib.LH_BF16, buf, 64)
+    kinds = set()
+    for i in range(n):
+        for j in range(4):
+            d.cfg[j] = buf[5 * i + j]
+        assert lib.lh_igemm_config(C.byref(d), _lib.LH_BF16, cfg) == 0
+        rows = lib.lh_igemm_stats_rows(C.byref(d), _lib.LH_BF16)
+        kinds.add(d.cfg[2] == 1)
+        assert rows == (64 * 64 + d.cfg[1] - 1) // d.cfg[1] if d.cfg[2] != 1 else rows in (8 * k for k in range(1, 65))
+    assert kinds == {True, False}
+
+
+def test_explicit_wgrad_configuration_must_fit():
+    from lighthand_amd import _lib
+    lib = _lib.load()
+    d = _conv_desc(64, 64, k=3)
+    bo, bi, ns, ring = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+    buf = (C.c_int * (5 * 128))()
+    n = lib.lh_wgrad_candidates(C.byref(d), 64, 64, _lib.LH_BF16, buf, 128)
+    assert n >= 1
+    for i in range(n):                                                 # every offered plan resolves
+        d.cfg[5], d.cfg[6], d.cfg[7] = buf[5 * i], buf[5 * i + 1], buf[5 * i + 2]
+        assert lib.lh_wgrad_tile(C.byref(d), 64, 64, _lib.LH_BF16, C.byref(bo), C.byref(bi), C.byref(ns), C.byref(ring)) == 0
+    big = _conv_desc(256, 256, k=3)
+    n = lib.lh_wgrad_candidates(C.byref(big), 256, 256, _lib.LH_BF16, buf, 128)
+    enc = next(buf[5 * i + 2] for i in range(n) if (buf[5 * i], buf[5 * i + 1]) == (256, 256))
+    d.cfg[5], d.cfg[6], d.cfg[7] = 256, 256, enc                       # a compiled-in 256 x 256 plan on a 64 x 64 gradient
+    assert lib.lh_wgrad_tile(C.byref(d), 64, 64, _lib.LH_BF16, C.byref(bo), C.byref(bi), C.byref(ns), C.byref(ring)) == -1
+    assert b"does not fit" in lib.lh_last_error()

@@ -575,3 +575,107 @@ def test_device_pck_curve_equals_pred_eval():
         got = auc_from_counts(counts, nvis[0], diff_sum[0], n_all[0], T_list, method)
         assert np.array_equal(got[2], want[2])
         assert abs(got[0] - want[0]) < 1e-12 and abs(got[1] - want[1]) < 1e-9 * max(1.0, abs(want[1]))
+
+
+PW_CASES = [
+    # cin, cout, stride, n, h, w -- the 1x1 layers of the bottleneck stages (pose_resnet.py:66-72, 180-184), the head, HRNet widths
+    (64, 256, 1, 2, 16, 16), (256, 64, 1, 2, 16, 16), (64, 64, 1, 1, 5, 7), (256, 128, 1, 3, 12, 20),
+    (128, 512, 1, 2, 8, 8), (512, 128, 1, 2, 8, 8), (256, 512, 2, 2, 16, 16), (256, 21, 1, 1, 8, 8), (96, 48, 1, 1, 9, 9),
+    (256, 1024, 1, 1, 8, 8),
+]
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+@pytest.mark.parametrize("case", PW_CASES)
+def test_pointwise_kernel_configurations(case, precision, forced_plans):
+    """Every configuration of the persistent pointwise kernel (igemm_pw_kernel.h: resident weight panel 64..256 channels,
+    16..64 pixels per wave step) that fits a 1x1 launch, forced on forward and data gradient: bit-equal with the tiled
+    LDS-DMA kernel (same K order, same epilogue arithmetic) and within tolerance of PyTorch."""
+    ConvNet, _ = _mods()
+    cin, cout, s_, n, h, w = case
+    torch.manual_seed(11)
+    bias = cout == 21
+    x = quant(torch.randn(n, cin, h, w), precision)
+    ref_m = nn.Conv2d(cin, cout, 1, s_, 0, bias=bias)
+    with torch.no_grad():
+        ref_m.weight.copy_(quant(ref_m.weight, precision))
+    xr = x.clone().requires_grad_(True)
+    ref = ref_m(xr)
+    dy = quant(torch.randn_like(ref), precision)
+    ref.backward(dy)
+
+    def run(pick):
+        forced_plans.force_cfg = pick
+        m = ConvNet(cin, cout, 1, s_, 0, bias=bias)
+        m.conv.load_state_dict(ref_m.state_dict())
+        return _run_plan(m, x, lambda o: dy, precision)
+
+    base = run(lambda cands: next(c for c in cands if c[2] != 1))        # a tiled configuration
+    assert rel_err(base[0], ref.detach()) < TOL[precision] and rel_err(base[1], xr.grad) < TOL[precision]
+    npw, idx = 1, 0
+    seen = set()
+    while idx < npw:
+        chosen = []
+
+        def pick(cands, idx=idx, chosen=chosen):
+            pw = [c for c in cands if c[2] == 1]
+            chosen.append((pw[idx % len(pw)] if pw else None, len(pw)))
+            return pw[idx % len(pw)] if pw else cands[0]
+        out, dx, _ = run(pick)
+        assert torch.equal(out, base[0]) and torch.equal(dx, base[1]), (case, chosen)
+        seen |= {c for c, _ in chosen if c}
+        npw = max(nc for _, nc in chosen)
+        idx += 1
+    print(case, precision, "pointwise configurations:", sorted(seen))
+    assert seen, "no pointwise configuration was offered"
+
+
+@pytest.mark.parametrize("case", [(64, 256, 2, 16, 16), (256, 64, 3, 12, 20), (128, 512, 1, 9, 9), (512, 128, 2, 8, 8)])
+def test_pointwise_kernel_bn_statistics(case, forced_plans):
+    """1x1 conv -> BN -> ReLU -> 1x1 with the pointwise kernel forced: it writes ONE statistics row per workgroup (sums
+    kept in registers over all its tiles).  Outputs equal the tiled kernel's bit for bit; running statistics and BN
+    gradients agree to fp32 summation order; everything within the 16-bit tolerance of PyTorch."""
+    import copy
+    from lighthand_amd.module import HipModule
+    cin, cout, n, h, w = case
+
+    class Net(HipModule):
+        def __init__(self):
+            super().__init__()
+            self.conv = nn.Conv2d(cin, cout, 1, bias=False)
+            self.bn = nn.BatchNorm2d(cout, momentum=0.1)
+            self.out = nn.Conv2d(cout, 8, 1, bias=False)
+
+        def describe(self, gb):
+            x = gb.input_act(cin)
+            gb.output(gb.conv(gb.fuse([(gb.conv(x, "conv", 1, 1, 0), "bn")]), "out", 1, 1, 0))
+
+        def torch_forward(self, x):
+            return self.out(F.relu(self.bn(self.conv(x))))
+
+    torch.manual_seed(21)
+    proto = Net()
+    with torch.no_grad():
+        for p_ in proto.parameters():
+            p_.copy_(p_.to(torch.bfloat16).float())
+    x = torch.randn(n, cin, h, w).to(torch.bfloat16).float()
+    res = {}
+    for which in ("tiled", "pw"):
+        if which == "tiled":
+            forced_plans.force_cfg = lambda cands: next(c for c in cands if c[2] != 1)
+        else:
+            forced_plans.force_cfg = lambda cands: max([c for c in cands if c[2] == 1] or cands[:1], key=lambda c: (c[2] == 1, c[0], c[1]))
+        m = copy.deepcopy(proto)
+        torch.manual_seed(22)
+        out, dx, grads = _run_plan(m, x, lambda o: torch.randn_like(o), "bf16")
+        res[which] = (out, dx, grads, {k: v.cpu().clone() for k, v in m.state_dict().items() if "running" in k})
+        plan = next(iter(m._lh_plans.values()))
+        assert any(meta[2].startswith("igemm_pw_kernel") and meta[2].endswith("true>") for meta in plan.profile_meta) == (which == "pw")
+    a, b = res["tiled"], res["pw"]
+    for k in a[3]:
+        assert rel_err(a[3][k], b[3][k]) < 1e-5, k
+    assert rel_err(a[0], b[0]) < 1e-2 and rel_err(a[1], b[1]) < 2e-2
+    for k in ("bn.weight", "bn.bias"):
+        assert rel_err(a[2][k], b[2][k]) < 2e-2, k
+    ref = copy.deepcopy(proto).train()
+    assert rel_err(b[0], ref.torch_forward(x).detach()) < TOL["bf16"]

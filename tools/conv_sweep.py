@@ -141,7 +141,12 @@ for name, cin, cout, k, s, n, h, w, tr in SHAPES:
         bad = [r for r in res if not r[2]]
         print(f"{name:24s} {c.what[:26]:26s} default {tuple(cur)} {t_def:7.1f} us ({fl / t_def / 1e6:6.0f} TF/s) | best "
               + "  ".join(f"{r[1]} {r[0]:.1f}" for r in res[:4]) + (f" | worst {res[-1][1]} {res[-1][0]:.1f}" if res else "")
-              + (f" | MISMATCH {[r[1] for r in bad]}" if bad else ""))
+              + (f" | MISMATCH {[r[1] for r in bad]}" if bad else "")
+              + (" | best tiled " + "  ".join(f"{r[1][:4]} {r[0]:.1f}" for r in [r for r in res if r[1][2] != 1][:1])
+                 + " | pointwise " + "  ".join(f"{r[1][:4]} {r[0]:.1f}" for r in res if r[1][2] == 1) if any(r[1][2] == 1 for r in res) else ""))
+    if os.environ.get("LH_SWEEP_NOWGRAD"):
+        del plan, m
+        continue
     # ---- weight gradient: every launch plan (tile, stage rows, ring depth, pixel splits), wgrad + fold timed together
     wcalls = [c for c in plan.bwd if getattr(c, "fn", None) == lib.lh_wgrad_fused]
     for cw in wcalls:
