@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256, 2) void igemm_pw_kernel(const IgemmArgs p) {
             const int grow = cblk * BM + row;
             const bool ok = grow < prow_lim && s * 64 < p.kpad;
             const unsigned char* src = ok ? p.w + ((long)grow * p.kpad + s * 64 + c * EPC) * ES : p.zero;
-            __builtin_amdgcn_global_load_lds((gbl_void_p)src, (lds_void_p)(smem + s * SPB + r8 * 1024), 16, 0, 0);
+            if (!(LH_ABL & 4)) __builtin_amdgcn_global_load_lds((gbl_void_p)src, (lds_void_p)(smem + s * SPB + r8 * 1024), 16, 0, 0);
         }
         float* cst = reinterpret_cast<float*>(smem + CST);
         for (int c = tid; c < BM; c += 256) {
@@ -105,7 +105,8 @@ __global__ __launch_bounds__(256, 2) void igemm_pw_kernel(const IgemmArgs p) {
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk) {
                 const unsigned char* src = (ok && kk * 32 + q * EPC < p.k_run) ? base + kk * 64 : p.zero;
-                B[j][kk] = *reinterpret_cast<const uint4*>(src);
+                if (LH_ABL & 4) B[j][kk] = uint4{(unsigned)(size_t)src, 1u, 2u, 3u};
+                else B[j][kk] = *reinterpret_cast<const uint4*>(src);
             }
         }
     };
@@ -144,7 +145,8 @@ __global__ __launch_bounds__(256, 2) void igemm_pw_kernel(const IgemmArgs p) {
             constexpr int kk = grp / (CT / 4), i0 = (grp % (CT / 4)) * 4;
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                dst[u] = *reinterpret_cast<const uint4*>(smem + (kk >> 1) * SPB + (i0 + u) * 2048 + ((kk & 1) ? aoff1 : aoff0));
+                if (LH_ABL & 2) dst[u] = uint4{aoff0 + u, aoff1, 5u, 7u};
+                else dst[u] = *reinterpret_cast<const uint4*>(smem + (kk >> 1) * SPB + (i0 + u) * 2048 + ((kk & 1) ? aoff1 : aoff0));
         };
         readA(ic<0>{}, A[0]);
         static_for<0, NG>([&](auto Gc) {
@@ -155,11 +157,23 @@ __global__ __launch_bounds__(256, 2) void igemm_pw_kernel(const IgemmArgs p) {
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int j = 0; j < PT; ++j) MmaR<T>::run(A[grp & 1][u], Bf[j][kk], acc[i0 + u][j]);
+                for (int j = 0; j < PT; ++j) {
+                    if (LH_ABL & 1) acc[i0 + u][j][0] += __builtin_bit_cast(float, A[grp & 1][u].x ^ Bf[j][kk].x);
+                    else MmaR<T>::run(A[grp & 1][u], Bf[j][kk], acc[i0 + u][j]);
+                }
             __builtin_amdgcn_sched_barrier(0);
         });
         prefetch();                                  // single register set: the next tile's rows fly under this epilogue
 
+        if (LH_ABL & 8) {                             // no epilogue, every accumulator stays live
+            float z = 0.f;
+#pragma unroll
+            for (int i = 0; i < CT; ++i)
+#pragma unroll
+                for (int j = 0; j < PT; ++j) z += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+            if (z == 123.456f) p.out[0] = 1;
+            return;
+        }
         const int m0 = t * PT * 16;
 #pragma unroll
         for (int sb = 0; sb < NSB; ++sb) {
@@ -232,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void igemm_pw_kernel(const IgemmArgs p) {
 #pragma unroll
                         for (int e = 0; e < EPC; ++e) { s1[sb][e] += fv[e]; s2[sb][e] += fv[e] * fv[e]; }
                     }
-                    *reinterpret_cast<uint4*>(p.out + ((long)m * p.out_pix_stride + col0) * ES) = u;
+                    if (!(LH_ABL & 16) || u.x == 0x12345678u) *reinterpret_cast<uint4*>(p.out + ((long)m * p.out_pix_stride + col0) * ES) = u;
                 }
             }
         }

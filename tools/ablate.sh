@@ -7,7 +7,7 @@ cd "$(dirname "$0")/../lighthand_amd/csrc"
 make -j8 > /dev/null
 mkdir -p ../../tools/abl
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -ffp-contract=off"
-UNITS="igemm_ring_bf16_big igemm_ring_bf16_mid igemm_ring_bf16_small wgrad_ring_bf16"
+UNITS="${LH_ABL_UNITS:-igemm_ring_bf16_big igemm_ring_bf16_mid igemm_ring_bf16_small wgrad_ring_bf16 igemm_pw_bf16}"
 for v in "$@"; do
   for u in $UNITS; do /opt/rocm/bin/hipcc $FLAGS -DLH_ABL=$v -c $u.hip -o /tmp/${u}_abl$v.o & done
   wait

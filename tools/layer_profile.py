@@ -14,12 +14,18 @@ ap.add_argument("--depth", type=int, default=50)
 ap.add_argument("--precision", default="bf16")
 ap.add_argument("--hrnet-width", type=int, default=0)
 ap.add_argument("--all", action="store_true", help="time every launch, not only the conv-family ones")
+ap.add_argument("--infer", action="store_true", help="the eval-mode inference plan (BN folded) instead of the training step")
 args = ap.parse_args()
-from lighthand_amd.runtime import TrainStep
+from lighthand_amd.runtime import InferStep, TrainStep
 model = bench.build_model(args.depth, args.precision, args.hrnet_width)
-step = TrainStep(model, args.batch, args.size, args.size, use_graph=False)
 images, joints = bench.synthetic_batch(args.batch, args.size, "cuda")
-step.images.copy_(images); step.joints.copy_(joints)
+if args.infer:
+    model.eval()
+    step = InferStep(model, args.batch, args.size, args.size, use_graph=False)
+    step.images.copy_(images)
+else:
+    step = TrainStep(model, args.batch, args.size, args.size, use_graph=False)
+    step.images.copy_(images); step.joints.copy_(joints)
 plan = step.plan
 meta = {id(c): (n, f, b) for w, c, n, f, b in plan.profile_meta}
 stream = torch.cuda.current_stream(); s = stream.cuda_stream
@@ -27,7 +33,7 @@ rows = []
 for it in range(3):
     evs = []
     plan.refresh_packs(s)
-    for which, lst in (("fwd", plan.fwd), ("bwd", plan.bwd)):
+    for which, lst in ((("fwd", plan.fwd),) if args.infer else (("fwd", plan.fwd), ("bwd", plan.bwd))):
         if which == "bwd":
             step._fwd_loss_tail(s)
         for i, call in enumerate(lst):
