@@ -302,6 +302,12 @@ int lh_maxpool3x3s2_bwd(const void* dout, const unsigned char* idx, void* dx, in
  * placed values are bit-identical to the reference's on the same host. */
 int lh_gaussian_target(const float* joints, int jstride, const float* patch, int radius,
                        float* target, int b, int j, int size, void* stream);
+/* GenerateHeatmap.__call__: src/utils/dataset_loader.py:22-53 (the alternate renderer the reference's dataset classes
+ * keep beside generate_target).  points fp32 [b][j][pstride] ALREADY in heat-map coordinates -> fp32 [b][j][res][res];
+ * `patch` = the (6*sigma+3)^2 Gaussian the host evaluates in float64 like the reference and rounds to fp32 (what the
+ * reference's float32 map stores); sigma = res / 64 must be an integer (the reference uses res = 64). */
+int lh_gaussian_target_alt(const float* points, int pstride, const float* patch, int sigma,
+                           float* target, int b, int j, int res, void* stream);
 /* JointsMSELoss(use_target_weight=False): src/utils/loss.py:306-325.  loss (fp32 scalar on
  * device) = 0.5*mean((p-g)^2); grad (optional) = (p-g) * grad_scale/(numel). workspace >=
  * lh_mse_workspace_bytes(numel). */

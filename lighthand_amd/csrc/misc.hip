@@ -485,6 +485,44 @@ __global__ void gaussian_target_kernel(const float* joints, int jstride, const f
     }
 }
 
+// GenerateHeatmap (src/utils/dataset_loader.py:22-53), the alternate renderer: points are ALREADY in heat-map coordinates,
+// sigma = res / 64 (an integer here), patch of (6 * sigma + 3)^2 centred on int(point), np.maximum blend with the zero
+// map (= plain placement: every joint owns its plane); a joint is skipped when x <= 0 or int(point) lies outside the map.
+__global__ void gaussian_target_alt_kernel(const float* points, int pstride, const float* patch, int sigma, float* target,
+                                           int bj, int res) {
+    const long total = (long)bj * res * res;
+    const int pw = 6 * sigma + 3;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % res);
+        const long t = i / res;
+        const int y = (int)(t % res);
+        const long j = t / res;
+        const float fx = points[j * pstride], fy = points[j * pstride + 1];
+        float v = 0.f;
+        if (fx > 0.f) {
+            const int px = (int)fx, py = (int)fy;                    // Python int(): truncation toward zero
+            if (px >= 0 && py >= 0 && px < res && py < res) {
+                const int ulx = px - 3 * sigma - 1, uly = py - 3 * sigma - 1;
+                const int gx = x - ulx, gy = y - uly;                // hms[aa:bb, cc:dd] <- g[a:b, c:d]: same offset on both axes
+                if (gx >= 0 && gx < pw && gy >= 0 && gy < pw) v = patch[gy * pw + gx];
+            }
+        }
+        target[i] = v;
+    }
+}
+
+extern "C" int lh_gaussian_target_alt(const float* points, int pstride, const float* patch, int sigma, float* target,
+                                      int b, int j, int res, void* stream) {
+    LH_REQUIRE(points && patch && target && pstride >= 2 && b > 0 && j > 0 && res > 0 && sigma >= 1 && res == 64 * sigma,
+               "lh_gaussian_target_alt: bad arguments (res must be 64 * sigma, sigma a positive integer)");
+    const long total = (long)b * j * res * res;
+    const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(gaussian_target_alt_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, points, pstride, patch, sigma,
+                       target, b * j, res);
+    LH_LAUNCH_CHECK("gaussian_target_alt launch");
+    return LH_OK;
+}
+
 extern "C" int lh_gaussian_target(const float* joints, int jstride, const float* patch, int radius, float* target,
                                   int b, int j, int size, void* stream) {
     LH_REQUIRE(joints && patch && target && jstride >= 2 && b > 0 && j > 0 && size > 0 && radius >= 0,

@@ -63,6 +63,44 @@ def generate_target(joints, device="cuda"):
     return render_targets(j[None])[0].cpu()
 
 
+class GenerateHeatmap:
+    """The reference's alternate renderer (src/utils/dataset_loader.py:22-53), same constructor and call: points
+    ``[num_parts, >=2]`` already in heat-map coordinates -> float32 ``[num_parts, res, res]`` (CPU, like the reference);
+    ``render(points)`` is the batched device form ``[B, J, >=2] -> [B, J, res, res]``.  sigma = output_res / 64 must be an
+    integer (the reference instantiates it with output_res = 64)."""
+
+    def __init__(self, output_res, num_parts, device="cuda"):
+        if output_res % 64:
+            raise ValueError("GenerateHeatmap on the device needs output_res = 64 * k (sigma = output_res / 64 integral)")
+        self.output_res, self.num_parts, self.device = output_res, num_parts, device
+        sigma = self.output_res / 64
+        self.sigma = sigma
+        size = 6 * sigma + 3
+        x = np.arange(0, size, 1, float)
+        y = x[:, np.newaxis]
+        x0, y0 = 3 * sigma + 1, 3 * sigma + 1
+        self.g = np.exp(-((x - x0) ** 2 + (y - y0) ** 2) / (2 * sigma ** 2))       # float64, as in the reference
+        self._patch = {}
+
+    def render(self, points, out=None):
+        if not points.is_cuda:
+            raise _lib.LightHandError("GenerateHeatmap.render needs a HIP device tensor")
+        p = points.to(torch.float32).contiguous()
+        b, nj, stride = p.shape
+        if out is None:
+            out = torch.empty(b, nj, self.output_res, self.output_res, dtype=torch.float32, device=p.device)
+        key = str(p.device)
+        if key not in self._patch:
+            self._patch[key] = torch.from_numpy(self.g.astype(np.float32)).to(p.device)
+        check(_lib.load().lh_gaussian_target_alt(p.data_ptr(), stride, self._patch[key].data_ptr(), int(self.sigma), out.data_ptr(),
+                                                 b, nj, self.output_res, _stream()), "lh_gaussian_target_alt")
+        return out
+
+    def __call__(self, p):
+        pts = torch.as_tensor(np.asarray(p, dtype=np.float32)[:, :2].copy()).to(self.device)
+        return self.render(pts[None])[0].cpu().numpy()
+
+
 class _MseFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, output, target):

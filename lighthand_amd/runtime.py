@@ -17,10 +17,12 @@ from ._lib import LightHandError, check
 from .optim import Adam
 
 
-def sample_color_jitter(n, brightness=0.5, contrast=0.5, saturation=0.5, hue=0.5, ratio=1.0, generator=None):
+def sample_color_jitter(n, brightness=0.5, contrast=0.5, saturation=0.5, hue=0.5, mask=None, generator=None):
     """torchvision ColorJitter.get_params per image (host side): factor ~ U[max(0, 1 - v), 1 + v] for brightness /
-    contrast / saturation, hue ~ U[-h, h], op order = randperm(4).  ``ratio`` = fraction of the samples that are
-    jittered at all (the reference's --ratio_of_aug, src/tools/dataset.py:133); the others get order -1 (skip).
+    contrast / saturation, hue ~ U[-h, h], op order = randperm(4).  ``mask`` (bool [n], optional) selects the samples
+    that are jittered at all; the others get order -1 (skip).  The reference jitters a FIXED subset of its dataset, the
+    samples with idx < len(meta) * ratio_of_aug (src/tools/dataset.py:133): the loader computes that flag per sample
+    (lighthand_amd.tools.train) and hands it in here -- it is not a per-batch random draw.
     Returns (factors fp32 [n][4], order int32 [n][4]) CPU tensors for Plan.jitter_factors / jitter_order."""
     g = generator
     u = torch.rand(n, 4, generator=g)
@@ -28,7 +30,8 @@ def sample_color_jitter(n, brightness=0.5, contrast=0.5, saturation=0.5, hue=0.5
     hi = torch.tensor([1 + brightness, 1 + contrast, 1 + saturation, hue])
     factors = (lo + (hi - lo) * u).to(torch.float32)
     order = torch.stack([torch.randperm(4, generator=g) for _ in range(n)]).to(torch.int32)
-    order[torch.rand(n, generator=g) >= ratio] = -1
+    if mask is not None:
+        order[~torch.as_tensor(mask, dtype=torch.bool).cpu()] = -1
     return factors, order
 
 
@@ -169,7 +172,9 @@ class TrainStep:
             if st is not None:
                 self.optimizer._sync_hyper(st, group)
 
-    def __call__(self, images=None, joints=None, target=None):
+    def __call__(self, images=None, joints=None, target=None, aug=None):
+        """``aug`` (bool [batch], optional; uint8 input with color_jitter only): which samples are jittered this step
+        (the reference's fixed --ratio_of_aug subset, src/tools/dataset.py:133); None = all of them."""
         if getattr(self.model, "_lh_generation", 0) != self._model_generation:
             raise LightHandError("the model's parameter storages were re-created (.to() / .cuda() / .float()) after this TrainStep "
                                  "was built: its graph still trains the old buffers -- build a new TrainStep")
@@ -178,7 +183,7 @@ class TrainStep:
         if images is not None:
             (self.images_u8 if images.dtype == torch.uint8 and self.images_u8 is not None else self.images).copy_(images, non_blocking=True)
         if self.color_jitter is not None and self.images_u8 is not None:
-            f, o = sample_color_jitter(self.joints.shape[0], *self.color_jitter)
+            f, o = sample_color_jitter(self.joints.shape[0], *self.color_jitter, mask=aug)
             self.plan.jitter_factors.copy_(f, non_blocking=True)
             self.plan.jitter_order.copy_(o, non_blocking=True)
         if joints is not None:
@@ -212,12 +217,13 @@ class InferStep:
     src/utils/argparser.py:246-281).  ``bn_train=True`` reproduces the reference quirk of running
     ``pred_store`` without ``model.eval()`` (batch statistics at evaluation time)."""
 
-    def __init__(self, model, batch, height, width, bn_train=False, use_graph=True):
+    def __init__(self, model, batch, height, width, bn_train=False, use_graph=True, input_u8=None):
         self.lib = _lib.load()
         self.plan = model.plan(batch, height, width, training=bn_train, backward=False)
         out = self.plan.out_nchw
         dev = out.device
-        self.images = self.plan.img_nchw
+        # input_u8=(hs, ws): raw uint8 HWC frames; ToTensor / Resize / Normalize run fused on the device (dataset.py:128-159)
+        self.images = self.plan.use_uint8_input(*input_u8) if input_u8 else self.plan.img_nchw
         self.heatmaps = out
         self.preds = torch.zeros(batch, out.shape[1], 2, dtype=torch.float32, device=dev)
         self.maxvals = torch.zeros(batch, out.shape[1], 1, dtype=torch.float32, device=dev)

@@ -11,6 +11,13 @@ CosineAnnealingLR(T_max=epoch) stepped per epoch, best-validation-loss checkpoin
 hard-codes 50), ``--hrnet_width``, ``--precision {fp32,bf16,fp16}``, ``--size``, ``--synthetic N`` (seeded
 synthetic samples; the reference's datasets are not redistributable), ``--no_graph``.
 
+Datasets (src/tools/train.py:24-38 builds them from files this repository cannot ship): ``main(args, train_set=,
+val_set=)`` takes any ``torch.utils.data.Dataset`` whose samples are tuples starting with ``(image, joint_2d)`` --
+the reference's ``CustomDataset`` yields ``(image, joint_2d, heatmap)`` and fits as it is; the heatmap is re-rendered on
+the device from ``joint_2d``.  ``image`` is either a normalised float tensor ``[3, S, S]`` or a RAW uint8 frame
+``[H, W, 3]``: raw frames go through the fused device pipeline (ToTensor, Resize(S), ColorJitter(0.5 x 4) on the
+samples with ``idx < len(dataset) * ratio_of_aug`` -- the reference's rule, src/tools/dataset.py:133 -- Normalize).
+
 What changes vs the reference loop (src/utils/method.py:160-183): the per-iteration ``loss.item()`` and
 full-heatmap D2H + NumPy arg-max are replaced by device-resident loss / keypoints that are read once per
 logging interval; everything else (BN momentum, loss, decode rule, optimizer) is the same arithmetic.
@@ -90,6 +97,33 @@ class SyntheticHands(torch.utils.data.Dataset):
         return self.images[i], self.joints[i]
 
 
+class _WithAugFlag(torch.utils.data.Dataset):
+    """(image, joint_2d, ...) -> (image, joint_2d, jitter?) with the reference's rule for the colour augmentation: the
+    FIXED subset idx < len(dataset) * ratio_of_aug is jittered (src/tools/dataset.py:133)."""
+
+    def __init__(self, base, ratio_of_aug):
+        self.base, self.limit = base, len(base) * ratio_of_aug
+
+    def __len__(self):
+        return len(self.base)
+
+    def __getitem__(self, i):
+        s = self.base[i]
+        return s[0], torch.as_tensor(s[1], dtype=torch.float32)[:, :2], i < self.limit
+
+
+def _sample_kind(ds):
+    """'u8' for raw uint8 HWC frames, 'f32' for normalised [3, S, S] float tensors; (H, W) of a raw frame."""
+    img = torch.as_tensor(ds[0][0])
+    if img.dtype == torch.uint8:
+        if img.dim() != 3 or img.shape[2] != 3:
+            raise SystemExit(f"raw frames must be uint8 [H, W, 3], got {tuple(img.shape)}")
+        return "u8", (int(img.shape[0]), int(img.shape[1]))
+    if img.dim() != 3 or img.shape[0] != 3:
+        raise SystemExit(f"normalised images must be float [3, S, S], got {tuple(img.shape)}")
+    return "f32", None
+
+
 def save_checkpoint(model, args, epoch, optimizer, best_loss, count, ment="good"):
     """Same file name and dict keys as src/tools/dataset.py:340-367; only rank 0 writes."""
     d = os.path.join(args.output_dir, "checkpoint-{}".format(ment))
@@ -109,21 +143,27 @@ def resume_checkpoint(model, path):
     return sd["best_loss"], sd["epoch"] + 1, sd["count"], sd.get("optimizer_state_dict")
 
 
-def validate(model, loader, args):
-    """Runner.run validation branch (src/utils/method.py:218-287): loss, PCK@0.2 (bbox-normalised), EPE."""
+def validate(model, loader, args, u8_step=None):
+    """Runner.run validation branch (src/utils/method.py:218-287): loss, PCK@0.2 (bbox-normalised), EPE.
+    ``u8_step``: an InferStep(input_u8=...) of the model for loaders that yield raw uint8 frames."""
     from lighthand_amd.heatmap import JointsMSELoss, max_preds_device, render_targets
     from lighthand_amd.metrics import device_pck_epe
     model.eval()
     crit = JointsMSELoss(False)
     acc = torch.zeros(5, device="cuda")          # loss*b, b, pck*b, epe sum, epe count -- reduced on the device
     with torch.no_grad():
-        for images, joints in loader:
-            images, joints = images.cuda(non_blocking=True), joints.cuda(non_blocking=True)
-            pred = model(images)
+        for batch in loader:
+            images, joints = batch[0].cuda(non_blocking=True), batch[1][..., :2].float().cuda(non_blocking=True)
+            if images.dtype == torch.uint8:
+                u8_step.refresh_weights()
+                u8_step(images)
+                pred = u8_step.heatmaps
+            else:
+                pred = model(images)
             hs = pred.shape[-1]
             target = render_targets(joints, size=hs)
             loss = crit(pred, target, None)
-            kp, _, _ = max_preds_device(pred, scale=float(images.shape[-1] // hs))
+            kp, _, _ = max_preds_device(pred, scale=float(args.size // hs))
             b = images.shape[0]
             pck, esum, ecnt = device_pck_epe(kp, joints, T=0.2)
             acc += torch.stack([loss * b, torch.tensor(float(b), device="cuda"), pck * b, esum, ecnt])
@@ -155,10 +195,12 @@ class EarlyStop:
         return False, self.count == self.patience
 
 
-def main(args):
+def main(args, train_set=None, val_set=None):
+    """``train_set`` / ``val_set``: any Dataset of (image, joint_2d, ...) samples (module docstring); without them
+    ``--synthetic N`` builds seeded synthetic ones.  Under torch.distributed every rank must be given ITS shard."""
     from lighthand_amd import parallel
     from lighthand_amd.optim import Adam
-    from lighthand_amd.runtime import TrainStep
+    from lighthand_amd.runtime import InferStep, TrainStep
 
     seed = 9001                                           # src/tools/train.py:15-22
     torch.manual_seed(seed)
@@ -166,13 +208,19 @@ def main(args):
     random.seed(seed)
     rank, world, local = parallel.init_distributed()
     torch.cuda.set_device(local)
-    if not args.synthetic:
-        raise SystemExit("the reference's datasets (LightHand99K / FreiHAND / ...) are not shipped: pass --synthetic N, "
-                         "or plug a Dataset yielding (image[3,S,S], joint_2d[21,2]) into lighthand_amd.tools.train.main")
-    train_set = SyntheticHands(args.synthetic, args.size, seed + rank)
-    val_set = SyntheticHands(args.val_synthetic or max(args.batch_size, args.synthetic // 8), args.size, seed + 1000)
-    train_loader = torch.utils.data.DataLoader(train_set, batch_size=args.batch_size, shuffle=True, drop_last=True, pin_memory=True)
-    val_loader = torch.utils.data.DataLoader(val_set, batch_size=args.batch_size, shuffle=False, drop_last=True, pin_memory=True)
+    if train_set is None:
+        if not args.synthetic:
+            raise SystemExit("the reference's datasets (LightHand99K / FreiHAND / ...) are not shipped: pass --synthetic N, or call "
+                             "lighthand_amd.tools.train.main(args, train_set=, val_set=) with Datasets of (image, joint_2d) samples")
+        train_set = SyntheticHands(args.synthetic, args.size, seed + rank)
+    if val_set is None:
+        val_set = SyntheticHands(args.val_synthetic or max(args.batch_size, max(args.synthetic, args.batch_size * 8) // 8), args.size, seed + 1000)
+    kind, raw_hw = _sample_kind(train_set)
+    val_kind, val_hw = _sample_kind(val_set)
+    train_set = _WithAugFlag(train_set, args.ratio_of_aug)
+    workers = args.num_workers if not isinstance(train_set.base, SyntheticHands) else 0
+    train_loader = torch.utils.data.DataLoader(train_set, batch_size=args.batch_size, shuffle=True, drop_last=True, pin_memory=True, num_workers=workers)
+    val_loader = torch.utils.data.DataLoader(val_set, batch_size=args.batch_size, shuffle=False, drop_last=True, pin_memory=True, num_workers=workers)
 
     model = build_model(args).cuda().set_precision(args.precision)
     best_loss, epo, count, opt_state = np.inf, 0, 0, None
@@ -184,22 +232,26 @@ def main(args):
     for _ in range(epo):
         scheduler.step()
     sync = parallel.GradSync(world) if world > 1 else None
-    step = TrainStep(model, args.batch_size, args.size, args.size, optimizer=optimizer, use_graph=not args.no_graph, grad_sync=sync)
+    # raw uint8 frames: ToTensor / Resize / ColorJitter(0.5, 0.5, 0.5, 0.5) / Normalize fused on the device (dataset.py:128-159)
+    jitter = (0.5, 0.5, 0.5, 0.5) if kind == "u8" and args.ratio_of_aug > 0 else None
+    step = TrainStep(model, args.batch_size, args.size, args.size, optimizer=optimizer, use_graph=not args.no_graph, grad_sync=sync,
+                     input_u8=raw_hw, color_jitter=jitter)
     if opt_state and not args.optim:                      # src/tools/train.py:50
         optimizer.load_state_dict(opt_state)
+    val_step = InferStep(model, args.batch_size, args.size, args.size, input_u8=val_hw) if val_kind == "u8" else None
 
     stopper = EarlyStop(best_loss, count, args.count)
     for epoch in range(epo, args.epoch):
         t0, seen, running = time.time(), 0, None
-        for it, (images, joints) in enumerate(train_loader):
-            step(images.cuda(non_blocking=True), joints.cuda(non_blocking=True))
+        for it, (images, joints, aug) in enumerate(train_loader):
+            step(images.cuda(non_blocking=True), joints.cuda(non_blocking=True), aug=aug if jitter else None)
             seen += images.shape[0]
             if it % args.logging_steps == 0:            # the ONLY device->host read of the loop
                 running = float(step.loss)
                 if rank == 0:
                     print(f"epoch {epoch} iter {it}/{len(train_loader)} loss {running:.6f} "
                           f"{world * seen / (time.time() - t0 + 1e-9):.0f} img/s lr {optimizer.param_groups[0]['lr']:.2e}")
-        val_loss, pck, epe = validate(model, val_loader, args)
+        val_loss, pck, epe = validate(model, val_loader, args, val_step)
         if rank == 0:
             print(f"epoch {epoch} valid loss {val_loss:.6f} pck {pck:.2f}% epe {epe * 0.26:.2f} mm")     # method.py:131
         improved, stop = stopper.update(val_loss)     # val_loss is rank-invariant (reduce_validation): collective decision

@@ -288,3 +288,48 @@ def test_gradients_well_conditioned_case_at_1e3(tag):
           f"per-tensor median {np.median(eh):.3e} / {np.median(ec):.3e}, max {max(eh):.3e} / {max(ec):.3e}")
     assert l2_h < FP32_REL
     assert np.median(eh) <= 2 * np.median(ec) + 1e-5
+
+
+def test_c2_r50_bf16_gradients_vs_fp32_oracle():
+    """The timed configuration's arithmetic (R50, bf16 activations / weight packs, fp32 accumulation and fp32 master
+    gradients) against the fp32 CPU oracle, whole-model dL/dtheta at batch 8, 128 x 128, on the well-conditioned
+    trained-like weights of test_gradients_well_conditioned_case_at_1e3 (random-init or over-fitted train-mode BN stacks
+    amplify ANY rounding to tens of percent, CPU fp32 included, and would measure conditioning, not kernels).
+    Declared bf16 tolerance: global relative L2 over all parameters <= 5e-2 (measured 3.2e-2),
+    i.e. cosine >= 0.998 between the two whole-model gradients; loss within 1e-3 relative.  Per TENSOR the errors are
+    larger (median 0.3): on this network the fp32 path's per-tensor median is 1e-4 = 1.7e3 units of fp32 round-off, and the
+    same amplification of bf16's 2^-9 is O(0.3) -- a property of train-mode BatchNorm gradients (sums with heavy
+    cancellation), not of the kernels; it averages out over steps (test_reduced_precision_trains_like_fp32).  The test
+    therefore also requires every tensor's gradient to point the right way: per-tensor cosine, median >= 0.9."""
+    from oracle import models as omod
+    from lighthand_amd.heatmap import JointsMSELoss
+    torch.manual_seed(11)
+    model, fwd = _build("r50")
+    model.load_state_dict(_trained_like(model.state_dict()))
+    rng = np.random.RandomState(5)
+    b, h, w = 8, 128, 128
+    x = torch.from_numpy(rng.randn(b, 3, h, w).astype(np.float32))
+    tgt = torch.from_numpy(rng.rand(b, 21, h // 4, w // 4).astype(np.float32))
+    sd = omod.clone_state(model.state_dict())
+    loss_ref, pred_ref, g32 = omod.loss_and_grads(sd, lambda s, xx: fwd(s, xx, True), x, tgt)
+    model = model.cuda().set_precision("bf16").train()
+    pred = model(x.cuda())
+    loss = JointsMSELoss(False)(pred, tgt.cuda(), None)
+    loss.backward()
+    num = den = dot = nh = 0.0
+    per, cos = [], []
+    for k, p in model.named_parameters():
+        gh, gr = p.grad.cpu().double().numpy().ravel(), g32[k].double().numpy().ravel()
+        num += ((gh - gr) ** 2).sum(); den += (gr ** 2).sum(); dot += (gh * gr).sum(); nh += (gh ** 2).sum()
+        per.append(float(np.sqrt(((gh - gr) ** 2).sum() / ((gr ** 2).sum() + 1e-30))))
+        cos.append(float((gh * gr).sum() / (np.sqrt((gh ** 2).sum() * (gr ** 2).sum()) + 1e-30)))
+    l2, gcos = float(np.sqrt(num / den)), float(dot / np.sqrt(nh * den))
+    herr = rel(pred.detach().cpu().numpy(), pred_ref.numpy())
+    lrel = abs(float(loss.detach()) - loss_ref) / abs(loss_ref)
+    print(f"C2 arithmetic (bf16) vs fp32 oracle on trained-like weights: gradient global rel-L2 {l2:.3e} (cosine {gcos:.5f}), per-tensor rel-L2 "
+          f"median {np.median(per):.3e} max {max(per):.3e}, per-tensor cosine median {np.median(cos):.4f} min {min(cos):.4f}; "
+          f"heat-map err {herr:.3e}; loss rel {lrel:.3e}")
+    assert l2 < 5e-2 and gcos > 0.998
+    assert np.median(cos) >= 0.9
+    assert herr < 5e-2            # flat random-feature maps; the forward pin is test_c2_r50_bf16_train_forward_matches_fp32_oracle
+    assert lrel < 1e-3

@@ -372,6 +372,29 @@ def test_gaussian_target_matches_oracle_and_golden(golden_dir):
     assert np.array_equal(generate_target(g["joints"][0]).numpy(), want[0])
 
 
+def test_generate_heatmap_alt_matches_oracle_and_golden(golden_dir):
+    """GenerateHeatmap (src/utils/dataset_loader.py:22-53) on the device: sigma = res / 64, 9 x 9 patch, maximum blend,
+    points in heat-map coordinates, the x > 0 / inside-the-map skip rules -- against the golden captured from the
+    reference (g1_target.npz["alt"] = GenerateHeatmap(64, 21)(joints / 4)) and the numpy oracle, incl. crafted edge points."""
+    import os
+    from lighthand_amd.heatmap import GenerateHeatmap
+    from oracle.heatmap import generate_heatmap_alt
+    g = np.load(os.path.join(golden_dir, "g1_target.npz"))
+    gh = GenerateHeatmap(64, 21)
+    pts = torch.from_numpy(g["joints"] / 4).cuda()
+    got = gh.render(pts).cpu().numpy()
+    assert got.shape == g["alt"].shape
+    assert np.abs(got - g["alt"]).max() <= 6e-8           # golden: equal up to the host's exp ulp
+    assert np.array_equal(got != 0, g["alt"] != 0)        # identical support (skip rules, clipping)
+    want = np.stack([generate_heatmap_alt(p) for p in g["joints"] / 4])
+    assert np.array_equal(got, want)                      # bit-exact vs the oracle on this host
+    edge = np.zeros((21, 2), np.float32)
+    edge[:9] = [(0.0, 5.0), (0.5, 5.0), (-3.0, 5.0), (63.9, 63.9), (64.0, 10.0), (10.0, 64.5), (1.0, 0.0), (3.2, -0.5), (62.0, 1.0)]
+    edge[9:] = np.random.RandomState(0).uniform(-4, 68, size=(12, 2))
+    assert np.array_equal(gh(edge), generate_heatmap_alt(edge))       # per-sample form with the reference's call signature
+    assert gh(edge)[0].max() == 0 and gh(edge)[1].max() > 0          # x = 0 is skipped, x = 0.5 is drawn (pt[0] > 0, int() = 0)
+
+
 def test_mse_loss_golden(golden_dir):
     import os
     from lighthand_amd.heatmap import JointsMSELoss
