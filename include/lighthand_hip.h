@@ -378,6 +378,12 @@ int lh_comm_destroy(lh_comm* comm);
 int lh_copy_strided_f32(float* dst, const float* src, const int* shape4, const long* dst_strides4, const long* src_strides4,
                         void* stream);
 
+
+/* Staging of a gradient bucket that travels as bfloat16 (parallel.GradSync(compress="bf16"); the reference has no
+ * multi-GPU path): to_f32 = 0 rounds the fp32 arena slice `f32` into the bf16 buffer `b16` (nearest even),
+ * to_f32 = 1 widens `b16` back into `f32`.  n elements, any alignment. */
+int lh_cast_f32_bf16(float* f32, void* b16, long n, int to_f32, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -919,3 +919,46 @@ extern "C" int lh_copy_strided_f32(float* dst, const float* src, const int* shap
     LH_LAUNCH_CHECK("copy_strided_f32 launch");
     return LH_OK;
 }
+
+// ---- gradient bucket staging for bf16 collectives (parallel.GradSync(compress="bf16")): fp32 arena slice <-> bf16 buffer,
+// 16 bytes of bf16 per lane (round to nearest even through the hardware convert; NaN stays NaN)
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ src, bf16* __restrict__ dst, long n) {
+    const long i0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    const long stride = (long)gridDim.x * blockDim.x * 8;
+    for (long i = i0; i < n; i += stride) {
+        if (i + 8 <= n && (((size_t)(src + i) | (size_t)(dst + i)) & 15) == 0) {
+            const float4 a = *reinterpret_cast<const float4*>(src + i), b = *reinterpret_cast<const float4*>(src + i + 4);
+            Vec16<bf16> v;
+            v.e[0] = (bf16)a.x; v.e[1] = (bf16)a.y; v.e[2] = (bf16)a.z; v.e[3] = (bf16)a.w;
+            v.e[4] = (bf16)b.x; v.e[5] = (bf16)b.y; v.e[6] = (bf16)b.z; v.e[7] = (bf16)b.w;
+            *reinterpret_cast<uint4*>(dst + i) = v.u;
+        } else {
+            for (long k = i; k < n && k < i + 8; ++k) dst[k] = (bf16)src[k];
+        }
+    }
+}
+
+__global__ void cast_bf16_f32_kernel(const bf16* __restrict__ src, float* __restrict__ dst, long n) {
+    const long i0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    const long stride = (long)gridDim.x * blockDim.x * 8;
+    for (long i = i0; i < n; i += stride) {
+        if (i + 8 <= n && (((size_t)(src + i) | (size_t)(dst + i)) & 15) == 0) {
+            Vec16<bf16> v;
+            v.u = *reinterpret_cast<const uint4*>(src + i);
+            *reinterpret_cast<float4*>(dst + i) = float4{(float)v.e[0], (float)v.e[1], (float)v.e[2], (float)v.e[3]};
+            *reinterpret_cast<float4*>(dst + i + 4) = float4{(float)v.e[4], (float)v.e[5], (float)v.e[6], (float)v.e[7]};
+        } else {
+            for (long k = i; k < n && k < i + 8; ++k) dst[k] = (float)src[k];
+        }
+    }
+}
+
+extern "C" int lh_cast_f32_bf16(float* src, void* dst, long n, int to_f32, void* stream) {
+    LH_REQUIRE(src && dst && n > 0, "lh_cast_f32_bf16: bad arguments");
+    const long groups = (n + 7) / 8;
+    const int grid = (int)((groups + 255) / 256 > 8192 ? 8192 : (groups + 255) / 256);
+    if (to_f32) hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)dst, src, n);
+    else hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (bf16*)dst, n);
+    LH_LAUNCH_CHECK("cast_f32_bf16 launch");
+    return LH_OK;
+}

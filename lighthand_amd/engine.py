@@ -255,10 +255,10 @@ class Plan:
         self.profile_meta = []             # (list name, call object, kernel name, flops, bytes)
         self._tune_bufs = {}
         Plan._tune_cache_io()
-        n_tuned = len(Plan._TUNE_CACHE)
+        n_tuned = len(Plan._tune_measured)
         self._compile()
         self._tune_bufs = {}               # scratch operands of the autotuner are only needed while compiling
-        if len(Plan._TUNE_CACHE) != n_tuned:
+        if len(Plan._tune_measured) != n_tuned:
             Plan._tune_cache_io(save=True)
 
     # ------------------------------------------------------------------ helpers
@@ -339,34 +339,58 @@ class Plan:
     fuse_head = True             # test hook: False keeps the inference head as separate launches (A/B against _fuse_head)
     _tune_file_loaded = False
 
+    _tune_measured = set()      # keys measured by this process or read from the user's cache file (what a save writes)
+
+    @staticmethod
+    def _tune_cache_path():
+        """Where measured choices persist.  LH_TUNE_CACHE=<file> names it, LH_TUNE_CACHE=0 turns persistence off; default
+        ON at $XDG_CACHE_HOME/lighthand_amd/tune_gfx950.txt: the weight gradient's pixel-split count (fp32 summation
+        order) and the forward tile (number of BN partial-sum rows) are measured choices, so a restarted or resumed job
+        must start from the SAME choices to reproduce its sums bit for bit (timing noise may flip a near-tie)."""
+        path = os.environ.get("LH_TUNE_CACHE")
+        if path in ("0", "off", "none"):
+            return None
+        if not path:
+            base = os.environ.get("XDG_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache")
+            path = os.path.join(base, "lighthand_amd", "tune_gfx950.txt")
+        return path
+
     @classmethod
     def _tune_cache_io(cls, save=False):
-        """LH_TUNE_CACHE=<file>: measured choices persist across processes (a restarted job, or a profiling run that
-        should not contain the tuner's own launches, starts from the file; new measurements are written back)."""
+        """Measured choices persist across processes (a restarted job, or a profiling run that should not contain the
+        tuner's own launches, starts from the file; new measurements are written back).  Precedence: the user's file
+        (local measurements) over the shipped database; a save writes only what was measured locally."""
         import ast
-        if not save and not cls._tune_file_loaded:
-            # the shipped database: choices measured on MI355X for the benchmark configurations (tools/make_tune_db.sh);
-            # entries are validated against the compiled-in configurations when used, anything else is measured on the fly
-            db = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tune_db_gfx950.txt")
-            if os.path.isfile(db) and os.environ.get("LH_TUNE_DB", "1") != "0":
-                for line in open(db):
-                    if line.strip() and not line.startswith("#"):
-                        k, v = ast.literal_eval(line)
-                        cls._TUNE_CACHE.setdefault(k, tuple(v))
-        path = os.environ.get("LH_TUNE_CACHE")
-        if not path:
-            cls._tune_file_loaded = True
-            return
+        path = cls._tune_cache_path()
         if save:
-            tmp = path + ".tmp%d" % os.getpid()
-            with open(tmp, "w") as f:
-                for k, v in cls._TUNE_CACHE.items():
-                    f.write(repr((k, v)) + "\n")
-            os.replace(tmp, path)
-        elif not cls._tune_file_loaded:
-            cls._tune_file_loaded = True
-            if os.path.isfile(path):
-                for line in open(path):
+            if not path:
+                return
+            try:
+                os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+                tmp = path + ".tmp%d" % os.getpid()
+                with open(tmp, "w") as f:
+                    for k in cls._tune_measured:
+                        if k in cls._TUNE_CACHE:
+                            f.write(repr((k, cls._TUNE_CACHE[k])) + "\n")
+                os.replace(tmp, path)
+            except OSError:
+                pass                                  # read-only home: the choices still hold for this process
+            return
+        if cls._tune_file_loaded:
+            return
+        cls._tune_file_loaded = True
+        if path and os.path.isfile(path):
+            for line in open(path):
+                if line.strip():
+                    k, v = ast.literal_eval(line)
+                    cls._TUNE_CACHE[k] = tuple(v)
+                    cls._tune_measured.add(k)
+        # the shipped database: choices measured on MI355X for the benchmark configurations (tools/make_tune_db.sh);
+        # entries are validated against the compiled-in configurations when used, anything else is measured on the fly
+        db = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tune_db_gfx950.txt")
+        if os.path.isfile(db) and os.environ.get("LH_TUNE_DB", "1") != "0":
+            for line in open(db):
+                if line.strip() and not line.startswith("#"):
                     k, v = ast.literal_eval(line)
                     cls._TUNE_CACHE.setdefault(k, tuple(v))
 
@@ -503,6 +527,7 @@ class Plan:
                         best = (t, cfg)
                 hit = best[1]
             Plan._TUNE_CACHE[key] = hit
+            Plan._tune_measured.add(key)
         for d in descs:
             d.cfg[0], d.cfg[1], d.cfg[2], d.cfg[3] = hit
 
@@ -552,6 +577,7 @@ class Plan:
                         best = (t, (bo, bi, enc))
                 hit = best[1]
             Plan._TUNE_CACHE[key] = hit
+            Plan._tune_measured.add(key)
         d.cfg[5], d.cfg[6], d.cfg[7] = hit
 
     def _igemm(self, lst, d, src, pack, dst, addend, bias, stats, what, flops=0, produces=None, addend_mask=None):
@@ -932,7 +958,6 @@ class Plan:
         gw = self.grads[nd["w"] + ".weight"]
         pad_out = y.c != cout
         gtmp = self._alloc(y.c, cin, k, k, dtype=torch.float32) if pad_out else gw
-        n_out_r = y.c if pad_out else cout
 
         def tune_launch(xp, dyp, ws, grad, sp):
             check(self.lib.lh_wgrad_fused(C.byref(d), 0, xp, dyp, y.c, y.c, cin, ws, grad, cin * k * k, k * k, k, 1, rs_arr, 0, self.dt, sp),

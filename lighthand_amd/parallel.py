@@ -64,9 +64,15 @@ class LhComm:
         return t
 
     def close(self):
-        if self.handle:
+        if getattr(self, "handle", None):
             self.lib.lh_comm_destroy(self.handle)
             self.handle = None
+
+    def __del__(self):                       # the communicator owns RCCL resources: release them with the object
+        try:
+            self.close()
+        except Exception:                    # noqa: BLE001 -- interpreter shutdown: the library may be gone already
+            pass
 
 
 def all_reduce_sum_(t, group=None):
@@ -75,6 +81,25 @@ def all_reduce_sum_(t, group=None):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
+
+
+def plan_with_shared_tuning(build):
+    """Build a plan under torch.distributed so that EVERY rank runs the same measured kernel choices: rank 0 builds (and
+    measures) first, its choices travel to the other ranks, which then build without measuring.  The weight gradient's
+    pixel-split count and the forward tile fix fp32 summation orders, and a timing near-tie may fall differently per
+    process: with per-rank tuning the ranks' weights would drift apart bit by bit (and every rank would pay the tuning)."""
+    from .engine import Plan
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return build()
+    rank = dist.get_rank()
+    plan = build() if rank == 0 else None
+    box = [dict(Plan._TUNE_CACHE) if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    if rank != 0:
+        Plan._tune_cache_io()
+        Plan._TUNE_CACHE.update(box[0])
+        plan = build()
+    return plan
 
 
 def wgrad_group_cuts(layer_bytes, max_layers, bucket_bytes=None):
@@ -169,9 +194,12 @@ class GradSync:
                     half = self._staging.get(bucket)
                     if half is None:
                         half = self._staging[bucket] = torch.empty(stop - start, dtype=torch.bfloat16, device=view.device)
-                    half.copy_(view)
+                    # staging through the C ABI (lh_cast_f32_bf16): the data-parallel step holds no framework compute
+                    from . import _lib
+                    lib, sp = _lib.load(), self.stream.cuda_stream
+                    _lib.check(lib.lh_cast_f32_bf16(view.data_ptr(), half.data_ptr(), stop - start, 0, sp), "lh_cast_f32_bf16")
                     reduce_(half)
-                    view.copy_(half)
+                    _lib.check(lib.lh_cast_f32_bf16(view.data_ptr(), half.data_ptr(), stop - start, 1, sp), "lh_cast_f32_bf16")
                 else:
                     reduce_(view)
                 done = torch.cuda.Event()
@@ -183,6 +211,11 @@ class GradSync:
             view.copy_(half)
         else:
             self._pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def close(self):
+        """Release the C-ABI communicator, if this object drives one (TrainStep.close / interpreter exit)."""
+        if self.comm is not None:
+            self.comm.close()
 
     def wait_all(self):
         for p in self._pending:

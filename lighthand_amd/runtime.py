@@ -43,8 +43,12 @@ class TrainStep:
         self.model = model
         self._model_generation = getattr(model, "_lh_generation", 0)
         model.train()
-        self.plan = model.plan(batch, height, width, training=True, backward=True,
-                               wgrad_bucket_bytes=grad_sync.bucket_bytes if grad_sync is not None else None)
+        if grad_sync is not None:               # data parallel: one set of measured kernel choices for all ranks
+            from . import parallel
+            self.plan = parallel.plan_with_shared_tuning(
+                lambda: model.plan(batch, height, width, training=True, backward=True, wgrad_bucket_bytes=grad_sync.bucket_bytes))
+        else:
+            self.plan = model.plan(batch, height, width, training=True, backward=True)
         self.arena = model.arena()
         dev = self.arena.device
         out = self.plan.out_nchw
@@ -164,6 +168,11 @@ class TrainStep:
                 st[k].copy_(moments[k]) if moments is not None else st[k].zero_()
         for gi, d in self.optimizer._dev.items():
             d["step"].copy_(steps[gi]) if gi in steps else d["step"].zero_()
+
+    def close(self):
+        """Release what the step owns outside PyTorch (the C-ABI communicator of a data-parallel step)."""
+        if self.grad_sync is not None:
+            self.grad_sync.close()
 
     def sync_hyper(self):
         """Push lr / betas / eps changes (e.g. CosineAnnealingLR.step()) to the device-side Adam state."""

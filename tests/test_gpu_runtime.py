@@ -430,28 +430,30 @@ def test_eval_tail_batch_runs_unpadded(tmp_path):
     assert agree / total >= 0.99
 
 
-def _dp_rank(rank, world, port, compress, q):
-    """One data-parallel rank (spawned fresh: the parent's GPU context is never re-used or re-exec'ed)."""
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
-                      LH_DIST_BACKEND="gloo", LH_AUTOTUNE="0")
+def _dp_rank(rank, world, port, compress, q, own_gpu=False, lh_comm=False):
+    """One data-parallel rank (spawned fresh: the parent's GPU context is never re-used or re-exec'ed).  own_gpu: one GPU
+    per rank and RCCL (multi-GPU nodes); otherwise both ranks share GPU 0 and the collective goes through gloo."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank) if own_gpu else "0", LH_DIST_BACKEND="nccl" if own_gpu else "gloo")
     import torch.distributed as dist
     from lighthand_amd import parallel
     from lighthand_amd.runtime import TrainStep
     parallel.init_distributed()
     m = _model(18)
     x, j = _batch(4, 64, 11 + rank)
-    sync = parallel.GradSync(world, bucket_bytes=2 << 20, compress=compress)
+    sync = parallel.GradSync(world, bucket_bytes=2 << 20, compress=compress, comm=parallel.LhComm() if lh_comm else None)
     step = TrainStep(m, 4, 64, 64, lr=1e-3, use_graph=True, grad_sync=sync)
     losses = [float(step(x, j)) for _ in range(2)]
     torch.cuda.synchronize()
     segs = sync.segments(step.plan)
     q.put((rank, m.arena().flat.cpu().numpy(), losses, len(segs), [b for _, _, b in segs]))   # by value: the rank may exit first
     dist.barrier()
+    step.close()
     dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("compress", [None, "bf16"])
-def test_two_process_data_parallel_step_with_real_collective(compress, monkeypatch):
+def test_two_process_data_parallel_step_with_real_collective(compress, monkeypatch, tmp_path):
     """The per-segment hipGraph path with a REAL collective between two processes (gloo through the host, both ranks on
     this GPU; on a multi-GPU node the same code runs over RCCL): after two steps both ranks hold identical weights,
     equal to the single-process emulation -- two micro-batches with their own BatchNorm statistics, gradients averaged,
@@ -460,10 +462,13 @@ def test_two_process_data_parallel_step_with_real_collective(compress, monkeypat
     import torch.multiprocessing as mp
     from lighthand_amd.heatmap import JointsMSELoss, render_targets
     from lighthand_amd.optim import Adam
-    # static kernel configurations in the ranks AND in the emulation: a measured choice may differ between processes
-    # (timing noise), a different split count reorders the fp32 sums of a weight gradient, and Adam's first steps turn a
-    # last-bit difference of a near-zero gradient into +-lr
-    monkeypatch.setenv("LH_AUTOTUNE", "0")
+    # MEASURED kernel configurations, identical everywhere: rank 0 tunes and broadcasts its choices to rank 1
+    # (parallel.plan_with_shared_tuning) and persists them (LH_TUNE_CACHE, default on); the emulation below -- another
+    # process, as a resumed job would be -- starts from that file.  (Per-process tuning could pick different pixel-split
+    # counts on a timing near-tie: a different fp32 summation order, which Adam's first steps amplify to +-lr.)
+    from lighthand_amd.engine import Plan
+    monkeypatch.setenv("LH_TUNE_CACHE", str(tmp_path / "tune.txt"))
+    monkeypatch.setenv("LH_TUNE_DB", "0")
     sock = socket.socket()
     sock.bind(("127.0.0.1", 0))
     port = sock.getsockname()[1]
@@ -482,6 +487,8 @@ def test_two_process_data_parallel_step_with_real_collective(compress, monkeypat
         assert p.exitcode == 0
     assert torch.equal(res[0][1], res[1][1]), "ranks diverged"
     assert res[0][3] >= 2 and res[0][4] == res[1][4]                 # several segments, same buckets on both ranks
+    assert os.path.getsize(str(tmp_path / "tune.txt")) > 0           # rank 0 measured and persisted its choices
+    monkeypatch.setattr(Plan, "_tune_file_loaded", False)            # this process now starts from rank 0's file
     # single-process emulation of the two ranks
     crit = JointsMSELoss(False)
     m = _model(18)
@@ -522,6 +529,54 @@ def test_two_process_data_parallel_step_with_real_collective(compress, monkeypat
         # nearly cancel the sign of the sum can flip, and Adam's first steps move such an element by +-lr either way
         print("bf16 buckets: max |dw|", float(diff.max()), "share of elements off by > 1e-4:", float((diff > 1e-4).float().mean()))
         assert float(diff.max()) <= 2 * 2 * 1e-3 * 1.05 and float((diff > 1e-4).float().mean()) < 0.02
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL with two ranks)")
+def test_lh_comm_two_gpus_single_graph_matches_torch_transport(monkeypatch, tmp_path):
+    """Two ranks on two GPUs: the C-ABI communicator (lh_comm_*: RCCL launches inside ONE captured graph per step) and
+    the default transport (torch.distributed all-reduce between per-segment graphs) give bit-identical weights, equal
+    across ranks.  Skipped on one-GPU boxes; `bench.py --gpus N --comm lh` stays experimental until this has run."""
+    import socket
+    import torch.multiprocessing as mp
+    monkeypatch.setenv("LH_TUNE_CACHE", str(tmp_path / "tune.txt"))
+    out = {}
+    for lh in (False, True):
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_dp_rank, args=(r, 2, port, None, q, True, lh)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res = {}
+        for _ in procs:
+            r = q.get(timeout=300)
+            res[r[0]] = torch.from_numpy(r[1])
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+        assert torch.equal(res[0], res[1]), "ranks diverged"
+        out[lh] = res[0]
+    assert torch.equal(out[False], out[True])
+
+
+def test_bf16_bucket_staging_c_abi():
+    """lh_cast_f32_bf16 (the staging of GradSync(compress='bf16')): round-to-nearest-even like the framework's cast,
+    NaN / inf preserved, any length and alignment; and back."""
+    from lighthand_amd import _lib
+    lib = _lib.load()
+    s = torch.cuda.current_stream().cuda_stream
+    for n, off in ((1 << 20, 0), (1003, 1), (7, 3)):
+        src = torch.randn(n + 8, device="cuda")[off:off + n]
+        src[:3] = torch.tensor([float("nan"), float("inf"), -float("inf")], device="cuda")[:min(3, n)]
+        half = torch.empty(n + 8, dtype=torch.bfloat16, device="cuda")[off:off + n]
+        _lib.check(lib.lh_cast_f32_bf16(src.data_ptr(), half.data_ptr(), n, 0, s))
+        assert torch.equal(half.view(torch.int16), src.to(torch.bfloat16).view(torch.int16))
+        back = torch.zeros_like(src)
+        _lib.check(lib.lh_cast_f32_bf16(back.data_ptr(), half.data_ptr(), n, 1, s))
+        assert torch.equal(back.view(torch.int32), half.float().view(torch.int32))
 
 
 def test_lh_comm_c_abi_single_rank():
