@@ -88,8 +88,11 @@ def synthetic_batch(batch, size, device, seed=9001):
 
 
 def profile_kernels(step, iters=3, plan=None, fwd_only=False):
-    """Per-launch HIP-event timing of every conv-family launch of the (eager) step, on the stream the
-    kernels are launched on.  Returns {kernel name: dict(ms, launches, flops, bytes)} per step."""
+    """Per-launch HIP-event timing of every conv-family launch of the (eager) step, on the stream the kernels are
+    launched on.  An event pair around ONE launch also times the two event packets and the launch gap: that overhead is
+    measured in the same pass (empty pairs interleaved with the real ones, median) and subtracted, so that the
+    per-kernel averages agree with the durations `rocprofv3 --kernel-trace --stats` reports for the same command.
+    Returns {kernel name: dict(ms, launches, flops, bytes)} per step."""
     plan = plan or step.plan
     meta = {}
     for which, call, name, flops, nbytes in plan.profile_meta:
@@ -98,7 +101,7 @@ def profile_kernels(step, iters=3, plan=None, fwd_only=False):
     stream = torch.cuda.current_stream()
     s = stream.cuda_stream
     for it in range(iters + 1):
-        evs = []
+        evs, empty = [], []
         plan.refresh_packs(s)
         for which, lst in (("fwd", plan.fwd),) if fwd_only else (("fwd", plan.fwd), ("bwd", plan.bwd)):
             if which == "bwd":
@@ -108,63 +111,64 @@ def profile_kernels(step, iters=3, plan=None, fwd_only=False):
                 if m is None:
                     call(s)
                     continue
+                parts = _split_wgrad(plan.lib, call) if getattr(call, "fn", None) is plan.lib.lh_wgrad_fused else None
+                if parts:                                        # weight gradient and its split-K fold are two kernels: time them apart
+                    for fn_, mm in zip(parts, (m, ("wgrad_reduce(kernels)", 0.0, 0.0))):
+                        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        a.record(stream)
+                        fn_(s)
+                        b.record(stream)
+                        evs.append((mm, a, b))
+                    continue
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record(stream)
                 call(s)
                 b.record(stream)
                 evs.append((m, a, b))
+                if len(evs) % 8 == 0:
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record(stream)
+                    b.record(stream)
+                    empty.append((a, b))
         torch.cuda.synchronize()
         if it == 0:
             continue                                             # first pass = warm-up
+        gap = float(np.median([a.elapsed_time(b) for a, b in empty])) if empty else 0.0
         for (name, flops, nbytes), a, b in evs:
-            d = agg.setdefault(name, dict(ms=0.0, launches=0, flops=0.0, bytes=0.0))
-            d["ms"] += a.elapsed_time(b)
+            d = agg.setdefault(name, dict(ms=0.0, launches=0, flops=0.0, bytes=0.0, gap_ms=0.0))
+            d["ms"] += max(a.elapsed_time(b) - gap, 0.0)
+            d["gap_ms"] += gap
             d["launches"] += 1
             d["flops"] += flops
             d["bytes"] += nbytes
     for d in agg.values():
-        for k in ("ms", "flops", "bytes"):
+        for k in ("ms", "flops", "bytes", "gap_ms"):
             d[k] /= iters
         d["launches"] //= iters
     return agg
 
 
-def cpu_baseline(depth, size, batch, seconds_budget=25.0, cores=None):
-    """The oracle (plain PyTorch fp32 on the host cores) running the same training step on a
-    bounded sample of the workload."""
-    from oracle import heatmap as oh
-    from oracle import models as omod
-    import types
-    from lighthand_amd.modeling.simplebaseline.pose_resnet import get_pose_net
-    ns = types.SimpleNamespace
-    extra = ns(NUM_LAYERS=depth, DECONV_WITH_BIAS=False, NUM_DECONV_LAYERS=3, NUM_DECONV_FILTERS=[256] * 3,
-               NUM_DECONV_KERNELS=[4] * 3, FINAL_CONV_KERNEL=1)
-    torch.manual_seed(9001)
-    sd = omod.clone_state(get_pose_net(ns(MODEL=ns(EXTRA=extra, STYLE="pytorch")), True).state_dict())
-    cores = cores or min(16, len(os.sched_getaffinity(0)))   # the GPU box gives one GPU a 16-core CPU share
-    torch.set_num_threads(cores)
-    rng = np.random.RandomState(9001)
-    x = torch.from_numpy(rng.randn(batch, 3, size, size).astype(np.float32))
-    joints = rng.uniform(20, size - 20, size=(batch, 21, 2)).astype(np.float32)
-    adam = omod.AdamState(lr=1e-3)
-    fwd = lambda s, xx: omod.pose_resnet_forward(s, xx, depth, "pytorch", training=True)
+def _split_wgrad(lib, call):
+    """lh_wgrad_fused = the weight-gradient kernel, then the fold of its pixel-split slabs: the same two launches through
+    their own entry points (lh_wgrad / lh_wgrad_rowfold, lh_wgrad_reduce), so that each can be timed by itself."""
+    from lighthand_amd._lib import check
+    d, rows, x, dy, dys, n_out, n_in, ws, grad, so, si, sr, ss, taps, acc, dt = call.args
+    if rows > 1:
+        first = lambda st: check(lib.lh_wgrad_rowfold(d, rows, x, dy, dys, n_out, ws, dt, st), "lh_wgrad_rowfold")
+    else:
+        first = lambda st: check(lib.lh_wgrad(d, x, dy, dys, n_out, n_in, ws, dt, st), "lh_wgrad")
+    return first, (lambda st: check(lib.lh_wgrad_reduce(d, ws, grad, n_out, n_in, so, si, sr, ss, taps, acc, dt, st), "lh_wgrad_reduce"))
 
-    def one():
-        tgt = torch.from_numpy(np.stack([oh.generate_target(j) for j in joints]))[:, :, :size // 4, :size // 4]
-        loss, pred, grads = omod.loss_and_grads(sd, fwd, x, tgt)
-        oh.get_max_preds(pred.numpy())
-        adam.step(sd, grads)
 
-    one()                                                       # warm-up
-    t0, n = time.time(), 0
-    while True:
-        one()
-        n += 1
-        if time.time() - t0 > seconds_budget * 0.6 or n >= (3 if batch >= 16 else 10):
-            break
-    dt = (time.time() - t0) / n
-    return dict(value=round(batch / dt, 2), unit="images/s", cores=cores, kind="port",
-                sample=f"oracle (plain PyTorch fp32 CPU) R{depth} {size}x{size} train step, batch {batch}, {n} timed step(s) of {dt:.2f} s")
+def kernel_roofline(flops, nbytes, ms, es=2):
+    """a launch's lower bounds on both roofs, the governing one, and the measured time against them."""
+    peak_tf = PEAK_BF16_TFLOPS if es == 2 else 157.3
+    t_mfma, t_hbm = flops / (peak_tf * 1e12) * 1e3, nbytes / (PEAK_HBM_GBS * 1e9) * 1e3
+    hbm = t_hbm >= t_mfma
+    ach = (nbytes / (ms * 1e-3) / 1e9) if hbm else (flops / (ms * 1e-3) / 1e12)
+    return {"bound": "hbm" if hbm else "mfma", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS if hbm else peak_tf,
+            "unit": "GB/s" if hbm else "TFLOP/s", "frac": round(max(t_mfma, t_hbm) / ms, 4),
+            "mfma_frac": round(t_mfma / ms, 4), "hbm_frac": round(t_hbm / ms, 4)}
 
 
 def main():
@@ -303,36 +307,40 @@ def main():
                     for f in ("ms", "flops", "bytes"):
                         m[f] += v[f] * n
                     m["launches"] += v["launches"] * n
-            # dominant SINGLE kernel (entries that aggregate several kernels of one C-ABI call are listed
-            # in the breakdown but cannot be matched to one rocprof row)
+            # dominant SINGLE kernel (entries that aggregate several kernels of one C-ABI call are reported as a FAMILY below:
+            # they cannot be matched to one rocprof row)
             name, _ = max(((k, v) for k, v in agg.items() if "(all kernels)" not in k), key=lambda kv: kv[1]["ms"])
             d = mix[name]
             tot = sum(v["ms"] for v in mix.values())
             avg_ms = d["ms"] / d["launches"]
-            flops_per_launch = d["flops"] / d["launches"]
-            if flops_per_launch > 0:
-                ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
-                out["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS if args.precision != "fp32" else 157.3,
-                                   "unit": "TFLOP/s", "frac": round(ach / (PEAK_BF16_TFLOPS if args.precision != "fp32" else 157.3), 4), "traffic": None}
-            else:
-                ach = d["bytes"] / d["launches"] / (avg_ms * 1e-3) / 1e9
-                out["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                   "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None}
+            es_ = 2 if args.precision != "fp32" else 4
+            # governing roof per launch = max(T_mfma, T_hbm) of its algorithmic FLOPs and bytes; both fractions reported
+            out["roofline"] = kernel_roofline(d["flops"] / d["launches"], d["bytes"] / d["launches"], avg_ms, es_)
+            out["roofline"]["traffic"] = None
             # HBM bytes per launch of that kernel from the committed PMC passes of this same command
             # (profiles/README.md; tools/pmc_traffic.py applies the guide's KiB unit and gfx950 FETCH_SIZE x2 correction)
             try:
-                pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")))
+                pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_traffic.json")))
                 if name in pmc and args.depth == 50 and args.batch == 64 and args.size == 256 and args.precision == "bf16":
                     out["roofline"]["traffic"] = pmc[name]["read_bytes_per_launch"] + pmc[name]["write_bytes_per_launch"]
                     out["roofline"]["traffic_note"] = ("bytes per launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, corrected per the "
-                                                       "MI355X guide), profiles/r02_pmc_hbm_traffic.txt; algorithmic bytes per launch = "
-                                                       f"{int(d['bytes'] / d['launches'])}")
+                                                       "MI355X guide), profiles/r03_pmc_hbm_traffic.txt")
             except (OSError, ValueError, KeyError):
                 pass
             out["roofline"].update({"kernel": name, "launches_per_train_step": agg[name]["launches"], "avg_launch_ms": round(avg_ms, 4),
+                                    "flops_per_launch": int(d["flops"] / d["launches"]), "algorithmic_bytes_per_launch": int(d["bytes"] / d["launches"]),
                                     "share_of_profiled_ms": round(d["ms"] / tot, 3),
-                                    "note": "average over every launch of this kernel in the process (train-step and inference-graph "
-                                            "launches, weighted by how often each ran), comparable with rocprofv3 --stats"})
+                                    "note": "average over every launch of this kernel in the process (train-step and inference-graph launches, "
+                                            "weighted by how often each ran), HIP events on the launch stream minus the measured empty-pair "
+                                            "overhead: comparable with the AverageNs of rocprofv3 --kernel-trace --stats (profiles/r03_bench_kernel_stats.csv)"})
+            # the largest FAMILY of the step: the BatchNorm / ReLU backward (reduce + coefficient fold + apply kernels per call)
+            fam = agg.get("fuse_bwd(all kernels)")
+            if fam and fam["ms"] > 0:
+                fr = kernel_roofline(0.0, fam["bytes"], fam["ms"], es_)
+                fr.update({"family": "fuse_bwd (fuse_bwd_reduce* + fuse_bwd_coef_fused + fuse_bwd_apply*)", "calls_per_train_step": fam["launches"],
+                           "ms_per_train_step": round(fam["ms"], 3), "algorithmic_bytes_per_step": int(fam["bytes"]),
+                           "share_of_profiled_ms": round(fam["ms"] / sum(v["ms"] for v in agg.values()), 3)})
+                out["roofline_family"] = fr
             out["kernel_breakdown_ms"] = {k: [round(v["ms"], 3), v["launches"],
                                               round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] else None]
                                           for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}

@@ -138,7 +138,9 @@ typedef struct {
     signed char dh[64];
     signed char dw[64];
     /* Kernel configuration chosen by the caller (all zero = the library's static default).  cfg[0..4] = convolution
-     * kernel: tile output channels, tile pixels, ring depth, K bytes per ring stage, reserved (0)
+     * kernel: tile output channels, tile pixels, ring depth, K bytes per ring stage, reserved (0); ring depth 1 selects
+     * the persistent pointwise kernel (1x1, dense output, K <= 512, 16-bit types): channels of the resident weight
+     * panel, pixels a wave takes per step, 1, padded K of the panel
      * -- one of lh_igemm_candidates().  cfg[5..7] = weight-gradient kernel (lh_wgrad*): tile output channels, tile
      * input channels, pixel splits -- one of lh_wgrad_candidates().  Results do not depend on cfg[0..4]; the
      * weight gradient's fp32 summation order depends on the split count (deterministic for a given cfg). */

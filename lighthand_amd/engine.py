@@ -1205,7 +1205,7 @@ class Plan:
             relu_bits = self._alloc(out.pixels * c // (16 // self.es), dtype=torch.uint8)
             fd.relu_mask = relu_bits.data_ptr()
         self.fwd.append(_Call(self.lib.lh_fuse_fwd, (C.byref(fd), obuf.data_ptr(), out.n, out.h, out.w, c, self.dt), "fuse fwd"))
-        self.profile_meta.append(("fwd", self.fwd[-1], "fuse_fwd_kernel", 0.0, (sum(a.pixels for a, _, _ in terms) + out.pixels) * c * self.es))
+        self.profile_meta.append(("fwd", self.fwd[-1], "fuse_fwd(all kernels)", 0.0, (sum(a.pixels for a, _, _ in terms) + out.pixels) * c * self.es))
         if not self.with_bwd:
             return
         self._ws_fuse = max(self._ws_fuse, self.lib.lh_fuse_bwd_workspace_bytes(out.n, out.h, out.w, c))
@@ -1243,7 +1243,12 @@ class Plan:
                 call.args = tuple(args)
             self._ws_users_fuse.append((set_ws, self._cur_lane))
             self.bwd.append(call)
-            self.profile_meta.append(("bwd", self.bwd[-1], "fuse_bwd(all kernels)", 0.0, 0.0))
+            # algorithmic bytes of the BN / ReLU backward of this node: the reduce pass reads dout and every BN term's x, the
+            # apply pass reads them again and writes one gradient per term that takes one (5 tensor passes per BN)
+            n_bn = sum(1 for _, bn, _ in terms if bn is not None)
+            n_dx = sum(1 for i in range(len(terms)) if bd.dx[i])
+            passes = (2 * (1 + n_bn) if n_bn else 1) + n_dx
+            self.profile_meta.append(("bwd", self.bwd[-1], "fuse_bwd(all kernels)", 0.0, float(passes) * out.pixels * c * self.es))
         blk.append(emit)
 
     def _next_writer_is_conv(self, a, nd):

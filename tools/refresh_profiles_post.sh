@@ -3,10 +3,17 @@
 set -e
 cd "$(dirname "$0")/.."
 O=gpurun_out/refresh
-cp $O/bench.json profiles/r02_bench.json
-cp "$(find $O/stats -name '*kernel_stats.csv' | head -1)" profiles/r02_bench_kernel_stats.csv
-cp $O/layers.txt profiles/r02_layers.txt
+R=${LH_ROUND:-r03}
+cp $O/bench.json profiles/${R}_bench.json
+cp "$(find $O/stats -name '*kernel_stats.csv' | head -1)" profiles/${R}_bench_kernel_stats.csv
+cp $O/layers.txt profiles/${R}_layers.txt
 python tools/pmc_traffic.py "$(find $O/pmc_fetch -name '*counter_collection.csv' | head -1)" \
-    "$(find $O/pmc_write -name '*counter_collection.csv' | head -1)" profiles/r02_pmc_hbm_traffic.txt profiles/r02_pmc_traffic.json
-python tools/pmc_mfma.py "$(find $O/pmc_mfma -name '*counter_collection.csv' | head -1)" profiles/r02_pmc_mfma.txt > /dev/null
+    "$(find $O/pmc_write -name '*counter_collection.csv' | head -1)" profiles/${R}_pmc_hbm_traffic.txt profiles/${R}_pmc_traffic.json
+python tools/pmc_mfma_step.py "$(find $O/pmc_mfma -name '*counter_collection.csv' | head -1)" profiles/${R}_pmc_mfma_step.txt > /dev/null
+cp "$(find $O/stats_hrnet -name '*kernel_stats.csv' | head -1)" profiles/${R}_hrnet_w32_bs32_kernel_stats.csv
+cp $O/layers_hrnet.txt profiles/${R}_hrnet_w32_bs32_layers.txt
+cp "$(find $O/stats_c5 -name '*kernel_stats.csv' | head -1)" profiles/${R}_c5_infer384_kernel_stats.csv
+cp $O/layers_c5.txt profiles/${R}_c5_infer384_layers.txt
+python tools/pmc_traffic.py "$(find $O/pmc_fetch_c5 -name '*counter_collection.csv' | head -1)" \
+    "$(find $O/pmc_write_c5 -name '*counter_collection.csv' | head -1)" profiles/${R}_c5_pmc_hbm_traffic.txt /tmp/c5_traffic.json
 ls -la profiles/
