@@ -206,6 +206,14 @@ int lh_wgrad_tile(const lh_igemm_desc* d, int n_out, int n_in, int dtype, int* b
  * the first three into lh_igemm_desc.cfg[5..7] selects the plan for lh_wgrad / lh_wgrad_slab_bytes / lh_wgrad_reduce
  * (0 when only the register-staged kernel applies: fp32, unaligned pixel rows). */
 int lh_wgrad_candidates(const lh_igemm_desc* d, int n_out, int n_in, int dtype, int* out, int max);
+/* n independent lh_igemm launches (one entry = the arguments of lh_igemm) as ONE grid: every descriptor's cfg must name the
+ * same TILED configuration (ring depth >= 2, a 4-wave tile, 16-bit types); the same layer position of HRNet's parallel
+ * branches (pose_hrnet.py:139-185).  Statistics slabs, addends, epilogue vectors are per problem. */
+typedef struct {
+    const lh_igemm_desc* d; const void* in; const void* wpack; void* out; const void* addend; const void* addend_mask;
+    const float* bias; const float* scale; const float* shift; float* stats;
+} lh_igemm_call;
+int lh_igemm_multi(const lh_igemm_call* calls, int n, int dtype, void* stream);
 /* rows of the stats slab lh_igemm writes for this descriptor (= number of pixel tiles) */
 int lh_igemm_stats_rows(const lh_igemm_desc* d, int dtype);
 
@@ -225,6 +233,13 @@ int lh_wgrad_reduce(const lh_igemm_desc* d, const float* slab, float* grad, int 
  * (lh_wgrad_workspace_bytes, device; launches that run one after another on a stream may share it), then lh_wgrad_reduce
  * into `grad`. */
 size_t lh_wgrad_workspace_bytes(const lh_igemm_desc* d, int n_out, int n_in, int dtype);
+/* n independent lh_wgrad_fused calls (one entry = its arguments; every problem needs its OWN workspace) as one weight-gradient
+ * launch + one fold launch where tile / stage / ring depth agree (cfg[5..7]; 4-wave tiles), one by one otherwise. */
+typedef struct {
+    const lh_igemm_desc* d; int rows; const void* x; const void* dy; int dy_pix_stride, n_out, n_in; void* workspace; float* grad;
+    long so, si, sr, ss; const int* taps_rs; int accumulate;
+} lh_wgrad_call;
+int lh_wgrad_fused_multi(const lh_wgrad_call* calls, int n, int dtype, void* stream);
 int lh_wgrad_fused(const lh_igemm_desc* d, int rows, const void* x, const void* dy, int dy_pix_stride, int n_out, int n_in,
                    void* workspace, float* grad, long so, long si, long sr, long ss, const int* taps_rs, int accumulate,
                    int dtype, void* stream);
@@ -245,6 +260,12 @@ int lh_bn_finalize(const float* stats, int rows, int count, int c, const float* 
                    const float* beta, float* running_mean, float* running_var,
                    long long* num_batches_tracked, float momentum, float eps, float* scale,
                    float* shift, float* save_mean, float* save_invstd, void* stream);
+/* n independent BatchNorm layers (one entry = the arguments of lh_bn_finalize) as one launch; see lh_fuse_fwd_multi. */
+typedef struct {
+    const float* stats; int rows, count, c; const float* gamma; const float* beta; float* running_mean; float* running_var;
+    long long* num_batches_tracked; float momentum, eps; float* scale; float* shift; float* save_mean; float* save_invstd;
+} lh_bn_finalize_call;
+int lh_bn_finalize_multi(const lh_bn_finalize_call* calls, int n, void* stream);
 /* Eval mode: scale/shift from running statistics. */
 int lh_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
                       const float* running_var, float eps, int c, float* scale, float* shift,
@@ -263,6 +284,12 @@ typedef struct {
                                  * backward pass read n*h*w*c/8 mask bytes instead of the whole stored activation */
 } lh_fuse_desc;
 int lh_fuse_fwd(const lh_fuse_desc* d, void* out, int n, int h, int w, int c, int dtype, void* stream);
+/* Multi-problem forms (pose_hrnet.py:139-185, 247-265: the same layer position of the 2-4 parallel branches of a
+ * HighResolutionModule): n INDEPENDENT calls -- one entry = the arguments of the single call -- run as one launch per
+ * kernel instead of n (the argument blocks travel in the kernel-argument segment, four problems per launch).  Calls
+ * that do not plan the same kernels (e.g. an upsampled term beside plain ones) run one by one: always legal, same results. */
+typedef struct { const lh_fuse_desc* d; void* out; int n, h, w, c; } lh_fuse_fwd_call;
+int lh_fuse_fwd_multi(const lh_fuse_fwd_call* calls, int n, int dtype, void* stream);
 
 /* Backward of lh_fuse_fwd, two launches per BN term:
  *  reduce: sums[t] = { sum g_t, sum g_t * xhat_t } with g = dout * (out > 0), g_t = g summed over
@@ -289,6 +316,9 @@ typedef struct {
 size_t lh_fuse_bwd_workspace_bytes(int n, int h, int w, int c);
 int lh_fuse_bwd(const lh_fuse_bwd_desc* d, int n, int h, int w, int c, void* workspace,
                 int dtype, void* stream);
+/* n independent nodes, each with its OWN workspace: their reduce / coefficient-fold / apply kernels as three launches. */
+typedef struct { const lh_fuse_bwd_desc* d; int n, h, w, c; void* workspace; } lh_fuse_bwd_call;
+int lh_fuse_bwd_multi(const lh_fuse_bwd_call* calls, int n, int dtype, void* stream);
 
 /* nn.MaxPool2d(3, 2, 1): pose_resnet.py:156.  idx (uint8 [n][ho][wo][c]) keeps the window
  * position (first maximum in scan order, NaN propagates) for the backward pass. */

@@ -37,6 +37,31 @@ class FuseBwdDesc(C.Structure):
                 ("relu_mask", C.c_void_p)]
 
 
+class IgemmCall(C.Structure):          # one entry of lh_igemm_multi = the arguments of lh_igemm
+    _fields_ = [("d", C.POINTER(IgemmDesc)), ("in_", C.c_void_p), ("wpack", C.c_void_p), ("out", C.c_void_p), ("addend", C.c_void_p),
+                ("addend_mask", C.c_void_p), ("bias", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p), ("stats", C.c_void_p)]
+
+
+class WgradCall(C.Structure):          # lh_wgrad_fused_multi
+    _fields_ = [("d", C.POINTER(IgemmDesc)), ("rows", C.c_int), ("x", C.c_void_p), ("dy", C.c_void_p), ("dy_pix_stride", C.c_int),
+                ("n_out", C.c_int), ("n_in", C.c_int), ("workspace", C.c_void_p), ("grad", C.c_void_p), ("so", C.c_long), ("si", C.c_long),
+                ("sr", C.c_long), ("ss", C.c_long), ("taps_rs", C.POINTER(C.c_int)), ("accumulate", C.c_int)]
+
+
+class FuseFwdCall(C.Structure):        # lh_fuse_fwd_multi
+    _fields_ = [("d", C.POINTER(FuseDesc)), ("out", C.c_void_p), ("n", C.c_int), ("h", C.c_int), ("w", C.c_int), ("c", C.c_int)]
+
+
+class FuseBwdCall(C.Structure):        # lh_fuse_bwd_multi
+    _fields_ = [("d", C.POINTER(FuseBwdDesc)), ("n", C.c_int), ("h", C.c_int), ("w", C.c_int), ("c", C.c_int), ("workspace", C.c_void_p)]
+
+
+class BnFinalizeCall(C.Structure):     # lh_bn_finalize_multi
+    _fields_ = [("stats", C.c_void_p), ("rows", C.c_int), ("count", C.c_int), ("c", C.c_int), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+                ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("num_batches_tracked", C.c_void_p), ("momentum", C.c_float),
+                ("eps", C.c_float), ("scale", C.c_void_p), ("shift", C.c_void_p), ("save_mean", C.c_void_p), ("save_invstd", C.c_void_p)]
+
+
 class Head(C.Structure):
     _fields_ = [("w", C.c_void_p), ("w_row_bytes", C.c_size_t), ("bias", C.c_void_p), ("out", C.c_void_p), ("n_out", C.c_int)]
 
@@ -75,6 +100,7 @@ SIGNATURES = {
     "lh_pack_weights_multi": (_I, [_P, _P, _P, _I, _I, _P]),
     "lh_pack_weights_tiled": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "lh_igemm": (_I, [C.POINTER(IgemmDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "lh_igemm_multi": (_I, [C.POINTER(IgemmCall), _I, _I, _P]),
     "lh_igemm_phases_rows": (_I, [C.POINTER(C.POINTER(IgemmDesc)), _I, _I]),
     "lh_igemm_phases": (_I, [C.POINTER(C.POINTER(IgemmDesc)), _I, _P, C.POINTER(C.c_void_p), _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "lh_igemm_phases_head": (_I, [C.POINTER(C.POINTER(IgemmDesc)), _I, _P, C.POINTER(C.c_void_p), _P, _P, C.POINTER(Head), _I, _P]),
@@ -89,13 +115,17 @@ SIGNATURES = {
     "lh_wgrad_rowfold": (_I, [C.POINTER(IgemmDesc), _I, _P, _P, _I, _I, _P, _I, _P]),
     "lh_wgrad_workspace_bytes": (_SZ, [C.POINTER(IgemmDesc), _I, _I, _I]),
     "lh_wgrad_fused": (_I, [C.POINTER(IgemmDesc), _I, _P, _P, _I, _I, _I, _P, _P, _L, _L, _L, _L, C.POINTER(_I), _I, _I, _P]),
+    "lh_wgrad_fused_multi": (_I, [C.POINTER(WgradCall), _I, _I, _P]),
     "lh_wgrad_reduce": (_I, [C.POINTER(IgemmDesc), _P, _P, _I, _I, _L, _L, _L, _L, C.POINTER(_I), _I, _I, _P]),
     "lh_bn_stats": (_I, [_P, _I, _I, _P, C.POINTER(_I), _I, _P]),
     "lh_bn_stats_rows": (_I, [_I, _I]),
     "lh_bn_stats_slab_bytes": (_SZ, [_I, _I]),
     "lh_bn_finalize": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
+    "lh_bn_finalize_multi": (_I, [C.POINTER(BnFinalizeCall), _I, _P]),
     "lh_bn_eval_affine": (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),
     "lh_fuse_fwd": (_I, [C.POINTER(FuseDesc), _P, _I, _I, _I, _I, _I, _P]),
+    "lh_fuse_fwd_multi": (_I, [C.POINTER(FuseFwdCall), _I, _I, _P]),
+    "lh_fuse_bwd_multi": (_I, [C.POINTER(FuseBwdCall), _I, _I, _P]),
     "lh_fuse_bwd_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
     "lh_fuse_bwd": (_I, [C.POINTER(FuseBwdDesc), _I, _I, _I, _I, _P, _I, _P]),
     "lh_maxpool3x3s2_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -2,6 +2,8 @@
 // elementwise op with its backward, and the 3x3/s2 max-pool -- all HBM-bound NHWC kernels:
 // one 16-byte chunk (8 x 16-bit or 4 x fp32 channels) per lane, per-channel vectors in fp32.
 #include "common.h"
+#include "multi.h"
+#include <vector>
 #include <stdlib.h>
 
 // ------------------------------------------------------------------------------------------------
@@ -30,9 +32,9 @@ __global__ __launch_bounds__(256) void colsum_kernel(const TI* src, int rows, in
 // One workgroup = 16 channels x 16 row lanes: totals of the sum / sum-of-squares (or g / g*xhat) columns of a
 // [rows][2][c] slab, handed to a per-channel functor by the first 16 threads (no second launch).
 template <typename TI, typename F>
-__device__ __forceinline__ void slab_totals_then(const TI* slab, int rows, int c, F&& fin) {
+__device__ __forceinline__ void slab_totals_then(const TI* slab, int rows, int c, int bid, F&& fin) {
     __shared__ double red[2][16][17];
-    const int ch = blockIdx.x * 16 + (threadIdx.x & 15), rl = threadIdx.x >> 4;
+    const int ch = bid * 16 + (threadIdx.x & 15), rl = threadIdx.x >> 4;
     double a = 0.0, b = 0.0;
     if (ch < c) {
         int r = rl;
@@ -141,32 +143,62 @@ extern "C" size_t lh_bn_stats_slab_bytes(int rows, int c) {
     return ((size_t)rows * 2 * c + 2) * 4 + (size_t)(ceil_div(rows, 256) + 1) * 2 * c * 8;
 }
 
+struct FinalizeArgs {
+    const void* slab;            // [rows][2][c] floats (or doubles: the second level of a two-launch fold)
+    int rows, count, c;
+    const float* gamma;
+    const float* beta;
+    float* rmean;
+    float* rvar;
+    long long* nbt;
+    float momentum, eps;
+    float* scale;
+    float* shift;
+    float* smean;
+    float* sinv;
+};
+
 template <typename TI>
-__global__ __launch_bounds__(256) void bn_finalize_fused_kernel(const TI* slab, int rows, int count, int c, const float* gamma,
-                                                                const float* beta, float* rmean, float* rvar, long long* nbt,
-                                                                float momentum, float eps, float* scale, float* shift,
-                                                                float* smean, float* sinv) {
-    if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
-    slab_totals_then(slab, rows, c, [&](int ch, double s0, double s1) {
+__device__ __forceinline__ void bn_finalize_fused_body(const FinalizeArgs& p, const int bid, const int nblk) {
+    if (bid == 0 && threadIdx.x == 0 && p.nbt) *p.nbt += 1;
+    const int count = p.count;
+    slab_totals_then((const TI*)p.slab, p.rows, p.c, bid, [&](int ch, double s0, double s1) {
         const double mean = s0 / count;
         double var = s1 / count - mean * mean;
         if (var < 0.0) var = 0.0;
-        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-        const float g = gamma ? gamma[ch] : 1.f, b = beta ? beta[ch] : 0.f;
+        const float invstd = (float)(1.0 / sqrt(var + (double)p.eps));
+        const float g = p.gamma ? p.gamma[ch] : 1.f, b = p.beta ? p.beta[ch] : 0.f;
         const float sc = g * invstd;
-        scale[ch] = sc;
-        shift[ch] = b - (float)mean * sc;
-        if (smean) smean[ch] = (float)mean;
-        if (sinv) sinv[ch] = invstd;
-        if (rmean) rmean[ch] = (1.f - momentum) * rmean[ch] + momentum * (float)mean;
-        if (rvar) {
+        p.scale[ch] = sc;
+        p.shift[ch] = b - (float)mean * sc;
+        if (p.smean) p.smean[ch] = (float)mean;
+        if (p.sinv) p.sinv[ch] = invstd;
+        if (p.rmean) p.rmean[ch] = (1.f - p.momentum) * p.rmean[ch] + p.momentum * (float)mean;
+        if (p.rvar) {
             const double unb = count > 1 ? var * ((double)count / (count - 1)) : var;
-            rvar[ch] = (1.f - momentum) * rvar[ch] + momentum * (float)unb;
+            p.rvar[ch] = (1.f - p.momentum) * p.rvar[ch] + p.momentum * (float)unb;
         }
     });
 }
+template <typename TI>
+__global__ __launch_bounds__(256) void bn_finalize_fused_kernel(const FinalizeArgs p) { bn_finalize_fused_body<TI>(p, blockIdx.x, gridDim.x); }
+template <typename TI>
+__global__ __launch_bounds__(256) void bn_finalize_fused_multi_kernel(const LhMulti<FinalizeArgs> m) {
+    int bid, nblk;
+    const int i = lh_multi_pick(m, bid, nblk);
+    bn_finalize_fused_body<TI>(m.a[i], bid, nblk);
+}
 
 // stats: [rows][2][c] floats followed by scratch for (ceil(rows/256) + 1) * 2c doubles.
+static FinalizeArgs finalize_args(const void* slab, int rows, int count, int c, const float* gamma, const float* beta, float* running_mean,
+                                  float* running_var, long long* nbt, float momentum, float eps, float* scale, float* shift,
+                                  float* save_mean, float* save_invstd) {
+    FinalizeArgs a;
+    a.slab = slab; a.rows = rows; a.count = count; a.c = c; a.gamma = gamma; a.beta = beta; a.rmean = running_mean; a.rvar = running_var;
+    a.nbt = nbt; a.momentum = momentum; a.eps = eps; a.scale = scale; a.shift = shift; a.smean = save_mean; a.sinv = save_invstd;
+    return a;
+}
+
 extern "C" int lh_bn_finalize(const float* stats, int rows, int count, int c, const float* gamma,
                               const float* beta, float* running_mean, float* running_var,
                               long long* num_batches_tracked, float momentum, float eps, float* scale,
@@ -175,29 +207,53 @@ extern "C" int lh_bn_finalize(const float* stats, int rows, int count, int c, co
     hipStream_t s = (hipStream_t)stream;
     const long slab_floats = (long)rows * 2 * c;
     double* scratch = (double*)(stats + ((slab_floats + 1) & ~1L));
-    double* totals = scratch + (long)ceil_div(rows, 256) * 2 * c;
     if (rows <= 1024) {      // one launch: fold the slab and finalize
-        hipLaunchKernelGGL((bn_finalize_fused_kernel<float>), dim3(ceil_div(c, 16)), dim3(256), 0, s, stats, rows, count, c, gamma, beta,
-                           running_mean, running_var, num_batches_tracked, momentum, eps, scale, shift, save_mean, save_invstd);
+        const FinalizeArgs a = finalize_args(stats, rows, count, c, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps,
+                                             scale, shift, save_mean, save_invstd);
+        hipLaunchKernelGGL((bn_finalize_fused_kernel<float>), dim3(ceil_div(c, 16)), dim3(256), 0, s, a);
         LH_LAUNCH_CHECK("bn_finalize launch");
         return LH_OK;
     }
-    {                        // two launches: 256-row partial folds (fp64), then fold + finalize
-        const int gy = ceil_div(rows, 256);
-        hipLaunchKernelGGL((colsum_kernel<float>), dim3(ceil_div(2 * c, 16), gy), dim3(256), 0, s, stats, rows, 2 * c, 256, scratch);
-        hipLaunchKernelGGL((bn_finalize_fused_kernel<double>), dim3(ceil_div(c, 16)), dim3(256), 0, s, (const double*)scratch, gy, count, c,
-                           gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, scale, shift, save_mean,
-                           save_invstd);
-        LH_LAUNCH_CHECK("bn_finalize launch");
-        return LH_OK;
-    }
-    int rc = column_totals(stats, rows, 2 * c, scratch, totals, s);
-    if (rc) return rc;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(c, 128)), dim3(128), 0, s, (const double*)totals, count, c,
-                       gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, scale, shift,
-                       save_mean, save_invstd);
+    // two launches: 256-row partial folds (fp64), then fold + finalize
+    const int gy = ceil_div(rows, 256);
+    hipLaunchKernelGGL((colsum_kernel<float>), dim3(ceil_div(2 * c, 16), gy), dim3(256), 0, s, stats, rows, 2 * c, 256, scratch);
+    const FinalizeArgs a = finalize_args(scratch, gy, count, c, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps,
+                                         scale, shift, save_mean, save_invstd);
+    hipLaunchKernelGGL((bn_finalize_fused_kernel<double>), dim3(ceil_div(c, 16)), dim3(256), 0, s, a);
     LH_LAUNCH_CHECK("bn_finalize launch");
     return LH_OK;
+}
+
+// The same folds for up to n independent BatchNorm layers as ONE launch (multi.h); layers whose slab has more than 1024
+// rows take the two-launch path of lh_bn_finalize one by one.
+extern "C" int lh_bn_finalize_multi(const lh_bn_finalize_call* calls, int n, void* stream) {
+    LH_REQUIRE(calls && n >= 1, "lh_bn_finalize_multi: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    LhMulti<FinalizeArgs> m;
+    m.n = 0; m.first[0] = 0;
+    auto flush = [&]() -> int {
+        if (m.n == 0) return LH_OK;
+        if (m.n == 1) hipLaunchKernelGGL((bn_finalize_fused_kernel<float>), dim3(m.first[1]), dim3(256), 0, s, m.a[0]);
+        else hipLaunchKernelGGL((bn_finalize_fused_multi_kernel<float>), dim3(m.first[m.n]), dim3(256), 0, s, m);
+        LH_LAUNCH_CHECK("bn_finalize_multi launch");
+        m.n = 0;
+        return LH_OK;
+    };
+    for (int i = 0; i < n; ++i) {
+        const lh_bn_finalize_call& q = calls[i];
+        LH_REQUIRE(q.stats && q.scale && q.shift && q.rows > 0 && q.count > 0 && q.c > 0, "lh_bn_finalize_multi: bad arguments (layer %d)", i);
+        if (q.rows > 1024) {
+            const int rc = lh_bn_finalize(q.stats, q.rows, q.count, q.c, q.gamma, q.beta, q.running_mean, q.running_var, q.num_batches_tracked,
+                                          q.momentum, q.eps, q.scale, q.shift, q.save_mean, q.save_invstd, stream);
+            if (rc) return rc;
+            continue;
+        }
+        m.a[m.n] = finalize_args(q.stats, q.rows, q.count, q.c, q.gamma, q.beta, q.running_mean, q.running_var, q.num_batches_tracked,
+                                 q.momentum, q.eps, q.scale, q.shift, q.save_mean, q.save_invstd);
+        m.first[m.n + 1] = m.first[m.n] + ceil_div(q.c, 16);
+        if (++m.n == LH_MULTI_MAX) { const int rc = flush(); if (rc) return rc; }
+    }
+    return flush();
 }
 
 __global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, const float* rm, const float* rv,
@@ -229,6 +285,7 @@ struct FuseArgs {
     unsigned char* out;
     unsigned char* mask;         // optional: one byte per 16-byte chunk of `out`, bit e = (element e > 0)
     int n, h, w, c;
+    long total;                  // 16-byte chunks of `out` (flat kernels)
 };
 
 // bit e of the result = (stored element e > 0): computed from the ROUNDED values so that it equals `out > 0`
@@ -247,11 +304,11 @@ template <int EPC> __device__ __forceinline__ void mask_by_bits(unsigned m, floa
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void fuse_fwd_kernel(const FuseArgs p) {
+__device__ __forceinline__ void fuse_fwd_body(const FuseArgs& p, const int bid, const int nblk) {
     constexpr int EPC = 16 / sizeof(T);
     const int nchunk = p.c / EPC;
     const long total = (long)p.n * p.h * p.w * nchunk;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    for (long idx = (long)bid * 256 + threadIdx.x; idx < total; idx += (long)nblk * 256) {
         const int ch = (int)(idx % nchunk);
         const long pix = idx / nchunk;
         const int x = (int)(pix % p.w);
@@ -288,6 +345,14 @@ __global__ __launch_bounds__(256) void fuse_fwd_kernel(const FuseArgs p) {
         if (p.mask) p.mask[idx] = positive_bits<T>(u);
     }
 }
+template <typename T>
+__global__ __launch_bounds__(256) void fuse_fwd_kernel(const FuseArgs p) { fuse_fwd_body<T>(p, blockIdx.x, gridDim.x); }
+template <typename T>
+__global__ __launch_bounds__(256) void fuse_fwd_multi_kernel(const LhMulti<FuseArgs> m) {
+    int bid, nblk;
+    const int i = lh_multi_pick(m, bid, nblk);
+    fuse_fwd_body<T>(m.a[i], bid, nblk);
+}
 
 // EPC consecutive floats of a per-channel vector with 16-byte loads.
 template <int EPC> __device__ __forceinline__ void load_vec(const float* p, float* dst) {
@@ -306,7 +371,8 @@ template <int EPC> __device__ __forceinline__ void fill_vec(float* dst, float v)
 // the chunk count, so a thread keeps ONE channel chunk: its scale/shift live in registers and the loop has no
 // integer division -- the kernel is a pure 16-byte-per-lane stream.
 template <typename T, int NT>
-__global__ __launch_bounds__(256) void fuse_fwd_flat_kernel(const FuseArgs p, long total) {
+__device__ __forceinline__ void fuse_fwd_flat_body(const FuseArgs& p, const int bid, const int nblk) {
+    const long total = p.total;
     constexpr int EPC = 16 / sizeof(T);
     const int nchunk = p.c / EPC;
     const int ch = threadIdx.x & (nchunk - 1);
@@ -316,8 +382,8 @@ __global__ __launch_bounds__(256) void fuse_fwd_flat_kernel(const FuseArgs p, lo
         if (p.scale[t]) { load_vec<EPC>(p.scale[t] + ch * EPC, sc[t]); load_vec<EPC>(p.shift[t] + ch * EPC, sh[t]); }
         else { fill_vec<EPC>(sc[t], 1.f); fill_vec<EPC>(sh[t], 0.f); }
     }
-    const long stride = (long)gridDim.x * 256;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += stride) {
+    const long stride = (long)nblk * 256;
+    for (long idx = (long)bid * 256 + threadIdx.x; idx < total; idx += stride) {
         float acc[EPC];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -343,12 +409,31 @@ __global__ __launch_bounds__(256) void fuse_fwd_flat_kernel(const FuseArgs p, lo
         if (p.mask) p.mask[idx] = positive_bits<T>(u);
     }
 }
+template <typename T, int NT>
+__global__ __launch_bounds__(256) void fuse_fwd_flat_kernel(const FuseArgs p) { fuse_fwd_flat_body<T, NT>(p, blockIdx.x, gridDim.x); }
+template <typename T, int NT>
+__global__ __launch_bounds__(256) void fuse_fwd_flat_multi_kernel(const LhMulti<FuseArgs> m) {
+    int bid, nblk;
+    const int i = lh_multi_pick(m, bid, nblk);
+    fuse_fwd_flat_body<T, NT>(m.a[i], bid, nblk);
+}
 
-extern "C" int lh_fuse_fwd(const lh_fuse_desc* d, void* out, int n, int h, int w, int c, int dtype, void* stream) {
+// ---- launch records: a C-ABI call is first PLANNED into the kernel launches it consists of (kind, grid, argument block),
+// then run -- one record as a plain launch, the records of several independent calls that agree in kind as one
+// multi-problem launch (multi.h).
+enum BnKind { K_FF_GEN, K_FF_FLAT1, K_FF_FLAT2, K_FB_REDUCE_GEN, K_FB_REDUCE_FLAT, K_FB_REDUCE_FLAT_X, K_FB_COEF, K_FB_APPLY_GEN,
+              K_FB_APPLY_FLAT, K_FB_APPLY_FLAT_X, K_FB_APPLY2 };
+struct FuseBwdArgs;
+struct FuseBwd2Args;
+struct CoefArgs;
+struct BnLaunch;
+static int bn_run(const BnLaunch* const* L, int n, int dtype, hipStream_t s);
+
+static int plan_fuse_fwd(const lh_fuse_desc* d, void* out, int n, int h, int w, int c, int dtype, FuseArgs* ap, int* kind, int* grid_out) {
     LH_REQUIRE(d && out && d->nterms >= 1 && d->nterms <= 4, "lh_fuse_fwd: bad descriptor");
     const int es = lh_dtype_size(dtype);
     LH_REQUIRE(es > 0 && c % (16 / es) == 0, "lh_fuse_fwd: c %d not a multiple of the 16-byte chunk", c);
-    FuseArgs a;
+    FuseArgs& a = *ap;
     for (int t = 0; t < 4; ++t) {
         a.x[t] = t < d->nterms ? (const unsigned char*)d->x[t] : nullptr;
         a.scale[t] = t < d->nterms ? d->scale[t] : nullptr;
@@ -363,22 +448,17 @@ extern "C" int lh_fuse_fwd(const lh_fuse_desc* d, void* out, int n, int h, int w
     }
     a.nterms = d->nterms; a.relu = d->relu; a.out = (unsigned char*)out; a.mask = (unsigned char*)d->relu_mask; a.n = n; a.h = h; a.w = w; a.c = c;
     const long total = (long)n * h * w * (c / (16 / es));
-    const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    a.total = total;
     const int nchunk = c / (16 / es);
     bool flat = d->nterms <= 2 && (nchunk & (nchunk - 1)) == 0 && nchunk <= 256;
     for (int t = 0; t < d->nterms; ++t) flat = flat && a.log2up[t] == 0;
     if (flat) {
-        const int grid = (int)((total + 1023) / 1024 > 2048 ? 2048 : (total + 1023) / 1024);      // >= 4 chunks per thread
-        if (d->nterms == 1) {
-            LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((fuse_fwd_flat_kernel<T, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a, total));
-        } else {
-            LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((fuse_fwd_flat_kernel<T, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a, total));
-        }
-        LH_LAUNCH_CHECK("fuse_fwd launch");
-        return LH_OK;
+        *grid_out = (int)((total + 1023) / 1024 > 2048 ? 2048 : (total + 1023) / 1024);      // >= 4 chunks per thread
+        *kind = d->nterms == 1 ? K_FF_FLAT1 : K_FF_FLAT2;
+    } else {
+        *grid_out = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+        *kind = K_FF_GEN;
     }
-    LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((fuse_fwd_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a));
-    LH_LAUNCH_CHECK("fuse_fwd launch");
     return LH_OK;
 }
 
@@ -404,6 +484,7 @@ struct FuseBwdArgs {
     const float* shift;
     int rows_per_strip;
     long count;                  // n * (h>>l) * (w>>l)
+    long total;                  // 16-byte chunks of dx (flat apply kernel)
 };
 
 template <typename T, int EPC>
@@ -431,15 +512,15 @@ __device__ __forceinline__ void cell_grad(const FuseBwdArgs& p, int n, int ys, i
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void fuse_bwd_reduce_kernel(const FuseBwdArgs p) {
+__device__ __forceinline__ void fuse_bwd_reduce_body(const FuseBwdArgs& p, const int bid, const int nblk) {
     constexpr int EPC = 16 / sizeof(T);
     __shared__ float red[256 * EPC * 2];
     const int nchunk = p.c / EPC;
     const int hs = p.h >> p.l, ws = p.w >> p.l;
-    const long r0 = (long)blockIdx.x * p.rows_per_strip;
+    const long r0 = (long)bid * p.rows_per_strip;
     long r1 = r0 + p.rows_per_strip;
     if (r1 > p.count) r1 = p.count;
-    float* out = p.partial + (long)blockIdx.x * 2 * p.c;
+    float* out = p.partial + (long)bid * 2 * p.c;
     // active threads: a whole number of row lanes over the chunks (chunk fixed per thread)
     for (int cb = 0; cb < nchunk; cb += 256) {
         const int nc = nchunk - cb < 256 ? nchunk - cb : 256;
@@ -476,14 +557,22 @@ __global__ __launch_bounds__(256) void fuse_bwd_reduce_kernel(const FuseBwdArgs 
         __syncthreads();
     }
 }
+template <typename T>
+__global__ __launch_bounds__(256) void fuse_bwd_reduce_kernel(const FuseBwdArgs p) { fuse_bwd_reduce_body<T>(p, blockIdx.x, gridDim.x); }
+template <typename T>
+__global__ __launch_bounds__(256) void fuse_bwd_reduce_multi_kernel(const LhMulti<FuseBwdArgs> m) {
+    int bid, nblk;
+    const int i = lh_multi_pick(m, bid, nblk);
+    fuse_bwd_reduce_body<T>(m.a[i], bid, nblk);
+}
 
 template <typename T>
-__global__ __launch_bounds__(256) void fuse_bwd_apply_kernel(const FuseBwdArgs p) {
+__device__ __forceinline__ void fuse_bwd_apply_body(const FuseBwdArgs& p, const int bid, const int nblk) {
     constexpr int EPC = 16 / sizeof(T);
     const int nchunk = p.c / EPC;
     const int hs = p.h >> p.l, ws = p.w >> p.l;
     const long total = p.count * nchunk;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    for (long idx = (long)bid * 256 + threadIdx.x; idx < total; idx += (long)nblk * 256) {
         const int chunk = (int)(idx % nchunk);
         const long r = idx / nchunk;
         const int xs = (int)(r % ws);
@@ -511,16 +600,24 @@ __global__ __launch_bounds__(256) void fuse_bwd_apply_kernel(const FuseBwdArgs p
         *dst = pack16<T>(g);
     }
 }
+template <typename T>
+__global__ __launch_bounds__(256) void fuse_bwd_apply_kernel(const FuseBwdArgs p) { fuse_bwd_apply_body<T>(p, blockIdx.x, gridDim.x); }
+template <typename T>
+__global__ __launch_bounds__(256) void fuse_bwd_apply_multi_kernel(const LhMulti<FuseBwdArgs> m) {
+    int bid, nblk;
+    const int i = lh_multi_pick(m, bid, nblk);
+    fuse_bwd_apply_body<T>(m.a[i], bid, nblk);
+}
 
 // ---- l == 0 fast paths: dout / out / x / dx share one flat element offset, the thread keeps one channel chunk.
 template <typename T, bool MASK_X>
-__global__ __launch_bounds__(256) void fuse_bwd_reduce_flat_kernel(const FuseBwdArgs p) {
+__device__ __forceinline__ void fuse_bwd_reduce_flat_body(const FuseBwdArgs& p, const int bid, const int nblk) {
     constexpr int EPC = 16 / sizeof(T);
     __shared__ float red[256 * EPC * 2];
     const int nchunk = p.c / EPC;                       // power of two <= 256
     const int lanes = 256 / nchunk;
     const int chunk = threadIdx.x & (nchunk - 1), rl = threadIdx.x / nchunk;
-    const long r0 = (long)blockIdx.x * p.rows_per_strip;
+    const long r0 = (long)bid * p.rows_per_strip;
     long r1 = r0 + p.rows_per_strip;
     if (r1 > p.count) r1 = p.count;
     float mean[EPC], inv[EPC], sc[EPC], sh[EPC], s1[EPC], s2[EPC];
@@ -575,7 +672,7 @@ __global__ __launch_bounds__(256) void fuse_bwd_reduce_flat_kernel(const FuseBwd
 #pragma unroll
     for (int e = 0; e < EPC; ++e) { red[(threadIdx.x * EPC + e) * 2] = s1[e]; red[(threadIdx.x * EPC + e) * 2 + 1] = s2[e]; }
     __syncthreads();
-    float* out = p.partial + (long)blockIdx.x * 2 * p.c;
+    float* out = p.partial + (long)bid * 2 * p.c;
     for (int t = threadIdx.x; t < nchunk * EPC; t += 256) {
         const int cl = t / EPC, e = t % EPC;
         float a = 0.f, b = 0.f;
@@ -584,9 +681,18 @@ __global__ __launch_bounds__(256) void fuse_bwd_reduce_flat_kernel(const FuseBwd
         out[p.c + cl * EPC + e] = b;
     }
 }
+template <typename T, bool MASK_X>
+__global__ __launch_bounds__(256) void fuse_bwd_reduce_flat_kernel(const FuseBwdArgs p) { fuse_bwd_reduce_flat_body<T, MASK_X>(p, blockIdx.x, gridDim.x); }
+template <typename T, bool MASK_X>
+__global__ __launch_bounds__(256) void fuse_bwd_reduce_flat_multi_kernel(const LhMulti<FuseBwdArgs> m) {
+    int bid, nblk;
+    const int i = lh_multi_pick(m, bid, nblk);
+    fuse_bwd_reduce_flat_body<T, MASK_X>(m.a[i], bid, nblk);
+}
 
 template <typename T, bool MASK_X>
-__global__ __launch_bounds__(256) void fuse_bwd_apply_flat_kernel(const FuseBwdArgs p, long total) {
+__device__ __forceinline__ void fuse_bwd_apply_flat_body(const FuseBwdArgs& p, const int bid, const int nblk) {
+    const long total = p.total;
     constexpr int EPC = 16 / sizeof(T);
     const int nchunk = p.c / EPC;
     const int chunk = threadIdx.x & (nchunk - 1);
@@ -607,8 +713,8 @@ __global__ __launch_bounds__(256) void fuse_bwd_apply_flat_kernel(const FuseBwdA
             load_vec<EPC>(p.shift + chunk * EPC, sh);
         }
     } else { fill_vec<EPC>(A, 1.f); fill_vec<EPC>(B, 0.f); fill_vec<EPC>(Cc, 0.f); }
-    const long stride = (long)gridDim.x * 256;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += stride) {
+    const long stride = (long)nblk * 256;
+    for (long idx = (long)bid * 256 + threadIdx.x; idx < total; idx += stride) {
         const long off = idx * 16;
         float g[EPC], xv[EPC];
         unpack16<T>(*reinterpret_cast<const uint4*>(p.dout + off), g);
@@ -638,6 +744,14 @@ __global__ __launch_bounds__(256) void fuse_bwd_apply_flat_kernel(const FuseBwdA
         *dst = pack16<T>(g);
     }
 }
+template <typename T, bool MASK_X>
+__global__ __launch_bounds__(256) void fuse_bwd_apply_flat_kernel(const FuseBwdArgs p) { fuse_bwd_apply_flat_body<T, MASK_X>(p, blockIdx.x, gridDim.x); }
+template <typename T, bool MASK_X>
+__global__ __launch_bounds__(256) void fuse_bwd_apply_flat_multi_kernel(const LhMulti<FuseBwdArgs> m) {
+    int bid, nblk;
+    const int i = lh_multi_pick(m, bid, nblk);
+    fuse_bwd_apply_flat_body<T, MASK_X>(m.a[i], bid, nblk);
+}
 
 // Two terms, no upsampling (the residual-unit tail: BN(main) + identity | BN(shortcut)): ONE pass reads dout / out once
 // and writes both input gradients.  Term k: BN when x[k] != null (dx = A*g + B*x + C) else identity (dx = g).
@@ -653,10 +767,12 @@ struct FuseBwd2Args {
     unsigned char* dx[2];
     int accumulate[2];
     int c, relu;
+    long total;
 };
 
 template <typename T>
-__global__ __launch_bounds__(256) void fuse_bwd_apply2_flat_kernel(const FuseBwd2Args p, long total) {
+__device__ __forceinline__ void fuse_bwd_apply2_flat_body(const FuseBwd2Args& p, const int bid, const int nblk) {
+    const long total = p.total;
     constexpr int EPC = 16 / sizeof(T);
     const int nchunk = p.c / EPC;
     const int chunk = threadIdx.x & (nchunk - 1);
@@ -674,8 +790,8 @@ __global__ __launch_bounds__(256) void fuse_bwd_apply2_flat_kernel(const FuseBwd
             for (int e = 0; e < EPC; ++e) { B[k][e] = -A[k][e] * iv[e] * c1[e]; Cc[k][e] = -A[k][e] * c0[e] - B[k][e] * mn[e]; }
         } else { fill_vec<EPC>(A[k], 1.f); fill_vec<EPC>(B[k], 0.f); fill_vec<EPC>(Cc[k], 0.f); }
     }
-    const long stride = (long)gridDim.x * 256;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += stride) {
+    const long stride = (long)nblk * 256;
+    for (long idx = (long)bid * 256 + threadIdx.x; idx < total; idx += stride) {
         const long off = idx * 16;
         float g[EPC];
         unpack16<T>(*reinterpret_cast<const uint4*>(p.dout + off), g);
@@ -711,6 +827,14 @@ __global__ __launch_bounds__(256) void fuse_bwd_apply2_flat_kernel(const FuseBwd
         }
     }
 }
+template <typename T>
+__global__ __launch_bounds__(256) void fuse_bwd_apply2_flat_kernel(const FuseBwd2Args p) { fuse_bwd_apply2_flat_body<T>(p, blockIdx.x, gridDim.x); }
+template <typename T>
+__global__ __launch_bounds__(256) void fuse_bwd_apply2_flat_multi_kernel(const LhMulti<FuseBwd2Args> m) {
+    int bid, nblk;
+    const int i = lh_multi_pick(m, bid, nblk);
+    fuse_bwd_apply2_flat_body<T>(m.a[i], bid, nblk);
+}
 
 __global__ void fuse_bwd_coef_kernel(const double* totals, long count, int c, float* coef, float* dgamma, float* dbeta) {
     const int ch = blockIdx.x * blockDim.x + threadIdx.x;
@@ -721,15 +845,30 @@ __global__ void fuse_bwd_coef_kernel(const double* totals, long count, int c, fl
     if (dgamma) dgamma[ch] = (float)totals[c + ch];
 }
 
-template <typename TI>
-__global__ __launch_bounds__(256) void fuse_bwd_coef_fused_kernel(const TI* slab, int rows, long count, int c, float* coef,
-                                                                  float* dgamma, float* dbeta) {
-    slab_totals_then(slab, rows, c, [&](int ch, double s0, double s1) {
-        coef[ch] = (float)(s0 / (double)count);
-        coef[c + ch] = (float)(s1 / (double)count);
-        if (dbeta) dbeta[ch] = (float)s0;
-        if (dgamma) dgamma[ch] = (float)s1;
+struct CoefArgs {
+    const float* slab;           // [rows][2][c]
+    int rows, c;
+    long count;
+    float* coef;
+    float* dgamma;
+    float* dbeta;
+};
+
+__device__ __forceinline__ void fuse_bwd_coef_fused_body(const CoefArgs& p, const int bid, const int nblk) {
+    const long count = p.count;
+    const int c = p.c;
+    slab_totals_then(p.slab, p.rows, p.c, bid, [&](int ch, double s0, double s1) {
+        p.coef[ch] = (float)(s0 / (double)count);
+        p.coef[c + ch] = (float)(s1 / (double)count);
+        if (p.dbeta) p.dbeta[ch] = (float)s0;
+        if (p.dgamma) p.dgamma[ch] = (float)s1;
     });
+}
+__global__ __launch_bounds__(256) void fuse_bwd_coef_fused_kernel(const CoefArgs p) { fuse_bwd_coef_fused_body(p, blockIdx.x, gridDim.x); }
+__global__ __launch_bounds__(256) void fuse_bwd_coef_fused_multi_kernel(const LhMulti<CoefArgs> m) {
+    int bid, nblk;
+    const int i = lh_multi_pick(m, bid, nblk);
+    fuse_bwd_coef_fused_body(m.a[i], bid, nblk);
 }
 
 static long fuse_bwd_strips(long count, int* rows_per_strip) {
@@ -746,13 +885,100 @@ extern "C" size_t lh_fuse_bwd_workspace_bytes(int n, int h, int w, int c) {
     return (size_t)strips * 2 * c * 4 + 16 + (size_t)(ceil_div(strips, 256) + 1) * 2 * c * 8 + (size_t)4 * c * 4;
 }
 
-extern "C" int lh_fuse_bwd(const lh_fuse_bwd_desc* d, int n, int h, int w, int c, void* workspace, int dtype,
-                           void* stream) {
+struct BnLaunch {
+    int kind, grid;
+    FuseArgs ff;
+    FuseBwdArgs fb;
+    FuseBwd2Args fb2;
+    CoefArgs co;
+};
+
+// Run n <= LH_MULTI_MAX records of ONE kind: a plain launch for one, a multi-problem launch for several.
+#define BN_RUN(KERNEL, MULTI, FIELD, ARGS_T)                                                                          \
+    do {                                                                                                               \
+        if (n == 1) {                                                                                                  \
+            hipLaunchKernelGGL(KERNEL, dim3(L[0]->grid), dim3(256), 0, s, L[0]->FIELD);                                \
+        } else {                                                                                                       \
+            LhMulti<ARGS_T> m;                                                                                         \
+            m.n = n; m.first[0] = 0;                                                                                   \
+            for (int i = 0; i < n; ++i) { m.a[i] = L[i]->FIELD; m.first[i + 1] = m.first[i] + L[i]->grid; }           \
+            hipLaunchKernelGGL(MULTI, dim3(m.first[n]), dim3(256), 0, s, m);                                           \
+        }                                                                                                              \
+    } while (0)
+
+static int bn_run(const BnLaunch* const* L, int n, int dtype, hipStream_t s) {
+    LH_REQUIRE(n >= 1 && n <= LH_MULTI_MAX, "bn_run: %d records", n);
+    switch (L[0]->kind) {
+        case K_FF_GEN: LH_DISPATCH_DTYPE(dtype, T, BN_RUN((fuse_fwd_kernel<T>), (fuse_fwd_multi_kernel<T>), ff, FuseArgs)); break;
+        case K_FF_FLAT1: LH_DISPATCH_DTYPE(dtype, T, BN_RUN((fuse_fwd_flat_kernel<T, 1>), (fuse_fwd_flat_multi_kernel<T, 1>), ff, FuseArgs)); break;
+        case K_FF_FLAT2: LH_DISPATCH_DTYPE(dtype, T, BN_RUN((fuse_fwd_flat_kernel<T, 2>), (fuse_fwd_flat_multi_kernel<T, 2>), ff, FuseArgs)); break;
+        case K_FB_REDUCE_GEN: LH_DISPATCH_DTYPE(dtype, T, BN_RUN((fuse_bwd_reduce_kernel<T>), (fuse_bwd_reduce_multi_kernel<T>), fb, FuseBwdArgs)); break;
+        case K_FB_REDUCE_FLAT: LH_DISPATCH_DTYPE(dtype, T, BN_RUN((fuse_bwd_reduce_flat_kernel<T, false>), (fuse_bwd_reduce_flat_multi_kernel<T, false>), fb, FuseBwdArgs)); break;
+        case K_FB_REDUCE_FLAT_X: LH_DISPATCH_DTYPE(dtype, T, BN_RUN((fuse_bwd_reduce_flat_kernel<T, true>), (fuse_bwd_reduce_flat_multi_kernel<T, true>), fb, FuseBwdArgs)); break;
+        case K_FB_COEF: BN_RUN(fuse_bwd_coef_fused_kernel, fuse_bwd_coef_fused_multi_kernel, co, CoefArgs); break;
+        case K_FB_APPLY_GEN: LH_DISPATCH_DTYPE(dtype, T, BN_RUN((fuse_bwd_apply_kernel<T>), (fuse_bwd_apply_multi_kernel<T>), fb, FuseBwdArgs)); break;
+        case K_FB_APPLY_FLAT: LH_DISPATCH_DTYPE(dtype, T, BN_RUN((fuse_bwd_apply_flat_kernel<T, false>), (fuse_bwd_apply_flat_multi_kernel<T, false>), fb, FuseBwdArgs)); break;
+        case K_FB_APPLY_FLAT_X: LH_DISPATCH_DTYPE(dtype, T, BN_RUN((fuse_bwd_apply_flat_kernel<T, true>), (fuse_bwd_apply_flat_multi_kernel<T, true>), fb, FuseBwdArgs)); break;
+        case K_FB_APPLY2: LH_DISPATCH_DTYPE(dtype, T, BN_RUN((fuse_bwd_apply2_flat_kernel<T>), (fuse_bwd_apply2_flat_multi_kernel<T>), fb2, FuseBwd2Args)); break;
+        default: lh_set_error("bn_run: unknown kind %d", L[0]->kind); return LH_ERR_ARG;
+    }
+    LH_LAUNCH_CHECK("BatchNorm / ReLU pass launch");
+    return LH_OK;
+}
+
+// Runs the records of n planned calls: position by position as multi-problem launches when every call planned the same
+// sequence of kinds (the parallel branches of an HRNet module do), else call by call.
+static int bn_run_calls(const std::vector<std::vector<BnLaunch>>& plans, int dtype, hipStream_t s) {
+    const int n = (int)plans.size();
+    bool same = n > 1;
+    for (int i = 1; i < n && same; ++i) {
+        same = plans[i].size() == plans[0].size();
+        for (size_t k = 0; same && k < plans[0].size(); ++k) same = plans[i][k].kind == plans[0][k].kind;
+    }
+    const BnLaunch* L[LH_MULTI_MAX];
+    if (!same) {
+        for (int i = 0; i < n; ++i)
+            for (const BnLaunch& r : plans[i]) {
+                L[0] = &r;
+                const int rc = bn_run(L, 1, dtype, s);
+                if (rc) return rc;
+            }
+        return LH_OK;
+    }
+    for (size_t k = 0; k < plans[0].size(); ++k)
+        for (int i0 = 0; i0 < n; i0 += LH_MULTI_MAX) {
+            const int m = n - i0 < LH_MULTI_MAX ? n - i0 : LH_MULTI_MAX;
+            for (int i = 0; i < m; ++i) L[i] = &plans[i0 + i][k];
+            const int rc = bn_run(L, m, dtype, s);
+            if (rc) return rc;
+        }
+    return LH_OK;
+}
+
+extern "C" int lh_fuse_fwd(const lh_fuse_desc* d, void* out, int n, int h, int w, int c, int dtype, void* stream) {
+    BnLaunch r;
+    const int rc = plan_fuse_fwd(d, out, n, h, w, c, dtype, &r.ff, &r.kind, &r.grid);
+    if (rc) return rc;
+    const BnLaunch* L[1] = {&r};
+    return bn_run(L, 1, dtype, (hipStream_t)stream);
+}
+
+extern "C" int lh_fuse_fwd_multi(const lh_fuse_fwd_call* calls, int n, int dtype, void* stream) {
+    LH_REQUIRE(calls && n >= 1, "lh_fuse_fwd_multi: bad arguments");
+    std::vector<std::vector<BnLaunch>> plans(n, std::vector<BnLaunch>(1));
+    for (int i = 0; i < n; ++i) {
+        BnLaunch& r = plans[i][0];
+        const int rc = plan_fuse_fwd(calls[i].d, calls[i].out, calls[i].n, calls[i].h, calls[i].w, calls[i].c, dtype, &r.ff, &r.kind, &r.grid);
+        if (rc) return rc;
+    }
+    return bn_run_calls(plans, dtype, (hipStream_t)stream);
+}
+
+static int plan_fuse_bwd(const lh_fuse_bwd_desc* d, int n, int h, int w, int c, void* workspace, int dtype, std::vector<BnLaunch>& v) {
     LH_REQUIRE(d && d->dout && d->nterms >= 1 && d->nterms <= 4, "lh_fuse_bwd: bad descriptor");
     LH_REQUIRE(!d->relu || d->out || d->relu_mask, "lh_fuse_bwd: relu needs the forward output or its mask bits");
     const int es = lh_dtype_size(dtype);
     LH_REQUIRE(es > 0 && c % (16 / es) == 0, "lh_fuse_bwd: c %d not a multiple of the 16-byte chunk", c);
-    hipStream_t s = (hipStream_t)stream;
     const int nchunk0 = c / (16 / es);
     const bool merge2 = d->nterms == 2 && d->log2up[0] == 0 && d->log2up[1] == 0 && (nchunk0 & (nchunk0 - 1)) == 0 &&
                         nchunk0 <= 256 && (d->dx[0] || d->dx[1]);
@@ -783,6 +1009,7 @@ extern "C" int lh_fuse_bwd(const lh_fuse_bwd_desc* d, int n, int h, int w, int c
         // single BN term under the ReLU: the mask is sign(x*scale+shift), no need to read the stored activation
         a.mask_from_x = (flat && d->relu && d->nterms == 1 && a.x && d->shift[t]) ? 1 : 0;
         if (a.mask_from_x) a.shift = d->shift[t];
+        a.total = a.count * (c / (16 / es));
         if (a.x) {
             LH_REQUIRE(workspace && a.scale && a.mean && a.invstd, "lh_fuse_bwd: BN term %d lacks workspace/statistics", t);
             long strips = fuse_bwd_strips(a.count, &a.rows_per_strip);
@@ -791,40 +1018,58 @@ extern "C" int lh_fuse_bwd(const lh_fuse_bwd_desc* d, int n, int h, int w, int c
             double* scratch = (double*)((float*)workspace + ((slab_floats + 3) & ~3L));
             double* totals = scratch + (long)ceil_div(strips, 256) * 2 * c;
             a.totals = totals;
-            if (flat && a.mask_from_x) {
-                LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((fuse_bwd_reduce_flat_kernel<T, true>), dim3((int)strips), dim3(256), 0, s, a));
-            } else if (flat) {
-                LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((fuse_bwd_reduce_flat_kernel<T, false>), dim3((int)strips), dim3(256), 0, s, a));
-            } else {
-                LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((fuse_bwd_reduce_kernel<T>), dim3((int)strips), dim3(256), 0, s, a));
-            }
-            LH_LAUNCH_CHECK("fuse_bwd_reduce launch");
             a.coef = (float*)(totals + 2 * c) + (size_t)(merge2 ? t : 0) * 2 * c;   // merging keeps one coefficient block per term
-            hipLaunchKernelGGL((fuse_bwd_coef_fused_kernel<float>), dim3(ceil_div(c, 16)), dim3(256), 0, s, (const float*)a.partial,
-                               (int)strips, a.count, c, a.coef, a.dgamma, a.dbeta);
-            LH_LAUNCH_CHECK("fuse_bwd_coef launch");
+            BnLaunch r;
+            r.kind = flat ? (a.mask_from_x ? K_FB_REDUCE_FLAT_X : K_FB_REDUCE_FLAT) : K_FB_REDUCE_GEN;
+            r.grid = (int)strips;
+            r.fb = a;
+            v.push_back(r);
+            BnLaunch q;
+            q.kind = K_FB_COEF; q.grid = ceil_div(c, 16);
+            q.co.slab = a.partial; q.co.rows = (int)strips; q.co.c = c; q.co.count = a.count; q.co.coef = a.coef; q.co.dgamma = a.dgamma; q.co.dbeta = a.dbeta;
+            v.push_back(q);
             if (merge2) m2.coef[t] = a.coef;
         }
         if (merge2) continue;                 // both gradients are written by ONE pass below
-        const long total = a.count * (c / (16 / es));
-        const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-        const int fgrid = (int)((total + 1023) / 1024 > 2048 ? 2048 : (total + 1023) / 1024);          // >= 4 chunks per thread
-        if (flat && a.mask_from_x) {
-            LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((fuse_bwd_apply_flat_kernel<T, true>), dim3(fgrid), dim3(256), 0, s, a, total));
-        } else if (flat) {
-            LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((fuse_bwd_apply_flat_kernel<T, false>), dim3(fgrid), dim3(256), 0, s, a, total));
+        BnLaunch r;
+        if (flat) {
+            r.kind = a.mask_from_x ? K_FB_APPLY_FLAT_X : K_FB_APPLY_FLAT;
+            r.grid = (int)((a.total + 1023) / 1024 > 2048 ? 2048 : (a.total + 1023) / 1024);          // >= 4 chunks per thread
         } else {
-            LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((fuse_bwd_apply_kernel<T>), dim3(grid), dim3(256), 0, s, a));
+            r.kind = K_FB_APPLY_GEN;
+            r.grid = (int)((a.total + 255) / 256 > 4096 ? 4096 : (a.total + 255) / 256);
         }
-        LH_LAUNCH_CHECK("fuse_bwd_apply launch");
+        r.fb = a;
+        v.push_back(r);
     }
     if (merge2) {
-        const long total = (long)n * h * w * nchunk0;
-        const int fgrid = (int)((total + 1023) / 1024 > 2048 ? 2048 : (total + 1023) / 1024);
-        LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((fuse_bwd_apply2_flat_kernel<T>), dim3(fgrid), dim3(256), 0, s, m2, total));
-        LH_LAUNCH_CHECK("fuse_bwd_apply2 launch");
+        BnLaunch r;
+        m2.total = (long)n * h * w * nchunk0;
+        r.kind = K_FB_APPLY2;
+        r.grid = (int)((m2.total + 1023) / 1024 > 2048 ? 2048 : (m2.total + 1023) / 1024);
+        r.fb2 = m2;
+        v.push_back(r);
     }
     return LH_OK;
+}
+
+extern "C" int lh_fuse_bwd(const lh_fuse_bwd_desc* d, int n, int h, int w, int c, void* workspace, int dtype,
+                           void* stream) {
+    std::vector<std::vector<BnLaunch>> plans(1);
+    const int rc = plan_fuse_bwd(d, n, h, w, c, workspace, dtype, plans[0]);
+    if (rc) return rc;
+    return bn_run_calls(plans, dtype, (hipStream_t)stream);
+}
+
+// n independent nodes (each with its OWN workspace): reduce / coefficient fold / apply of all of them as three launches.
+extern "C" int lh_fuse_bwd_multi(const lh_fuse_bwd_call* calls, int n, int dtype, void* stream) {
+    LH_REQUIRE(calls && n >= 1, "lh_fuse_bwd_multi: bad arguments");
+    std::vector<std::vector<BnLaunch>> plans(n);
+    for (int i = 0; i < n; ++i) {
+        const int rc = plan_fuse_bwd(calls[i].d, calls[i].n, calls[i].h, calls[i].w, calls[i].c, calls[i].workspace, dtype, plans[i]);
+        if (rc) return rc;
+    }
+    return bn_run_calls(plans, dtype, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------------

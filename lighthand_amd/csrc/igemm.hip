@@ -18,6 +18,7 @@
 #include <stdlib.h>
 
 #include "igemm_args.h"
+#include "multi.h"
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16> {
@@ -337,7 +338,8 @@ struct PhaseSet {                 // lh_igemm_phases: the other descriptors / pa
 
 static int igemm_impl(const lh_igemm_desc* d, const void* in, const void* wpack, void* out,
                       const void* addend, const void* addend_mask, const float* bias, const float* scale, const float* shift, float* stats,
-                      int dtype, void* stream, const PhaseSet* phases = nullptr, const lh_head* head = nullptr) {
+                      int dtype, void* stream, const PhaseSet* phases = nullptr, const lh_head* head = nullptr,
+                      IgemmArgs* prep_args = nullptr, RingCfg* prep_cfg = nullptr) {
     LH_REQUIRE(d && in && wpack && (out || head), "lh_igemm: null pointer");
     const int es = lh_dtype_size(dtype);
     LH_REQUIRE(es > 0, "lh_igemm: bad dtype %d", dtype);
@@ -403,6 +405,14 @@ static int igemm_impl(const lh_igemm_desc* d, const void* in, const void* wpack,
         a.head_w = (const unsigned char*)head->w; a.head_bias = head->bias; a.head_out = head->out;
         a.head_j = head->n_out; a.head_wstride = (int)head->w_row_bytes;
     }
+    if (prep_args) {            // lh_igemm_multi: hand the argument block back instead of launching
+        LH_REQUIRE(ring && rc_.depth >= 2, "lh_igemm_multi: problem does not run on the LDS-DMA ring kernel (its cfg must name a tiled configuration)");
+        lh_tap_grid(d, &a.tw, &a.dh0, &a.dhs, &a.dw0, &a.dws);
+        a.kspt = (d->k_run * es + rc_.kb - 1) / rc_.kb;
+        *prep_args = a;
+        *prep_cfg = rc_;
+        return LH_OK;
+    }
     if (ring) {
         lh_tap_grid(d, &a.tw, &a.dh0, &a.dhs, &a.dw0, &a.dws);
         a.kspt = (d->k_run * es + rc_.kb - 1) / rc_.kb;
@@ -431,6 +441,35 @@ extern "C" int lh_igemm(const lh_igemm_desc* d, const void* in, const void* wpac
                         const void* addend, const void* addend_mask, const float* bias, const float* scale, const float* shift,
                         float* stats, int dtype, void* stream) {
     return igemm_impl(d, in, wpack, out, addend, addend_mask, bias, scale, shift, stats, dtype, stream);
+}
+
+// n independent convolutions that share ONE kernel configuration (every descriptor's cfg names the same tiled
+// configuration of the LDS-DMA kernel) as one grid: the same layer position of HRNet's parallel branches
+// (pose_hrnet.py:139-185).  Groups of LH_MULTI_MAX problems per launch.
+extern "C" int lh_igemm_multi(const lh_igemm_call* calls, int n, int dtype, void* stream) {
+    LH_REQUIRE(calls && n >= 1, "lh_igemm_multi: bad arguments");
+    for (int i0 = 0; i0 < n; i0 += LH_MULTI_MAX) {
+        const int cnt = n - i0 < LH_MULTI_MAX ? n - i0 : LH_MULTI_MAX;
+        LhMulti<IgemmArgs> m;
+        RingCfg cfg0 = {0, 0, 0, 0};
+        m.n = cnt; m.first[0] = 0;
+        for (int i = 0; i < cnt; ++i) {
+            const lh_igemm_call& q = calls[i0 + i];
+            RingCfg c;
+            const int rc = igemm_impl(q.d, q.in, q.wpack, q.out, q.addend, q.addend_mask, q.bias, q.scale, q.shift, q.stats, dtype, stream,
+                                      nullptr, nullptr, &m.a[i], &c);
+            if (rc) return rc;
+            if (i == 0) cfg0 = c;
+            LH_REQUIRE(c.bm == cfg0.bm && c.bp == cfg0.bp && c.depth == cfg0.depth && c.kb == cfg0.kb,
+                       "lh_igemm_multi: problem %d runs tile %dx%d depth %d kb %d, problem 0 %dx%d depth %d kb %d -- one configuration per call",
+                       i0 + i, c.bm, c.bp, c.depth, c.kb, cfg0.bm, cfg0.bp, cfg0.depth, cfg0.kb);
+            m.first[i + 1] = m.first[i] + ceil_div(m.a[i].M, c.bp) * ceil_div(m.a[i].cout, c.bm);
+        }
+        const int rc = cnt == 1 ? lh_igemm_ring_launch(m.a[0], cfg0, dtype, (hipStream_t)stream)
+                                : lh_igemm_ring_multi_launch(m, cfg0, dtype, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return LH_OK;
 }
 
 // ---- phase batching ------------------------------------------------------------------------------------------------

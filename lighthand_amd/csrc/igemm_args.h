@@ -66,6 +66,8 @@ int lh_ring_resolve(const lh_igemm_desc* d, int dtype, RingCfg* out);
 void lh_ring_default_cfg(const lh_igemm_desc* d, int dtype, RingCfg* out);
 int lh_ring_candidates(const lh_igemm_desc* d, int dtype, int* out, int max);
 int lh_igemm_ring_launch(const IgemmArgs& a, const RingCfg& c, int dtype, hipStream_t s);
+template <typename A> struct LhMulti;
+int lh_igemm_ring_multi_launch(LhMulti<IgemmArgs>& m, const RingCfg& c, int dtype, hipStream_t s);
 bool lh_pw_supported(const lh_igemm_desc* d, int dtype);
 int lh_pw_rows(const lh_igemm_desc* d, const RingCfg& c, int dtype);
 int lh_pw_occupancy(const RingCfg& c, int dtype, bool stats);

@@ -3,6 +3,7 @@
 #include "common.h"
 
 #include "igemm_args.h"
+#include "multi.h"
 #include "igemm_ring_cfgs.h"
 #include "igemm_pw_cfgs.h"
 #include <stdlib.h>
@@ -15,6 +16,8 @@ int lh_ring_launch_f16_big(const IgemmArgs& a, const RingCfg& c, hipStream_t s);
 int lh_ring_launch_f16_mid(const IgemmArgs& a, const RingCfg& c, hipStream_t s);
 int lh_ring_launch_f16_small(const IgemmArgs& a, const RingCfg& c, hipStream_t s);
 int lh_ring_launch_f32(const IgemmArgs& a, const RingCfg& c, hipStream_t s);
+int lh_ring_multi_launch_bf16(const LhMulti<IgemmArgs>& m, const RingCfg& c, hipStream_t s);
+int lh_ring_multi_launch_f16(const LhMulti<IgemmArgs>& m, const RingCfg& c, hipStream_t s);
 int lh_pw_launch_bf16(const IgemmArgs& a, const RingCfg& c, hipStream_t s);
 int lh_pw_launch_f16(const IgemmArgs& a, const RingCfg& c, hipStream_t s);
 int lh_pw_occ_bf16(const RingCfg& c, bool stats);
@@ -261,6 +264,24 @@ int lh_igemm_ring_launch(const IgemmArgs& a0, const RingCfg& c, int dtype, hipSt
     }
     if (rc == 1) {
         lh_set_error("igemm_ring: no kernel for tile %dx%d depth %d kb %d dtype %d", c.bm, c.bp, c.depth, c.kb, dtype);
+        return LH_ERR_UNSUPPORTED;
+    }
+    return rc;
+}
+
+int lh_igemm_ring_multi_launch(LhMulti<IgemmArgs>& m, const RingCfg& c, int dtype, hipStream_t s) {
+    const unsigned char* z = zero_page();
+    if (!z) {
+        lh_set_error("igemm_ring_multi: cannot resolve the zero page on this device");
+        return LH_ERR_HIP;
+    }
+    for (int i = 0; i < m.n; ++i) m.a[i].zero = z;
+    int rc = 1;
+    if (dtype == LH_BF16) rc = lh_ring_multi_launch_bf16(m, c, s);
+    else if (dtype == LH_F16) rc = lh_ring_multi_launch_f16(m, c, s);
+    if (rc == 1) {
+        lh_set_error("igemm_ring_multi: no multi-problem kernel for tile %dx%d depth %d kb %d dtype %d (4-wave tiles, 16-bit types)",
+                     c.bm, c.bp, c.depth, c.kb, dtype);
         return LH_ERR_UNSUPPORTED;
     }
     return rc;

@@ -28,6 +28,7 @@
 #include "common.h"
 #include "igemm_args.h"
 #include "igemm_epilogue.h"
+#include "multi.h"
 
 #include <type_traits>
 
@@ -81,9 +82,10 @@ template <int L, int MAXS> __device__ __forceinline__ void wait_stages(int stage
     }
 }
 
+// The kernel proper, for workgroup `bid` of `nblk` of ONE problem: the plain kernel passes its block index, the
+// multi-problem kernel (multi.h) the index inside the problem the workgroup belongs to.
 template <typename T, int BM, int BP, int WC, int WP, int D, int KB>
-__global__ __launch_bounds__(64 * WC * WP, 2) void igemm_ring_kernel(const IgemmArgs p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void igemm_ring_body(const IgemmArgs& p, unsigned char* smem, const int bid, const int nblk) {
     constexpr int ES = sizeof(T);
     constexpr int EPC = 16 / ES;
     constexpr int KSTEP = KB / ES;                    // elements per ring stage (KB bytes per row)
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(64 * WC * WP, 2) void igemm_ring_kernel(const Igemm
     // 1-D grid; work item w = (pixel tile, channel tile) with the channel tile fastest: the channel tiles of one pixel
     // tile and neighbouring pixel tiles (3x3 halos) run on one XCD at about the same time and share its L2.
     const int CB = (p.cout + BM - 1) / BM;
-    int w = p.xcd ? lh_xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    int w = p.xcd ? lh_xcd_remap(bid, nblk) : bid;
     // per-phase quantities (scalars; the kernel argument block itself is never copied)
     const unsigned char* wgt = p.w;
     int ntaps = p.ntaps, tw = p.tw, dh0 = p.dh0, dhs = p.dhs, dw0 = p.dw0, dws = p.dws, ooh = p.ooh, oow = p.oow;
@@ -270,6 +272,21 @@ __global__ __launch_bounds__(64 * WC * WP, 2) void igemm_ring_kernel(const Igemm
 }
 
 template <typename T, int BM, int BP, int WC, int WP, int D, int KB>
+__global__ __launch_bounds__(64 * WC * WP, 2) void igemm_ring_kernel(const IgemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    igemm_ring_body<T, BM, BP, WC, WP, D, KB>(p, smem, blockIdx.x, gridDim.x);
+}
+
+// Up to LH_MULTI_MAX independent convolutions that share the kernel configuration as ONE grid (lh_igemm_multi).
+template <typename T, int BM, int BP, int WC, int WP, int D, int KB>
+__global__ __launch_bounds__(64 * WC * WP, 2) void igemm_ring_multi_kernel(const LhMulti<IgemmArgs> m) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int bid, nblk;
+    const int i = lh_multi_pick(m, bid, nblk);
+    igemm_ring_body<T, BM, BP, WC, WP, D, KB>(m.a[i], smem, bid, nblk);
+}
+
+template <typename T, int BM, int BP, int WC, int WP, int D, int KB>
 static int launch_ring(const IgemmArgs& a, hipStream_t s) {
     constexpr int ES = sizeof(T);
     constexpr int ring = D * (BM + BP) * KB;
@@ -292,3 +309,23 @@ static int launch_ring(const IgemmArgs& a, hipStream_t s) {
     return LH_OK;
 }
 
+
+template <typename T, int BM, int BP, int WC, int WP, int D, int KB>
+static int launch_ring_multi(const LhMulti<IgemmArgs>& m, hipStream_t s) {
+    constexpr int ES = sizeof(T);
+    constexpr int ring = D * (BM + BP) * KB;
+    constexpr int epi = BP * (BM * ES + 8);
+    constexpr int lds = ring > epi ? ring : epi;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_ring_multi_kernel<T, BM, BP, WC, WP, D, KB>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) {
+            lh_set_error("igemm_ring_multi: cannot raise dynamic LDS to %d bytes: %s", lds, hipGetErrorString(e));
+            return LH_ERR_HIP;
+        }
+    }
+    hipLaunchKernelGGL((igemm_ring_multi_kernel<T, BM, BP, WC, WP, D, KB>), dim3(m.first[m.n]), dim3(64 * WC * WP), lds, s, m);
+    LH_LAUNCH_CHECK("igemm_ring_multi launch");
+    return LH_OK;
+}

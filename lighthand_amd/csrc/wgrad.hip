@@ -203,8 +203,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_contig_kernel(const WreduceA
 }
 
 // Generic layout / small tensors: one thread per (tap, o, i) -- coalesced slab reads, strided writes.
-__global__ void wgrad_reduce_kernel(const WreduceArgs p) {
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void wgrad_reduce_body(const WreduceArgs& p, const int bid, const int nblk) {
+    const long idx = (long)bid * blockDim.x + threadIdx.x;
     const long per = (long)p.n_out * p.n_in;
     if (idx >= per * p.ntaps) return;
     const int t = (int)(idx / per);
@@ -224,6 +224,12 @@ __global__ void wgrad_reduce_kernel(const WreduceArgs p) {
     const float a = (a0 + a1) + (a2 + a3);
     float* g = p.grad + o * p.so + i * p.si + p.r[t] * p.sr + p.s[t] * p.ss;
     *g = p.accumulate ? *g + a : a;
+}
+__global__ void wgrad_reduce_kernel(const WreduceArgs p) { wgrad_reduce_body(p, blockIdx.x, gridDim.x); }
+__global__ void wgrad_reduce_multi_kernel(const LhMulti<WreduceArgs> m) {
+    int bid, nblk;
+    const int i = lh_multi_pick(m, bid, nblk);
+    wgrad_reduce_body(m.a[i], bid, nblk);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -246,6 +252,8 @@ struct WgradPlan {
 
 int lh_wgrad_ring_launch_bf16(const WgradArgs& a, const WgradPlan& c, hipStream_t s);
 int lh_wgrad_ring_launch_f16(const WgradArgs& a, const WgradPlan& c, hipStream_t s);
+int lh_wgrad_ring_multi_launch_bf16(const LhMulti<WgradArgs>& m, const WgradPlan& c, hipStream_t s);
+int lh_wgrad_ring_multi_launch_f16(const LhMulti<WgradArgs>& m, const WgradPlan& c, hipStream_t s);
 
 struct WgradCfg { int bo, bi, depth, kps; };
 static const WgradCfg kWCfg[] = {
@@ -401,7 +409,8 @@ static int launch_wgrad(const WgradArgs& a, hipStream_t s) {
 }
 
 static int wgrad_impl(const lh_igemm_desc* d, const void* x, const void* dy, int dy_pix_stride,
-                      int n_out, int n_in, float* slab, int dtype, void* stream, int fold_rows) {
+                      int n_out, int n_in, float* slab, int dtype, void* stream, int fold_rows,
+                      WgradArgs* prep_args = nullptr, WgradPlan* prep_plan = nullptr) {
     LH_REQUIRE(d && x && dy && slab, "lh_wgrad: null pointer");
     const int es = lh_dtype_size(dtype);
     LH_REQUIRE(es > 0, "lh_wgrad: bad dtype %d", dtype);
@@ -437,6 +446,11 @@ static int wgrad_impl(const lh_igemm_desc* d, const void* x, const void* dy, int
         a.adv_n = c.kps / hw;
         a.adv_a = (c.kps % hw) / d->wo;
         a.adv_b = c.kps % d->wo;
+        if (prep_args) {          // lh_wgrad_fused_multi: hand the argument block back instead of launching
+            *prep_args = a;
+            *prep_plan = c;
+            return LH_OK;
+        }
         const int r = dtype == LH_BF16 ? lh_wgrad_ring_launch_bf16(a, c, s) : lh_wgrad_ring_launch_f16(a, c, s);
         if (r == 1) {
             lh_set_error("lh_wgrad: no kernel for tile %dx%d stage %d depth %d", c.bo, c.bi, c.kps, c.depth);
@@ -444,6 +458,7 @@ static int wgrad_impl(const lh_igemm_desc* d, const void* x, const void* dy, int
         }
         return r;
     }
+    LH_REQUIRE(!prep_args, "lh_wgrad_fused_multi: problem does not run on the LDS-DMA weight-gradient kernel");
 #define LH_WT(T)                                                                 \
     if (c.bo == 128 && c.bi == 128) return launch_wgrad<T, 128, 128, 2, 2>(a, s); \
     if (c.bo == 128 && c.bi == 64) return launch_wgrad<T, 128, 64, 4, 1>(a, s);   \
@@ -483,12 +498,12 @@ extern "C" int lh_wgrad_fused(const lh_igemm_desc* d, int rows, const void* x, c
     return lh_wgrad_reduce(d, (const float*)workspace, grad, n_out, n_in, so, si, sr, ss, taps_rs, accumulate, dtype, stream);
 }
 
-extern "C" int lh_wgrad_reduce(const lh_igemm_desc* d, const float* slab, float* grad, int n_out,
-                               int n_in, long so, long si, long sr, long ss, const int* taps_rs,
-                               int accumulate, int dtype, void* stream) {
+// Argument block + launch shape of the fold of one weight gradient: contig = the transposing fast path applies.
+static int reduce_prepare(const lh_igemm_desc* d, const float* slab, float* grad, int n_out, int n_in, long so, long si, long sr, long ss,
+                          const int* taps_rs, int accumulate, int dtype, WreduceArgs* ap, bool* contig_out) {
     LH_REQUIRE(d && slab && grad && taps_rs, "lh_wgrad_reduce: null pointer");
     LH_REQUIRE(d->ntaps > 0 && d->ntaps <= 64, "lh_wgrad_reduce: ntaps %d out of range", d->ntaps);
-    WreduceArgs a;
+    WreduceArgs& a = *ap;
     WgradPlan c;
     const int rc = wgrad_plan(d, n_out, n_in, dtype, &c);
     if (rc) return rc;
@@ -502,7 +517,19 @@ extern "C" int lh_wgrad_reduce(const lh_igemm_desc* d, const float* slab, float*
     const long per = (long)n_out * n_in;
     bool contig = so == (long)n_in * d->ntaps && si == d->ntaps && ss == 1;
     for (int t = 0; t < d->ntaps && contig; ++t) contig = (a.r[t] * sr + a.s[t] * ss) == t;
-    if (contig && per * d->ntaps > (2L << 20)) {
+    *contig_out = contig && per * d->ntaps > (2L << 20);
+    return LH_OK;
+}
+
+extern "C" int lh_wgrad_reduce(const lh_igemm_desc* d, const float* slab, float* grad, int n_out,
+                               int n_in, long so, long si, long sr, long ss, const int* taps_rs,
+                               int accumulate, int dtype, void* stream) {
+    WreduceArgs a;
+    bool contig;
+    const int rc = reduce_prepare(d, slab, grad, n_out, n_in, so, si, sr, ss, taps_rs, accumulate, dtype, &a, &contig);
+    if (rc) return rc;
+    const long per = (long)n_out * n_in;
+    if (contig) {
         hipLaunchKernelGGL(wgrad_reduce_contig_kernel, dim3(ceil_div(per, 256)), dim3(256), 256 * (d->ntaps + 1) * sizeof(float),
                            (hipStream_t)stream, a);
         LH_LAUNCH_CHECK("wgrad_reduce launch");
@@ -511,4 +538,69 @@ extern "C" int lh_wgrad_reduce(const lh_igemm_desc* d, const float* slab, float*
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(per * d->ntaps, 256)), dim3(256), 0, (hipStream_t)stream, a);
     LH_LAUNCH_CHECK("wgrad_reduce launch");
     return LH_OK;
+}
+
+// n independent weight gradients (each with its OWN slab workspace) that share tile / stage / ring depth: ONE launch of
+// the LDS-DMA kernel for all of them, then ONE launch that folds all their pixel-split slabs (the same layer position of
+// HRNet's parallel branches, pose_hrnet.py:139-185).  Problems that need another kernel -- row folds, the register-staged
+// kernel, the transposing fold of very large tensors -- run through lh_wgrad_fused one by one.
+extern "C" int lh_wgrad_fused_multi(const lh_wgrad_call* calls, int n, int dtype, void* stream) {
+    LH_REQUIRE(calls && n >= 1, "lh_wgrad_fused_multi: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    LhMulti<WgradArgs> m;
+    LhMulti<WreduceArgs> r;
+    WgradPlan plan0 = {0, 0, 0, 0, 0, 0};
+    m.n = r.n = 0; m.first[0] = r.first[0] = 0;
+    auto flush = [&]() -> int {
+        if (m.n == 0) return LH_OK;
+        int rc;
+        if (m.n == 1) rc = dtype == LH_BF16 ? lh_wgrad_ring_launch_bf16(m.a[0], plan0, s) : lh_wgrad_ring_launch_f16(m.a[0], plan0, s);
+        else rc = dtype == LH_BF16 ? lh_wgrad_ring_multi_launch_bf16(m, plan0, s) : lh_wgrad_ring_multi_launch_f16(m, plan0, s);
+        if (rc == 1) {
+            lh_set_error("lh_wgrad_fused_multi: no multi-problem kernel for tile %dx%d stage %d depth %d", plan0.bo, plan0.bi, plan0.kps, plan0.depth);
+            return LH_ERR_UNSUPPORTED;
+        }
+        if (rc) return rc;
+        if (r.n == 1) hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(r.first[1]), dim3(256), 0, s, r.a[0]);
+        else hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(r.first[r.n]), dim3(256), 0, s, r);
+        LH_LAUNCH_CHECK("wgrad_reduce_multi launch");
+        m.n = r.n = 0;
+        return LH_OK;
+    };
+    for (int i = 0; i < n; ++i) {
+        const lh_wgrad_call& q = calls[i];
+        LH_REQUIRE(q.d && q.workspace && q.grad && q.taps_rs, "lh_wgrad_fused_multi: null pointer (problem %d)", i);
+        WgradPlan c;
+        int rc = wgrad_plan(q.d, q.n_out, q.n_in, dtype, &c);
+        if (rc) return rc;
+        WreduceArgs ra;
+        bool contig = false;
+        rc = reduce_prepare(q.d, (const float*)q.workspace, q.grad, q.n_out, q.n_in, q.so, q.si, q.sr, q.ss, q.taps_rs, q.accumulate, dtype, &ra, &contig);
+        if (rc) return rc;
+        const bool batchable = lh_dtype_size(dtype) == 2 && c.kps && q.rows <= 1 && !contig &&
+                               (c.bo <= 128 && c.bi <= 128);           // 4-wave tiles only
+        const bool same = m.n == 0 || (c.bo == plan0.bo && c.bi == plan0.bi && c.kps == plan0.kps && c.depth == plan0.depth);
+        if (!batchable || !same) {
+            rc = flush();
+            if (rc) return rc;
+        }
+        if (!batchable) {
+            rc = lh_wgrad_fused(q.d, q.rows, q.x, q.dy, q.dy_pix_stride, q.n_out, q.n_in, q.workspace, q.grad, q.so, q.si, q.sr, q.ss, q.taps_rs,
+                                q.accumulate, dtype, stream);
+            if (rc) return rc;
+            continue;
+        }
+        rc = wgrad_impl(q.d, q.x, q.dy, q.dy_pix_stride, q.n_out, q.n_in, (float*)q.workspace, dtype, stream, 0, &m.a[m.n], &c);
+        if (rc) return rc;
+        if (m.n == 0) plan0 = c;
+        m.first[m.n + 1] = m.first[m.n] + m.a[m.n].tiles * m.a[m.n].ntaps * m.a[m.n].nsplit;
+        r.a[r.n] = ra;
+        r.first[r.n + 1] = r.first[r.n] + ceil_div((long)q.n_out * q.n_in * q.d->ntaps, 256);
+        ++m.n; ++r.n;
+        if (m.n == LH_MULTI_MAX) {
+            rc = flush();
+            if (rc) return rc;
+        }
+    }
+    return flush();
 }

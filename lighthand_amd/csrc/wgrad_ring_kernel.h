@@ -22,6 +22,7 @@
 //    every split count this network uses, and its registers slowed the large tiles; removed.
 #pragma once
 #include "common.h"
+#include "multi.h"
 
 #include <type_traits>
 
@@ -79,9 +80,10 @@ template <> struct WMma<f16> {
     }
 };
 
+// The kernel proper for workgroup `bid` of `nblk` of ONE problem (plain launch: the block index; multi-problem launch,
+// multi.h: the index inside the problem the workgroup belongs to).
 template <typename T, int BO, int BI, int WO, int WI, int D, int KPS>
-__global__ __launch_bounds__(64 * WO * WI, 2) void wgrad_ring_kernel(const WgradArgs p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void wgrad_ring_body(const WgradArgs& p, unsigned char* smem, const int bid, const int nblk) {
     static_assert(sizeof(T) == 2, "16-bit types only");
     constexpr int KP = 32;                                    // pixels per logical step (one MFMA K slice)
     constexpr int KSUB = KPS / KP;
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(64 * WO * WI, 2) void wgrad_ring_kernel(const Wgrad
     const int wo_ = wave / WI, wi_ = wave % WI;
     // work item w = (split, tap, tile), tile fastest: every XCD gets a contiguous range of pixel splits with all their
     // taps and tiles, which re-read the same dy / x rows from that XCD's L2 instead of the Infinity Cache
-    const int w = p.xcd ? lh_xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int w = p.xcd ? lh_xcd_remap(bid, nblk) : bid;
     const int tile = w % p.tiles, tap = (w / p.tiles) % p.ntaps, split = w / (p.tiles * p.ntaps);
     const int otile = tile / p.i_tiles, itile = tile % p.i_tiles;
     const int dh = p.dh[tap], dw = p.dw[tap];
@@ -289,4 +291,19 @@ __global__ __launch_bounds__(64 * WO * WI, 2) void wgrad_ring_kernel(const Wgrad
                 *reinterpret_cast<float4*>(slab + (long)o * p.n_in + ci) = float4{acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
         }
     }
+}
+
+template <typename T, int BO, int BI, int WO, int WI, int D, int KPS>
+__global__ __launch_bounds__(64 * WO * WI, 2) void wgrad_ring_kernel(const WgradArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    wgrad_ring_body<T, BO, BI, WO, WI, D, KPS>(p, smem, blockIdx.x, gridDim.x);
+}
+
+// Up to LH_MULTI_MAX independent weight gradients that share the tile / stage / ring depth as ONE grid (lh_wgrad_fused_multi).
+template <typename T, int BO, int BI, int WO, int WI, int D, int KPS>
+__global__ __launch_bounds__(64 * WO * WI, 2) void wgrad_ring_multi_kernel(const LhMulti<WgradArgs> m) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int bid, nblk;
+    const int i = lh_multi_pick(m, bid, nblk);
+    wgrad_ring_body<T, BO, BI, WO, WI, D, KPS>(m.a[i], smem, bid, nblk);
 }

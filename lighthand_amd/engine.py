@@ -152,12 +152,14 @@ def _taps_array(rs):
 class _Call:
     """A pre-bound C-ABI call; the stream is appended at run time.  ``lane`` 1 marks work that may run on
     the side stream of the backward pass (weight gradients: they only feed the optimizer)."""
-    __slots__ = ("fn", "args", "what", "keep", "lane", "ig", "slane")
+    __slots__ = ("fn", "args", "what", "keep", "lane", "ig", "slane", "mtag", "keep_desc")
 
     def __init__(self, fn, args, what, keep=None, lane=0):
         self.fn, self.args, self.what, self.keep, self.lane = fn, args, what, keep, lane
         self.ig = None               # argument positions for Plan._patch (lh_igemm layout unless set)
         self.slane = 0               # stream lane (branch) the call belongs to
+        self.keep_desc = None        # weight-gradient calls: their descriptor (Plan._batch_wgrads)
+        self.mtag = None             # (group, section, member, position): calls of one batch group that may merge (Plan._merge_groups)
 
     def __call__(self, stream):
         rc = self.fn(*self.args, stream)
@@ -220,6 +222,14 @@ class Plan:
         self.node_lanes = gb.node_lanes
         self.n_lanes = max(gb.node_lanes) + 1 if gb.node_lanes else 1
         self.use_lanes = self.n_lanes > 1
+        # Multi-problem launches: the nodes at the same position of the parallel chains of a fork .. join region (HRNet's
+        # branches) are compiled as a GROUP whose launches merge into lh_*_multi calls (one grid for 2-4 problems) on the
+        # main stream, instead of one launch per branch on stream lanes.  16-bit types; LH_BATCH=0 keeps the lanes.
+        self.batch = os.environ.get("LH_BATCH", "1") != "0" and self.es == 2 and self.n_lanes > 1
+        self.batch_split = os.environ.get("LH_BATCH", "1") == "2"
+        self.wgrad_batch = os.environ.get("LH_WGRAD_BATCH", "1") != "0" and self.es == 2
+        self._forced = None                # kernel choices of the group being compiled (see _tune_group)
+        self._n_groups = 0
         self._lane_streams = {L: torch.cuda.Stream(device=self.device) for L in range(1, self.n_lanes)} if self.use_lanes else {}
         self._cur_lane = 0
         # Deferred weight gradients: the weight-gradient launches (+ folds) of a GROUP of layers are appended behind one
@@ -452,13 +462,17 @@ class Plan:
             self._tune_bufs[name] = t
         return t
 
-    def _tune(self, descs, with_stats=False, addend=None):
+    def _tune(self, descs, with_stats=False, addend=None, role=None):
         """Measured kernel choice (cdna guide: measure, don't guess): time every compiled-in configuration that fits
         this launch (lh_igemm_candidates) on scratch operands of the real size and write the fastest into the
         descriptors' cfg.  One descriptor = lh_igemm; several = the phases of lh_igemm_phases (one shared choice).
         Results do not depend on the choice (the K-loop order is the same for every tile).  LH_AUTOTUNE=0 keeps the
         library's static default."""
         if os.environ.get("LH_AUTOTUNE", "1") == "0":
+            return
+        if self._forced is not None and role in self._forced and len(descs) == 1:     # member of a batch group: the group's choice
+            for d in descs:
+                d.cfg[0], d.cfg[1], d.cfg[2], d.cfg[3] = self._forced[role]
             return
         lead = max(descs, key=lambda d: d.ntaps)
         if lead.ntaps == 0:
@@ -538,6 +552,9 @@ class Plan:
         that every plan of a process computes the same sums."""
         if os.environ.get("LH_AUTOTUNE", "1") == "0":
             return
+        if self._forced is not None and "wgrad" in self._forced and not tag:
+            d.cfg[5], d.cfg[6], d.cfg[7] = self._forced["wgrad"][self._forced["member"]]
+            return
         key = ("w", self.dt, self._desc_key(d), n_out, n_in, dy_stride) + tuple(tag)
         hit = Plan._TUNE_CACHE.get(key) if Plan.force_wgrad is None else None
         buf = (C.c_int * (5 * 128))()
@@ -611,7 +628,7 @@ class Plan:
             yield max(descs, key=lambda d: d.ntaps), sum(d.ntaps for d in descs)
             return
         for dd, pk in zip(descs, packs):
-            self._tune([dd], addend=kind)
+            self._tune([dd], addend=kind, role="dgrad")
             self._igemm(self.bwd, dd, dy, pk, dx, addend, None, None, what, addend_mask=amask)
             yield dd, dd.ntaps
 
@@ -704,10 +721,51 @@ class Plan:
             c.slane = lane
         for ent in p["ws"]:                  # the group's slab workspace follows its stream
             ent[2] = lane
+        if self.wgrad_batch:
+            p["calls"] = self._batch_wgrads(p["calls"])
         self.bwd += p["calls"]
         if p["names"]:
             self.bwd_marks.append((len(self.bwd), p["names"]))
         self._pend[src] = dict(calls=[], names=[], layers=0, ws=[], bytes=0)
+
+    def _batch_wgrads(self, calls):
+        """The weight gradients of a deferred group are independent of each other and of everything else on their side
+        stream: launches of the SAME shape and kernel plan (the repeated blocks of a stage) are brought next to each other
+        and tagged to merge four at a time into lh_wgrad_fused_multi -- one weight-gradient launch and one fold launch for
+        four layers.  The small late-stage layers (a few hundred workgroups, 20-40 us each) fill the machine together."""
+        fused = self.lib.lh_wgrad_fused
+        units, keys = [], []
+        for c in calls:
+            if isinstance(c, _Call) and c.fn is fused and c.mtag is None:
+                units.append([c])
+            elif units and not (isinstance(c, _Call) and c.fn is fused):
+                units[-1].append(c)
+            else:
+                units.append([c])
+        def key(u):
+            c = u[0]
+            if not (isinstance(c, _Call) and c.fn is fused and c.mtag is None and len(u) == 1 and c.keep_desc is not None):
+                return None
+            d = c.keep_desc
+            return (self._desc_key(d), d.cfg[5], d.cfg[6], d.cfg[7])
+        order, out = {}, []
+        for u in units:
+            k = key(u)
+            order.setdefault(k if k is not None else ("single", id(u)), []).append(u)
+        for k, us in order.items():
+            if isinstance(k, tuple) and k and k[0] == "single" or len(us) < 2:
+                for u in us:
+                    out += u
+                continue
+            for i0 in range(0, len(us), 4):
+                chunk = us[i0:i0 + 4]
+                if len(chunk) >= 2:
+                    self._n_groups += 1
+                    for j, u in enumerate(chunk):
+                        u[0].mtag = (("wb", self._n_groups), "w", j, 0)
+                for u in chunk:
+                    out += u
+        return out
 
     def _first_write(self, a):
         """True the first time a gradient buffer is produced in the backward list (every writer calls this once)."""
@@ -748,17 +806,31 @@ class Plan:
                     self._uses.setdefault(id(a), []).append((kind, nd))
             elif kind == "output":
                 self._uses.setdefault(id(nd["y"]), []).append((kind, nd))
-        bwd_blocks = []
-        for (kind, nd), lane in zip(self.nodes, self.node_lanes):
-            blk = []
-            n0 = len(self.fwd)
-            getattr(self, "_c_" + kind)(nd, blk)
-            for c in self.fwd[n0:]:
-                c.slane = lane
-            out_act = nd.get("y", nd.get("out")) if isinstance(nd, dict) else nd
-            if out_act is not None:
-                self._ready[id(out_act)] = len(self.fwd)      # list position from which this activation is complete
-            bwd_blocks.append(blk)
+        items = self._batch_order()        # lists of node indices; more than one = a batch group
+        bwd_blocks, group_forced = {}, {}
+        for item in items:
+            gid = None
+            if len(item) > 1:
+                self._n_groups += 1
+                gid = self._n_groups
+                self._forced = self._tune_group([self.nodes[i][1] for i in item]) if self.nodes[item[0]][0] == "conv" else None
+                group_forced[item[0]] = self._forced
+            for j, i in enumerate(item):
+                (kind, nd), lane = self.nodes[i], self.node_lanes[i]
+                if self._forced is not None:
+                    self._forced["member"] = j
+                blk = []
+                n0 = len(self.fwd)
+                getattr(self, "_c_" + kind)(nd, blk)
+                for k, c in enumerate(self.fwd[n0:]):
+                    c.slane = lane
+                    if gid is not None and isinstance(c, _Call):
+                        c.mtag = (gid, "f", j, k)
+                out_act = nd.get("y", nd.get("out")) if isinstance(nd, dict) else nd
+                if out_act is not None:
+                    self._ready[id(out_act)] = len(self.fwd)      # list position from which this activation is complete
+                bwd_blocks[i] = blk
+            self._forced = None
         # backward list: node blocks in reverse order; accumulate flags resolved in that order
         if self._pack_items:       # every weight pack of the model is rebuilt by ONE launch
             arr = (_lib.PackItem * len(self._pack_items))(*self._pack_items)
@@ -791,35 +863,57 @@ class Plan:
                                      max(cv.rs for cv in convs), self.dt), "weight packs (tiled)"))
         self.bwd_marks = []        # (end index in self.bwd, parameter names whose gradient is final there)
         if self.with_bwd:
-            for (kind, nd), blk, lane in zip(reversed(self.nodes), reversed(bwd_blocks), reversed(self.node_lanes)):
-                self._cur_lane = lane
-                if kind == "fork" and self.wgrad_group > 0:      # end of a branch region in backward order: every lane hands
-                    for src in sorted(self._pend):                # its group over before the main stream joins
-                        self._flush_wgrads(src)
-                n0 = len(self.bwd)
-                for emit in blk:
-                    emit()
-                for c in self.bwd[n0:]:
-                    c.slane = lane
-                names = []
-                if kind in ("conv", "deconv"):
-                    wnames = [nd["w"] + ".weight"] + ([nd["bias"]] if nd["bias"] else [])
-                    if self.wgrad_group > 0:
-                        p = self._pending()
-                        p["names"] += wnames
-                        p["layers"] += 1
-                        p["bytes"] += sum(self.params[k].numel() * 4 for k in wnames)
-                        # same rule as parallel.wgrad_group_cuts (tested on the CPU with the real parameter sizes)
-                        if p["layers"] >= self.wgrad_group or (self.wgrad_bucket_bytes and p["bytes"] >= self.wgrad_bucket_bytes):
-                            self._flush_wgrads(lane)
-                    else:
-                        names += wnames
-                elif kind == "fuse":
-                    for _, bn, _ in nd["terms"]:
-                        if bn is not None:
-                            names += [bn + ".weight", bn + ".bias"]
-                if names:
-                    self.bwd_marks.append((len(self.bwd), names))
+            gcount = self._n_groups
+            for item in reversed(items):
+                gid = None
+                if len(item) > 1:
+                    gcount += 1
+                    gid = gcount
+                flush_lanes = []
+                self._forced = group_forced.get(item[0])          # the data gradients are tuned while the blocks are emitted
+                for j, i in enumerate(item):
+                    (kind, nd), blk, lane = self.nodes[i], bwd_blocks[i], self.node_lanes[i]
+                    self._cur_lane = lane
+                    if self._forced is not None:
+                        self._forced["member"] = j
+                    if kind == "fork" and self.wgrad_group > 0:      # end of a branch region in backward order: every lane hands
+                        for src in sorted(self._pend):                # its group over before the main stream joins
+                            self._flush_wgrads(src)
+                    n0 = len(self.bwd)
+                    w0 = len(self._pending()["calls"]) if self.wgrad_group > 0 else 0
+                    for emit in blk:
+                        emit()
+                    for k, c in enumerate(self.bwd[n0:]):
+                        c.slane = lane
+                        if gid is not None and isinstance(c, _Call):
+                            c.mtag = (gid, "b", j, k)
+                    if gid is not None and self.wgrad_group > 0:
+                        for k, c in enumerate(self._pending()["calls"][w0:]):
+                            if isinstance(c, _Call):
+                                c.mtag = (gid, "w", j, k)
+                    names = []
+                    if kind in ("conv", "deconv"):
+                        wnames = [nd["w"] + ".weight"] + ([nd["bias"]] if nd["bias"] else [])
+                        if self.wgrad_group > 0:
+                            p = self._pending()
+                            p["names"] += wnames
+                            p["layers"] += 1
+                            p["bytes"] += sum(self.params[k].numel() * 4 for k in wnames)
+                            # same rule as parallel.wgrad_group_cuts (tested on the CPU with the real parameter sizes)
+                            if p["layers"] >= self.wgrad_group or (self.wgrad_bucket_bytes and p["bytes"] >= self.wgrad_bucket_bytes):
+                                flush_lanes.append(lane)          # after the whole item: a batch group hands over together
+                        else:
+                            names += wnames
+                    elif kind == "fuse":
+                        for _, bn, _ in nd["terms"]:
+                            if bn is not None:
+                                names += [bn + ".weight", bn + ".bias"]
+                    if names:
+                        self.bwd_marks.append((len(self.bwd), names))
+                self._forced = None
+                for lane in dict.fromkeys(flush_lanes):
+                    self._cur_lane = lane
+                    self._flush_wgrads(lane)
             for src in sorted(self._pend):
                 self._flush_wgrads(src)
             self.bwd_marks.sort(key=lambda m: m[0])
@@ -834,6 +928,302 @@ class Plan:
                 setter(ws_w[L].data_ptr())
             for setter, lane in self._ws_users_fuse:
                 setter(ws_f[lane if self.use_lanes else 0].data_ptr())
+        if self._n_groups:
+            self._merge_groups()
+
+    def _c_nop(self, nd, blk):
+        pass
+
+    def _batch_order(self):
+        """Compile order of the nodes: a list of items, each a list of node indices.  A fork .. join region (chains that are
+        independent of each other, one per lane) is re-ordered position by position: the heads of the chains that are nodes
+        of the same kind (convolution / BN-ReLU node) form ONE item, a batch group; every chain keeps its own order, so
+        every dependency holds.  The region then runs on the main stream (its markers become no-ops)."""
+        items, i, n = [], 0, len(self.nodes)
+        while i < n:
+            if self.nodes[i][0] != "fork" or not self.batch:
+                items.append([i])
+                i += 1
+                continue
+            j = i + 1
+            while self.nodes[j][0] != "join":
+                j += 1
+            lanes = {}
+            for t in range(i + 1, j):
+                lanes.setdefault(self.node_lanes[t], []).append(t)
+            if len(lanes) < 2:
+                items += [[t] for t in range(i, j + 1)]
+                i = j + 1
+                continue
+            # LH_BATCH=2: two half-groups (branches 0-1 | the rest) on two stream lanes, each merged pairwise -- the deep-K,
+            # few-workgroup convolutions of the low-resolution branches then overlap the wide shallow ones of the others
+            order = sorted(lanes)
+            halves = [order[:2], order[2:]] if self.batch_split and len(order) >= 3 else [order]
+            if len(halves) == 1:
+                self.nodes[i] = self.nodes[j] = ("nop", {})
+            items.append([i])
+            for hi, half in enumerate(halves):
+                for L in half:
+                    for t in lanes[L]:
+                        self.node_lanes[t] = hi
+                queues = [list(lanes[L]) for L in half]
+                while any(queues):
+                    heads = {}
+                    for q in queues:
+                        if q:
+                            heads.setdefault(self.nodes[q[0]][0], []).append(q)
+                    kind = max(heads, key=lambda k: (len(heads[k]), k == "conv"))
+                    qs = heads[kind]
+                    if len(qs) >= 2 and kind in ("conv", "fuse"):
+                        items.append([q.pop(0) for q in qs])
+                    else:
+                        items.append([qs[0].pop(0)])
+            items.append([j])
+            i = j + 1
+        return items
+
+    # ---- batch groups: joint kernel choice, then merging of the members' launches ------------------------------------
+    def _conv_descs(self, nd):
+        """Forward and (stride 1) data-gradient descriptor of a convolution node, as _c_conv builds them."""
+        x, y, k, s, p = nd["x"], nd["y"], nd["k"], nd["s"], nd["p"]
+        wt = self.params[nd["w"] + ".weight"]
+        cout, cin = wt.shape[0], wt.shape[1]
+        all_rs = [(r, q) for r in range(k) for q in range(k)]
+        fwd = _desc(x.n, x.h, x.w, x.c, cin, y.h, y.w, s, s, y.c, y.h, y.w, 1, 1, 0, 0, y.c, [(r - p, q - p) for r, q in all_rs])
+        dg = None
+        if s == 1 and x.needs_grad and self.with_bwd:
+            dg = _desc(y.n, y.h, y.w, y.c, y.c if y.c != cout else cout, x.h, x.w, 1, 1, x.c, x.h, x.w, 1, 1, 0, 0, x.c,
+                       [(p - r, p - q) for r, q in all_rs])
+        return fwd, dg
+
+    _MULTI_TILES = ((64, 64), (64, 128), (128, 64), (128, 128))       # tiles the multi-problem kernels are instantiated for
+
+    def _tune_group(self, nds):
+        """ONE kernel configuration for the launches of a batch group of convolutions that will merge (forward, data
+        gradient, weight gradient): the merged launch needs a common tile, so the members are not tuned one by one --
+        every configuration that fits all of them is timed on the merged launch (scratch operands, cold caches).
+        Returns the forced choices _tune / _tune_wgrad pick up while the members compile."""
+        if os.environ.get("LH_AUTOTUNE", "1") == "0" or Plan.force_cfg is not None or Plan.force_wgrad is not None:
+            return None
+        if any(nd["x"].is_image for nd in nds):
+            return None
+        descs = [self._conv_descs(nd) for nd in nds]
+        forced = {"member": 0}
+        es = self.es
+        for role, idx in (("fwd", 0), ("dgrad", 1)):
+            ds = [d[idx] for d in descs]
+            if any(d is None for d in ds):
+                continue
+            with_stats = role == "fwd" and self.training and all(id(nd["y"]) in self._bn_inputs for nd in nds)
+            key = ("g", role, self.dt, with_stats) + tuple(self._desc_key(d) for d in ds)
+            common = None
+            for d in ds:
+                buf = (C.c_int * (5 * 64))()
+                n = self.lib.lh_igemm_candidates(C.byref(d), self.dt, buf, 64)
+                c = {tuple(buf[5 * i:5 * i + 4]) for i in range(n)}
+                common = c if common is None else common & c
+            cands = sorted(c for c in (common or ()) if c[2] >= 2 and (c[0], c[1]) in self._MULTI_TILES)
+            hit = Plan._TUNE_CACHE.get(key)
+            if hit is not None and hit not in cands:
+                hit = None
+            if hit is None and cands:
+                arr = (_lib.IgemmCall * len(ds))()
+                warm = []
+                for i, d in enumerate(ds):
+                    kpad = (d.k_run * es + 127) // 128 * 128
+                    src = self._scratch(f"g{i}in", d.n * d.hi * d.wi * d.in_pix_stride * es + 256)
+                    arr[i].d = C.pointer(d)
+                    arr[i].in_ = src.data_ptr()
+                    arr[i].wpack = self._scratch(f"g{i}pack", (d.cout + 255) // 256 * 256 * max(d.ntaps, 1) * kpad + 256).data_ptr()
+                    arr[i].out = self._scratch(f"g{i}out", d.n * d.OH * d.OW * d.out_pix_stride * es + 256).data_ptr()
+                    if with_stats:
+                        arr[i].stats = self._scratch(f"g{i}stats", max((d.n * d.ho * d.wo + 63) // 64, 1024) * 2 * d.cout * 4 + 256).data_ptr()
+                    warm.append(src[:d.n * d.hi * d.wi * d.in_pix_stride * es])
+                sp = torch.cuda.current_stream().cuda_stream
+
+                def run():
+                    check(self.lib.lh_igemm_multi(arr, len(ds), self.dt, sp), "group autotune lh_igemm_multi")
+                best = None
+                for cfg in cands:
+                    for d in ds:
+                        d.cfg[0], d.cfg[1], d.cfg[2], d.cfg[3] = cfg
+                    run()
+                    t = self._timed_cold(run, warm, Plan.tune_iters())
+                    if best is None or t < best[0]:
+                        best = (t, cfg)
+                hit = best[1]
+                Plan._TUNE_CACHE[key] = hit
+                Plan._tune_measured.add(key)
+            if hit is not None:
+                forced[role] = hit
+        # weight gradient: common (tile, stage rows, ring depth); per member the plan with the fewest workgroups -- the batch
+        # fills the machine, a member need not
+        if self.with_bwd:
+            per, common = [], None
+            for (d, _), nd in zip(descs, nds):
+                y, wt = nd["y"], self.params[nd["w"] + ".weight"]
+                buf = (C.c_int * (5 * 128))()
+                n = self.lib.lh_wgrad_candidates(C.byref(d), y.c, wt.shape[1], self.dt, buf, 128)
+                cs = [tuple(buf[5 * i:5 * i + 5]) for i in range(n)]
+                per.append(cs)
+                keys = {(c[0], c[1], (c[2] >> 16) & 255, (c[2] >> 24) & 255) for c in cs if c[0] <= 128 and c[1] <= 128}
+                common = keys if common is None else common & keys
+            key = ("gw", self.dt) + tuple(self._desc_key(d) for d, _ in descs)
+            hit = Plan._TUNE_CACHE.get(key)
+            if hit is not None and tuple(hit[:4]) not in (common or ()):
+                hit = None
+            if hit is None and common:
+                arr = (_lib.WgradCall * len(nds))()
+                warm, keep = [], []
+                for i, ((d, _), nd) in enumerate(zip(descs, nds)):
+                    y, wt, k = nd["y"], self.params[nd["w"] + ".weight"], nd["k"]
+                    cin = wt.shape[1]
+                    rs = _taps_array([(r, q) for r in range(k) for q in range(k)])
+                    dys = self._scratch(f"g{i}dy", d.n * d.ho * d.wo * y.c * es + 256)
+                    slab = self._scratch(f"g{i}wws", (max(c[4] for c in per[i]) + 1) << 20)
+                    arr[i].d, arr[i].rows = C.pointer(d), 0
+                    arr[i].x = self._scratch(f"g{i}in", d.n * d.hi * d.wi * d.in_pix_stride * es + 256).data_ptr()
+                    arr[i].dy, arr[i].dy_pix_stride, arr[i].n_out, arr[i].n_in = dys.data_ptr(), y.c, y.c, cin
+                    arr[i].workspace = slab.data_ptr()
+                    arr[i].grad = self._scratch(f"g{i}stats", y.c * cin * k * k * 4 + 256).data_ptr()
+                    arr[i].so, arr[i].si, arr[i].sr, arr[i].ss = cin * k * k, k * k, k, 1
+                    arr[i].taps_rs = C.cast(rs, C.POINTER(C.c_int))
+                    keep.append(rs)
+                    warm.append(dys[:d.n * d.ho * d.wo * y.c * es])
+                sp = torch.cuda.current_stream().cuda_stream
+
+                def runw():
+                    check(self.lib.lh_wgrad_fused_multi(arr, len(nds), self.dt, sp), "group autotune lh_wgrad_fused_multi")
+                best = None
+                for tk in sorted(common):
+                    for policy in (0, 1):                 # fewest workgroups per member / next larger split count
+                        encs = []
+                        for cs in per:
+                            opts = sorted((c for c in cs if (c[0], c[1], (c[2] >> 16) & 255, (c[2] >> 24) & 255) == tk), key=lambda c: c[3])
+                            encs.append(opts[min(policy, len(opts) - 1)][2])
+                        for (d, _), enc in zip(descs, encs):
+                            d.cfg[5], d.cfg[6], d.cfg[7] = tk[0], tk[1], enc
+                        runw()
+                        t = self._timed_cold(runw, warm, Plan.tune_iters())
+                        if best is None or t < best[0]:
+                            best = (t, tk + (tuple(encs),))
+                hit = best[1]
+                Plan._TUNE_CACHE[key] = hit
+                Plan._tune_measured.add(key)
+            if hit is not None:
+                forced["wgrad"] = [(hit[0], hit[1], enc) for enc in hit[4]]
+        return forced
+
+    _MULTI_FN = None
+
+    def _merge_groups(self):
+        """Final pass of _compile: inside every run of launches that belong to one batch group, the k-th launch of each
+        member merges with the others' into one lh_*_multi call when they are the same C-ABI function (and, for the
+        convolutions, resolve to the same kernel configuration).  Members are independent of each other, so ordering the
+        run position by position is legal.  Weight-gradient slabs and BN-backward workspaces, shared one after another on a
+        stream by single launches, are handed out side by side to the members of a merged call."""
+        lib = self.lib
+        mergeable = (lib.lh_igemm, lib.lh_bn_finalize, lib.lh_fuse_fwd, lib.lh_fuse_bwd, lib.lh_wgrad_fused)     # ctypes functions do not hash
+        pools, binds = {}, []               # (kind, stream lane) -> bytes needed; (struct array, index, field, pool key, offset)
+        meta = {id(c): (name, fl, nb) for _, c, name, fl, nb in self.profile_meta}
+
+        def build(fn, calls):
+            n = len(calls)
+            what = calls[0].what.split(" ")[-1] if fn is not lib.lh_igemm else " ".join(calls[0].what.split(" ")[1:])
+            what = f"{n} x {what}"
+            if fn is lib.lh_igemm:
+                cfgs = set()
+                for c in calls:
+                    cfg = (C.c_int * 5)()
+                    check(lib.lh_igemm_config(c.args[0], self.dt, cfg), "lh_igemm_config")
+                    cfgs.add(tuple(cfg[:4]))
+                cfg = next(iter(cfgs))
+                if len(cfgs) != 1 or cfg[2] < 2 or (cfg[0], cfg[1]) not in self._MULTI_TILES:
+                    return None
+                arr = (_lib.IgemmCall * n)()
+                for i, c in enumerate(calls):
+                    a = c.args
+                    arr[i].d = C.pointer(a[0]._obj)
+                    (arr[i].in_, arr[i].wpack, arr[i].out, arr[i].addend, arr[i].addend_mask, arr[i].bias, arr[i].scale, arr[i].shift,
+                     arr[i].stats) = a[1:10]
+                m = _Call(lib.lh_igemm_multi, (arr, n, self.dt), what, keep=[c.keep for c in calls])
+            elif fn is lib.lh_bn_finalize:
+                arr = (_lib.BnFinalizeCall * n)(*[_lib.BnFinalizeCall(*c.args) for c in calls])
+                m = _Call(lib.lh_bn_finalize_multi, (arr, n), what)
+            elif fn is lib.lh_fuse_fwd:
+                arr = (_lib.FuseFwdCall * n)()
+                for i, c in enumerate(calls):
+                    a = c.args
+                    arr[i].d, arr[i].out, arr[i].n, arr[i].h, arr[i].w, arr[i].c = C.pointer(a[0]._obj), a[1], a[2], a[3], a[4], a[5]
+                m = _Call(lib.lh_fuse_fwd_multi, (arr, n, self.dt), what)
+            elif fn is lib.lh_fuse_bwd:
+                arr = (_lib.FuseBwdCall * n)()
+                off = 0
+                for i, c in enumerate(calls):
+                    a = c.args
+                    arr[i].d, arr[i].n, arr[i].h, arr[i].w, arr[i].c = C.pointer(a[0]._obj), a[1], a[2], a[3], a[4]
+                    binds.append((arr, i, "workspace", ("f", calls[0].slane), off))
+                    off += (lib.lh_fuse_bwd_workspace_bytes(a[1], a[2], a[3], a[4]) + 255) // 256 * 256
+                pools[("f", calls[0].slane)] = max(pools.get(("f", calls[0].slane), 0), off)
+                m = _Call(lib.lh_fuse_bwd_multi, (arr, n, self.dt), what)
+            else:
+                arr = (_lib.WgradCall * n)()
+                off = 0
+                for i, c in enumerate(calls):
+                    a = c.args
+                    arr[i].d, arr[i].rows, arr[i].x, arr[i].dy, arr[i].dy_pix_stride, arr[i].n_out, arr[i].n_in = C.pointer(a[0]._obj), *a[1:7]
+                    arr[i].grad, arr[i].so, arr[i].si, arr[i].sr, arr[i].ss = a[8:13]
+                    arr[i].taps_rs, arr[i].accumulate = C.cast(a[13], C.POINTER(C.c_int)), a[14]
+                    binds.append((arr, i, "workspace", ("w", calls[0].slane), off))
+                    off += (lib.lh_wgrad_workspace_bytes(a[0], a[5], a[6], self.dt) + 255) // 256 * 256
+                pools[("w", calls[0].slane)] = max(pools.get(("w", calls[0].slane), 0), off)
+                m = _Call(lib.lh_wgrad_fused_multi, (arr, n, self.dt), what, keep=[c.keep for c in calls], lane=calls[0].lane)
+            m.slane = calls[0].slane
+            self.keep += [arr] + list(calls)
+            ms = [meta[id(c)] for c in calls if id(c) in meta]
+            if ms:
+                name = ms[0][0].replace("igemm_ring_kernel", "igemm_ring_multi_kernel").replace("wgrad_ring_kernel", "wgrad_ring_multi_kernel")
+                self.profile_meta.append(("fwd" if calls[0].mtag[1] == "f" else "bwd", m, name, sum(x[1] for x in ms), sum(x[2] for x in ms)))
+            return m
+
+        def merged(lst):
+            out, remap, i = [], {}, 0
+            while i < len(lst):
+                c = lst[i]
+                tag = getattr(c, "mtag", None)
+                if tag is None:
+                    remap[i] = len(out)
+                    out.append(c)
+                    i += 1
+                    continue
+                j = i
+                while j < len(lst) and getattr(lst[j], "mtag", None) is not None and lst[j].mtag[:2] == tag[:2]:
+                    j += 1
+                members = {}
+                for c2 in lst[i:j]:
+                    members.setdefault(c2.mtag[2], []).append(c2)
+                chains = [members[k] for k in sorted(members)]
+                new = []
+                for k in range(max(len(ch) for ch in chains)):
+                    row = [ch[k] for ch in chains if k < len(ch)]
+                    m = None
+                    if len(row) >= 2 and all(r.fn is row[0].fn for r in row) and any(row[0].fn is f for f in mergeable) and all(r.slane == row[0].slane for r in row):
+                        m = build(row[0].fn, row)
+                    new += [m] if m is not None else row
+                for t in range(i, j):
+                    remap[t] = len(out) + len(new)        # a position inside the run maps to the run's end
+                out += new
+                i = j
+            remap[len(lst)] = len(out)
+            return out, remap
+
+        self.unmerged = (list(self.fwd), list(self.bwd))      # the same launches one by one (tests: bit-equal results)
+        self.fwd, _ = merged(self.fwd)
+        self.bwd, remap = merged(self.bwd)
+        self.bwd_marks = [(remap[e], names) for e, names in self.bwd_marks]
+        bufs = {k: self._alloc(max(v, 256), dtype=torch.uint8) for k, v in pools.items()}
+        for arr, i, field, k, off in binds:
+            setattr(arr[i], field, bufs[k].data_ptr() + off)
 
     def _c_fork(self, nd, blk):
         self.fwd.append(_Marker("fork"))
@@ -944,7 +1334,7 @@ class Plan:
         if self._fuse_head(nd, pack, bias):
             return
         stats_ptr = None
-        self._tune([d], with_stats=id(y) in self._bn_inputs and self.training)
+        self._tune([d], with_stats=id(y) in self._bn_inputs and self.training, role="fwd")
         if id(y) in self._bn_inputs and self.training:
             self._stats_for(y, [d])
             stats_ptr = y.stats
@@ -982,6 +1372,7 @@ class Plan:
             a = [C.byref(d), 0, xbuf.data_ptr(), dy.data_ptr(), y.c, y.c, cin, 0, gtmp.data_ptr(), cin * k * k, k * k, k, 1, rs_arr, 0, self.dt]
             tail = 1
             cw = _Call(self.lib.lh_wgrad_fused, None, nd["w"] + " wgrad", keep=rs_arr, lane=1)
+            cw.keep_desc = d
 
             def set_ws(ptr, cw=cw, a=a):
                 a[7] = ptr

@@ -333,3 +333,59 @@ def test_c2_r50_bf16_gradients_vs_fp32_oracle():
     assert np.median(cos) >= 0.9
     assert herr < 5e-2            # flat random-feature maps; the forward pin is test_c2_r50_bf16_train_forward_matches_fp32_oracle
     assert lrel < 1e-3
+
+
+def test_hrnet_branch_batching_is_bit_exact_and_cuts_launches(monkeypatch):
+    """HRNet's parallel branches as multi-problem launches (lh_igemm_multi / lh_bn_finalize_multi / lh_fuse_fwd_multi /
+    lh_fuse_bwd_multi / lh_wgrad_fused_multi; pose_hrnet.py:139-185, 247-265): the merged launch lists give BIT-IDENTICAL
+    heat-maps and parameter gradients to the same launches run one by one on the same plan, the batched plan issues well
+    under half the C-ABI calls of the stream-lane plan (LH_BATCH=0), and the two plans agree to the bf16 tolerance
+    (they differ in tile choice, i.e. in the number of BN partial-sum rows)."""
+    from lighthand_amd.engine import _Call
+    torch.manual_seed(3)
+    model, _ = _build("hrnet_w32")
+    model = model.cuda().set_precision("bf16").train()
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    rng = np.random.RandomState(2)
+    b, h, w = 4, 128, 96
+    x = torch.from_numpy(rng.randn(b, 3, h, w).astype(np.float32)).cuda()
+    dheat = torch.from_numpy(rng.randn(b, 21, h // 4, w // 4).astype(np.float32)).cuda()
+
+    def run(plan, lists):
+        model.load_state_dict(sd0)
+        s = torch.cuda.current_stream().cuda_stream
+        plan.img_nchw.copy_(x)
+        plan.dout_nchw.copy_(dheat)
+        plan.refresh_packs(s)
+        saved = plan.fwd, plan.bwd
+        plan.fwd, plan.bwd = lists
+        try:
+            plan.run_forward(s)
+            plan.run_backward(s)
+            torch.cuda.synchronize()
+        finally:
+            plan.fwd, plan.bwd = saved
+        return plan.out_nchw.clone(), model.arena().flat_grad.clone()
+
+    plan = model.plan(b, h, w, training=True, backward=True)
+    assert plan.batch and plan._n_groups > 0
+    n_multi = sum(1 for c in plan.fwd + plan.bwd if isinstance(c, _Call) and c.fn.__name__.endswith("_multi"))
+    calls_b = sum(1 for c in plan.fwd + plan.bwd if isinstance(c, _Call))
+    calls_u = sum(1 for c in plan.unmerged[0] + plan.unmerged[1] if isinstance(c, _Call))
+    out_m, g_m = run(plan, (plan.fwd, plan.bwd))
+    out_u, g_u = run(plan, plan.unmerged)
+    assert torch.equal(out_m, out_u) and torch.equal(g_m, g_u)
+    assert float(g_m.abs().sum()) > 0 and torch.isfinite(g_m).all()
+    import collections
+    left = collections.Counter(c.fn.__name__ for c in plan.fwd + plan.bwd if isinstance(c, _Call))
+    print(f"HRNet-W32 batched plan: {calls_b} C-ABI calls ({n_multi} multi-problem) instead of {calls_u}: {dict(left)}")
+    assert n_multi > 100 and calls_b < 0.6 * calls_u
+    # against the stream-lane plan
+    monkeypatch.setenv("LH_BATCH", "0")
+    model._lh_plans.clear()
+    lanes = model.plan(b, h, w, training=True, backward=True)
+    assert not lanes.batch
+    out_l, g_l = run(lanes, (lanes.fwd, lanes.bwd))
+    assert rel(out_m.cpu().numpy(), out_l.cpu().numpy()) < 3e-2
+    d = (g_m - g_l).double()
+    assert float(d.norm() / g_l.double().norm()) < 5e-2
