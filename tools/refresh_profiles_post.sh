@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.."
 O=gpurun_out/refresh
 R=${LH_ROUND:-r03}
 cp $O/bench.json profiles/${R}_bench.json
-cp "$(find $O/stats -name '*kernel_stats.csv' | head -1)" profiles/${R}_bench_kernel_stats.csv
+cp "$(find $O/stats -name "${R}_kernel_stats.csv" | head -1)" profiles/${R}_bench_kernel_stats.csv
 cp $O/layers.txt profiles/${R}_layers.txt
 python tools/pmc_traffic.py "$(find $O/pmc_fetch -name '*counter_collection.csv' | head -1)" \
     "$(find $O/pmc_write -name '*counter_collection.csv' | head -1)" profiles/${R}_pmc_hbm_traffic.txt profiles/${R}_pmc_traffic.json
