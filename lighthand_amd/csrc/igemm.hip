@@ -321,6 +321,10 @@ extern "C" int lh_igemm_candidates(const lh_igemm_desc* d, int dtype, int* cfgs,
 
 extern "C" int lh_igemm_stats_rows(const lh_igemm_desc* d, int dtype) {
     int bm, bp;
+    if (d->cfg[2] == 100 && lh_ring_supported(d, dtype)) {        // direct 3x3 kernel: one row per workgroup
+        RingCfg c;
+        if (lh_ring_resolve(d, dtype, &c) == LH_OK && c.depth == 100) return lh_d3_rows(d);
+    }
     if (d->cfg[2] == 1 && lh_ring_supported(d, dtype)) {          // persistent pointwise kernel: one row per workgroup
         RingCfg c;
         if (lh_ring_resolve(d, dtype, &c) == LH_OK && c.depth == 1) return lh_pw_rows(d, c, dtype);
@@ -354,7 +358,7 @@ static int igemm_impl(const lh_igemm_desc* d, const void* in, const void* wpack,
                "lh_igemm: output placement exceeds the %dx%d image", d->OH, d->OW);
     IgemmArgs a;
     a.in = (const unsigned char*)in; a.w = (const unsigned char*)wpack; a.out = (unsigned char*)out;
-    a.addend = (const unsigned char*)addend; a.bias = bias; a.stats = stats; a.zero = nullptr;
+    a.addend = (const unsigned char*)addend; a.bias = bias; a.stats = stats; a.zero = nullptr; a.dump = nullptr;
     a.addend_mask = (const unsigned char*)addend_mask;
     LH_REQUIRE(!addend_mask || (addend && d->out_pix_stride == d->cout), "lh_igemm: addend_mask needs an addend and a dense output (mask bits index 16-byte chunks)");
     a.scale = scale; a.shift = shift;
@@ -381,7 +385,7 @@ static int igemm_impl(const lh_igemm_desc* d, const void* in, const void* wpack,
     a.tw = 1; a.dh0 = a.dhs = a.dw0 = a.dws = 0;
     a.xcd = 1;
     a.nphase = 1; a.phase_blocks = 0;
-    LH_REQUIRE(!(ring && rc_.depth == 1 && (phases || head)), "lh_igemm_phases: the pointwise kernel takes single launches only");
+    LH_REQUIRE(!(ring && (rc_.depth == 1 || rc_.depth == 100) && (phases || head)), "lh_igemm_phases: the persistent kernels take single launches only");
     if (phases) {
         LH_REQUIRE(ring, "lh_igemm_phases: the form is not supported by the LDS-DMA kernel");
         a.nphase = phases->n;
@@ -406,7 +410,7 @@ static int igemm_impl(const lh_igemm_desc* d, const void* in, const void* wpack,
         a.head_j = head->n_out; a.head_wstride = (int)head->w_row_bytes;
     }
     if (prep_args) {            // lh_igemm_multi: hand the argument block back instead of launching
-        LH_REQUIRE(ring && rc_.depth >= 2, "lh_igemm_multi: problem does not run on the LDS-DMA ring kernel (its cfg must name a tiled configuration)");
+        LH_REQUIRE(ring && rc_.depth >= 2 && rc_.depth < 100, "lh_igemm_multi: problem does not run on the LDS-DMA ring kernel (its cfg must name a tiled configuration)");
         lh_tap_grid(d, &a.tw, &a.dh0, &a.dhs, &a.dw0, &a.dws);
         a.kspt = (d->k_run * es + rc_.kb - 1) / rc_.kb;
         *prep_args = a;

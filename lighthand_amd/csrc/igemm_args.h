@@ -9,6 +9,7 @@ struct IgemmArgs {
     const unsigned char* addend;
     const unsigned char* addend_mask; // optional: ReLU mask bits (lh_fuse_fwd relu_mask) gating the addend element-wise
     const unsigned char* zero;       // 16 zero bytes in device memory (LDS-DMA kernel: what masked lanes fetch)
+    unsigned char* dump;             // 1 KiB nobody reads: where the persistent kernels' masked lanes STORE (fixed store count per tile)
     const float* bias;
     const float* scale;      // optional per-output-channel affine applied to the fp32 accumulator (eval-mode BN fold)
     const float* shift;
@@ -37,7 +38,8 @@ struct IgemmArgs {
 };
 
 // One configuration of the LDS-DMA kernel: tile (output channels x pixels), ring depth, K bytes per stage
-// (igemm_ring_kernel.h).  depth == 1 selects the persistent pointwise kernel (igemm_pw_kernel.h): bm = channels of the
+// (igemm_ring_kernel.h).  depth == 100 selects the direct 3x3 kernel (conv3x3_direct_kernel.h): bm = 64, bp = 256 (a 16 x 16
+// output tile), kb = input channels per tap (32 | 64);  depth == 1 selects the persistent pointwise kernel (igemm_pw_kernel.h): bm = channels of the
 // resident weight panel, bp = pixels a wave takes per step (16 * PT), kb = padded K of the panel in elements.
 struct RingCfg {
     int bm, bp, depth, kb;
@@ -69,5 +71,7 @@ int lh_igemm_ring_launch(const IgemmArgs& a, const RingCfg& c, int dtype, hipStr
 template <typename A> struct LhMulti;
 int lh_igemm_ring_multi_launch(LhMulti<IgemmArgs>& m, const RingCfg& c, int dtype, hipStream_t s);
 bool lh_pw_supported(const lh_igemm_desc* d, int dtype);
+bool lh_d3_supported(const lh_igemm_desc* d, int dtype);
+int lh_d3_rows(const lh_igemm_desc* d);
 int lh_pw_rows(const lh_igemm_desc* d, const RingCfg& c, int dtype);
 int lh_pw_occupancy(const RingCfg& c, int dtype, bool stats);

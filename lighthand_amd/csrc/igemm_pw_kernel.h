@@ -19,6 +19,7 @@
 // results are bit-identical to every other configuration (tests/test_gpu_ops.py::test_every_conv_kernel_configuration).
 #pragma once
 #include "igemm_ring_kernel.h"
+#include "igemm_wave_epilogue.h"
 #include <stdlib.h>
 
 template <typename T, int BM, int KC, int PT, bool STATS>
@@ -128,7 +129,6 @@ __global__ __launch_bounds__(256, 2) void igemm_pw_kernel(const IgemmArgs p) {
 #pragma unroll
         for (int e = 0; e < EPC; ++e) s1[i][e] = s2[i][e] = 0.f;
 
-    const int rrow = lane >> 3, rch = lane & 7;         // read-back: 8 lanes x 16 bytes = one 128-byte line of a pixel row
     auto tilework = [&](const int t, uint4 (&Bf)[PT][KS], auto&& prefetch) {
         f32x4 acc[CT][PT];
 #pragma unroll
@@ -175,81 +175,7 @@ __global__ __launch_bounds__(256, 2) void igemm_pw_kernel(const IgemmArgs p) {
             return;
         }
         const int m0 = t * PT * 16;
-#pragma unroll
-        for (int sb = 0; sb < NSB; ++sb) {
-            __builtin_amdgcn_sched_barrier(0);
-            // accumulators (+ per-channel affine) -> staging patch [16 * PT pixels][64 channels]
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int i = sb * 4 + it;
-                const int col = i * 16 + q * 4;
-                const float4 sv = *reinterpret_cast<const float4*>(cst + col);
-                const float4 bv = *reinterpret_cast<const float4*>(cst + BM + col);
-#pragma unroll
-                for (int j = 0; j < PT; ++j) {
-                    union { uint2 u; T e[4]; } pk;
-                    pk.e[0] = from_f<T>(acc[i][j][0] * sv.x + bv.x);
-                    pk.e[1] = from_f<T>(acc[i][j][1] * sv.y + bv.y);
-                    pk.e[2] = from_f<T>(acc[i][j][2] * sv.z + bv.z);
-                    pk.e[3] = from_f<T>(acc[i][j][3] * sv.w + bv.w);
-                    *reinterpret_cast<uint2*>(stg + (j * 16 + pl) * RS + (it * 16 + q * 4) * ES) = pk.u;
-                }
-            }
-            // rows back out, 16 bytes per lane: full-line stores with addend / ReLU / statistics of the stored values
-            const int col0 = cblk * BM + sb * SUBW + rch * EPC;
-            const bool col_ok = col0 < p.cout;
-            constexpr int NP = PT * 2;
-            uint4 ad[NP];
-            unsigned mb[NP];
-#pragma unroll
-            for (int k = 0; k < NP; ++k) {
-                const int m = m0 + k * 8 + rrow;
-                ad[k] = uint4{0u, 0u, 0u, 0u};
-                mb[k] = 0xffu;
-                if (p.addend && m < M && col_ok) {
-                    const long eoff = (long)m * p.out_pix_stride + col0;
-                    ad[k] = *reinterpret_cast<const uint4*>(p.addend + eoff * ES);
-                    if (p.addend_mask) mb[k] = p.addend_mask[eoff / EPC];
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < NP; ++k) {
-                const int row = k * 8 + rrow;
-                const int m = m0 + row;
-                const unsigned char* src = stg + row * RS + rch * 16;
-                const uint2 lo = *reinterpret_cast<const uint2*>(src);
-                const uint2 hi = *reinterpret_cast<const uint2*>(src + 8);
-                uint4 u = uint4{lo.x, lo.y, hi.x, hi.y};
-                if (p.addend || p.relu) {
-                    float v[EPC];
-                    unpack16<T>(u, v);
-                    if (p.addend) {
-                        float av[EPC];
-                        unpack16<T>(ad[k], av);
-                        if (p.addend_mask) {
-#pragma unroll
-                            for (int e = 0; e < EPC; ++e) av[e] = ((mb[k] >> e) & 1u) ? av[e] : 0.f;
-                        }
-#pragma unroll
-                        for (int e = 0; e < EPC; ++e) v[e] += av[e];
-                    }
-                    if (p.relu) {
-#pragma unroll
-                        for (int e = 0; e < EPC; ++e) v[e] = fmaxf(v[e], 0.f);
-                    }
-                    u = pack16<T>(v);
-                }
-                if (m < M && col_ok) {
-                    if constexpr (STATS) {
-                        float fv[EPC];
-                        unpack16<T>(u, fv);
-#pragma unroll
-                        for (int e = 0; e < EPC; ++e) { s1[sb][e] += fv[e]; s2[sb][e] += fv[e] * fv[e]; }
-                    }
-                    if (!(LH_ABL & 16) || u.x == 0x12345678u) *reinterpret_cast<uint4*>(p.out + ((long)m * p.out_pix_stride + col0) * ES) = u;
-                }
-            }
-        }
+        wave_epilogue<T, BM, PT, STATS>(p, acc, stg, cst, cblk, lane, [&](int row) { const int m = m0 + row; return m < M ? (long)m : -1L; }, s1, s2);
     };
     if constexpr (DB) {
         while (t < ntile) {
@@ -266,32 +192,9 @@ __global__ __launch_bounds__(256, 2) void igemm_pw_kernel(const IgemmArgs p) {
     }
 
     if constexpr (STATS) {
-        // one slab row per workgroup: lanes that share a channel chunk (lane & 7) fold over their 8 row groups, then
-        // the four waves fold through LDS in a fixed order
+        // one slab row per workgroup (rows = workgroups per channel block)
         __syncthreads();                                 // every wave is done with the panel
-        float* red = reinterpret_cast<float*>(smem);     // [4 waves][2][BM]
-#pragma unroll
-        for (int sb = 0; sb < NSB; ++sb)
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) {
-                float a = s1[sb][e], c = s2[sb][e];
-#pragma unroll
-                for (int o = 8; o < 64; o <<= 1) { a += __shfl_xor(a, o); c += __shfl_xor(c, o); }
-                if (lane < 8) {
-                    red[(wave * 2 + 0) * BM + sb * SUBW + lane * EPC + e] = a;
-                    red[(wave * 2 + 1) * BM + sb * SUBW + lane * EPC + e] = c;
-                }
-            }
-        __syncthreads();
-        if (p.stats) {
-            for (int i = tid; i < 2 * BM; i += 256) {
-                const int which = i / BM, col = i - which * BM;
-                const float a = ((red[(0 * 2 + which) * BM + col] + red[(1 * 2 + which) * BM + col]) + red[(2 * 2 + which) * BM + col]) +
-                                red[(3 * 2 + which) * BM + col];
-                const int gc = cblk * BM + col;
-                if (gc < p.cout) p.stats[((long)g * 2 + which) * p.cout + gc] = a;
-            }
-        }
+        wave_stats_row<BM, 4>(s1, s2, reinterpret_cast<float*>(smem), p.stats ? p.stats + (long)g * 2 * p.cout : nullptr, cblk, p.cout, tid);
     }
 }
 

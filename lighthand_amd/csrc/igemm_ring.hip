@@ -20,6 +20,8 @@ int lh_ring_multi_launch_bf16(const LhMulti<IgemmArgs>& m, const RingCfg& c, hip
 int lh_ring_multi_launch_f16(const LhMulti<IgemmArgs>& m, const RingCfg& c, hipStream_t s);
 int lh_pw_launch_bf16(const IgemmArgs& a, const RingCfg& c, hipStream_t s);
 int lh_pw_launch_f16(const IgemmArgs& a, const RingCfg& c, hipStream_t s);
+int lh_d3_launch_bf16(const IgemmArgs& a, const RingCfg& c, hipStream_t s);
+int lh_d3_launch_f16(const IgemmArgs& a, const RingCfg& c, hipStream_t s);
 int lh_pw_occ_bf16(const RingCfg& c, bool stats);
 int lh_pw_occ_f16(const RingCfg& c, bool stats);
 
@@ -133,6 +135,39 @@ int lh_pw_rows(const lh_igemm_desc* d, const RingCfg& c, int dtype) {
     return g;
 }
 
+// ---- direct 3x3 kernel (conv3x3_direct_kernel.h): nine taps (-1..1)^2 in either order, stride 1, same-size dense output,
+//      32 or 64 input channels per tap, 16-bit types
+bool lh_d3_supported(const lh_igemm_desc* d, int dtype) {
+    if (lh_dtype_size(dtype) != 2 || d->ntaps != 9) return false;
+    if (d->k_run != 32 && d->k_run != 64) return false;
+    if (d->sh != 1 || d->sw != 1 || d->hi != d->ho || d->wi != d->wo) return false;
+    if (d->osh != 1 || d->osw != 1 || d->OH != d->ho || d->OW != d->wo || d->ooh != 0 || d->oow != 0) return false;
+    if ((d->in_pix_stride * 2) % 16 != 0) return false;
+    unsigned seen = 0;
+    for (int t = 0; t < 9; ++t) {
+        if (d->dh[t] < -1 || d->dh[t] > 1 || d->dw[t] < -1 || d->dw[t] > 1) return false;
+        seen |= 1u << ((d->dh[t] + 1) * 3 + d->dw[t] + 1);
+    }
+    return seen == 0x1ffu;
+}
+
+static bool d3_fits(const lh_igemm_desc* d, int dtype, const RingCfg& c) {
+    return lh_d3_supported(d, dtype) && c.bm == 64 && c.bp == 256 && c.kb == d->k_run;
+}
+
+int lh_d3_rows(const lh_igemm_desc* d) {
+    const int cb = (d->cout + 63) / 64;
+    const int patch = 18 * 18 * d->k_run * 2, stg = 8 * 2 * 16 * 136;
+    const int lds = 9 * 64 * d->k_run * 2 + 2 * patch + (stg <= patch ? 0 : stg) + 512;
+    const int occ = lds <= 80 * 1024 ? 2 : 1;
+    const long ntile = (long)d->n * ((d->ho + 15) / 16) * ((d->wo + 15) / 16);
+    long g = 256L * occ / cb / 8 * 8;
+    const long need = (ntile + 7) / 8 * 8;
+    if (g > need) g = need;
+    if (g < 8) g = 8;
+    return (int)g;
+}
+
 // Static default (cfg all zero): the largest tile that still gives >= 2 workgroups per CU, a 2-stage ring for K loops
 // of <= 4 steps (store-bound 1x1 convolutions: 4 workgroups share a CU) else 4 stages, no look-ahead.  The plan's
 // autotuner replaces this by a measured choice (lh_igemm_candidates).
@@ -167,6 +202,14 @@ int lh_ring_resolve(const lh_igemm_desc* d, int dtype, RingCfg* out) {
         return LH_OK;
     }
     const RingCfg c = {d->cfg[0], d->cfg[1], d->cfg[2], d->cfg[3]};
+    if (c.depth == 100) {                                // direct 3x3 kernel
+        if (!d3_fits(d, dtype, c)) {
+            lh_set_error("igemm: the direct 3x3 configuration (64, 256, 100, %d) does not fit this launch", c.kb);
+            return LH_ERR_ARG;
+        }
+        *out = c;
+        return LH_OK;
+    }
     if (c.depth == 1) {                                  // persistent pointwise kernel
         if (!pw_fits(d, dtype, c)) {
             lh_set_error("igemm: pointwise configuration panel %d x K %d, %d pixels per wave does not exist or does not fit this launch",
@@ -200,6 +243,10 @@ int lh_ring_candidates(const lh_igemm_desc* d, int dtype, int* out, int max) {
         out[5 * k] = t[i].bm; out[5 * k + 1] = t[i].bp; out[5 * k + 2] = t[i].depth; out[5 * k + 3] = t[i].kb; out[5 * k + 4] = 0;
         ++k;
     }
+    if (k < max && lh_d3_supported(d, dtype)) {          // direct 3x3 kernel: depth = 100
+        out[5 * k] = 64; out[5 * k + 1] = 256; out[5 * k + 2] = 100; out[5 * k + 3] = d->k_run; out[5 * k + 4] = 0;
+        ++k;
+    }
     for (const PwCfg& c : kCfgPw) {                      // pointwise configurations: depth = 1
         const RingCfg r = {c.bm, 16 * c.pt, 1, c.kc};
         if (k >= max || !pw_fits(d, dtype, r)) continue;
@@ -212,6 +259,25 @@ int lh_ring_candidates(const lh_igemm_desc* d, int dtype, int* out, int max) {
 // 16 zero bytes in device memory: the source of every LDS-DMA lane that falls outside the image or the K run.
 // One copy per device (module memory); its address is looked up once per device.
 __device__ __attribute__((aligned(16))) unsigned int lh_zero_page[4] = {0u, 0u, 0u, 0u};
+
+// 1 KiB that is only ever written: the persistent kernels store the lanes that fall outside the problem here instead of
+// predicating the store away, so every tile issues the same number of store instructions and the counted waits
+// (s_waitcnt vmcnt) that keep a tile's stores in flight across the next tile stay exact.
+__device__ __attribute__((aligned(16))) unsigned int lh_dump_page[256];
+
+static unsigned char* dump_page() {
+    static std::mutex mu;
+    static unsigned char* ptr[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!ptr[dev]) {
+        void* q = nullptr;
+        if (hipGetSymbolAddress(&q, HIP_SYMBOL(lh_dump_page)) != hipSuccess) return nullptr;
+        ptr[dev] = (unsigned char*)q;
+    }
+    return ptr[dev];
+}
 
 static const unsigned char* zero_page() {
     static std::mutex mu;
@@ -230,11 +296,21 @@ static const unsigned char* zero_page() {
 int lh_igemm_ring_launch(const IgemmArgs& a0, const RingCfg& c, int dtype, hipStream_t s) {
     IgemmArgs a = a0;
     a.zero = zero_page();
-    if (!a.zero) {
+    a.dump = dump_page();
+    if (!a.zero || !a.dump) {
         lh_set_error("igemm_ring: cannot resolve the zero page on this device");
         return LH_ERR_HIP;
     }
     int rc = 1;
+    if (c.depth == 100) {
+        if (dtype == LH_BF16) rc = lh_d3_launch_bf16(a, c, s);
+        else if (dtype == LH_F16) rc = lh_d3_launch_f16(a, c, s);
+        if (rc == 1) {
+            lh_set_error("conv3x3_direct: no kernel for %d input channels, dtype %d", c.kb, dtype);
+            return LH_ERR_UNSUPPORTED;
+        }
+        return rc;
+    }
     if (c.depth == 1) {
         if (dtype == LH_BF16) rc = lh_pw_launch_bf16(a, c, s);
         else if (dtype == LH_F16) rc = lh_pw_launch_f16(a, c, s);
@@ -275,7 +351,7 @@ int lh_igemm_ring_multi_launch(LhMulti<IgemmArgs>& m, const RingCfg& c, int dtyp
         lh_set_error("igemm_ring_multi: cannot resolve the zero page on this device");
         return LH_ERR_HIP;
     }
-    for (int i = 0; i < m.n; ++i) m.a[i].zero = z;
+    for (int i = 0; i < m.n; ++i) { m.a[i].zero = z; m.a[i].dump = dump_page(); }
     int rc = 1;
     if (dtype == LH_BF16) rc = lh_ring_multi_launch_bf16(m, c, s);
     else if (dtype == LH_F16) rc = lh_ring_multi_launch_f16(m, c, s);

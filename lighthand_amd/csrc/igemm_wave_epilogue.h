@@ -1,0 +1,135 @@
+// Per-wave epilogue shared by the persistent kernels (igemm_pw_kernel.h, conv3x3_direct_kernel.h): a wave owns a tile of
+// 16 * PT output pixels x BM channels in MFMA accumulators (acc[i][j][r]: channel 16 i + 4 (lane >> 4) + r of pixel
+// 16 j + (lane & 15)) and writes it out WITHOUT a workgroup barrier: 64 channels at a time the tile goes through a
+// wave-private LDS patch (row pitch 34 dwords: the ds_write_b64 of 16 pixels hit 32 banks once) and comes back 16 bytes
+// per lane, 8 lanes = one 128-byte line of an NHWC row, so every global store is a full line.  Arithmetic and order are
+// those of igemm_epilogue.h (per-channel affine on the fp32 accumulator, rounding, [masked] addend, ReLU, statistics of
+// the STORED values): results are bit-identical to the tiled kernels'.
+#pragma once
+#include "common.h"
+#include "igemm_args.h"
+
+#ifndef LH_ABL
+#define LH_ABL 0
+#endif
+
+// pix(row) -> output pixel index of staging row `row` (0 .. 16 * PT - 1), or -1 when the row lies outside the problem.
+// s1 / s2: running per-lane sums of the stored values / their squares, [BM / 64][8] (STATS).
+template <typename T, int BM, int PT, bool STATS, typename PixFn, int NS>
+__device__ __forceinline__ void wave_epilogue(const IgemmArgs& p, f32x4 (&acc)[BM / 16][PT], unsigned char* stg, const float* cst,
+                                              const int cblk, const int lane, PixFn&& pix, float (&s1)[NS][8], float (&s2)[NS][8]) {
+    constexpr int ES = sizeof(T), EPC = 8, SUBW = 64, NSB = BM / SUBW, RS = SUBW * ES + 8;
+    const int q = lane >> 4, pl = lane & 15;
+    const int rrow = lane >> 3, rch = lane & 7;         // read-back: 8 lanes x 16 bytes = one 128-byte line of a pixel row
+#pragma unroll
+    for (int sb = 0; sb < NSB; ++sb) {
+        __builtin_amdgcn_sched_barrier(0);
+        // accumulators (+ per-channel affine) -> staging patch [16 * PT pixels][64 channels]
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int i = sb * 4 + it;
+            const int col = i * 16 + q * 4;
+            const float4 sv = *reinterpret_cast<const float4*>(cst + col);
+            const float4 bv = *reinterpret_cast<const float4*>(cst + BM + col);
+#pragma unroll
+            for (int j = 0; j < PT; ++j) {
+                union { uint2 u; T e[4]; } pk;
+                pk.e[0] = from_f<T>(acc[i][j][0] * sv.x + bv.x);
+                pk.e[1] = from_f<T>(acc[i][j][1] * sv.y + bv.y);
+                pk.e[2] = from_f<T>(acc[i][j][2] * sv.z + bv.z);
+                pk.e[3] = from_f<T>(acc[i][j][3] * sv.w + bv.w);
+                *reinterpret_cast<uint2*>(stg + (j * 16 + pl) * RS + (it * 16 + q * 4) * ES) = pk.u;
+            }
+        }
+        // rows back out, 16 bytes per lane: full-line stores with addend / ReLU / statistics of the stored values
+        const int col0 = cblk * BM + sb * SUBW + rch * EPC;
+        const bool col_ok = col0 < p.cout;
+        constexpr int NP = PT * 2;
+        uint4 ad[NP];
+        unsigned mb[NP];
+        long opix[NP];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            opix[k] = col_ok ? pix(k * 8 + rrow) : -1L;
+            ad[k] = uint4{0u, 0u, 0u, 0u};
+            mb[k] = 0xffu;
+            if (p.addend) {                                 // every lane loads (masked lanes: the zero page): fixed instruction count
+                const long eoff = opix[k] * p.out_pix_stride + col0;
+                ad[k] = *reinterpret_cast<const uint4*>(opix[k] >= 0 ? p.addend + eoff * ES : p.zero);
+                if (p.addend_mask) mb[k] = opix[k] >= 0 ? p.addend_mask[eoff / EPC] : (unsigned char)0;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int row = k * 8 + rrow;
+            const unsigned char* src = stg + row * RS + rch * 16;
+            const uint2 lo = *reinterpret_cast<const uint2*>(src);
+            const uint2 hi = *reinterpret_cast<const uint2*>(src + 8);
+            uint4 u = uint4{lo.x, lo.y, hi.x, hi.y};
+            if (p.addend || p.relu) {
+                float v[EPC];
+                unpack16<T>(u, v);
+                if (p.addend) {
+                    float av[EPC];
+                    unpack16<T>(ad[k], av);
+                    if (p.addend_mask) {
+#pragma unroll
+                        for (int e = 0; e < EPC; ++e) av[e] = ((mb[k] >> e) & 1u) ? av[e] : 0.f;
+                    }
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) v[e] += av[e];
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                u = pack16<T>(v);
+            }
+            if constexpr (STATS) {
+                if (opix[k] >= 0) {
+                    float fv[EPC];
+                    unpack16<T>(u, fv);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) { s1[sb][e] += fv[e]; s2[sb][e] += fv[e] * fv[e]; }
+                }
+            }
+            // every lane stores, every pass (lanes outside the problem: the dump page): the number of store instructions per
+            // tile is fixed, so the waits on the NEXT tile's operand loads can leave exactly these stores in flight
+            unsigned char* dst = opix[k] >= 0 ? p.out + (opix[k] * p.out_pix_stride + col0) * ES : p.dump + lane * 16;
+            if (!(LH_ABL & 16) || u.x == 0x12345678u) *reinterpret_cast<uint4*>(dst) = u;
+        }
+    }
+}
+
+// One statistics row per workgroup from the waves' running sums (STATS kernels, at the very end): lanes that share a channel
+// chunk (lane & 7) fold over their 8 row groups, then the NWAVE waves fold through LDS in a fixed order.  `red` = LDS scratch
+// of NWAVE * 2 * BM floats that no wave uses any more (the caller has put a barrier before this call).
+template <int BM, int NWAVE, int NS>
+__device__ __forceinline__ void wave_stats_row(float (&s1)[NS][8], float (&s2)[NS][8], float* red, float* stats_row, const int cblk,
+                                               const int cout, const int tid) {
+    constexpr int EPC = 8, SUBW = 64, NSB = BM / SUBW;
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int sb = 0; sb < NSB; ++sb)
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            float a = s1[sb][e], c = s2[sb][e];
+#pragma unroll
+            for (int o = 8; o < 64; o <<= 1) { a += __shfl_xor(a, o); c += __shfl_xor(c, o); }
+            if (lane < 8) {
+                red[(wave * 2 + 0) * BM + sb * SUBW + lane * EPC + e] = a;
+                red[(wave * 2 + 1) * BM + sb * SUBW + lane * EPC + e] = c;
+            }
+        }
+    __syncthreads();
+    if (stats_row) {
+        for (int i = tid; i < 2 * BM; i += 64 * NWAVE) {
+            const int which = i / BM, col = i - which * BM;
+            float a = red[(0 * 2 + which) * BM + col];
+#pragma unroll
+            for (int w = 1; w < NWAVE; ++w) a += red[(w * 2 + which) * BM + col];
+            const int gc = cblk * BM + col;
+            if (gc < cout) stats_row[(long)which * cout + gc] = a;
+        }
+    }
+}

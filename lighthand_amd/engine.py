@@ -485,7 +485,7 @@ class Plan:
         n = self.lib.lh_igemm_candidates(C.byref(lead), self.dt, buf, 64)
         cands = [tuple(buf[5 * i:5 * i + 4]) for i in range(n)]
         if len(descs) > 1:
-            cands = [c for c in cands if c[2] != 1]             # the persistent pointwise kernel takes single launches only
+            cands = [c for c in cands if c[2] not in (1, 100)]  # the persistent kernels take single launches only
         if len(descs) > 1 and self._phase_rows(descs) <= 0:
             cands = []                                          # phases that cannot be batched: keep the default
         if hit is not None and hit != (0, 0, 0, 0) and hit not in cands:
@@ -683,6 +683,8 @@ class Plan:
             bm, bp, depth, kb = cfg[0], cfg[1], cfg[2], cfg[3]
             if depth == 1:
                 return f"igemm_pw_kernel<{t}, {bm}, {kb}, {bp // 16}, {'true' if stats else 'false'}>"
+            if depth == 100:
+                return f"conv3x3_direct_kernel<{t}, {kb}, {'true' if stats else 'false'}>"
             wc, wp = {(256, 256): (2, 4), (128, 256): (2, 2), (128, 128): (2, 2), (128, 64): (4, 1), (64, 128): (1, 4), (64, 64): (2, 2)}[(bm, bp)]
             if depth:
                 return f"igemm_ring_kernel<{t}, {bm}, {bp}, {wc}, {wp}, {depth}, {kb}>"
@@ -1022,7 +1024,7 @@ class Plan:
                 n = self.lib.lh_igemm_candidates(C.byref(d), self.dt, buf, 64)
                 c = {tuple(buf[5 * i:5 * i + 4]) for i in range(n)}
                 common = c if common is None else common & c
-            cands = sorted(c for c in (common or ()) if c[2] >= 2 and (c[0], c[1]) in self._MULTI_TILES)
+            cands = sorted(c for c in (common or ()) if 2 <= c[2] < 100 and (c[0], c[1]) in self._MULTI_TILES)
             hit = Plan._TUNE_CACHE.get(key)
             if hit is not None and hit not in cands:
                 hit = None
@@ -1138,7 +1140,7 @@ class Plan:
                     check(lib.lh_igemm_config(c.args[0], self.dt, cfg), "lh_igemm_config")
                     cfgs.add(tuple(cfg[:4]))
                 cfg = next(iter(cfgs))
-                if len(cfgs) != 1 or cfg[2] < 2 or (cfg[0], cfg[1]) not in self._MULTI_TILES:
+                if len(cfgs) != 1 or not 2 <= cfg[2] < 100 or (cfg[0], cfg[1]) not in self._MULTI_TILES:
                     return None
                 arr = (_lib.IgemmCall * n)()
                 for i, c in enumerate(calls):
