@@ -17,3 +17,17 @@ cp $O/layers_c5.txt profiles/${R}_c5_infer384_layers.txt
 python tools/pmc_traffic.py "$(find $O/pmc_fetch_c5 -name '*counter_collection.csv' | head -1)" \
     "$(find $O/pmc_write_c5 -name '*counter_collection.csv' | head -1)" profiles/${R}_c5_pmc_hbm_traffic.txt /tmp/c5_traffic.json
 ls -la profiles/
+# the bench line was printed before the PMC passes of the same session existed: fill its roofline.traffic from them
+python - <<'PY'
+import json, os
+R = os.environ.get("LH_ROUND", "r03")
+b = json.load(open(f"profiles/{R}_bench.json"))
+pmc = json.load(open(f"profiles/{R}_pmc_traffic.json"))
+k = b.get("roofline", {}).get("kernel")
+if k in pmc and b["roofline"].get("traffic") is None:
+    b["roofline"]["traffic"] = pmc[k]["read_bytes_per_launch"] + pmc[k]["write_bytes_per_launch"]
+    b["roofline"]["traffic_note"] = ("bytes per launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of the same session (separate passes, corrected per the "
+                                     f"MI355X guide), profiles/{R}_pmc_hbm_traffic.txt")
+    json.dump(b, open(f"profiles/{R}_bench.json", "w"))
+    print("roofline.traffic <-", b["roofline"]["traffic"])
+PY
