@@ -78,7 +78,7 @@ class TrainStep:
 
     # ---- the work of one iteration, enqueued on the current stream --------------------------------
     def _fwd_loss(self, stream):
-        self.plan.refresh_packs(stream)
+        self.plan.refresh_packs(stream, overlap=True)
         self.plan.run_forward(stream)
         self._fwd_loss_tail(stream)
 
