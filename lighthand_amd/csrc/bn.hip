@@ -63,6 +63,45 @@ __device__ __forceinline__ void slab_totals_then(const TI* slab, int rows, int c
 }
 
 // Sum `rows` rows of `ncol` floats into totals[ncol] (double).  scratch: >= ceil(rows/256)*ncol doubles.
+// The same totals with 4 channels x 64 row lanes per workgroup, for slabs of >= 256 rows: four times the workgroups and a
+// quarter of the rows per lane (the fold kernels sit on the dependency chain of every BatchNorm: their length is a
+// latency chain of row loads, 16 deep at 1 024 rows with 16 lanes, 4 deep with 64).  Lanes of a wave that share a channel
+// fold by shuffles, the four waves through LDS, in a fixed order.
+template <typename TI, typename F>
+__device__ __forceinline__ void slab_totals_then64(const TI* slab, int rows, int c, int bid, F&& fin) {
+    __shared__ double red64[2][4][4];
+    const int ch = bid * 4 + (threadIdx.x & 3), rl = threadIdx.x >> 2;
+    double a = 0.0, b = 0.0;
+    if (ch < c) {
+        int r = rl;
+        for (; r + 192 < rows; r += 256) {        // four independent row groups in flight
+            const TI a0 = slab[((long)r * 2) * c + ch], b0 = slab[((long)r * 2 + 1) * c + ch];
+            const TI a1 = slab[((long)(r + 64) * 2) * c + ch], b1 = slab[((long)(r + 64) * 2 + 1) * c + ch];
+            const TI a2 = slab[((long)(r + 128) * 2) * c + ch], b2 = slab[((long)(r + 128) * 2 + 1) * c + ch];
+            const TI a3 = slab[((long)(r + 192) * 2) * c + ch], b3 = slab[((long)(r + 192) * 2 + 1) * c + ch];
+            a += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+            b += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
+        }
+        for (; r < rows; r += 64) {
+            a += (double)slab[((long)r * 2) * c + ch];
+            b += (double)slab[((long)r * 2 + 1) * c + ch];
+        }
+    }
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane < 4) { red64[0][wave][lane] = a; red64[1][wave][lane] = b; }
+    __syncthreads();
+    if (threadIdx.x < 4 && ch < c) {
+        const double s0 = ((red64[0][0][threadIdx.x] + red64[0][1][threadIdx.x]) + red64[0][2][threadIdx.x]) + red64[0][3][threadIdx.x];
+        const double s1 = ((red64[1][0][threadIdx.x] + red64[1][1][threadIdx.x]) + red64[1][2][threadIdx.x]) + red64[1][3][threadIdx.x];
+        fin(ch, s0, s1);
+    }
+}
+
+constexpr int LH_FOLD_WIDE_ROWS = 256;        // slabs with at least this many rows use the 64-lane fold (grid = c / 4)
+static inline int fold_grid(int rows, int c) { return rows >= LH_FOLD_WIDE_ROWS ? ceil_div(c, 4) : ceil_div(c, 16); }
+
 static int column_totals(const float* slab, int rows, int ncol, double* scratch, double* totals, hipStream_t s) {
     const int gx = ceil_div(ncol, 16);
     if (rows <= 512) {
@@ -162,7 +201,7 @@ template <typename TI>
 __device__ __forceinline__ void bn_finalize_fused_body(const FinalizeArgs& p, const int bid, const int nblk) {
     if (bid == 0 && threadIdx.x == 0 && p.nbt) *p.nbt += 1;
     const int count = p.count;
-    slab_totals_then((const TI*)p.slab, p.rows, p.c, bid, [&](int ch, double s0, double s1) {
+    auto fin = [&](int ch, double s0, double s1) {
         const double mean = s0 / count;
         double var = s1 / count - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -178,7 +217,9 @@ __device__ __forceinline__ void bn_finalize_fused_body(const FinalizeArgs& p, co
             const double unb = count > 1 ? var * ((double)count / (count - 1)) : var;
             p.rvar[ch] = (1.f - p.momentum) * p.rvar[ch] + p.momentum * (float)unb;
         }
-    });
+    };
+    if (p.rows >= LH_FOLD_WIDE_ROWS) slab_totals_then64((const TI*)p.slab, p.rows, p.c, bid, fin);
+    else slab_totals_then((const TI*)p.slab, p.rows, p.c, bid, fin);
 }
 template <typename TI>
 __global__ __launch_bounds__(256) void bn_finalize_fused_kernel(const FinalizeArgs p) { bn_finalize_fused_body<TI>(p, blockIdx.x, gridDim.x); }
@@ -210,7 +251,7 @@ extern "C" int lh_bn_finalize(const float* stats, int rows, int count, int c, co
     if (rows <= 1024) {      // one launch: fold the slab and finalize
         const FinalizeArgs a = finalize_args(stats, rows, count, c, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps,
                                              scale, shift, save_mean, save_invstd);
-        hipLaunchKernelGGL((bn_finalize_fused_kernel<float>), dim3(ceil_div(c, 16)), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((bn_finalize_fused_kernel<float>), dim3(fold_grid(rows, c)), dim3(256), 0, s, a);
         LH_LAUNCH_CHECK("bn_finalize launch");
         return LH_OK;
     }
@@ -219,7 +260,7 @@ extern "C" int lh_bn_finalize(const float* stats, int rows, int count, int c, co
     hipLaunchKernelGGL((colsum_kernel<float>), dim3(ceil_div(2 * c, 16), gy), dim3(256), 0, s, stats, rows, 2 * c, 256, scratch);
     const FinalizeArgs a = finalize_args(scratch, gy, count, c, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps,
                                          scale, shift, save_mean, save_invstd);
-    hipLaunchKernelGGL((bn_finalize_fused_kernel<double>), dim3(ceil_div(c, 16)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((bn_finalize_fused_kernel<double>), dim3(fold_grid(gy, c)), dim3(256), 0, s, a);
     LH_LAUNCH_CHECK("bn_finalize launch");
     return LH_OK;
 }
@@ -250,7 +291,7 @@ extern "C" int lh_bn_finalize_multi(const lh_bn_finalize_call* calls, int n, voi
         }
         m.a[m.n] = finalize_args(q.stats, q.rows, q.count, q.c, q.gamma, q.beta, q.running_mean, q.running_var, q.num_batches_tracked,
                                  q.momentum, q.eps, q.scale, q.shift, q.save_mean, q.save_invstd);
-        m.first[m.n + 1] = m.first[m.n] + ceil_div(q.c, 16);
+        m.first[m.n + 1] = m.first[m.n] + fold_grid(q.rows, q.c);
         if (++m.n == LH_MULTI_MAX) { const int rc = flush(); if (rc) return rc; }
     }
     return flush();
@@ -857,12 +898,14 @@ struct CoefArgs {
 __device__ __forceinline__ void fuse_bwd_coef_fused_body(const CoefArgs& p, const int bid, const int nblk) {
     const long count = p.count;
     const int c = p.c;
-    slab_totals_then(p.slab, p.rows, p.c, bid, [&](int ch, double s0, double s1) {
+    auto fin = [&](int ch, double s0, double s1) {
         p.coef[ch] = (float)(s0 / (double)count);
         p.coef[c + ch] = (float)(s1 / (double)count);
         if (p.dbeta) p.dbeta[ch] = (float)s0;
         if (p.dgamma) p.dgamma[ch] = (float)s1;
-    });
+    };
+    if (p.rows >= LH_FOLD_WIDE_ROWS) slab_totals_then64(p.slab, p.rows, p.c, bid, fin);
+    else slab_totals_then(p.slab, p.rows, p.c, bid, fin);
 }
 __global__ __launch_bounds__(256) void fuse_bwd_coef_fused_kernel(const CoefArgs p) { fuse_bwd_coef_fused_body(p, blockIdx.x, gridDim.x); }
 __global__ __launch_bounds__(256) void fuse_bwd_coef_fused_multi_kernel(const LhMulti<CoefArgs> m) {
@@ -1025,7 +1068,7 @@ static int plan_fuse_bwd(const lh_fuse_bwd_desc* d, int n, int h, int w, int c, 
             r.fb = a;
             v.push_back(r);
             BnLaunch q;
-            q.kind = K_FB_COEF; q.grid = ceil_div(c, 16);
+            q.kind = K_FB_COEF; q.grid = fold_grid((int)strips, c);
             q.co.slab = a.partial; q.co.rows = (int)strips; q.co.c = c; q.co.count = a.count; q.co.coef = a.coef; q.co.dgamma = a.dgamma; q.co.dbeta = a.dbeta;
             v.push_back(q);
             if (merge2) m2.coef[t] = a.coef;
