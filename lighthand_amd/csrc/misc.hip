@@ -348,7 +348,7 @@ extern "C" int lh_pack_weight(const float* w, void* out, size_t* bytes, int n_ou
 
 // All packs of a model in ONE launch: the host cuts every pack into chunks of PACK_CHUNK output elements and
 // blockIdx.x walks the chunk table (device arrays), so big and small packs are balanced over the grid.
-constexpr int PACK_CHUNK = 32768;
+constexpr int PACK_CHUNK = 2048;         // elements per workgroup: 8 dependent gathers per thread (the stem pack is 57k elements: 28 workgroups, not 2)
 
 template <typename T>
 __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const lh_pack_item* items, const int* chunk_item,
