@@ -270,7 +270,17 @@ __global__ void nchw_to_nhwc_kernel(const float* src, T* dst, int n, int hw, int
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int b = (int)(i / hw), p = (int)(i % hw);
         T* d = dst + i * cs;
-        for (int ch = 0; ch < cs; ++ch) d[ch] = from_f<T>(ch < c ? src[((long)b * c + ch) * hw + p] : 0.f);
+        constexpr int EPC = 16 / sizeof(T);
+        if (cs % EPC == 0) {                     // whole 16-byte chunks per pixel: gather EPC channels, one vector store
+            for (int c0 = 0; c0 < cs; c0 += EPC) {
+                float v[EPC];
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) v[e] = c0 + e < c ? src[((long)b * c + c0 + e) * hw + p] : 0.f;
+                *reinterpret_cast<uint4*>(d + c0) = pack16<T>(v);
+            }
+        } else {
+            for (int ch = 0; ch < cs; ++ch) d[ch] = from_f<T>(ch < c ? src[((long)b * c + ch) * hw + p] : 0.f);
+        }
     }
 }
 
