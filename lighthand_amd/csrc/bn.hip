@@ -4,6 +4,7 @@
 #include "common.h"
 #include "multi.h"
 #include <vector>
+#include <algorithm>
 #include <stdlib.h>
 
 // ------------------------------------------------------------------------------------------------
@@ -921,15 +922,21 @@ static long fuse_bwd_strips(long count, int* rows_per_strip) {
     return (count + rps - 1) / rps;
 }
 
-extern "C" size_t lh_fuse_bwd_workspace_bytes(int n, int h, int w, int c) {
+// bytes of ONE term's slice: partial slab + colsum scratch + totals (doubles) + coefficients, rounded to 256
+static size_t fuse_bwd_term_bytes(int n, int h, int w, int c) {
     int rps;
     const long strips = fuse_bwd_strips((long)n * h * w, &rps);
-    // partial slab + colsum scratch + totals (doubles)
-    return (size_t)strips * 2 * c * 4 + 16 + (size_t)(ceil_div(strips, 256) + 1) * 2 * c * 8 + (size_t)4 * c * 4;
+    const size_t b = (size_t)strips * 2 * c * 4 + 16 + (size_t)(ceil_div(strips, 256) + 1) * 2 * c * 8 + (size_t)4 * c * 4;
+    return (b + 255) & ~(size_t)255;
 }
+
+// every term of a node owns a slice of the workspace: the terms' passes are independent of each other and run as
+// multi-problem launches (all reduce passes, then all coefficient folds, then all apply passes)
+extern "C" size_t lh_fuse_bwd_workspace_bytes(int n, int h, int w, int c) { return 4 * fuse_bwd_term_bytes(n, h, w, c); }
 
 struct BnLaunch {
     int kind, grid;
+    int phase;                   // backward passes: 0 reduce, 1 coefficient fold, 2 apply (a pass only depends on the passes of lower phase)
     FuseArgs ff;
     FuseBwdArgs fb;
     FuseBwd2Args fb2;
@@ -966,6 +973,104 @@ static int bn_run(const BnLaunch* const* L, int n, int dtype, hipStream_t s) {
         default: lh_set_error("bn_run: unknown kind %d", L[0]->kind); return LH_ERR_ARG;
     }
     LH_LAUNCH_CHECK("BatchNorm / ReLU pass launch");
+    return LH_OK;
+}
+
+// Reduce / apply passes of DIFFERENT kinds in one grid (the terms of an HRNet exchange sum: BN terms without and with
+// upsampling, identity terms): the kind is a per-problem tag next to the argument blocks.
+struct KindTags { int k[LH_MULTI_MAX]; };
+template <typename T>
+__global__ __launch_bounds__(256) void fuse_bwd_reduce_mixed_kernel(const LhMulti<FuseBwdArgs> m, const KindTags kt) {
+    int bid, nblk;
+    const int i = lh_multi_pick(m, bid, nblk);
+    switch (kt.k[i]) {
+        case K_FB_REDUCE_GEN: fuse_bwd_reduce_body<T>(m.a[i], bid, nblk); break;
+        case K_FB_REDUCE_FLAT: fuse_bwd_reduce_flat_body<T, false>(m.a[i], bid, nblk); break;
+        default: fuse_bwd_reduce_flat_body<T, true>(m.a[i], bid, nblk); break;
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void fuse_bwd_apply_mixed_kernel(const LhMulti<FuseBwdArgs> m, const KindTags kt) {
+    int bid, nblk;
+    const int i = lh_multi_pick(m, bid, nblk);
+    switch (kt.k[i]) {
+        case K_FB_APPLY_GEN: fuse_bwd_apply_body<T>(m.a[i], bid, nblk); break;
+        case K_FB_APPLY_FLAT: fuse_bwd_apply_flat_body<T, false>(m.a[i], bid, nblk); break;
+        default: fuse_bwd_apply_flat_body<T, true>(m.a[i], bid, nblk); break;
+    }
+}
+
+static int bn_run_mixed(const BnLaunch* const* L, int n, int dtype, hipStream_t s) {
+    LhMulti<FuseBwdArgs> m;
+    KindTags kt;
+    m.n = n; m.first[0] = 0;
+    for (int i = 0; i < n; ++i) { m.a[i] = L[i]->fb; kt.k[i] = L[i]->kind; m.first[i + 1] = m.first[i] + L[i]->grid; }
+    for (int i = n; i < LH_MULTI_MAX; ++i) kt.k[i] = 0;
+    if (L[0]->phase == 0) { LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((fuse_bwd_reduce_mixed_kernel<T>), dim3(m.first[n]), dim3(256), 0, s, m, kt)); }
+    else { LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((fuse_bwd_apply_mixed_kernel<T>), dim3(m.first[n]), dim3(256), 0, s, m, kt)); }
+    LH_LAUNCH_CHECK("BatchNorm / ReLU mixed pass launch");
+    return LH_OK;
+}
+
+// The backward passes of n planned calls, phase by phase (all reduce passes, all coefficient folds, all apply passes):
+// inside a phase the passes are independent -- every term has its own workspace slice and its own gradient -- so they
+// run LH_MULTI_MAX per launch, passes of one kind through that kind's kernel, the rest through the mixed kernels.
+static int bn_run_phases(const std::vector<std::vector<BnLaunch>>& plans, int dtype, hipStream_t s) {
+    // two passes that write ONE gradient buffer (an activation that enters a node twice) must keep their recorded order
+    std::vector<const void*> dsts;
+    for (const auto& pl : plans)
+        for (const BnLaunch& r : pl) {
+            if (r.phase != 2) continue;
+            if (r.kind == K_FB_APPLY2) { if (r.fb2.dx[0]) dsts.push_back(r.fb2.dx[0]); if (r.fb2.dx[1]) dsts.push_back(r.fb2.dx[1]); }
+            else dsts.push_back(r.fb.dx);
+        }
+    std::sort(dsts.begin(), dsts.end());
+    if (std::adjacent_find(dsts.begin(), dsts.end()) != dsts.end()) {
+        const BnLaunch* L[1];
+        for (const auto& pl : plans)
+            for (const BnLaunch& r : pl) {
+                L[0] = &r;
+                const int rc = bn_run(L, 1, dtype, s);
+                if (rc) return rc;
+            }
+        return LH_OK;
+    }
+    for (int phase = 0; phase < 3; ++phase) {
+        std::vector<const BnLaunch*> fbk, other;        // FuseBwdArgs reduce / apply passes | coefficient folds, two-term applies
+        for (const auto& pl : plans)
+            for (const BnLaunch& r : pl) {
+                if (r.phase != phase) continue;
+                (r.kind == K_FB_COEF || r.kind == K_FB_APPLY2 ? other : fbk).push_back(&r);
+            }
+        // passes of one kind first (their own kernels, no kind switch), what is left over goes to the mixed kernel
+        std::vector<const BnLaunch*> rest;
+        for (int kind = K_FF_GEN; kind <= K_FB_APPLY2; ++kind) {
+            std::vector<const BnLaunch*> same;
+            for (const BnLaunch* r : fbk) if (r->kind == kind) same.push_back(r);
+            const size_t whole = same.size() / LH_MULTI_MAX * LH_MULTI_MAX;
+            for (size_t i = 0; i < whole; i += LH_MULTI_MAX) {
+                const int rc = bn_run(&same[i], LH_MULTI_MAX, dtype, s);
+                if (rc) return rc;
+            }
+            rest.insert(rest.end(), same.begin() + whole, same.end());
+        }
+        for (size_t i = 0; i < rest.size(); i += LH_MULTI_MAX) {
+            const int m = (int)(rest.size() - i < (size_t)LH_MULTI_MAX ? rest.size() - i : LH_MULTI_MAX);
+            bool one = true;
+            for (int k = 1; k < m; ++k) one = one && rest[i + k]->kind == rest[i]->kind;
+            const int rc = one ? bn_run(&rest[i], m, dtype, s) : bn_run_mixed(&rest[i], m, dtype, s);
+            if (rc) return rc;
+        }
+        for (int kind : {(int)K_FB_COEF, (int)K_FB_APPLY2}) {
+            std::vector<const BnLaunch*> same;
+            for (const BnLaunch* r : other) if (r->kind == kind) same.push_back(r);
+            for (size_t i = 0; i < same.size(); i += LH_MULTI_MAX) {
+                const int m = (int)(same.size() - i < (size_t)LH_MULTI_MAX ? same.size() - i : LH_MULTI_MAX);
+                const int rc = bn_run(&same[i], m, dtype, s);
+                if (rc) return rc;
+            }
+        }
+    }
     return LH_OK;
 }
 
@@ -1025,6 +1130,7 @@ static int plan_fuse_bwd(const lh_fuse_bwd_desc* d, int n, int h, int w, int c, 
     const int nchunk0 = c / (16 / es);
     const bool merge2 = d->nterms == 2 && d->log2up[0] == 0 && d->log2up[1] == 0 && (nchunk0 & (nchunk0 - 1)) == 0 &&
                         nchunk0 <= 256 && (d->dx[0] || d->dx[1]);
+    const size_t term_bytes = fuse_bwd_term_bytes(n, h, w, c);
     FuseBwd2Args m2;
     if (merge2) {
         m2.dout = (const unsigned char*)d->dout; m2.out = (const unsigned char*)d->out; m2.c = c; m2.relu = d->relu;
@@ -1056,18 +1162,20 @@ static int plan_fuse_bwd(const lh_fuse_bwd_desc* d, int n, int h, int w, int c, 
         if (a.x) {
             LH_REQUIRE(workspace && a.scale && a.mean && a.invstd, "lh_fuse_bwd: BN term %d lacks workspace/statistics", t);
             long strips = fuse_bwd_strips(a.count, &a.rows_per_strip);
-            a.partial = (float*)workspace;
+            a.partial = (float*)((unsigned char*)workspace + (size_t)t * term_bytes);
             const long slab_floats = strips * 2 * c;
-            double* scratch = (double*)((float*)workspace + ((slab_floats + 3) & ~3L));
+            double* scratch = (double*)(a.partial + ((slab_floats + 3) & ~3L));
             double* totals = scratch + (long)ceil_div(strips, 256) * 2 * c;
             a.totals = totals;
             a.coef = (float*)(totals + 2 * c) + (size_t)(merge2 ? t : 0) * 2 * c;   // merging keeps one coefficient block per term
             BnLaunch r;
             r.kind = flat ? (a.mask_from_x ? K_FB_REDUCE_FLAT_X : K_FB_REDUCE_FLAT) : K_FB_REDUCE_GEN;
             r.grid = (int)strips;
+            r.phase = 0;
             r.fb = a;
             v.push_back(r);
             BnLaunch q;
+            q.phase = 1;
             q.kind = K_FB_COEF; q.grid = fold_grid((int)strips, c);
             q.co.slab = a.partial; q.co.rows = (int)strips; q.co.c = c; q.co.count = a.count; q.co.coef = a.coef; q.co.dgamma = a.dgamma; q.co.dbeta = a.dbeta;
             v.push_back(q);
@@ -1082,11 +1190,13 @@ static int plan_fuse_bwd(const lh_fuse_bwd_desc* d, int n, int h, int w, int c, 
             r.kind = K_FB_APPLY_GEN;
             r.grid = (int)((a.total + 255) / 256 > 4096 ? 4096 : (a.total + 255) / 256);
         }
+        r.phase = 2;
         r.fb = a;
         v.push_back(r);
     }
     if (merge2) {
         BnLaunch r;
+        r.phase = 2;
         m2.total = (long)n * h * w * nchunk0;
         r.kind = K_FB_APPLY2;
         r.grid = (int)((m2.total + 1023) / 1024 > 2048 ? 2048 : (m2.total + 1023) / 1024);
@@ -1101,7 +1211,7 @@ extern "C" int lh_fuse_bwd(const lh_fuse_bwd_desc* d, int n, int h, int w, int c
     std::vector<std::vector<BnLaunch>> plans(1);
     const int rc = plan_fuse_bwd(d, n, h, w, c, workspace, dtype, plans[0]);
     if (rc) return rc;
-    return bn_run_calls(plans, dtype, (hipStream_t)stream);
+    return bn_run_phases(plans, dtype, (hipStream_t)stream);
 }
 
 // n independent nodes (each with its OWN workspace): reduce / coefficient fold / apply of all of them as three launches.
@@ -1112,7 +1222,7 @@ extern "C" int lh_fuse_bwd_multi(const lh_fuse_bwd_call* calls, int n, int dtype
         const int rc = plan_fuse_bwd(calls[i].d, calls[i].n, calls[i].h, calls[i].w, calls[i].c, calls[i].workspace, dtype, plans[i]);
         if (rc) return rc;
     }
-    return bn_run_calls(plans, dtype, (hipStream_t)stream);
+    return bn_run_phases(plans, dtype, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -15,6 +15,7 @@
 //  * epilogue through LDS: bias, then full-line NHWC stores with optional addend / ReLU,
 //    and per-block column sums / sums of squares of the STORED values for BatchNorm.
 #include "common.h"
+#include <algorithm>
 #include <stdlib.h>
 
 #include "igemm_args.h"
@@ -455,19 +456,28 @@ extern "C" int lh_igemm_multi(const lh_igemm_call* calls, int n, int dtype, void
     for (int i0 = 0; i0 < n; i0 += LH_MULTI_MAX) {
         const int cnt = n - i0 < LH_MULTI_MAX ? n - i0 : LH_MULTI_MAX;
         LhMulti<IgemmArgs> m;
+        IgemmArgs tmp[LH_MULTI_MAX];
         RingCfg cfg0 = {0, 0, 0, 0};
         m.n = cnt; m.first[0] = 0;
         for (int i = 0; i < cnt; ++i) {
             const lh_igemm_call& q = calls[i0 + i];
             RingCfg c;
             const int rc = igemm_impl(q.d, q.in, q.wpack, q.out, q.addend, q.addend_mask, q.bias, q.scale, q.shift, q.stats, dtype, stream,
-                                      nullptr, nullptr, &m.a[i], &c);
+                                      nullptr, nullptr, &tmp[i], &c);
             if (rc) return rc;
             if (i == 0) cfg0 = c;
             LH_REQUIRE(c.bm == cfg0.bm && c.bp == cfg0.bp && c.depth == cfg0.depth && c.kb == cfg0.kb,
                        "lh_igemm_multi: problem %d runs tile %dx%d depth %d kb %d, problem 0 %dx%d depth %d kb %d -- one configuration per call",
                        i0 + i, c.bm, c.bp, c.depth, c.kb, cfg0.bm, cfg0.bp, cfg0.depth, cfg0.kb);
-            m.first[i + 1] = m.first[i] + ceil_div(m.a[i].M, c.bp) * ceil_div(m.a[i].cout, c.bm);
+        }
+        // longest K loop first: workgroups are dispatched in grid order, so the problem whose tiles take longest must not
+        // be the one that starts last (the launch ends with its last tile)
+        int order[LH_MULTI_MAX];
+        for (int i = 0; i < cnt; ++i) order[i] = i;
+        std::stable_sort(order, order + cnt, [&](int x, int y) { return tmp[x].ntaps * tmp[x].kspt > tmp[y].ntaps * tmp[y].kspt; });
+        for (int i = 0; i < cnt; ++i) {
+            m.a[i] = tmp[order[i]];
+            m.first[i + 1] = m.first[i] + ceil_div(m.a[i].M, cfg0.bp) * ceil_div(m.a[i].cout, cfg0.bm);
         }
         const int rc = cnt == 1 ? lh_igemm_ring_launch(m.a[0], cfg0, dtype, (hipStream_t)stream)
                                 : lh_igemm_ring_multi_launch(m, cfg0, dtype, (hipStream_t)stream);

@@ -12,6 +12,7 @@
 //  * split-K over pixels -> fp32 slabs [split][tap][o][i], folded (deterministically, in
 //    split order) into the reference-layout gradient by wgrad_reduce_kernel.
 #include "common.h"
+#include <algorithm>
 #include <stdlib.h>
 
 #include "wgrad_ring_kernel.h"
@@ -554,6 +555,17 @@ extern "C" int lh_wgrad_fused_multi(const lh_wgrad_call* calls, int n, int dtype
     auto flush = [&]() -> int {
         if (m.n == 0) return LH_OK;
         int rc;
+        if (m.n > 1) {
+            // longest split first: workgroups are dispatched in grid order, and the launch ends with its last one
+            int order[LH_MULTI_MAX];
+            for (int i = 0; i < m.n; ++i) order[i] = i;
+            std::stable_sort(order, order + m.n, [&](int x, int y) { return m.a[x].steps_per_split > m.a[y].steps_per_split; });
+            LhMulti<WgradArgs> t = m;
+            for (int i = 0; i < m.n; ++i) {
+                m.a[i] = t.a[order[i]];
+                m.first[i + 1] = m.first[i] + m.a[i].tiles * m.a[i].ntaps * m.a[i].nsplit;
+            }
+        }
         if (m.n == 1) rc = dtype == LH_BF16 ? lh_wgrad_ring_launch_bf16(m.a[0], plan0, s) : lh_wgrad_ring_launch_f16(m.a[0], plan0, s);
         else rc = dtype == LH_BF16 ? lh_wgrad_ring_multi_launch_bf16(m, plan0, s) : lh_wgrad_ring_multi_launch_f16(m, plan0, s);
         if (rc == 1) {

@@ -1239,21 +1239,22 @@ class Plan:
 
     def _c_fork(self, nd, blk):
         self.fwd.append(_Marker("fork"))
-        self._region = [self.fwd[-1], None]
+        self._regions = getattr(self, "_regions", [])
+        self._regions.append([self.fwd[-1], None])
         blk.append(lambda: self.bwd.append(_Marker("join")))          # backward walks the region in reverse
 
     def _c_join(self, nd, blk):
         self.fwd.append(_Marker("join"))
-        self._region[1] = self.fwd[-1]
+        self._regions[-1][1] = self.fwd[-1]
         blk.append(lambda: self.bwd.append(_Marker("fork")))
 
     def _in_closed_region(self, call):
-        """True when `call` sits inside the most recent fork..join region and that region is already closed: work moved
-        into it from a later node (eval-mode folding of a cross-branch sum) would read another lane's output unordered."""
-        r = getattr(self, "_region", None)
-        if not self.use_lanes or r is None or r[1] is None:
+        """True when `call` sits inside a fork..join region that is already closed: work moved into it from a later node
+        (eval-mode folding of a cross-branch sum) would read another lane's output unordered."""
+        if not self.use_lanes:
             return False
-        return self.fwd.index(r[0]) < self.fwd.index(call) < self.fwd.index(r[1])
+        i = self.fwd.index(call)
+        return any(r[1] is not None and self.fwd.index(r[0]) < i < self.fwd.index(r[1]) for r in getattr(self, "_regions", []))
 
     def _c_input(self, a, blk):
         pass        # the consumer (stem conv) owns the image transform

@@ -110,7 +110,15 @@ class HighResolutionModule(nn.Module):
                         else:
                             pre[(i, j)] = (y, f"{q}.{k}.1")
         gb.join()
-        return [gb.fuse([pre[(i, j)] for j in range(self.num_branches)]) for i in range(len(self.fuse_layers))]
+        # the cross-resolution sums (pose_hrnet.py:247-265) are independent of each other: one lane each, so the plan runs
+        # them -- and the BatchNorm / ReLU backward of all their terms -- as multi-problem launches
+        gb.fork()
+        outs = []
+        for i in range(len(self.fuse_layers)):
+            gb.lane = i
+            outs.append(gb.fuse([pre[(i, j)] for j in range(self.num_branches)]))
+        gb.join()
+        return outs
 
 
 class PoseHighResolutionNet(HipModule):
