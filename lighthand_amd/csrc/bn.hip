@@ -1258,9 +1258,13 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* x, T* out, un
             }
         }
         *reinterpret_cast<uint4*>(out + i * EPC) = pack16<T>(best);
-        unsigned char* ip = idx + i * EPC;
+        // the EPC window positions of the chunk as ONE store (i * EPC bytes in: 4- or 8-byte aligned)
+        unsigned pk[EPC / 4];
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) ip[e] = bi[e];
+        for (int e = 0; e < EPC / 4; ++e)
+            pk[e] = (unsigned)bi[4 * e] | ((unsigned)bi[4 * e + 1] << 8) | ((unsigned)bi[4 * e + 2] << 16) | ((unsigned)bi[4 * e + 3] << 24);
+        if constexpr (EPC == 8) *reinterpret_cast<uint2*>(idx + i * EPC) = uint2{pk[0], pk[1]};
+        else *reinterpret_cast<unsigned*>(idx + i * EPC) = pk[0];
     }
 }
 
@@ -1290,10 +1294,12 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* dout, const u
                 const long o = (((long)b * ho + oh) * wo + ow) * c + ch * EPC;
                 float d[EPC];
                 unpack16<T>(*reinterpret_cast<const uint4*>(dout + o), d);
-                const unsigned char* ip = idx + o;
+                unsigned pk[EPC / 4];
+                if constexpr (EPC == 8) { const uint2 v = *reinterpret_cast<const uint2*>(idx + o); pk[0] = v.x; pk[1] = v.y; }
+                else pk[0] = *reinterpret_cast<const unsigned*>(idx + o);
 #pragma unroll
                 for (int e = 0; e < EPC; ++e)
-                    if (ip[e] == r * 3 + s) g[e] += d[e];
+                    if (((pk[e >> 2] >> (8 * (e & 3))) & 0xffu) == (unsigned)(r * 3 + s)) g[e] += d[e];
             }
         }
         *reinterpret_cast<uint4*>(dx + i * EPC) = pack16<T>(g);

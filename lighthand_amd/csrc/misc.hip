@@ -827,7 +827,15 @@ __global__ __launch_bounds__(256) void channel_sum_nchw_kernel(const float* x, i
     double acc = 0.0;
     for (int b = n0; b < n1; ++b) {
         const float* p = x + ((long)b * c + ch) * hw;
-        for (int i = threadIdx.x; i < hw; i += 256) acc += (double)p[i];
+        if ((hw & 3) == 0) {                     // planes are 16-byte aligned: four elements per load, same summation order per thread
+            const float4* p4 = reinterpret_cast<const float4*>(p);
+            for (int i = threadIdx.x; i < hw / 4; i += 256) {
+                const float4 v = p4[i];
+                acc += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+            }
+        } else {
+            for (int i = threadIdx.x; i < hw; i += 256) acc += (double)p[i];
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
@@ -844,11 +852,11 @@ __global__ void channel_sum_final_kernel(const double* partial, int c, int slice
     out[ch] = (float)a;
 }
 
-extern "C" size_t lh_channel_sum_workspace_bytes(int c) { return (size_t)c * 16 * sizeof(double); }
+extern "C" size_t lh_channel_sum_workspace_bytes(int c) { return (size_t)c * 64 * sizeof(double); }
 
 extern "C" int lh_channel_sum_nchw(const float* x, int n, int c, int hw, float* out, void* workspace, void* stream) {
     LH_REQUIRE(x && out && workspace && n > 0 && c > 0 && hw > 0, "lh_channel_sum_nchw: bad arguments");
-    const int slices = n < 16 ? n : 16;
+    const int slices = n < 64 ? n : 64;
     hipLaunchKernelGGL(channel_sum_nchw_kernel, dim3(c, slices), dim3(256), 0, (hipStream_t)stream, x, n, c, hw, (double*)workspace, slices);
     hipLaunchKernelGGL(channel_sum_final_kernel, dim3((c + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const double*)workspace, c, slices, out);
     LH_LAUNCH_CHECK("channel_sum launch");

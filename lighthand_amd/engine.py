@@ -1745,16 +1745,17 @@ class Plan:
         return self.img_u8
 
     # ------------------------------------------------------------------ run
-    def refresh_packs(self, stream, overlap=False):
+    def refresh_packs(self, stream, overlap=False, side_work=None):
         """Rebuild the device-side weight packs from the parameter arena.  overlap=True (the captured training step): the
         one large launch -- the tiled transposing pack of every regular convolution, ~0.12 ms -- runs on a side stream
         under the image transform, the stem and the pool; the forward list waits for it at its 'packjoin' marker, just
-        before the first launch that reads a regular pack."""
+        before the first launch that reads a regular pack.  side_work(stream): more work for that side stream that only
+        depends on the step's inputs (the target render); returns True when it was run there."""
         side = getattr(self, "_pack_stream", None)
         if not overlap or side is None or self._packjoin_at is None:
             for c in self.packs:
                 c(stream)
-            return
+            return False
         main = torch.cuda.current_stream()
         assert main.cuda_stream == stream
         side.wait_event(main.record_event())
@@ -1763,7 +1764,10 @@ class Plan:
                 c(side.cuda_stream)
             else:
                 c(stream)
+        if side_work is not None:
+            side_work(side.cuda_stream)
         self._pack_event = side.record_event()
+        return side_work is not None
 
     def _run_lanes(self, calls, stream):
         """Launch `calls` with the independent branch chains (stream lane > 0) on side streams: a lane's first launch

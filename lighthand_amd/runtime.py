@@ -77,23 +77,35 @@ class TrainStep:
         self.steps = 0
 
     # ---- the work of one iteration, enqueued on the current stream --------------------------------
-    def _fwd_loss(self, stream):
-        self.plan.refresh_packs(stream, overlap=True)
-        self.plan.run_forward(stream)
-        self._fwd_loss_tail(stream)
+    def _render_target(self, stream):
+        out = self.plan.out_nchw
+        b, j, hs = self.joints.shape[0], self.joints.shape[1], out.shape[2]
+        check(self.lib.lh_gaussian_target(self.joints.data_ptr(), 2, self._patch.data_ptr(), heatmap.RADIUS,
+                                          self.target.data_ptr(), b, j, hs, stream), "lh_gaussian_target")
 
-    def _fwd_loss_tail(self, stream):
+    def _fwd_loss(self, stream):
+        # the target only depends on the joints: it is rendered on the weight-pack side stream, under the stem
+        rendered = self.plan.refresh_packs(stream, overlap=True, side_work=self._render_target if self.targets_from_joints else None)
+        self.plan.run_forward(stream)
+        self._fwd_loss_tail(stream, target_done=rendered)
+
+    def _fwd_loss_tail(self, stream, target_done=False):
         p, out = self.plan, self.plan.out_nchw
-        if self.targets_from_joints:
-            b, j, hs = self.joints.shape[0], self.joints.shape[1], out.shape[2]
-            check(self.lib.lh_gaussian_target(self.joints.data_ptr(), 2, self._patch.data_ptr(), heatmap.RADIUS,
-                                              self.target.data_ptr(), b, j, hs, stream), "lh_gaussian_target")
+        if self.targets_from_joints and not target_done:
+            self._render_target(stream)
+        aux = None
+        if self.decode and torch.cuda.current_stream().cuda_stream == stream:
+            # the arg-max decode only reads the heat-maps: on a side stream under the loss kernels
+            aux = self._aux_stream = getattr(self, "_aux_stream", None) or torch.cuda.Stream()
+            aux.wait_event(torch.cuda.current_stream().record_event())
         check(self.lib.lh_mse_heatmap(out.data_ptr(), self.target.data_ptr(), out.numel(), self.loss.data_ptr(),
                                       p.dout_nchw.data_ptr(), None, self._mse_ws.data_ptr(), stream), "lh_mse_heatmap")
         if self.decode:
             check(self.lib.lh_heatmap_argmax(out.data_ptr(), out.shape[0] * out.shape[1], out.shape[2], out.shape[3],
-                                             self.heat_scale, self.preds.data_ptr(), self.maxvals.data_ptr(), None, stream),
-                  "lh_heatmap_argmax")
+                                             self.heat_scale, self.preds.data_ptr(), self.maxvals.data_ptr(), None,
+                                             aux.cuda_stream if aux is not None else stream), "lh_heatmap_argmax")
+            if aux is not None:
+                torch.cuda.current_stream().wait_event(aux.record_event())
 
     def _enqueue_all(self):
         stream = torch.cuda.current_stream().cuda_stream
