@@ -312,6 +312,8 @@ typedef struct {
     int nterms;
     int relu;
     const void* relu_mask;      /* mask bits written by lh_fuse_fwd; when set, `out` is not read and may be NULL */
+    int strips_cap;             /* 0 = default (512): upper bound on the strips of the streaming reduce pass = rows of the
+                                 * partial-sum slab; 256 is the measured choice for nodes that share lh_fuse_bwd_multi launches */
 } lh_fuse_bwd_desc;
 size_t lh_fuse_bwd_workspace_bytes(int n, int h, int w, int c);
 int lh_fuse_bwd(const lh_fuse_bwd_desc* d, int n, int h, int w, int c, void* workspace,

@@ -34,7 +34,7 @@ class FuseBwdDesc(C.Structure):
                 ("shift", C.c_void_p * 4), ("save_mean", C.c_void_p * 4), ("save_invstd", C.c_void_p * 4), ("dx", C.c_void_p * 4),
                 ("dgamma", C.c_void_p * 4), ("dbeta", C.c_void_p * 4), ("log2up", C.c_int * 4),
                 ("accumulate", C.c_int * 4), ("nterms", C.c_int), ("relu", C.c_int),
-                ("relu_mask", C.c_void_p)]
+                ("relu_mask", C.c_void_p), ("strips_cap", C.c_int)]
 
 
 class IgemmCall(C.Structure):          # one entry of lh_igemm_multi = the arguments of lh_igemm

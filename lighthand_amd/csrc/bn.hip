@@ -39,6 +39,13 @@ __device__ __forceinline__ void slab_totals_then(const TI* slab, int rows, int c
     double a = 0.0, b = 0.0;
     if (ch < c) {
         int r = rl;
+        for (; r + 112 < rows; r += 128) {        // eight independent row groups in flight (the fold is a latency chain)
+            TI av[8], bv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { av[u] = slab[((long)(r + 16 * u) * 2) * c + ch]; bv[u] = slab[((long)(r + 16 * u) * 2 + 1) * c + ch]; }
+            a += (((double)av[0] + (double)av[1]) + ((double)av[2] + (double)av[3])) + (((double)av[4] + (double)av[5]) + ((double)av[6] + (double)av[7]));
+            b += (((double)bv[0] + (double)bv[1]) + ((double)bv[2] + (double)bv[3])) + (((double)bv[4] + (double)bv[5]) + ((double)bv[6] + (double)bv[7]));
+        }
         for (; r + 48 < rows; r += 64) {          // four independent row groups in flight
             const TI a0 = slab[((long)r * 2) * c + ch], b0 = slab[((long)r * 2 + 1) * c + ch];
             const TI a1 = slab[((long)(r + 16) * 2) * c + ch], b1 = slab[((long)(r + 16) * 2 + 1) * c + ch];
@@ -75,6 +82,13 @@ __device__ __forceinline__ void slab_totals_then64(const TI* slab, int rows, int
     double a = 0.0, b = 0.0;
     if (ch < c) {
         int r = rl;
+        for (; r + 448 < rows; r += 512) {        // eight independent row groups in flight (the fold is a latency chain)
+            TI av[8], bv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { av[u] = slab[((long)(r + 64 * u) * 2) * c + ch]; bv[u] = slab[((long)(r + 64 * u) * 2 + 1) * c + ch]; }
+            a += (((double)av[0] + (double)av[1]) + ((double)av[2] + (double)av[3])) + (((double)av[4] + (double)av[5]) + ((double)av[6] + (double)av[7]));
+            b += (((double)bv[0] + (double)bv[1]) + ((double)bv[2] + (double)bv[3])) + (((double)bv[4] + (double)bv[5]) + ((double)bv[6] + (double)bv[7]));
+        }
         for (; r + 192 < rows; r += 256) {        // four independent row groups in flight
             const TI a0 = slab[((long)r * 2) * c + ch], b0 = slab[((long)r * 2 + 1) * c + ch];
             const TI a1 = slab[((long)(r + 64) * 2) * c + ch], b1 = slab[((long)(r + 64) * 2 + 1) * c + ch];
@@ -915,8 +929,13 @@ __global__ __launch_bounds__(256) void fuse_bwd_coef_fused_multi_kernel(const Lh
     fuse_bwd_coef_fused_body(m.a[i], bid, nblk);
 }
 
-static long fuse_bwd_strips(long count, int* rows_per_strip) {
-    long rps = (count + 1023) / 1024;        // <= 1024 strips keep the streaming reduce at >= 4 workgroups per CU
+// Strips of the streaming reduce pass = rows of the partial-sum slab the coefficient fold reads.  Measured on the R50 and
+// HRNet-W32 steps: 512 strips for a node that runs alone (1 024: the fold is a longer latency chain, -0.08 ms per step
+// for 512; 256: the reduce pass loses occupancy), 256 per node when several nodes share a launch (lh_fuse_bwd_multi;
+// the caller says so in lh_fuse_bwd_desc.strips_cap, so that a node plans the same strips alone and in company).
+static long fuse_bwd_strips(long count, int* rows_per_strip, int strips_cap = 0) {
+    const long cap = strips_cap >= 16 && strips_cap <= 512 ? strips_cap : 512;
+    long rps = (count + cap - 1) / cap;
     if (rps < 16) rps = 16;
     *rows_per_strip = (int)rps;
     return (count + rps - 1) / rps;
@@ -1161,7 +1180,7 @@ static int plan_fuse_bwd(const lh_fuse_bwd_desc* d, int n, int h, int w, int c, 
         a.total = a.count * (c / (16 / es));
         if (a.x) {
             LH_REQUIRE(workspace && a.scale && a.mean && a.invstd, "lh_fuse_bwd: BN term %d lacks workspace/statistics", t);
-            long strips = fuse_bwd_strips(a.count, &a.rows_per_strip);
+            long strips = fuse_bwd_strips(a.count, &a.rows_per_strip, d->strips_cap);
             a.partial = (float*)((unsigned char*)workspace + (size_t)t * term_bytes);
             const long slab_floats = strips * 2 * c;
             double* scratch = (double*)(a.partial + ((slab_floats + 3) & ~3L));

@@ -232,6 +232,7 @@ class Plan:
         self._n_groups = 0
         self._lane_streams = {L: torch.cuda.Stream(device=self.device) for L in range(1, self.n_lanes)} if self.use_lanes else {}
         self._cur_lane = 0
+        self._emit_group = 1           # size of the batch group whose backward blocks are being emitted
         # Deferred weight gradients: the weight-gradient launches (+ folds) of a GROUP of layers are appended behind one
         # event and run on a side stream while the stream that produced their dy walks on (the main stream of a
         # single-lane network; a branch lane of HRNet: its chain inside one module).  Groups alternate over the side
@@ -872,6 +873,7 @@ class Plan:
                     gcount += 1
                     gid = gcount
                 flush_lanes = []
+                self._emit_group = len(item)
                 self._forced = group_forced.get(item[0])          # the data gradients are tuned while the blocks are emitted
                 for j, i in enumerate(item):
                     (kind, nd), blk, lane = self.nodes[i], bwd_blocks[i], self.node_lanes[i]
@@ -1619,6 +1621,7 @@ class Plan:
             bd.out = obuf.data_ptr() if relu else None
             bd.relu_mask = relu_bits.data_ptr() if relu_bits is not None else None
             bd.nterms, bd.relu = len(terms), int(relu)
+            bd.strips_cap = 256 if self._emit_group > 1 else 0      # nodes of a batch group share their launches
             for i, (a, bn, l) in enumerate(terms):
                 bd.log2up[i] = l
                 if not a.needs_grad:
