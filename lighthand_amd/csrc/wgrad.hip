@@ -203,26 +203,59 @@ __global__ __launch_bounds__(256) void wgrad_reduce_contig_kernel(const WreduceA
     }
 }
 
-// Generic layout / small tensors: one thread per (tap, o, i) -- coalesced slab reads, strided writes.
+// Generic layout / small tensors: one thread per (tap, o, FOUR consecutive i) -- 16-byte coalesced slab reads, eight splits
+// requested before the first is added (the fold is a latency chain over the splits), the sum itself strictly in split
+// order; strided writes.  n_in not a multiple of 4: one element per thread.
+static inline long wgrad_reduce_threads(long n_out, long n_in, long ntaps) {
+    return (n_in & 3) == 0 ? n_out * n_in * ntaps / 4 : n_out * n_in * ntaps;
+}
 __device__ __forceinline__ void wgrad_reduce_body(const WreduceArgs& p, const int bid, const int nblk) {
     const long idx = (long)bid * blockDim.x + threadIdx.x;
     const long per = (long)p.n_out * p.n_in;
+    if ((p.n_in & 3) == 0) {
+        const long per4 = per >> 2;
+        if (idx >= per4 * p.ntaps) return;
+        const int t = (int)(idx / per4);
+        const long pair4 = idx - (long)t * per4;
+        const int n4 = p.n_in >> 2;
+        const int o = (int)(pair4 / n4), i = (int)(pair4 - (long)o * n4) * 4;
+        const float4* src = reinterpret_cast<const float4*>(p.slab + (long)t * per + (long)o * p.n_in + i);
+        const long stride = (long)p.ntaps * per4;          // float4 units between splits
+        float4 a = float4{0.f, 0.f, 0.f, 0.f};
+        int sp = 0;
+        for (; sp + 8 <= p.nsplit; sp += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(long)(sp + u) * stride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+        }
+        for (; sp < p.nsplit; ++sp) {
+            const float4 v = src[(long)sp * stride];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        float* g = p.grad + o * p.so + i * p.si + p.r[t] * p.sr + p.s[t] * p.ss;
+        const float r[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g[k * p.si] = p.accumulate ? g[k * p.si] + r[k] : r[k];
+        return;
+    }
     if (idx >= per * p.ntaps) return;
     const int t = (int)(idx / per);
     const long pair = idx - (long)t * per;
     const int o = (int)(pair / p.n_in), i = (int)(pair - (long)o * p.n_in);
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    float a = 0.f;
     const float* src = p.slab + (long)t * per + pair;
     const long stride = (long)p.ntaps * per;
     int sp = 0;
-    for (; sp + 4 <= p.nsplit; sp += 4) {
-        a0 += src[(long)sp * stride];
-        a1 += src[(long)(sp + 1) * stride];
-        a2 += src[(long)(sp + 2) * stride];
-        a3 += src[(long)(sp + 3) * stride];
+    for (; sp + 8 <= p.nsplit; sp += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(long)(sp + u) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a += v[u];
     }
-    for (; sp < p.nsplit; ++sp) a0 += src[(long)sp * stride];
-    const float a = (a0 + a1) + (a2 + a3);
+    for (; sp < p.nsplit; ++sp) a += src[(long)sp * stride];
     float* g = p.grad + o * p.so + i * p.si + p.r[t] * p.sr + p.s[t] * p.ss;
     *g = p.accumulate ? *g + a : a;
 }
@@ -536,7 +569,7 @@ extern "C" int lh_wgrad_reduce(const lh_igemm_desc* d, const float* slab, float*
         LH_LAUNCH_CHECK("wgrad_reduce launch");
         return LH_OK;
     }
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(per * d->ntaps, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(wgrad_reduce_threads(n_out, n_in, d->ntaps), 256)), dim3(256), 0, (hipStream_t)stream, a);
     LH_LAUNCH_CHECK("wgrad_reduce launch");
     return LH_OK;
 }
@@ -607,7 +640,7 @@ extern "C" int lh_wgrad_fused_multi(const lh_wgrad_call* calls, int n, int dtype
         if (m.n == 0) plan0 = c;
         m.first[m.n + 1] = m.first[m.n] + m.a[m.n].tiles * m.a[m.n].ntaps * m.a[m.n].nsplit;
         r.a[r.n] = ra;
-        r.first[r.n + 1] = r.first[r.n] + ceil_div((long)q.n_out * q.n_in * q.d->ntaps, 256);
+        r.first[r.n + 1] = r.first[r.n] + ceil_div(wgrad_reduce_threads(q.n_out, q.n_in, q.d->ntaps), 256);
         ++m.n; ++r.n;
         if (m.n == LH_MULTI_MAX) {
             rc = flush();
