@@ -323,7 +323,7 @@ typedef struct { const lh_fuse_bwd_desc* d; int n, h, w, c; void* workspace; } l
 int lh_fuse_bwd_multi(const lh_fuse_bwd_call* calls, int n, int dtype, void* stream);
 
 /* nn.MaxPool2d(3, 2, 1): pose_resnet.py:156.  idx (uint8 [n][ho][wo][c]) keeps the window
- * position (first maximum in scan order, NaN propagates) for the backward pass. */
+ * position (first maximum in scan order, NaN propagates) for the backward pass; NULL when no backward pass follows. */
 int lh_maxpool3x3s2_fwd(const void* x, void* out, unsigned char* idx, int n, int h, int w, int c,
                         int dtype, void* stream);
 int lh_maxpool3x3s2_bwd(const void* dout, const unsigned char* idx, void* dx, int n, int h, int w,

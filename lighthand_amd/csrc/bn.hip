@@ -365,11 +365,13 @@ __device__ __forceinline__ void fuse_fwd_body(const FuseArgs& p, const int bid, 
     const int nchunk = p.c / EPC;
     const long total = (long)p.n * p.h * p.w * nchunk;
     for (long idx = (long)bid * 256 + threadIdx.x; idx < total; idx += (long)nblk * 256) {
-        const int ch = (int)(idx % nchunk);
-        const long pix = idx / nchunk;
-        const int x = (int)(pix % p.w);
-        const long t2 = pix / p.w;
-        const int y = (int)(t2 % p.h), n = (int)(t2 / p.h);
+        // 32-bit index arithmetic (plan_fuse_fwd checks total < 2^31): 64-bit divisions cost more than the rest of the loop
+        const unsigned iu = (unsigned)idx;
+        const unsigned pix = iu / (unsigned)nchunk;
+        const int ch = (int)(iu - pix * (unsigned)nchunk);
+        const unsigned t2 = pix / (unsigned)p.w;
+        const int x = (int)(pix - t2 * (unsigned)p.w);
+        const int n = (int)(t2 / (unsigned)p.h), y = (int)(t2 - (unsigned)n * (unsigned)p.h);
         float acc[EPC];
 #pragma unroll
         for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
@@ -504,6 +506,7 @@ static int plan_fuse_fwd(const lh_fuse_desc* d, void* out, int n, int h, int w, 
     }
     a.nterms = d->nterms; a.relu = d->relu; a.out = (unsigned char*)out; a.mask = (unsigned char*)d->relu_mask; a.n = n; a.h = h; a.w = w; a.c = c;
     const long total = (long)n * h * w * (c / (16 / es));
+    LH_REQUIRE(total < (1L << 31), "lh_fuse_fwd: tensor too large for 32-bit chunk indices");
     a.total = total;
     const int nchunk = c / (16 / es);
     bool flat = d->nterms <= 2 && (nchunk & (nchunk - 1)) == 0 && nchunk <= 256;
@@ -590,9 +593,9 @@ __device__ __forceinline__ void fuse_bwd_reduce_body(const FuseBwdArgs& p, const
 #pragma unroll
             for (int e = 0; e < EPC; ++e) { mean[e] = p.mean[chunk * EPC + e]; inv[e] = p.invstd[chunk * EPC + e]; }
             for (long r = r0 + rl; r < r1; r += lanes) {
-                const int xs = (int)(r % ws);
-                const long t2 = r / ws;
-                const int ys = (int)(t2 % hs), n = (int)(t2 / hs);
+                const unsigned t2 = (unsigned)r / (unsigned)ws;          // 32-bit: count < 2^31 (plan_fuse_bwd)
+                const int xs = (int)((unsigned)r - t2 * (unsigned)ws);
+                const int n = (int)(t2 / (unsigned)hs), ys = (int)(t2 - (unsigned)n * (unsigned)hs);
                 float g[EPC], xv[EPC];
                 cell_grad<T, EPC>(p, n, ys, xs, chunk, g);
                 unpack16<T>(*reinterpret_cast<const uint4*>(p.x + (r * p.c + chunk * EPC) * sizeof(T)), xv);
@@ -629,11 +632,12 @@ __device__ __forceinline__ void fuse_bwd_apply_body(const FuseBwdArgs& p, const 
     const int hs = p.h >> p.l, ws = p.w >> p.l;
     const long total = p.count * nchunk;
     for (long idx = (long)bid * 256 + threadIdx.x; idx < total; idx += (long)nblk * 256) {
-        const int chunk = (int)(idx % nchunk);
-        const long r = idx / nchunk;
-        const int xs = (int)(r % ws);
-        const long t2 = r / ws;
-        const int ys = (int)(t2 % hs), n = (int)(t2 / hs);
+        const unsigned iu = (unsigned)idx;                               // 32-bit: total < 2^31 (plan_fuse_bwd)
+        const unsigned r = iu / (unsigned)nchunk;
+        const int chunk = (int)(iu - r * (unsigned)nchunk);
+        const unsigned t2 = r / (unsigned)ws;
+        const int xs = (int)(r - t2 * (unsigned)ws);
+        const int n = (int)(t2 / (unsigned)hs), ys = (int)(t2 - (unsigned)n * (unsigned)hs);
         float g[EPC];
         cell_grad<T, EPC>(p, n, ys, xs, chunk, g);
         if (p.x) {
@@ -1178,6 +1182,7 @@ static int plan_fuse_bwd(const lh_fuse_bwd_desc* d, int n, int h, int w, int c, 
         a.mask_from_x = (flat && d->relu && d->nterms == 1 && a.x && d->shift[t]) ? 1 : 0;
         if (a.mask_from_x) a.shift = d->shift[t];
         a.total = a.count * (c / (16 / es));
+        LH_REQUIRE((long)n * h * w * (c / (16 / es)) < (1L << 31), "lh_fuse_bwd: tensor too large for 32-bit chunk indices");
         if (a.x) {
             LH_REQUIRE(workspace && a.scale && a.mean && a.invstd, "lh_fuse_bwd: BN term %d lacks workspace/statistics", t);
             long strips = fuse_bwd_strips(a.count, &a.rows_per_strip, d->strips_cap);
@@ -1252,27 +1257,43 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* x, T* out, un
     const int nchunk = c / EPC;
     const long total = (long)n * ho * wo * nchunk;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int ch = (int)(i % nchunk);
-        const long pix = i / nchunk;
-        const int ow = (int)(pix % wo);
-        const long t2 = pix / wo;
-        const int oh = (int)(t2 % ho), b = (int)(t2 / ho);
+        // 32-bit index arithmetic (the launcher checks total < 2^31): 64-bit divisions were most of this kernel's instructions
+        const unsigned iu = (unsigned)i;
+        const unsigned pix = iu / (unsigned)nchunk;
+        const int ch = (int)(iu - pix * (unsigned)nchunk);
+        const unsigned t2 = pix / (unsigned)wo;
+        const int ow = (int)(pix - t2 * (unsigned)wo);
+        const int b = (int)(t2 / (unsigned)ho), oh = (int)(t2 - (unsigned)b * (unsigned)ho);
+        // all nine taps are requested before the first compare (taps outside the image re-read the centre tap, which is
+        // always inside, and are skipped below): the loads of a window overlap instead of alternating with the compares
+        uint4 raw[9];
+        bool ok[9];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int ih = oh * 2 - 1 + r, iw = ow * 2 - 1 + s;
+                ok[r * 3 + s] = (unsigned)ih < (unsigned)h && (unsigned)iw < (unsigned)w;
+                const int jh = ok[r * 3 + s] ? ih : oh * 2, jw = ok[r * 3 + s] ? iw : ow * 2;
+                raw[r * 3 + s] = *reinterpret_cast<const uint4*>(x + (((long)b * h + jh) * w + jw) * c + ch * EPC);
+            }
         float best[EPC];
         unsigned char bi[EPC];
+        bool any = false;
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) { best[e] = -INFINITY; bi[e] = 255; }
-        for (int r = 0; r < 3; ++r) {
-            const int ih = oh * 2 - 1 + r;
-            if ((unsigned)ih >= (unsigned)h) continue;
-            for (int s = 0; s < 3; ++s) {
-                const int iw = ow * 2 - 1 + s;
-                if ((unsigned)iw >= (unsigned)w) continue;
-                float v[EPC];
-                unpack16<T>(*reinterpret_cast<const uint4*>(x + (((long)b * h + ih) * w + iw) * c + ch * EPC), v);
+        for (int t = 0; t < 9; ++t) {
+            if (!ok[t]) continue;
+            float v[EPC];
+            unpack16<T>(raw[t], v);
+            if (!any) {                              // first tap inside the image (scan order)
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) { best[e] = v[e]; bi[e] = (unsigned char)t; }
+                any = true;
+            } else {
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) {
                     // same rule as the framework's CPU kernel: strictly greater or NaN replaces
-                    if (v[e] > best[e] || v[e] != v[e] || bi[e] == 255) { best[e] = v[e]; bi[e] = (unsigned char)(r * 3 + s); }
+                    if (v[e] > best[e] || v[e] != v[e]) { best[e] = v[e]; bi[e] = (unsigned char)t; }
                 }
             }
         }
@@ -1282,8 +1303,10 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* x, T* out, un
 #pragma unroll
         for (int e = 0; e < EPC / 4; ++e)
             pk[e] = (unsigned)bi[4 * e] | ((unsigned)bi[4 * e + 1] << 8) | ((unsigned)bi[4 * e + 2] << 16) | ((unsigned)bi[4 * e + 3] << 24);
-        if constexpr (EPC == 8) *reinterpret_cast<uint2*>(idx + i * EPC) = uint2{pk[0], pk[1]};
-        else *reinterpret_cast<unsigned*>(idx + i * EPC) = pk[0];
+        if (idx) {
+            if constexpr (EPC == 8) *reinterpret_cast<uint2*>(idx + i * EPC) = uint2{pk[0], pk[1]};
+            else *reinterpret_cast<unsigned*>(idx + i * EPC) = pk[0];
+        }
     }
 }
 
@@ -1294,32 +1317,40 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* dout, const u
     const int nchunk = c / EPC;
     const long total = (long)n * h * w * nchunk;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int ch = (int)(i % nchunk);
-        const long pix = i / nchunk;
-        const int iw = (int)(pix % w);
-        const long t2 = pix / w;
-        const int ih = (int)(t2 % h), b = (int)(t2 / h);
+        const unsigned iu = (unsigned)i;             // 32-bit index arithmetic (total < 2^31, checked by the launcher)
+        const unsigned pix = iu / (unsigned)nchunk;
+        const int ch = (int)(iu - pix * (unsigned)nchunk);
+        const unsigned t2 = pix / (unsigned)w;
+        const int iw = (int)(pix - t2 * (unsigned)w);
+        const int b = (int)(t2 / (unsigned)h), ih = (int)(t2 - (unsigned)b * (unsigned)h);
+        // an input pixel lies in at most 2 x 2 windows: all four (gradient chunk, position bytes) pairs are requested
+        // up front (windows that do not exist re-read the first one and are skipped), then added in window order
         float g[EPC];
 #pragma unroll
         for (int e = 0; e < EPC; ++e) g[e] = 0.f;
-        for (int oh = (ih >> 1); oh <= ((ih + 1) >> 1); ++oh) {
-            if (oh >= ho) continue;
-            const int r = ih + 1 - 2 * oh;
-            if (r < 0 || r > 2) continue;
-            for (int ow = (iw >> 1); ow <= ((iw + 1) >> 1); ++ow) {
-                if (ow >= wo) continue;
-                const int s = iw + 1 - 2 * ow;
-                if (s < 0 || s > 2) continue;
-                const long o = (((long)b * ho + oh) * wo + ow) * c + ch * EPC;
-                float d[EPC];
-                unpack16<T>(*reinterpret_cast<const uint4*>(dout + o), d);
-                unsigned pk[EPC / 4];
-                if constexpr (EPC == 8) { const uint2 v = *reinterpret_cast<const uint2*>(idx + o); pk[0] = v.x; pk[1] = v.y; }
-                else pk[0] = *reinterpret_cast<const unsigned*>(idx + o);
+        uint4 dv[4];
+        unsigned pk[4][2];
+        int code[4];                                 // window position this pixel has in window k, -1: no such window
 #pragma unroll
-                for (int e = 0; e < EPC; ++e)
-                    if (((pk[e >> 2] >> (8 * (e & 3))) & 0xffu) == (unsigned)(r * 3 + s)) g[e] += d[e];
-            }
+        for (int k = 0; k < 4; ++k) {
+            const int oh = (ih >> 1) + (k >> 1), ow = (iw >> 1) + (k & 1);
+            const int r = ih + 1 - 2 * oh, s2 = iw + 1 - 2 * ow;
+            const bool ok = oh <= ((ih + 1) >> 1) && ow <= ((iw + 1) >> 1) && oh < ho && ow < wo && r >= 0 && r <= 2 && s2 >= 0 && s2 <= 2;
+            code[k] = ok ? r * 3 + s2 : -1;
+            const int jh = ok ? oh : (ih >> 1) < ho ? (ih >> 1) : ho - 1, jw = ok ? ow : (iw >> 1) < wo ? (iw >> 1) : wo - 1;
+            const long o = (((long)b * ho + jh) * wo + jw) * c + ch * EPC;
+            dv[k] = *reinterpret_cast<const uint4*>(dout + o);
+            if constexpr (EPC == 8) { const uint2 v = *reinterpret_cast<const uint2*>(idx + o); pk[k][0] = v.x; pk[k][1] = v.y; }
+            else { pk[k][0] = *reinterpret_cast<const unsigned*>(idx + o); pk[k][1] = 0u; }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (code[k] < 0) continue;
+            float d[EPC];
+            unpack16<T>(dv[k], d);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e)
+                if (((pk[k][e >> 2] >> (8 * (e & 3))) & 0xffu) == (unsigned)code[k]) g[e] += d[e];
         }
         *reinterpret_cast<uint4*>(dx + i * EPC) = pack16<T>(g);
     }
@@ -1327,11 +1358,12 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* dout, const u
 
 extern "C" int lh_maxpool3x3s2_fwd(const void* x, void* out, unsigned char* idx, int n, int h, int w, int c,
                                    int dtype, void* stream) {
-    LH_REQUIRE(x && out && idx && n > 0 && h > 0 && w > 0, "lh_maxpool3x3s2_fwd: bad arguments");
+    LH_REQUIRE(x && out && n > 0 && h > 0 && w > 0, "lh_maxpool3x3s2_fwd: bad arguments");
     const int es = lh_dtype_size(dtype);
     LH_REQUIRE(es > 0 && c % (16 / es) == 0, "lh_maxpool3x3s2_fwd: c %d not a multiple of the 16-byte chunk", c);
     const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
     const long total = (long)n * ho * wo * (c / (16 / es));
+    LH_REQUIRE((long)n * h * w * (c / (16 / es)) < (1L << 31), "lh_maxpool3x3s2_fwd: tensor too large for 32-bit chunk indices");
     const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
     LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((maxpool_fwd_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
                                                    (const T*)x, (T*)out, idx, n, h, w, c, ho, wo));
@@ -1346,6 +1378,7 @@ extern "C" int lh_maxpool3x3s2_bwd(const void* dout, const unsigned char* idx, v
     LH_REQUIRE(es > 0 && c % (16 / es) == 0, "lh_maxpool3x3s2_bwd: c %d not a multiple of the 16-byte chunk", c);
     const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
     const long total = (long)n * h * w * (c / (16 / es));
+    LH_REQUIRE(total < (1L << 31), "lh_maxpool3x3s2_bwd: tensor too large for 32-bit chunk indices");
     const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
     LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
                                                    (const T*)dout, idx, (T*)dx, n, h, w, c, ho, wo));

@@ -215,10 +215,12 @@ __device__ __forceinline__ void wgrad_reduce_body(const WreduceArgs& p, const in
     if ((p.n_in & 3) == 0) {
         const long per4 = per >> 2;
         if (idx >= per4 * p.ntaps) return;
-        const int t = (int)(idx / per4);
-        const long pair4 = idx - (long)t * per4;
-        const int n4 = p.n_in >> 2;
-        const int o = (int)(pair4 / n4), i = (int)(pair4 - (long)o * n4) * 4;
+        // 32-bit index arithmetic: a weight tensor has far fewer than 2^31 elements (reduce_prepare checks)
+        const unsigned iu = (unsigned)idx, p4 = (unsigned)per4;
+        const int t = (int)(iu / p4);
+        const unsigned pair4 = iu - (unsigned)t * p4;
+        const unsigned n4 = (unsigned)p.n_in >> 2;
+        const int o = (int)(pair4 / n4), i = (int)(pair4 - (unsigned)o * n4) * 4;
         const float4* src = reinterpret_cast<const float4*>(p.slab + (long)t * per + (long)o * p.n_in + i);
         const long stride = (long)p.ntaps * per4;          // float4 units between splits
         float4 a = float4{0.f, 0.f, 0.f, 0.f};
@@ -241,9 +243,10 @@ __device__ __forceinline__ void wgrad_reduce_body(const WreduceArgs& p, const in
         return;
     }
     if (idx >= per * p.ntaps) return;
-    const int t = (int)(idx / per);
-    const long pair = idx - (long)t * per;
-    const int o = (int)(pair / p.n_in), i = (int)(pair - (long)o * p.n_in);
+    const unsigned iu = (unsigned)idx, pu = (unsigned)per;
+    const int t = (int)(iu / pu);
+    const unsigned pair = iu - (unsigned)t * pu;
+    const int o = (int)(pair / (unsigned)p.n_in), i = (int)(pair - (unsigned)o * (unsigned)p.n_in);
     float a = 0.f;
     const float* src = p.slab + (long)t * per + pair;
     const long stride = (long)p.ntaps * per;
@@ -537,6 +540,7 @@ static int reduce_prepare(const lh_igemm_desc* d, const float* slab, float* grad
                           const int* taps_rs, int accumulate, int dtype, WreduceArgs* ap, bool* contig_out) {
     LH_REQUIRE(d && slab && grad && taps_rs, "lh_wgrad_reduce: null pointer");
     LH_REQUIRE(d->ntaps > 0 && d->ntaps <= 64, "lh_wgrad_reduce: ntaps %d out of range", d->ntaps);
+    LH_REQUIRE((long)n_out * n_in * d->ntaps < (1L << 31), "lh_wgrad_reduce: weight tensor too large for 32-bit element indices");
     WreduceArgs& a = *ap;
     WgradPlan c;
     const int rc = wgrad_plan(d, n_out, n_in, dtype, &c);

@@ -1710,8 +1710,8 @@ class Plan:
     def _c_maxpool(self, nd, blk):
         x, y = nd["x"], nd["y"]
         xbuf, ybuf = self._act_buf(x), self._act_buf(y)
-        idx = self._alloc(y.n, y.h, y.w, y.c, dtype=torch.uint8)
-        self.fwd.append(_Call(self.lib.lh_maxpool3x3s2_fwd, (xbuf.data_ptr(), ybuf.data_ptr(), idx.data_ptr(), x.n, x.h, x.w, x.c, self.dt), "maxpool fwd"))
+        idx = self._alloc(y.n, y.h, y.w, y.c, dtype=torch.uint8) if self.with_bwd else None     # window positions: only the backward pass reads them
+        self.fwd.append(_Call(self.lib.lh_maxpool3x3s2_fwd, (xbuf.data_ptr(), ybuf.data_ptr(), _ptr(idx), x.n, x.h, x.w, x.c, self.dt), "maxpool fwd"))
         if not self.with_bwd:
             return
 

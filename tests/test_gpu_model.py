@@ -345,6 +345,9 @@ def test_hrnet_branch_batching_is_bit_exact_and_cuts_launches(monkeypatch):
     from lighthand_amd.engine import _Call
     torch.manual_seed(3)
     model, _ = _build("hrnet_w32")
+    # trained-like weights: with the default random init the train-mode BN stack amplifies ANY last-bit difference between
+    # two kernel choices to tens of percents of the gradient, which would make the cross-plan bound below meaningless
+    model.load_state_dict(_trained_like(model.state_dict()))
     model = model.cuda().set_precision("bf16").train()
     sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
     rng = np.random.RandomState(2)
@@ -395,8 +398,9 @@ def test_hrnet_branch_batching_is_bit_exact_and_cuts_launches(monkeypatch):
     out_l, g_l = run(lanes, (lanes.fwd, lanes.bwd))
     assert torch.equal(out_s, out_l) and torch.equal(g_s, g_l)
     # measured vs static kernel choice: two equally valid bf16 evaluations (different tiles -> different BN partial-sum rows
-    # -> last-bit differences of the statistics) of a random-init train-mode network: its chaos amplifies them to percents
-    # 
-    assert rel(out_m.cpu().numpy(), out_l.cpu().numpy()) < 1e-1
+    # -> last-bit differences of the statistics and of bf16 roundings downstream); on well-conditioned weights they stay
+    # at the bf16 level
+    assert rel(out_m.cpu().numpy(), out_l.cpu().numpy()) < 3e-2
     d = (g_m - g_l).double()
-    assert float(d.norm() / g_l.double().norm()) < 1e-1
+    print("measured vs static kernel choice: heat-maps", rel(out_m.cpu().numpy(), out_l.cpu().numpy()), "gradients", float(d.norm() / g_l.double().norm()))
+    assert float(d.norm() / g_l.double().norm()) < 5e-2
