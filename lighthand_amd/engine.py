@@ -152,7 +152,7 @@ def _taps_array(rs):
 class _Call:
     """A pre-bound C-ABI call; the stream is appended at run time.  ``lane`` 1 marks work that may run on
     the side stream of the backward pass (weight gradients: they only feed the optimizer)."""
-    __slots__ = ("fn", "args", "what", "keep", "lane", "ig", "slane", "mtag", "keep_desc")
+    __slots__ = ("fn", "args", "what", "keep", "lane", "ig", "slane", "mtag", "keep_desc", "ws_ent")
 
     def __init__(self, fn, args, what, keep=None, lane=0):
         self.fn, self.args, self.what, self.keep, self.lane = fn, args, what, keep, lane
@@ -160,6 +160,7 @@ class _Call:
         self.slane = 0               # stream lane (branch) the call belongs to
         self.keep_desc = None        # weight-gradient calls: their descriptor (Plan._batch_wgrads)
         self.mtag = None             # (group, section, member, position): calls of one batch group that may merge (Plan._merge_groups)
+        self.ws_ent = None           # weight-gradient calls: their entry in Plan._ws_users (the slab follows the call's stream)
 
     def __call__(self, stream):
         rc = self.fn(*self.args, stream)
@@ -705,28 +706,54 @@ class Plan:
         self._ws_users.append(ent)
         if self.wgrad_group > 0:
             self._pending()["ws"].append(ent)
+        return ent
 
     def _wl(self):
         """List that takes the weight-gradient work of the node being emitted (deferred group or the backward list)."""
         return self._pending()["calls"] if self.wgrad_group > 0 else self.bwd
 
-    def _flush_wgrads(self, src):
-        """Append the deferred weight-gradient group of source lane `src` behind a 'wfork' event of that lane."""
+    def _flush_wgrads(self, src, spread=False):
+        """Append the deferred weight-gradient group of source lane `src` behind a 'wfork' event of that lane.
+        spread: the LAST group of the backward pass -- nothing is left on the main stream to overlap it with, so its
+        launches (each far from filling the machine) are dealt over all weight-gradient streams instead of queueing on one."""
         p = self._pend.get(src)
         if not p or not p["calls"]:
             return
-        lane = -1 - (self._w_flushes % self._w_lanes)
-        self._w_flushes += 1
-        m = _Marker("wfork")
-        m.slane, m.lane = lane, src          # .lane of a wfork marker = the stream whose progress the group waits for
-        self.bwd.append(m)
-        for c in p["calls"]:
-            c.slane = lane
-        for ent in p["ws"]:                  # the group's slab workspace follows its stream
-            ent[2] = lane
         if self.wgrad_batch:
             p["calls"] = self._batch_wgrads(p["calls"])
-        self.bwd += p["calls"]
+        lanes = [-1 - ((self._w_flushes + i) % self._w_lanes) for i in range(self._w_lanes if spread else 1)]
+        self._w_flushes += 1
+        # units that must stay together on one stream, in order: a weight-gradient call with the small calls that follow
+        # it (crop / unstage / bias), and the calls tagged to merge into one multi-problem launch
+        fused, clusters = self.lib.lh_wgrad_fused, []
+        for c in p["calls"]:
+            head = isinstance(c, _Call) and c.fn is fused
+            same = head and clusters and c.mtag is not None and getattr(clusters[-1][0], "mtag", None) is not None \
+                and clusters[-1][0].mtag[:2] == c.mtag[:2]
+            if clusters and (same or not head):
+                clusters[-1].append(c)
+            else:
+                clusters.append([c])
+        cost = {id(call): nbytes for _, call, _, _, nbytes in self.profile_meta}
+        load = {L: 0.0 for L in lanes}
+        where = {}
+        for i in sorted(range(len(clusters)), key=lambda i: -sum(cost.get(id(c), 0.0) for c in clusters[i])):
+            L = min(lanes, key=lambda L: (load[L], lanes.index(L)))
+            where[i] = L
+            load[L] += sum(cost.get(id(c), 0.0) for c in clusters[i]) + 1.0
+        for L in lanes:
+            mine = [clusters[i] for i in range(len(clusters)) if where[i] == L]
+            if not mine:
+                continue
+            m = _Marker("wfork")
+            m.slane, m.lane = L, src         # .lane of a wfork marker = the stream whose progress the group waits for
+            self.bwd.append(m)
+            for cl in mine:
+                for c in cl:
+                    c.slane = L
+                    if getattr(c, "ws_ent", None) is not None:
+                        c.ws_ent[2] = L      # the slab workspace follows the call's stream
+                self.bwd += cl
         if p["names"]:
             self.bwd_marks.append((len(self.bwd), p["names"]))
         self._pend[src] = dict(calls=[], names=[], layers=0, ws=[], bytes=0)
@@ -919,7 +946,7 @@ class Plan:
                     self._cur_lane = lane
                     self._flush_wgrads(lane)
             for src in sorted(self._pend):
-                self._flush_wgrads(src)
+                self._flush_wgrads(src, spread=os.environ.get("LH_TAIL_SPREAD", "1") != "0")
             self.bwd_marks.sort(key=lambda m: m[0])
             # two workspaces: the weight-gradient chain may run concurrently with the BN-backward chain
             # (stream lanes run concurrently: each lane has its own pair)
@@ -1392,7 +1419,7 @@ class Plan:
             def set_ws(ptr, cw=cw, a=a):
                 a[7] = ptr
                 cw.args = tuple(a)
-            self._ws_note(set_ws, slab_bytes)
+            cw.ws_ent = self._ws_note(set_ws, slab_bytes)
             wl = self._wl()
             wl.append(cw)
             self.profile_meta.append(("bwd", wl[-1], self._kname(d, (y.c, cin)), flops, (x.pixels * x.c + y.pixels * y.c) * self.es))
@@ -1480,7 +1507,7 @@ class Plan:
             def set_ws(ptr):
                 a[7] = ptr
                 cw.args = tuple(a)
-            self._ws_note(set_ws, slab_bytes)
+            cw.ws_ent = self._ws_note(set_ws, slab_bytes)
             wl = self._wl()
             wl.append(cw)
             self.profile_meta.append(("bwd", wl[-1], self._kname(dw, (y.c, n_in_w)), flops, (x.pixels * 4 + y.pixels * y.c) * self.es))
@@ -1559,7 +1586,7 @@ class Plan:
             def set_ws(ptr):
                 a[7] = ptr
                 cw.args = tuple(a)
-            self._ws_note(set_ws, slab_bytes)
+            cw.ws_ent = self._ws_note(set_ws, slab_bytes)
             wl = self._wl()
             wl.append(cw)
             self.profile_meta.append(("bwd", wl[-1], self._kname(dg, (cin, cout)), flops, (x.pixels * x.c + y.pixels * y.c) * self.es))
