@@ -544,6 +544,7 @@ struct FuseBwdArgs {
     int rows_per_strip;
     long count;                  // n * (h>>l) * (w>>l)
     long total;                  // 16-byte chunks of dx (flat apply kernel)
+    int fold_rows;               // > 0: the flat apply pass folds partial[fold_rows][2][c] itself (no coefficient launch)
 };
 
 template <typename T, int EPC>
@@ -669,6 +670,64 @@ __global__ __launch_bounds__(256) void fuse_bwd_apply_multi_kernel(const LhMulti
     fuse_bwd_apply_body<T>(m.a[i], bid, nblk);
 }
 
+// Coefficient fold INSIDE the apply pass (small tensors only, plan_fuse_bwd): every workgroup folds the reduce pass's
+// [rows][2][c] partial sums itself -- rows * 2c <= 16 Ki floats, all of its loads in flight at once, fp64 sums in a fixed
+// order, so every workgroup gets bit-identical coefficients -- and the separate fold launch (5-6 us on the dependency chain
+// of every BatchNorm of HRNet's branches) disappears.  coefL[0..c) = mean(g), coefL[c..2c) = mean(g * xhat); workgroup 0
+// also stores the parameter gradients dbeta = sum(g), dgamma = sum(g * xhat).
+constexpr int LH_FOLD_IN_APPLY_FLOATS = 16384;
+__device__ __forceinline__ void fold_coef_block(const float* slab, int rows, int c, long count, float* dgamma, float* dbeta,
+                                                bool writer, float* coefL) {
+    __shared__ double fold_part[512];
+    const int ncol = 2 * c;                              // power of two, <= 512
+    const int t = threadIdx.x;
+    if (ncol <= 256) {
+        const int parts = 256 / ncol, col = t & (ncol - 1), part = t / ncol;
+        double a = 0.0;
+        int r = part;
+        for (; r + 7 * parts < rows; r += 8 * parts) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = slab[(long)(r + u * parts) * ncol + col];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += (double)v[u];
+        }
+        for (; r < rows; r += parts) a += (double)slab[(long)r * ncol + col];
+        fold_part[t] = a;
+        __syncthreads();
+        if (t < ncol) {
+            double tot = 0.0;
+            for (int q = 0; q < parts; ++q) tot += fold_part[q * ncol + t];
+            coefL[t] = (float)(tot / (double)count);
+            if (writer) {
+                if (t < c) { if (dbeta) dbeta[t] = (float)tot; }
+                else if (dgamma) dgamma[t - c] = (float)tot;
+            }
+        }
+    } else {                                             // 2c = 512: two columns per thread, every row
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int col = t + 256 * h;
+            double a = 0.0;
+            int r = 0;
+            for (; r + 8 <= rows; r += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = slab[(long)(r + u) * ncol + col];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a += (double)v[u];
+            }
+            for (; r < rows; ++r) a += (double)slab[(long)r * ncol + col];
+            coefL[col] = (float)(a / (double)count);
+            if (writer) {
+                if (col < c) { if (dbeta) dbeta[col] = (float)a; }
+                else if (dgamma) dgamma[col - c] = (float)a;
+            }
+        }
+    }
+    __syncthreads();
+}
+
 // ---- l == 0 fast paths: dout / out / x / dx share one flat element offset, the thread keeps one channel chunk.
 template <typename T, bool MASK_X>
 __device__ __forceinline__ void fuse_bwd_reduce_flat_body(const FuseBwdArgs& p, const int bid, const int nblk) {
@@ -762,8 +821,15 @@ __device__ __forceinline__ void fuse_bwd_apply_flat_body(const FuseBwdArgs& p, c
         float iv[EPC], c0[EPC], c1[EPC], mn[EPC];
         load_vec<EPC>(p.scale + chunk * EPC, A);
         load_vec<EPC>(p.invstd + chunk * EPC, iv);
-        load_vec<EPC>(p.coef + chunk * EPC, c0);
-        load_vec<EPC>(p.coef + p.c + chunk * EPC, c1);
+        if (p.fold_rows > 0) {
+            __shared__ float coefL[512];
+            fold_coef_block(p.partial, p.fold_rows, p.c, p.count, p.dgamma, p.dbeta, bid == 0, coefL);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) { c0[e] = coefL[chunk * EPC + e]; c1[e] = coefL[p.c + chunk * EPC + e]; }
+        } else {
+            load_vec<EPC>(p.coef + chunk * EPC, c0);
+            load_vec<EPC>(p.coef + p.c + chunk * EPC, c1);
+        }
         load_vec<EPC>(p.mean + chunk * EPC, mn);
 #pragma unroll
         for (int e = 0; e < EPC; ++e) { B[e] = -A[e] * iv[e] * c1[e]; Cc[e] = -A[e] * c0[e] - B[e] * mn[e]; }
@@ -828,6 +894,11 @@ struct FuseBwd2Args {
     int accumulate[2];
     int c, relu;
     long total;
+    const float* fold_slab[2];   // term k folds fold_slab[k][fold_rows[k]][2][c] itself (see fold_coef_block); null: coef[k]
+    int fold_rows[2];
+    long count;
+    float* dgamma[2];
+    float* dbeta[2];
 };
 
 template <typename T>
@@ -843,8 +914,16 @@ __device__ __forceinline__ void fuse_bwd_apply2_flat_body(const FuseBwd2Args& p,
             float iv[EPC], c0[EPC], c1[EPC], mn[EPC];
             load_vec<EPC>(p.scale[k] + chunk * EPC, A[k]);
             load_vec<EPC>(p.invstd[k] + chunk * EPC, iv);
-            load_vec<EPC>(p.coef[k] + chunk * EPC, c0);
-            load_vec<EPC>(p.coef[k] + p.c + chunk * EPC, c1);
+            if (p.fold_slab[k]) {
+                __shared__ float coefL2[512];
+                if (k) __syncthreads();                  // the other term's coefficients have been read by every thread
+                fold_coef_block(p.fold_slab[k], p.fold_rows[k], p.c, p.count, p.dgamma[k], p.dbeta[k], bid == 0, coefL2);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) { c0[e] = coefL2[chunk * EPC + e]; c1[e] = coefL2[p.c + chunk * EPC + e]; }
+            } else {
+                load_vec<EPC>(p.coef[k] + chunk * EPC, c0);
+                load_vec<EPC>(p.coef[k] + p.c + chunk * EPC, c1);
+            }
             load_vec<EPC>(p.mean[k] + chunk * EPC, mn);
 #pragma unroll
             for (int e = 0; e < EPC; ++e) { B[k][e] = -A[k][e] * iv[e] * c1[e]; Cc[k][e] = -A[k][e] * c0[e] - B[k][e] * mn[e]; }
@@ -1164,9 +1243,14 @@ static int plan_fuse_bwd(const lh_fuse_bwd_desc* d, int n, int h, int w, int c, 
             m2.accumulate[k] = d->accumulate[k];
         }
     }
+    if (merge2) {
+        m2.count = (long)n * h * w;
+        for (int k = 0; k < 2; ++k) { m2.fold_slab[k] = nullptr; m2.fold_rows[k] = 0; m2.dgamma[k] = nullptr; m2.dbeta[k] = nullptr; }
+    }
     for (int t = 0; t < d->nterms; ++t) {
         if (!d->dx[t]) continue;
         FuseBwdArgs a;
+        a.fold_rows = 0;
         a.dout = (const unsigned char*)d->dout; a.out = (const unsigned char*)d->out;
         a.mask = (const unsigned char*)d->relu_mask;
         a.x = (const unsigned char*)d->x[t]; a.scale = d->scale[t]; a.mean = d->save_mean[t]; a.invstd = d->save_invstd[t];
@@ -1186,6 +1270,18 @@ static int plan_fuse_bwd(const lh_fuse_bwd_desc* d, int n, int h, int w, int c, 
         if (a.x) {
             LH_REQUIRE(workspace && a.scale && a.mean && a.invstd, "lh_fuse_bwd: BN term %d lacks workspace/statistics", t);
             long strips = fuse_bwd_strips(a.count, &a.rows_per_strip, d->strips_cap);
+            // small tensors (HRNet's branches): few enough strips that the apply pass folds them itself; a strip must stay
+            // short (<= 64 KiB of the operand), else the reduce pass would lose the workgroups it streams with
+            bool fold_in_apply = false;
+            if (flat && c <= 256 && getenv("LH_FOLD_IN_APPLY") == nullptr) {
+                int rps2;
+                const long s2 = fuse_bwd_strips(a.count, &rps2, (int)std::min<long>(d->strips_cap >= 16 ? d->strips_cap : 512, LH_FOLD_IN_APPLY_FLOATS / (2 * c)));
+                if (s2 * 2 * c <= LH_FOLD_IN_APPLY_FLOATS && (long)rps2 * c * es <= 65536) {
+                    fold_in_apply = true;
+                    strips = s2;
+                    a.rows_per_strip = rps2;
+                }
+            }
             a.partial = (float*)((unsigned char*)workspace + (size_t)t * term_bytes);
             const long slab_floats = strips * 2 * c;
             double* scratch = (double*)(a.partial + ((slab_floats + 3) & ~3L));
@@ -1198,11 +1294,16 @@ static int plan_fuse_bwd(const lh_fuse_bwd_desc* d, int n, int h, int w, int c, 
             r.phase = 0;
             r.fb = a;
             v.push_back(r);
-            BnLaunch q;
-            q.phase = 1;
-            q.kind = K_FB_COEF; q.grid = fold_grid((int)strips, c);
-            q.co.slab = a.partial; q.co.rows = (int)strips; q.co.c = c; q.co.count = a.count; q.co.coef = a.coef; q.co.dgamma = a.dgamma; q.co.dbeta = a.dbeta;
-            v.push_back(q);
+            if (fold_in_apply) {
+                if (merge2) { m2.fold_slab[t] = a.partial; m2.fold_rows[t] = (int)strips; m2.dgamma[t] = a.dgamma; m2.dbeta[t] = a.dbeta; }
+                else a.fold_rows = (int)strips;
+            } else {
+                BnLaunch q;
+                q.phase = 1;
+                q.kind = K_FB_COEF; q.grid = fold_grid((int)strips, c);
+                q.co.slab = a.partial; q.co.rows = (int)strips; q.co.c = c; q.co.count = a.count; q.co.coef = a.coef; q.co.dgamma = a.dgamma; q.co.dbeta = a.dbeta;
+                v.push_back(q);
+            }
             if (merge2) m2.coef[t] = a.coef;
         }
         if (merge2) continue;                 // both gradients are written by ONE pass below
