@@ -338,6 +338,38 @@ def test_bn_fuse_fwd_bwd_fp32(mode):
             assert int(msd[k]) == int(v) == 1
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("mode", ["plain", "residual", "two_bn", "up"])
+def test_bn_backward_fold_in_apply_equals_fold_launch(mode, precision, monkeypatch):
+    """Small tensors: the BN-backward apply pass folds the reduce pass's partial sums itself (bn.hip fold_coef_block, no
+    coefficient launch); LH_FOLD_IN_APPLY=0 forces the separate fold launch.  Both paths sum the same partial sums in fp64,
+    in two fixed orders: input gradients and d(gamma) / d(beta) agree to the last fp32 digits (pose_resnet.py:45-47,
+    pose_hrnet.py:247-265 are the nodes this serves)."""
+    _, BnNet = _mods()
+    import copy
+    torch.manual_seed(5)
+    m0 = BnNet(64, mode)
+    with torch.no_grad():
+        m0.bn.weight.uniform_(0.5, 1.5)
+        m0.bn.bias.uniform_(-0.5, 0.5)
+    x = torch.randn(4, 64, 16, 24)
+    torch.manual_seed(6)
+    dy = None
+    res = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("LH_FOLD_IN_APPLY", "0")
+        m = copy.deepcopy(m0)
+        out, dx, grads = _run_plan(m, x, lambda o: torch.randn(o.shape, generator=torch.Generator().manual_seed(7)), precision)
+        res.append((out, dx, grads))
+    (o1, d1, g1), (o2, d2, g2) = res
+    assert torch.equal(o1, o2)
+    tol = 1e-6 if precision == "fp32" else 1e-2          # bf16: a coefficient that moves by one fp32 ulp may move a rounding
+    assert rel_err(d1, d2) < tol
+    for k in g1:
+        assert rel_err(g1[k], g2[k]) < (1e-6 if precision == "fp32" else 1e-2), k
+
+
 def test_maxpool_ties_route_to_first():
     """All-equal windows (post-ReLU zeros): gradient goes to the first element in scan order."""
     from lighthand_amd import _lib
