@@ -390,6 +390,22 @@ def main():
             # the other single-GPU configurations of BASELINE.json, timed the same way (hipGraph replays, inputs resident)
             extra = {}
             del inf
+            # the same inference with TWO batches in flight (runtime.InferPipeline: one captured graph per slot, a stream each):
+            # the serving form -- infer_images_per_s above stays the one-batch-in-flight number of the earlier rounds
+            from lighthand_amd.runtime import InferPipeline
+            pipe = InferPipeline(model, args.batch, args.size, args.size, depth=2)
+            for st_ in pipe.steps:
+                st_.images.copy_(images)
+            for _ in range(6):
+                pipe.submit()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            for _ in range(2 * args.steps):
+                pipe.submit()
+            torch.cuda.synchronize()
+            extra["r50_infer_256_bs64_two_in_flight"] = {"images_per_s": round(args.batch * 2 * args.steps / (time.perf_counter() - t2), 1),
+                                                         "in_flight": 2, "dtype": args.precision}
+            del pipe
             m4 = build_model(precision=args.precision, hrnet_width=32)                      # configs[3], one GPU's share
             s4 = TrainStep(m4, 32, 256, 256, lr=1e-3)
             im4, j4 = synthetic_batch(32, 256, dev)

@@ -132,11 +132,13 @@ class HipModule(nn.Module):
             self._lh_arena = ParamArena(self)
         return self._lh_arena
 
-    def plan(self, n, h, w, training=None, backward=None, wgrad_bucket_bytes=None):
+    def plan(self, n, h, w, training=None, backward=None, wgrad_bucket_bytes=None, slot=0):
+        """slot: plans of the same shape with different slots own separate activation buffers and weight packs (several
+        batches in flight on different streams: runtime.InferPipeline)."""
         training = self.training if training is None else training
         backward = training if backward is None else backward
         self.arena()
-        key = (n, h, w, self._lh_precision, training, backward, wgrad_bucket_bytes)
+        key = (n, h, w, self._lh_precision, training, backward, wgrad_bucket_bytes) + ((slot,) if slot else ())
         p = self._lh_plans.get(key)
         if p is None:
             p = Plan(self, n, h, w, self._lh_precision, training=training, backward=backward, wgrad_bucket_bytes=wgrad_bucket_bytes)

@@ -693,3 +693,31 @@ def test_fused_inference_head_matches_separate_launches(precision):
     assert out[True][1] == out[False][1] - 2
     scale = float(out[False][0].abs().max())
     assert float((out[True][0] - out[False][0]).abs().max()) <= scale * 2.0 ** (-8 if precision == "bf16" else -10)
+
+
+def test_infer_pipeline_two_batches_in_flight_equals_infer_step():
+    """runtime.InferPipeline (several eval-mode batches in flight, a captured graph and a stream per slot; the decode of
+    src/utils/argparser.py:246-281): every batch's key points and confidences equal InferStep's bit for bit, in submission
+    order, for more batches than slots; a ticket that is no longer in flight is refused."""
+    from lighthand_amd._lib import LightHandError
+    from lighthand_amd.modeling.simplebaseline.pose_resnet import get_pose_net
+    from lighthand_amd.runtime import InferPipeline, InferStep
+    from conftest import resnet_cfg
+    torch.manual_seed(3)
+    model = get_pose_net(resnet_cfg(18), True).cuda().set_precision("bf16").eval()
+    b, h, w = 4, 128, 96
+    batches = [torch.randn(b, 3, h, w, device="cuda") for _ in range(5)]
+    ref = InferStep(model, b, h, w, slot=7)
+    want = []
+    for x in batches:
+        p = ref(x)
+        torch.cuda.synchronize()
+        want.append((p.clone(), ref.maxvals.clone()))
+    pipe = InferPipeline(model, b, h, w, depth=2)
+    got = list(pipe.map(batches))
+    assert len(got) == len(want)
+    for (p, m), (pw, mw) in zip(got, want):
+        assert torch.equal(p, pw) and torch.equal(m, mw)
+    with pytest.raises(LightHandError):
+        pipe.result(0)
+
