@@ -385,11 +385,6 @@ __device__ __forceinline__ void fuse_fwd_body(const FuseArgs& p, const int bid, 
                 const float* sh = p.shift[t] + ch * EPC;
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) v[e] = v[e] * sc[e] + sh[e];
-                if (p.nterms > 1) {
-                    // each BN output is a stored tensor in the reference: round it like one
-#pragma unroll
-                    for (int e = 0; e < EPC; ++e) v[e] = to_f<T>(from_f<T>(v[e]));
-                }
             }
 #pragma unroll
             for (int e = 0; e < EPC; ++e) acc[e] += v[e];
@@ -450,10 +445,6 @@ __device__ __forceinline__ void fuse_fwd_flat_body(const FuseArgs& p, const int 
             if (p.scale[t]) {
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) v[e] = v[e] * sc[t][e] + sh[t][e];
-                if (NT > 1) {
-#pragma unroll
-                    for (int e = 0; e < EPC; ++e) v[e] = to_f<T>(from_f<T>(v[e]));
-                }
             }
 #pragma unroll
             for (int e = 0; e < EPC; ++e) acc[e] = t == 0 ? v[e] : acc[e] + v[e];
