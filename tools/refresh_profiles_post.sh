@@ -12,6 +12,8 @@ python tools/pmc_traffic.py "$(find $O/pmc_fetch -name '*counter_collection.csv'
 python tools/pmc_mfma_step.py "$(find $O/pmc_mfma -name '*counter_collection.csv' | head -1)" profiles/${R}_pmc_mfma_step.txt > /dev/null
 cp "$(find $O/stats_hrnet -name '*kernel_stats.csv' | head -1)" profiles/${R}_hrnet_w32_bs32_kernel_stats.csv
 cp $O/layers_hrnet.txt profiles/${R}_hrnet_w32_bs32_layers.txt
+python tools/step_timeline.py "$(find $O/stats -name "${R}_kernel_trace.csv" | head -1)" profiles/${R}_step_timeline.txt
+python tools/step_timeline.py "$(find $O/stats_hrnet -name '*kernel_trace.csv' | head -1)" profiles/${R}_hrnet_w32_bs32_step_timeline.txt
 cp "$(find $O/stats_c5 -name '*kernel_stats.csv' | head -1)" profiles/${R}_c5_infer384_kernel_stats.csv
 cp $O/layers_c5.txt profiles/${R}_c5_infer384_layers.txt
 python tools/pmc_traffic.py "$(find $O/pmc_fetch_c5 -name '*counter_collection.csv' | head -1)" \
