@@ -877,20 +877,39 @@ class Plan:
             self.keep += [table, t_item, t_start]
             self.packs.append(_Call(self.lib.lh_pack_weights_multi,
                                     (table.data_ptr(), t_item.data_ptr(), t_start.data_ptr(), len(c_item), self.dt), "weight packs"))
-        if self._pack_convs:       # regular conv / deconv weights: one launch of the tiled transposing pack kernel
-            convs = list(self._pack_convs.values())
-            arr = (_lib.PackConv * len(convs))(*convs)
-            table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
-            c_conv, c_t0, c_t1 = [], [], []
-            for i, cv in enumerate(convs):
-                for a in range((cv.d0 + 31) // 32):
-                    for b in range((cv.d1 + 31) // 32):
-                        c_conv.append(i); c_t0.append(a); c_t1.append(b)
-            tabs = [torch.tensor(v, dtype=torch.int32, device=self.device) for v in (c_conv, c_t0, c_t1)]
-            self.keep += [table] + tabs
-            self.packs.append(_Call(self.lib.lh_pack_weights_tiled,
-                                    (table.data_ptr(), tabs[0].data_ptr(), tabs[1].data_ptr(), tabs[2].data_ptr(), len(c_conv),
-                                     max(cv.rs for cv in convs), self.dt), "weight packs (tiled)"))
+        self._late_packs = None    # (pack buffer pointers of the late group, index of the conv whose first use is the fork point)
+        if self._pack_convs:       # regular conv / deconv weights: the tiled transposing pack kernel
+            convs = list(self._pack_convs.values())        # in the order the forward pass first uses them
+            # Training plans split the launch: the layers the forward pass reaches LATE and that hold most of the bytes
+            # (R50: stage 4 + the head's transposed convolutions, 75 % of the parameters) are packed by a second launch that
+            # runs under the latency-bound middle of the forward pass instead of beside the HBM-bound stem and stage 1.
+            groups = [convs]
+            if self.with_bwd and len(convs) >= 16 and os.environ.get("LH_LATE_PACK", "1") != "0":
+                size = [cv.d0 * cv.d1 * cv.rs for cv in convs]
+                total, acc, cut = sum(size), 0, len(convs)
+                while cut > 0 and acc + size[cut - 1] <= 0.8 * total:
+                    cut -= 1
+                    acc += size[cut]
+                if 8 <= cut < len(convs) and acc >= 0.5 * total:
+                    groups = [convs[:cut], convs[cut:]]
+                    fork_conv = max(1, cut - max(8, int(0.35 * len(convs))))
+                    self._late_packs = ({convs[i].packs[k].out for i in range(cut, len(convs)) for k in range(convs[i].npacks)},
+                                        {convs[fork_conv].packs[k].out for k in range(convs[fork_conv].npacks)})
+            for gi, grp in enumerate(groups):
+                arr = (_lib.PackConv * len(grp))(*grp)
+                table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+                c_conv, c_t0, c_t1 = [], [], []
+                for i, cv in enumerate(grp):
+                    for a in range((cv.d0 + 31) // 32):
+                        for b in range((cv.d1 + 31) // 32):
+                            c_conv.append(i); c_t0.append(a); c_t1.append(b)
+                tabs = [torch.tensor(v, dtype=torch.int32, device=self.device) for v in (c_conv, c_t0, c_t1)]
+                self.keep += [table] + tabs
+                call = _Call(self.lib.lh_pack_weights_tiled,
+                             (table.data_ptr(), tabs[0].data_ptr(), tabs[1].data_ptr(), tabs[2].data_ptr(), len(c_conv),
+                              max(cv.rs for cv in grp), self.dt), "weight packs (tiled)" + (", late group" if gi else ""))
+                call.lane = gi           # 1 = the late group (refresh_packs(overlap=True) defers it to the 'packfork2' marker)
+                self.packs.append(call)
         self.bwd_marks = []        # (end index in self.bwd, parameter names whose gradient is final there)
         if self.with_bwd:
             gcount = self._n_groups
@@ -971,6 +990,27 @@ class Plan:
                     self._packjoin_at = i
                     self._pack_stream = torch.cuda.Stream(device=self.device)
                     break
+            if self._late_packs is not None and self._packjoin_at is not None:
+                late, fork_at = self._late_packs
+                first = lambda ptrs: next((i for i, c in enumerate(self.fwd) if isinstance(c, _Call) and self._call_packs(c) & ptrs), None)
+                j, f = first(late), first(fork_at)
+                if j is not None and f is not None and self._packjoin_at < f < j:
+                    self.fwd.insert(j, _Marker("packjoin2"))
+                    self.fwd.insert(f, _Marker("packfork2"))
+                else:
+                    self._late_packs = None
+        self._pack_late, self._pack_event2 = None, None
+
+    def _call_packs(self, c):
+        """Pack buffers a forward convolution call reads (addresses)."""
+        lib = self.lib
+        if c.fn is lib.lh_igemm:
+            return {c.args[2]}
+        if c.fn is lib.lh_igemm_multi:
+            return {c.args[0][i].wpack for i in range(c.args[1])}
+        if c.fn is lib.lh_igemm_phases or c.fn is lib.lh_igemm_phases_head:
+            return {c.args[3][i] for i in range(c.args[1])}
+        return set()
 
     def _c_nop(self, nd, blk):
         pass
@@ -1789,9 +1829,13 @@ class Plan:
         main = torch.cuda.current_stream()
         assert main.cuda_stream == stream
         side.wait_event(main.record_event())
+        self._pack_late = None
         for c in self.packs:
             if c.fn is self.lib.lh_pack_weights_tiled:
-                c(side.cuda_stream)
+                if c.lane == 1 and self._late_packs is not None:
+                    self._pack_late = c          # launched when the forward list reaches its 'packfork2' marker
+                else:
+                    c(side.cuda_stream)
             else:
                 c(stream)
         if side_work is not None:
@@ -1814,6 +1858,16 @@ class Plan:
                     if self._pack_event is not None:
                         main.wait_event(self._pack_event)
                         self._pack_event = None
+                elif c.kind == "packfork2":      # the late pack group starts here, on the pack stream, under the launches that follow
+                    if self._pack_late is not None:
+                        self._pack_stream.wait_event(main.record_event())
+                        self._pack_late(self._pack_stream.cuda_stream)
+                        self._pack_event2 = self._pack_stream.record_event()
+                        self._pack_late = None
+                elif c.kind == "packjoin2":
+                    if self._pack_event2 is not None:
+                        main.wait_event(self._pack_event2)
+                        self._pack_event2 = None
                 elif c.kind == "wfork":          # the deferred weight gradients that follow may start once their source
                     src = main if c.lane == 0 else self._lane_streams[c.lane]      # stream got here
                     wev[c.slane] = src.record_event()
@@ -1869,6 +1923,9 @@ class Plan:
             elif c.kind == "packjoin" and self._pack_event is not None:
                 torch.cuda.current_stream().wait_event(self._pack_event)
                 self._pack_event = None
+            elif c.kind == "packfork2" and self._pack_late is not None:
+                self._pack_late(stream)              # no side streams in this plan: the late group runs in place
+                self._pack_late = None
 
     def run_backward(self, stream, lo=0, hi=None):
         """Run bwd[lo:hi] (a segment of the backward list: data-parallel plans replay it bucket by bucket)."""
