@@ -239,7 +239,7 @@ class Plan:
         # single-lane network; a branch lane of HRNet: its chain inside one module).  Groups alternate over the side
         # streams, each with its own split-K slab.  LH_WGRAD_GROUP = layers per group (0 = weight gradients in place).
         n_convs = sum(1 for k, _ in self.nodes if k in ("conv", "deconv"))
-        auto_group = max(4, -(-n_convs * 42 // 100))         # ~2.4 groups per backward pass: 24 layers for R50 (measured best)
+        auto_group = max(4, -(-n_convs * 62 // 100))         # 36 layers for R50 (re-measured in round 3: 24: 9.65 ms, 32-40: 9.59-9.61, 48: 9.77)
         if self.n_lanes > 1:
             auto_group = 16                                   # branch lanes hand over at every module end; 16 on the main lane
         self.wgrad_group = int(os.environ.get("LH_WGRAD_GROUP", str(auto_group))) if self.with_bwd else 0
