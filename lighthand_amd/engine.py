@@ -248,7 +248,7 @@ class Plan:
         self.wgrad_bucket_bytes = wgrad_bucket_bytes
         if self.wgrad_group > 0:
             self.use_lanes = True
-            self._w_lanes = 2 if self.n_lanes == 1 else 4
+            self._w_lanes = int(os.environ.get("LH_WGRAD_LANES", "2" if self.n_lanes == 1 else "4"))
             for i in range(self._w_lanes):
                 self._lane_streams[-1 - i] = torch.cuda.Stream(device=self.device)
         self._pend = {}                    # source lane -> dict(calls, names, layers, ws)
