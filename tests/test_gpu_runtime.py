@@ -785,4 +785,15 @@ def test_infer_pipeline_two_batches_in_flight_equals_infer_step():
         assert torch.equal(p, pw) and torch.equal(m, mw)
     with pytest.raises(LightHandError):
         pipe.result(0)
+    # raw uint8 frames (ToTensor / Resize / Normalize fused on the device, dataset.py:128-159): same equality per slot
+    frames = [torch.randint(0, 256, (b, 100, 80, 3), dtype=torch.uint8, device="cuda") for _ in range(3)]
+    ref8 = InferStep(model, b, h, w, input_u8=(100, 80), slot=8)
+    want8 = []
+    for f in frames:
+        p = ref8(f)
+        torch.cuda.synchronize()
+        want8.append(p.clone())
+    pipe8 = InferPipeline(model, b, h, w, depth=2, input_u8=(100, 80))
+    for (p, _), pw in zip(pipe8.map(frames), want8):
+        assert torch.equal(p, pw)
 
