@@ -35,10 +35,14 @@ def sample_color_jitter(n, brightness=0.5, contrast=0.5, saturation=0.5, hue=0.5
     return factors, order
 
 
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
 class TrainStep:
     def __init__(self, model, batch, height, width, lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
                  optimizer=None, decode=True, use_graph=True, grad_sync=None, targets_from_joints=True,
-                 input_u8=None, color_jitter=None):
+                 input_u8=None, color_jitter=None, loss_scale=None):
         self.lib = _lib.load()
         self.model = model
         self._model_generation = getattr(model, "_lh_generation", 0)
@@ -71,6 +75,15 @@ class TrainStep:
         self.optimizer.bind_arena(self.arena)
         self.grad_sync = grad_sync                                     # parallel.GradSync or None
         self.grad_scale = 1.0 if grad_sync is None else 1.0 / grad_sync.world_size
+        # static loss scaling (fp16 plans: 1024 by default): the loss GRADIENT is multiplied by S where it is formed
+        # (lh_mse_heatmap), every gradient of the backward pass carries S, Adam divides it out again -- the loss value, the
+        # moments and the update are those of the unscaled step, but heat-map gradients of 1e-7 no longer flush to zero in
+        # the 16-bit backward pass.  bf16 / fp32 need none (fp32's exponent range).
+        if loss_scale is None:
+            loss_scale = 1024.0 if self.plan.tdtype == torch.float16 else 1.0
+        self.loss_scale = float(loss_scale)
+        self._loss_scale_dev = torch.tensor([self.loss_scale], dtype=torch.float32, device=dev) if self.loss_scale != 1.0 else None
+        self.grad_scale /= self.loss_scale
         self.graphs = None
         self.use_graph = use_graph
         self.heat_scale = float(height // out.shape[2])               # x4 of method.py:157
@@ -99,7 +112,7 @@ class TrainStep:
             aux = self._aux_stream = getattr(self, "_aux_stream", None) or torch.cuda.Stream()
             aux.wait_event(torch.cuda.current_stream().record_event())
         check(self.lib.lh_mse_heatmap(out.data_ptr(), self.target.data_ptr(), out.numel(), self.loss.data_ptr(),
-                                      p.dout_nchw.data_ptr(), None, self._mse_ws.data_ptr(), stream), "lh_mse_heatmap")
+                                      p.dout_nchw.data_ptr(), _ptr(self._loss_scale_dev), self._mse_ws.data_ptr(), stream), "lh_mse_heatmap")
         if self.decode:
             check(self.lib.lh_heatmap_argmax(out.data_ptr(), out.shape[0] * out.shape[1], out.shape[2], out.shape[3],
                                              self.heat_scale, self.preds.data_ptr(), self.maxvals.data_ptr(), None,

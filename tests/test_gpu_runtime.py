@@ -760,6 +760,29 @@ def test_fused_inference_head_matches_separate_launches(precision):
     assert float((out[True][0] - out[False][0]).abs().max()) <= scale * 2.0 ** (-8 if precision == "bf16" else -10)
 
 
+def test_static_loss_scale_is_exact_and_defaults_to_1024_for_fp16():
+    """TrainStep(loss_scale=S): the loss gradient is multiplied by S where it is formed and Adam divides it out again.  A
+    power of two commutes with every rounding of the backward pass (no overflow / underflow at these magnitudes), so a bf16
+    step with S = 64 leaves bit-identical weights and the same loss as S = 1; fp16 plans default to S = 1024 (their
+    1e-7-sized heat-map gradients flush to zero otherwise: R50 loss after 100 steps 4.6e-3 unscaled vs 1.5e-3 scaled = bf16's),
+    bf16 / fp32 plans to 1 (src/utils/method.py:160-183 is the loop this step replaces)."""
+    from lighthand_amd.runtime import TrainStep
+    x, j = _batch(4, 128, 5)
+    res = []
+    for scale in (1.0, 64.0):
+        m = _model(18, precision="bf16")
+        step = TrainStep(m, 4, 128, 128, lr=1e-3, loss_scale=scale)
+        losses = []
+        for _ in range(3):
+            step(x, j)
+            losses.append(float(step.loss))
+        res.append((losses, m.arena().flat.clone()))
+    assert res[0][0] == res[1][0]
+    assert torch.equal(res[0][1], res[1][1])
+    assert TrainStep(_model(18, precision="fp16"), 4, 128, 128).loss_scale == 1024.0
+    assert TrainStep(_model(18, precision="bf16"), 4, 128, 128).loss_scale == 1.0
+
+
 def test_infer_pipeline_two_batches_in_flight_equals_infer_step():
     """runtime.InferPipeline (several eval-mode batches in flight, a captured graph and a stream per slot; the decode of
     src/utils/argparser.py:246-281): every batch's key points and confidences equal InferStep's bit for bit, in submission
