@@ -404,7 +404,8 @@ def test_c2_r50_bf16_train_forward_matches_fp32_oracle():
     assert lrel < 5e-2
 
 
-def test_c4_hrnet_w32_bf16_train_forward_matches_fp32_oracle():
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_c4_hrnet_w32_bf16_train_forward_matches_fp32_oracle(precision):
     """BASELINE.json config 4's model in its timed dtype (HRNet-W32, 256 x 256, bf16; batch cut to 8 for the CPU oracle),
     pinned by VALUE to the fp32 oracle like C2 above: train-mode forward + JointsMSELoss of the bf16 HIP path (merged
     multi-problem launches, mixed BN-backward grids during the training that produces the weights) vs oracle.models
@@ -417,7 +418,8 @@ def test_c4_hrnet_w32_bf16_train_forward_matches_fp32_oracle():
     4): heat-maps within 2e-2 of the oracle's peak in RMS (measured 0.7e-2 .. 1.1e-2 over runs) and 2.5e-1 at the 99.9th
     percentile (5.5e-2 .. 1.5e-1), arg-max key points within ONE heat-map pixel on >= 90 % of the joints (93-97 %; exactly
     equal on 81-89 %), loss within 1e-1 relative (2e-2 .. 6e-2); the worst single element is reported, not bounded
-    (0.30-0.58 of the peak)."""
+    (0.30-0.58 of the peak).  The fp16 case trains the same plan with its static loss scale (TrainStep default 1024) and is
+    held to tighter bounds: RMS 4e-3 (measured 1.2e-3), 99.9th percentile 5e-2, within one pixel on >= 97 % of the joints."""
     from lighthand_amd.heatmap import JointsMSELoss, render_targets
     from lighthand_amd.modeling.hrnet.pose_hrnet import get_hrnet, hrnet_cfg
     from lighthand_amd.runtime import TrainStep
@@ -425,7 +427,7 @@ def test_c4_hrnet_w32_bf16_train_forward_matches_fp32_oracle():
     from oracle.heatmap import get_max_preds
     b, size = 8, 256
     torch.manual_seed(9001)
-    m = get_hrnet(hrnet_cfg(32), True).cuda().set_precision("bf16")
+    m = get_hrnet(hrnet_cfg(32), True).cuda().set_precision(precision)
     rng = np.random.RandomState(33)
     cen = rng.uniform(70, size - 70, size=(b, 1, 2)).astype(np.float32)
     joints = cen + rng.uniform(-48, 48, size=(1, 21, 2)).astype(np.float32)
@@ -437,6 +439,7 @@ def test_c4_hrnet_w32_bf16_train_forward_matches_fp32_oracle():
     x, j = torch.from_numpy(img).cuda(), torch.from_numpy(joints).cuda()
     step = TrainStep(m, b, size, size, lr=1e-3)
     assert step.plan.batch and step.plan._n_groups > 0          # the merged-launch plan is the one that trains
+    assert step.loss_scale == (1024.0 if precision == "fp16" else 1.0)
     for _ in range(1500):
         step(x, j)
     torch.cuda.synchronize()
@@ -458,13 +461,18 @@ def test_c4_hrnet_w32_bf16_train_forward_matches_fp32_oracle():
     near = float((np.abs(pg - pw).max(-1) <= 1).mean())
     p999 = float(np.quantile(np.abs(got - want), 0.999) / peak)
     lrel = abs(float(loss) - loss_ref) / abs(loss_ref)
-    print(f"C4 (HRNet-W32) bf16 forward parity: heatmap rms / peak {rms:.3e}, 99.9th percentile {p999:.3e}, max {err:.3e} (peak {peak:.3f}), "
+    print(f"C4 (HRNet-W32) {precision} forward parity: heatmap rms / peak {rms:.3e}, 99.9th percentile {p999:.3e}, max {err:.3e} (peak {peak:.3f}), "
           f"arg-max equal {match:.4f}, within one pixel {near:.4f}, loss rel {lrel:.3e}")
     assert got.shape == want.shape == (b, 21, 64, 64)
     assert peak > 0.5                                           # the network did learn peaks
-    assert rms < 2e-2 and p999 < 2.5e-1
-    assert near >= 0.90
-    assert lrel < 1e-1
+    if precision == "fp16":
+        assert rms < 4e-3 and p999 < 5e-2
+        assert near >= 0.97
+        assert lrel < 5e-2
+    else:
+        assert rms < 2e-2 and p999 < 2.5e-1
+        assert near >= 0.90
+        assert lrel < 1e-1
 
 
 def test_eval_tail_batch_runs_unpadded(tmp_path):
