@@ -4,6 +4,8 @@ import ctypes as C
 import os
 import re
 
+import pytest
+
 from conftest import ROOT
 
 
@@ -119,3 +121,42 @@ def test_explicit_wgrad_configuration_must_fit():
     d.cfg[5], d.cfg[6], d.cfg[7] = 256, 256, enc                       # a compiled-in 256 x 256 plan on a 64 x 64 gradient
     assert lib.lh_wgrad_tile(C.byref(d), 64, 64, _lib.LH_BF16, C.byref(bo), C.byref(bi), C.byref(ns), C.byref(ring)) == -1
     assert b"does not fit" in lib.lh_last_error()
+
+
+def test_ctypes_structs_mirror_the_header_layout(tmp_path):
+    """The ctypes mirrors in lighthand_amd/_lib.py must have the size and the field offsets of the structs that
+    include/lighthand_hip.h declares: a probe compiled with gcc against the header prints sizeof / offsetof of every field
+    (a field added on one side only would shift every later argument silently)."""
+    import ctypes as C
+    import shutil
+    import subprocess
+    from lighthand_amd import _lib
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    pairs = {"lh_igemm_desc": _lib.IgemmDesc, "lh_fuse_desc": _lib.FuseDesc, "lh_fuse_bwd_desc": _lib.FuseBwdDesc,
+             "lh_igemm_call": _lib.IgemmCall, "lh_wgrad_call": _lib.WgradCall, "lh_fuse_fwd_call": _lib.FuseFwdCall,
+             "lh_fuse_bwd_call": _lib.FuseBwdCall, "lh_bn_finalize_call": _lib.BnFinalizeCall, "lh_head": _lib.Head,
+             "lh_pack_item": _lib.PackItem, "lh_pack_out": _lib.PackOut, "lh_pack_conv": _lib.PackConv}
+    rename = {"in_": "in", "pad_": None}                       # ctypes-side spellings; None = padding without a C name
+    lines = []
+    for cname, cls in pairs.items():
+        lines.append(f'printf("{cname} size %zu\\n", sizeof({cname}));')
+        for fname, *_ in cls._fields_:
+            cf = rename.get(fname, fname)
+            if cf is not None:
+                lines.append(f'printf("{cname} {fname} %zu\\n", offsetof({cname}, {cf}));')
+    src = tmp_path / "probe.c"
+    src.write_text("#include <stdio.h>\n#include <stddef.h>\n#include \"lighthand_hip.h\"\nint main(void) {\n" + "\n".join(lines) + "\nreturn 0; }\n")
+    exe = tmp_path / "probe"
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    subprocess.run(["gcc", "-std=c99", "-I", inc, str(src), "-o", str(exe)], check=True)
+    got = {}
+    for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines():
+        cname, field, val = line.split()
+        got[(cname, field)] = int(val)
+    for cname, cls in pairs.items():
+        assert got[(cname, "size")] == C.sizeof(cls), (cname, got[(cname, "size")], C.sizeof(cls))
+        for fname, *_ in cls._fields_:
+            if rename.get(fname, fname) is not None:
+                assert got[(cname, fname)] == getattr(cls, fname).offset, (cname, fname)
+
