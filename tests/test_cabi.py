@@ -28,6 +28,27 @@ def test_library_exports_every_declared_symbol():
     assert [lib.lh_dtype_size(i) for i in range(4)] == [4, 2, 2, 0]
 
 
+def test_ctypes_prototypes_have_the_header_arity():
+    """Every prototype of include/lighthand_hip.h has as many parameters as its ctypes mirror in _lib.SIGNATURES, and pointer /
+    integer / floating parameters sit at the same positions."""
+    from lighthand_amd import _lib
+    text = open(os.path.join(ROOT, "include", "lighthand_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    protos = dict(re.findall(r"\b(lh_[a-z0-9_]+)\s*\(([^;{}]*?)\)\s*;", text, flags=re.S))
+    assert set(protos) == set(_lib.SIGNATURES)
+    for name, args in protos.items():
+        params = [a.strip() for a in args.split(",")] if args.strip() not in ("", "void") else []
+        want = _lib.SIGNATURES[name][1]
+        assert len(params) == len(want), (name, params, want)
+        for prm, ct in zip(params, want):
+            is_ptr = "*" in prm
+            c_ptr = ct in (C.c_void_p, C.c_char_p) or isinstance(ct, type) and issubclass(ct, C._Pointer)
+            assert is_ptr == c_ptr, (name, prm, ct)
+            if not is_ptr:
+                floating = bool(re.match(r"(const\s+)?(float|double)\b", prm))
+                assert floating == (ct in (C.c_float, C.c_double)), (name, prm, ct)
+
+
 def test_argument_validation_sets_error_text():
     from lighthand_amd import _lib
     lib = _lib.load()
