@@ -212,6 +212,35 @@ def cpu_baseline(depth, size, batch, seconds_budget=25.0, cores=None):
                 sample=f"oracle (plain PyTorch fp32 CPU) R{depth} {size}x{size} train step, batch {batch}, {n} timed step(s) of {dt:.2f} s")
 
 
+def spawn_ranks(n):
+    """Run this script under torch.distributed.run with n ranks on this node (one per GPU) and pass its output through.
+    Returns the launcher's exit code; non-zero too when no rank printed the JSON line or the line reports another rank count."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    ranks_seen = None
+    for line in proc.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+        if line.startswith("{") and '"metric"' in line:
+            try:
+                ranks_seen = json.loads(line).get("n_gpus")
+            except ValueError:
+                pass
+    rc = proc.wait()
+    if rc == 0 and ranks_seen != n:
+        print(f"bench.py: --gpus {n} but the run reported n_gpus = {ranks_seen}", file=sys.stderr)
+        return 3
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -233,14 +262,25 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the extra configurations (HRNet-W32 training, R50 384x384 fp16 inference)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: this parent (which has made no GPU call yet) starts the N ranks
+        # as a CHILD launcher process, relays rank 0's JSON line and returns the launcher's exit code.  A worker never
+        # re-executes itself.
+        raise SystemExit(spawn_ranks(args.gpus))
+
     from lighthand_amd import parallel
     from lighthand_amd.runtime import InferStep, TrainStep
 
     rank, world, local = parallel.init_distributed()
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    ranks_seen = 1
+    if world > 1:                                            # the rank count the collective itself sees
+        one = torch.ones(1, device=dev)
+        torch.distributed.all_reduce(one)
+        ranks_seen = int(one.item())
     model = build_model(args.depth, args.precision, args.hrnet_width)
     name = f"HRNet-W{args.hrnet_width}" if args.hrnet_width else f"SimpleBaseline-ResNet{args.depth}"
     if args.infer_only:
@@ -309,7 +349,8 @@ def main():
                                f"(fwd + JointsMSELoss + argmax decode + bwd + Adam), batch {args.batch}/GPU, 21 joints, "
                                f"random init (seed 9001), hipGraph replay" + (f", dp{world} RCCL all-reduce ({args.comm}, {args.grad_buckets} buckets)" if world > 1 else ""),
                    "global_batch": world * args.batch, "parallelism": f"dp{world}"},
-        "ms_per_step_median": round(median_ms, 3),
+        "ms_per_step_median": round(median_ms, 3), "ranks_seen": ranks_seen,
+        "dist_backend": torch.distributed.get_backend() if world > 1 else None,
         "loss_after": round(loss_val, 6),
         "train_tflops": round(value * (TRAIN_GFLOP_PER_IMG if (args.depth, args.size) == (50, 256) else 0) / 1e3, 1),
     }

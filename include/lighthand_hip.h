@@ -385,6 +385,12 @@ int lh_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg
 size_t lh_channel_sum_workspace_bytes(int c);
 int lh_channel_sum_nchw(const float* x, int n, int c, int hw, float* out, void* workspace, void* stream);
 
+/* Bias gradient of a convolution / transposed convolution WITH bias inside the network (DECONV_WITH_BIAS:
+ * src/modeling/simplebaseline/pose_resnet.py:149,227; what autograd's loss.backward() adds for nn.ConvTranspose2d(bias=True)):
+ * out[ch] = sum over `pixels` rows of an NHWC gradient of the run precision, channels [0, c) of rows of pix_stride
+ * elements (16-byte aligned rows).  fp64 partials in a fixed order (deterministic); same workspace size. */
+int lh_channel_sum_nhwc(const void* x, long pixels, int c, int pix_stride, float* out, void* workspace, int dtype, void* stream);
+
 /* PCK curve of pred_eval (src/utils/argparser.py:326-388) on the device: counts[t] += visible joints (gt[..][2] == 1) whose
  * error (pixel distance; divided by bb[sample] when bb != NULL, the 'pckb' mode) is < thr[t]; *nvis += visible joints;
  * diff_row[s] = sum of pixel errors over ALL joints of sample s.  float64 arithmetic like the NumPy original; counts /

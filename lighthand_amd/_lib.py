@@ -137,6 +137,7 @@ SIGNATURES = {
     "lh_heatmap_argmax": (_I, [_P, _I, _I, _I, _F, _P, _P, _P, _P]),
     "lh_channel_sum_workspace_bytes": (C.c_size_t, [_I]),
     "lh_channel_sum_nchw": (_I, [_P, _I, _I, _I, _P, _P, _P]),
+    "lh_channel_sum_nhwc": (_I, [_P, C.c_long, _I, _I, _P, _P, _I, _P]),
     "lh_copy_strided_f32": (_I, [_P, _P, _P, _P, _P, _P]),
     "lh_pck_curve": (_I, [_P, _P, _I, _P, _I, _I, _P, _I, _P, _P, _P, _P]),
     "lh_heatmap_soft_argmax": (_I, [_P, _I, _I, _I, _F, _F, _P, _P]),

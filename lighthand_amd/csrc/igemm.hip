@@ -20,6 +20,7 @@
 
 #include "igemm_args.h"
 #include "multi.h"
+#include "igemm_ring_cfgs.h"
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16> {
@@ -411,7 +412,7 @@ static int igemm_impl(const lh_igemm_desc* d, const void* in, const void* wpack,
         a.head_j = head->n_out; a.head_wstride = (int)head->w_row_bytes;
     }
     if (prep_args) {            // lh_igemm_multi: hand the argument block back instead of launching
-        LH_REQUIRE(ring && rc_.depth >= 2 && rc_.depth < 100, "lh_igemm_multi: problem does not run on the LDS-DMA ring kernel (its cfg must name a tiled configuration)");
+        LH_REQUIRE(ring && rc_.depth >= 2 && rc_.depth < LH_WIDE_DEPTH, "lh_igemm_multi: problem does not run on the LDS-DMA ring kernel (its cfg must name a tiled configuration)");
         lh_tap_grid(d, &a.tw, &a.dh0, &a.dhs, &a.dw0, &a.dws);
         a.kspt = (d->k_run * es + rc_.kb - 1) / rc_.kb;
         *prep_args = a;

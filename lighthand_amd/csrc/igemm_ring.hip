@@ -15,6 +15,8 @@ int lh_ring_launch_bf16_small(const IgemmArgs& a, const RingCfg& c, hipStream_t 
 int lh_ring_launch_f16_big(const IgemmArgs& a, const RingCfg& c, hipStream_t s);
 int lh_ring_launch_f16_mid(const IgemmArgs& a, const RingCfg& c, hipStream_t s);
 int lh_ring_launch_f16_small(const IgemmArgs& a, const RingCfg& c, hipStream_t s);
+int lh_ring_launch_bf16_wide(const IgemmArgs& a, const RingCfg& c, hipStream_t s);
+int lh_ring_launch_f16_wide(const IgemmArgs& a, const RingCfg& c, hipStream_t s);
 int lh_ring_launch_f32(const IgemmArgs& a, const RingCfg& c, hipStream_t s);
 int lh_ring_multi_launch_bf16(const LhMulti<IgemmArgs>& m, const RingCfg& c, hipStream_t s);
 int lh_ring_multi_launch_f16(const LhMulti<IgemmArgs>& m, const RingCfg& c, hipStream_t s);
@@ -28,6 +30,9 @@ int lh_pw_occ_f16(const RingCfg& c, bool stats);
 static const RingCfg kCfg16[] = {
 #define X(BM, BP, WC, WP, D, KB) {BM, BP, D, KB},
     LH_RING_CFGS_16BIT(X)
+#undef X
+#define X(BM, BP, WC, WP, D, KB) {BM, BP, D + LH_WIDE_DEPTH, KB},
+    LH_RING_CFGS_WIDE(X)
 #undef X
 };
 static const RingCfg kCfg32[] = {
@@ -47,6 +52,10 @@ static void cfg_table(int dtype, const RingCfg** t, int* n) {
     if (dtype == LH_F32) { *t = kCfg32; *n = (int)(sizeof(kCfg32) / sizeof(RingCfg)); }
     else { *t = kCfg16; *n = (int)(sizeof(kCfg16) / sizeof(RingCfg)); }
 }
+
+// ring depth of a tiled configuration (the wide-wave form carries it as depth + LH_WIDE_DEPTH)
+static inline int ring_depth(const RingCfg& c) { return c.depth >= LH_WIDE_DEPTH && c.depth < 100 ? c.depth - LH_WIDE_DEPTH : c.depth; }
+static inline bool ring_wide(const RingCfg& c) { return c.depth >= LH_WIDE_DEPTH && c.depth < 100; }
 
 static bool cfg_exists(int dtype, const RingCfg& c) {
     const RingCfg* t; int n;
@@ -101,7 +110,9 @@ static bool cfg_fits(const lh_igemm_desc* d, int dtype, const RingCfg& c) {
     if (!cfg_safe(d, dtype, c)) return false;
     if (c.bm > 64 && d->cout <= c.bm / 2) return false;               // (these three only multiply zeros / repeat a shallower ring)
     if (c.bp > 64 && M <= c.bp / 2) return false;
-    if (c.depth > 2 && c.depth - 1 > stages) return false;
+    if (ring_depth(c) > 2 && ring_depth(c) - 1 > stages) return false;
+    // the wide-wave tile pays for 256 x 256 of prologue / epilogue with one wave per SIMD: large launches only
+    if (ring_wide(c) && (((M + 255) / 256) * ((d->cout + 255) / 256) < 128 || stages < 4)) return false;
     return true;
 }
 
@@ -325,11 +336,13 @@ int lh_igemm_ring_launch(const IgemmArgs& a0, const RingCfg& c, int dtype, hipSt
             rc = lh_ring_launch_bf16_big(a, c, s);
             if (rc == 1) rc = lh_ring_launch_bf16_mid(a, c, s);
             if (rc == 1) rc = lh_ring_launch_bf16_small(a, c, s);
+            if (rc == 1) rc = lh_ring_launch_bf16_wide(a, c, s);
             break;
         case LH_F16:
             rc = lh_ring_launch_f16_big(a, c, s);
             if (rc == 1) rc = lh_ring_launch_f16_mid(a, c, s);
             if (rc == 1) rc = lh_ring_launch_f16_small(a, c, s);
+            if (rc == 1) rc = lh_ring_launch_f16_wide(a, c, s);
             break;
         case LH_F32:
             rc = lh_ring_launch_f32(a, c, s);

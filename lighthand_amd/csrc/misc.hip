@@ -863,6 +863,59 @@ extern "C" int lh_channel_sum_nchw(const float* x, int n, int c, int hw, float* 
     return LH_OK;
 }
 
+// Bias gradient of a convolution / transposed convolution with bias inside the network (DECONV_WITH_BIAS,
+// pose_resnet.py:149,227): out[ch] = sum over the pixels of an NHWC gradient of the run precision, channels [0, c) of rows of
+// `stride` elements.  A workgroup takes a slice of the pixels: thread (row group r, 16-byte chunk q) sums its chunk's
+// elements over rows r, r + R, ... in fp64, the row groups are folded through LDS in a fixed order, and the slices by
+// channel_sum_final_kernel: deterministic.
+template <typename T>
+__global__ __launch_bounds__(256) void channel_sum_nhwc_kernel(const T* x, long pixels, int c, int stride, double* partial, int slices) {
+    constexpr int EPC = 16 / sizeof(T);
+    __shared__ double red[256 * EPC];
+    const int nchunk = (c + EPC - 1) / EPC;              // 16-byte chunks per row that hold requested channels
+    const int sl = blockIdx.x;
+    const long p0 = pixels * sl / slices, p1 = pixels * (sl + 1) / slices;
+    for (int q0 = 0; q0 < nchunk; q0 += 256) {           // <= 256 chunks at a time (2048 bf16 channels)
+        const int cw = nchunk - q0 < 256 ? nchunk - q0 : 256;
+        int R = 1;                                       // row groups: the largest power of two with R * cw <= 256
+        while (R * 2 * cw <= 256) R *= 2;
+        const int r = threadIdx.x / cw, q = threadIdx.x - r * cw;
+        double acc[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) acc[e] = 0.0;
+        if (r < R) {
+            for (long px = p0 + r; px < p1; px += R) {
+                float v[EPC];
+                unpack16<T>(*reinterpret_cast<const uint4*>(x + px * stride + (long)(q0 + q) * EPC), v);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) acc[e] += (double)v[e];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) red[threadIdx.x * EPC + e] = acc[e];
+        __syncthreads();
+        for (int t = threadIdx.x; t < cw * EPC; t += 256) {
+            const int qq = t / EPC, e = t - qq * EPC, ch = (q0 + qq) * EPC + e;
+            double a = 0.0;
+            for (int rr = 0; rr < R; ++rr) a += red[(rr * cw + qq) * EPC + e];
+            if (ch < c) partial[(long)ch * slices + sl] = a;
+        }
+    }
+}
+
+extern "C" int lh_channel_sum_nhwc(const void* x, long pixels, int c, int pix_stride, float* out, void* workspace, int dtype, void* stream) {
+    LH_REQUIRE(x && out && workspace && pixels > 0 && c > 0 && pix_stride >= c, "lh_channel_sum_nhwc: bad arguments");
+    const int es = lh_dtype_size(dtype);
+    LH_REQUIRE(es > 0 && (pix_stride * es) % 16 == 0, "lh_channel_sum_nhwc: pixel rows must be 16-byte aligned (stride %d, dtype %d)", pix_stride, dtype);
+    const int slices = pixels < 64 ? (int)pixels : 64;
+    LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((channel_sum_nhwc_kernel<T>), dim3(slices), dim3(256), 0, (hipStream_t)stream,
+                                                   (const T*)x, pixels, c, pix_stride, (double*)workspace, slices));
+    hipLaunchKernelGGL(channel_sum_final_kernel, dim3((c + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const double*)workspace, c, slices, out);
+    LH_LAUNCH_CHECK("channel_sum_nhwc launch");
+    return LH_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ PCK curve / AUC
 // pred_eval (src/utils/argparser.py:326-388) on the device: for every threshold, the number of VISIBLE
 // joints (gt[..][2] == 1) whose error -- pixel distance, divided by the sample's bbox size when bb is given ('pckb') --

@@ -179,17 +179,6 @@ class _Marker:
         return None
 
 
-class _TorchCall:
-    """Host-side glue expressed with torch ops on tiny tensors (layout shuffles of <10k values)."""
-    __slots__ = ("fn", "what", "lane", "slane")
-
-    def __init__(self, fn, what, lane=0):
-        self.fn, self.what, self.lane, self.slane = fn, what, lane, 0
-
-    def __call__(self, stream):
-        self.fn()
-
-
 # --------------------------------------------------------------------------------------- plan
 class Plan:
     """Everything needed to run one model at one static shape."""
@@ -367,12 +356,34 @@ class Plan:
             path = os.path.join(base, "lighthand_amd", "tune_gfx950.txt")
         return path
 
+    @staticmethod
+    def _lib_stamp():
+        """Identifies the build of the kernel library the choices were measured with (size + modification time of the
+        .so): a cache file written by another build is ignored, its choices may name kernels that no longer exist or no
+        longer win."""
+        try:
+            st = os.stat(_lib.LIB_PATH)
+            return "lib %d %d" % (st.st_size, int(st.st_mtime))
+        except OSError:
+            return "lib ?"
+
+    @staticmethod
+    def _parse_tune_line(line):
+        """(key, value) of one line of a tuning file, or None for a line that does not parse (a truncated write, an edit)."""
+        import ast
+        try:
+            k, v = ast.literal_eval(line)
+            return k, tuple(v)
+        except (ValueError, SyntaxError, TypeError):
+            return None
+
     @classmethod
     def _tune_cache_io(cls, save=False):
         """Measured choices persist across processes (a restarted job, or a profiling run that should not contain the
         tuner's own launches, starts from the file; new measurements are written back).  Precedence: the user's file
-        (local measurements) over the shipped database; a save writes only what was measured locally."""
-        import ast
+        (local measurements, only when written by THIS build of the library) over the shipped database; a save writes
+        only what was measured locally.  Unparsable lines are skipped; every entry is validated against the compiled-in
+        candidates where it is used (a stale one is measured again)."""
         path = cls._tune_cache_path()
         if save:
             if not path:
@@ -381,6 +392,7 @@ class Plan:
                 os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
                 tmp = path + ".tmp%d" % os.getpid()
                 with open(tmp, "w") as f:
+                    f.write("# " + cls._lib_stamp() + "\n")
                     for k in cls._tune_measured:
                         if k in cls._TUNE_CACHE:
                             f.write(repr((k, cls._TUNE_CACHE[k])) + "\n")
@@ -392,19 +404,21 @@ class Plan:
             return
         cls._tune_file_loaded = True
         if path and os.path.isfile(path):
-            for line in open(path):
-                if line.strip():
-                    k, v = ast.literal_eval(line)
-                    cls._TUNE_CACHE[k] = tuple(v)
-                    cls._tune_measured.add(k)
+            lines = open(path).read().splitlines()
+            if lines and lines[0].strip() == "# " + cls._lib_stamp():
+                for line in lines[1:]:
+                    kv = cls._parse_tune_line(line) if line.strip() and not line.startswith("#") else None
+                    if kv is not None:
+                        cls._TUNE_CACHE[kv[0]] = kv[1]
+                        cls._tune_measured.add(kv[0])
         # the shipped database: choices measured on MI355X for the benchmark configurations (tools/make_tune_db.sh);
         # entries are validated against the compiled-in configurations when used, anything else is measured on the fly
         db = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tune_db_gfx950.txt")
         if os.path.isfile(db) and os.environ.get("LH_TUNE_DB", "1") != "0":
             for line in open(db):
-                if line.strip() and not line.startswith("#"):
-                    k, v = ast.literal_eval(line)
-                    cls._TUNE_CACHE.setdefault(k, tuple(v))
+                kv = cls._parse_tune_line(line) if line.strip() and not line.startswith("#") else None
+                if kv is not None:
+                    cls._TUNE_CACHE.setdefault(kv[0], kv[1])
 
     @staticmethod
     def _desc_key(d):
@@ -675,6 +689,12 @@ class Plan:
         ss = (C.c_long * 4)(*([0] * pad + list(src.stride())))
         return _Call(self.lib.lh_copy_strided_f32, (dst.data_ptr(), src.data_ptr(), shape, ds, ss), what, keep=(shape, ds, ss, dst, src), lane=lane)
 
+    def _bias_grad(self, dy, y, cout, gb_):
+        """d(bias) of a convolution / transposed convolution inside the network = the per-channel sum of its output
+        gradient (NHWC, run precision): lh_channel_sum_nhwc, fp64 partial sums in a fixed order."""
+        ws = self._alloc(self.lib.lh_channel_sum_workspace_bytes(cout), dtype=torch.uint8)
+        return _Call(self.lib.lh_channel_sum_nhwc, (dy.data_ptr(), y.pixels, cout, y.c, gb_.data_ptr(), ws.data_ptr(), self.dt), "bias grad", lane=1)
+
     def _kname(self, d, wgrad=None, stats=False):
         """Kernel instantiation name as rocprofv3 prints it (for roofline attribution)."""
         t = {"fp32": "float", "bf16": "__bf16", "fp16": "_Float16"}[self.precision]
@@ -688,6 +708,8 @@ class Plan:
             if depth == 100:
                 return f"conv3x3_direct_kernel<{t}, {kb}, {'true' if stats else 'false'}>"
             wc, wp = {(256, 256): (2, 4), (128, 256): (2, 2), (128, 128): (2, 2), (128, 64): (4, 1), (64, 128): (1, 4), (64, 64): (2, 2)}[(bm, bp)]
+            if 10 <= depth < 100:               # the wide-wave form of the 256 x 256 tile (four waves, igemm_ring_cfgs.h)
+                wc, wp, depth = 2, 2, depth - 10
             if depth:
                 return f"igemm_ring_kernel<{t}, {bm}, {bp}, {wc}, {wp}, {depth}, {kb}>"
             return f"igemm_kernel<{t}, {bm}, {bp}, {wc}, {wp}>"
@@ -1151,8 +1173,9 @@ class Plan:
                 common = keys if common is None else common & keys
             key = ("gw", self.dt) + tuple(self._desc_key(d) for d, _ in descs)
             hit = Plan._TUNE_CACHE.get(key)
-            if hit is not None and tuple(hit[:4]) not in (common or ()):
-                hit = None
+            if hit is not None and (len(hit) != 5 or tuple(hit[:4]) not in (common or ()) or len(hit[4]) != len(per)
+                                    or any((hit[0], hit[1], enc) not in {c[:3] for c in cs} for enc, cs in zip(hit[4], per))):
+                hit = None                                    # stale entry (tile or a member's split encoding no longer offered): measure again
             if hit is None and common:
                 arr = (_lib.WgradCall * len(nds))()
                 warm, keep = [], []
@@ -1473,7 +1496,7 @@ class Plan:
                     wl.append(_Call(self.lib.lh_channel_sum_nchw, (dn.data_ptr(), dn.shape[0], dn.shape[1], dn.shape[2] * dn.shape[3],
                                                                           gb_.data_ptr(), ws.data_ptr()), "head bias grad"))
                 else:
-                    wl.append(_TorchCall(lambda: gb_.copy_(dy.view(-1, y.c)[:, :cout].sum(0, dtype=torch.float32)), "bias grad"))
+                    wl.append(self._bias_grad(dy, y, cout, gb_))
             if x.needs_grad:
                 for dd, ntaps in self._dgrad(ddescs, dy, dpacks, x, nd["w"] + " dgrad"):
                     batched = ntaps != dd.ntaps or (len(ddescs) > 1 and self.bwd[-1].ig is not None)
@@ -1632,7 +1655,7 @@ class Plan:
             self.profile_meta.append(("bwd", wl[-1], self._kname(dg, (cin, cout)), flops, (x.pixels * x.c + y.pixels * y.c) * self.es))
             if nd["bias"]:
                 gb_ = self.grads[nd["bias"]]
-                wl.append(_TorchCall(lambda: gb_.copy_(dy.view(-1, y.c)[:, :cout].sum(0, dtype=torch.float32)), "bias grad"))
+                wl.append(self._bias_grad(dy, y, cout, gb_))
             if x.needs_grad:
                 for _dd, _nt in self._dgrad([dg], dy, [gpack], x, nd["w"] + " deconv dgrad"):
                     self.profile_meta.append(("bwd", self.bwd[-1], self._kname(dg), flops, (x.pixels * x.c + y.pixels * y.c) * self.es))
@@ -1890,11 +1913,7 @@ class Plan:
                 elif L not in wused:
                     s.wait_stream(main)        # slice starts inside a group (data-parallel segments)
                 wused.add(L)
-                if isinstance(c, _TorchCall):
-                    with torch.cuda.stream(s):
-                        c(s.cuda_stream)
-                else:
-                    c(s.cuda_stream)
+                c(s.cuda_stream)
                 continue
             s = self._lane_streams.get(L)
             if s is None:
@@ -1906,11 +1925,7 @@ class Plan:
                     s.wait_stream(main)
                 forked.add(L)
             used.add(L)
-            if isinstance(c, _TorchCall):
-                with torch.cuda.stream(s):
-                    c(s.cuda_stream)
-            else:
-                c(s.cuda_stream)
+            c(s.cuda_stream)
         for L in used | wused:
             main.wait_stream(self._lane_streams[L])
 

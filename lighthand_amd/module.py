@@ -132,13 +132,18 @@ class HipModule(nn.Module):
             self._lh_arena = ParamArena(self)
         return self._lh_arena
 
-    def plan(self, n, h, w, training=None, backward=None, wgrad_bucket_bytes=None, slot=0):
+    def plan(self, n, h, w, training=None, backward=None, wgrad_bucket_bytes=None, slot=0, owner=None):
         """slot: plans of the same shape with different slots own separate activation buffers and weight packs (several
-        batches in flight on different streams: runtime.InferPipeline)."""
+        batches in flight on different streams: runtime.InferPipeline).
+        owner: a step object that REWIRES or replays its plan on its own (runtime.InferStep with uint8 input or on a
+        pipeline stream, runtime.TrainStep) names itself here and gets a plan of its own: ``model(x)`` keeps the
+        (shape, mode) plan without an owner, whose input is always the float NCHW image and whose buffers no
+        asynchronous replay touches."""
         training = self.training if training is None else training
         backward = training if backward is None else backward
         self.arena()
-        key = (n, h, w, self._lh_precision, training, backward, wgrad_bucket_bytes) + ((slot,) if slot else ())
+        key = (n, h, w, self._lh_precision, training, backward, wgrad_bucket_bytes) + ((slot,) if slot else ()) \
+            + ((("owner", owner),) if owner is not None else ())
         p = self._lh_plans.get(key)
         if p is None:
             p = Plan(self, n, h, w, self._lh_precision, training=training, backward=backward, wgrad_bucket_bytes=wgrad_bucket_bytes)

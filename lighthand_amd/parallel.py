@@ -92,12 +92,23 @@ def plan_with_shared_tuning(build):
     if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
         return build()
     rank = dist.get_rank()
-    plan = build() if rank == 0 else None
-    box = [dict(Plan._TUNE_CACHE) if rank == 0 else None]
+    plan, err = None, None
+    if rank == 0:
+        try:
+            plan = build()
+        except Exception as e:                   # noqa: BLE001 -- the other ranks wait in the broadcast below: tell them
+            err = e
+    # NOTE: ranks != 0 wait here while rank 0 measures; a cold HRNet tune takes 1-3 minutes, well inside the process
+    # group's default collective timeout (10 min for nccl) -- ship / pre-warm the tuning database for larger models
+    box = [("error", repr(err)) if err is not None else ("ok", dict(Plan._TUNE_CACHE))] if rank == 0 else [None]
     dist.broadcast_object_list(box, src=0)
+    if box[0][0] == "error":
+        if err is not None:
+            raise err
+        raise RuntimeError("rank 0 failed to build the plan: " + box[0][1])
     if rank != 0:
         Plan._tune_cache_io()
-        Plan._TUNE_CACHE.update(box[0])
+        Plan._TUNE_CACHE.update(box[0][1])
         plan = build()
     return plan
 

@@ -47,12 +47,14 @@ class TrainStep:
         self.model = model
         self._model_generation = getattr(model, "_lh_generation", 0)
         model.train()
+        # uint8 input rewires the plan's image launch: such a step owns its plan (model(x) in train mode keeps the float one)
+        owner = ("train", "u8") if input_u8 else None
         if grad_sync is not None:               # data parallel: one set of measured kernel choices for all ranks
             from . import parallel
             self.plan = parallel.plan_with_shared_tuning(
-                lambda: model.plan(batch, height, width, training=True, backward=True, wgrad_bucket_bytes=grad_sync.bucket_bytes))
+                lambda: model.plan(batch, height, width, training=True, backward=True, wgrad_bucket_bytes=grad_sync.bucket_bytes, owner=owner))
         else:
-            self.plan = model.plan(batch, height, width, training=True, backward=True)
+            self.plan = model.plan(batch, height, width, training=True, backward=True, owner=owner)
         self.arena = model.arena()
         dev = self.arena.device
         out = self.plan.out_nchw
@@ -251,9 +253,15 @@ class InferStep:
     src/utils/argparser.py:246-281).  ``bn_train=True`` reproduces the reference quirk of running
     ``pred_store`` without ``model.eval()`` (batch statistics at evaluation time)."""
 
+    _serial = 0
+
     def __init__(self, model, batch, height, width, bn_train=False, use_graph=True, input_u8=None, slot=0):
         self.lib = _lib.load()
-        self.plan = model.plan(batch, height, width, training=bn_train, backward=False, slot=slot)
+        # a plan of its own (never the one model(x) runs): use_uint8_input rewires the plan's image launch, and a pipeline
+        # slot replays asynchronously on its own stream -- neither may happen to the plan model.forward() uses
+        InferStep._serial += 1
+        self.plan = model.plan(batch, height, width, training=bn_train, backward=False, slot=slot,
+                               owner=("infer", "u8" if input_u8 else "f32", InferStep._serial))
         out = self.plan.out_nchw
         dev = out.device
         # input_u8=(hs, ws): raw uint8 HWC frames; ToTensor / Resize / Normalize run fused on the device (dataset.py:128-159)
@@ -327,6 +335,10 @@ class InferPipeline:
         i = self.count % len(self.steps)
         st = self.streams[i]
         st.wait_stream(torch.cuda.current_stream())          # the caller's copy of `images` into place is ordered before
+        if images is not None and images.is_cuda:
+            # the slot's copy of `images` runs on `st`: tell the caching allocator, or a caller that drops the batch right
+            # after submit() gets the same block back for the next batch while this copy is still queued
+            images.record_stream(st)
         with torch.cuda.stream(st):
             self.steps[i](images)
             self.events[i] = st.record_event()

@@ -102,7 +102,10 @@ class _WithAugFlag(torch.utils.data.Dataset):
     FIXED subset idx < len(dataset) * ratio_of_aug is jittered (src/tools/dataset.py:133)."""
 
     def __init__(self, base, ratio_of_aug):
-        self.base, self.limit = base, len(base) * ratio_of_aug
+        # the reference compares the sample index with len(self.meta) * ratio_of_aug (dataset.py:133), and len(meta) can
+        # differ from __len__ (= num_our): a dataset that carries `meta` supplies the limit the same way
+        meta = getattr(base, "meta", None)
+        self.base, self.limit = base, (len(meta) if meta is not None else len(base)) * ratio_of_aug
 
     def __len__(self):
         return len(self.base)

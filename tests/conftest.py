@@ -11,6 +11,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # measured kernel choices of a test session never come from (or go to) state an earlier run left in $HOME: the tuning
+    # cache of the session is a fresh file (LH_TUNE_CACHE set by the caller is respected; the shipped database still applies)
+    if "LH_TUNE_CACHE" not in os.environ:
+        import tempfile
+        os.environ["LH_TUNE_CACHE"] = os.path.join(tempfile.mkdtemp(prefix="lh_tune_"), "tune_gfx950.txt")
 
 
 @pytest.fixture(scope="session")

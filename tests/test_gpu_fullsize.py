@@ -23,6 +23,54 @@ def rel(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
 
 
+def test_c1_r18_256_bs8_training_step_matches_oracle():
+    """BASELINE.json configs[0] at its OWN size -- SimpleBaseline-ResNet18, 256 x 256, batch 8, 21 joints, fp32, random init
+    (seed 9001), synthetic images; the reference's CPU-runnable case (src/tools/train.py:13-120 with --batch_size 8) -- on the
+    HIP path against the CPU oracle: train-mode forward within 1e-3 of the peak, JointsMSELoss within 1e-4 relative, arg-max
+    key points EQUAL on every joint (both decoders applied to their own heat-maps), the whole-model gradient as close to an
+    fp64 run of the oracle as the oracle's own fp32 run is, and after one Adam step (lr 1e-3) the weights within 2 x lr of
+    the oracle's."""
+    from lighthand_amd.heatmap import JointsMSELoss, get_max_preds, render_targets
+    from lighthand_amd.modeling.simplebaseline.pose_resnet import get_pose_net
+    from lighthand_amd.optim import Adam
+    from oracle import models as omod
+    from oracle.heatmap import get_max_preds as oracle_decode
+    torch.manual_seed(9001)                                          # src/tools/train.py:15
+    model = get_pose_net(resnet_cfg(18), True)
+    rng = np.random.RandomState(9001)
+    x = torch.from_numpy(rng.randn(8, 3, 256, 256).astype(np.float32))
+    joints = torch.from_numpy(rng.uniform(20, 236, size=(8, 21, 2)).astype(np.float32))
+    tgt = render_targets(joints.cuda()).cpu()
+    fwd = lambda s, xx: omod.pose_resnet_forward(s, xx, 18, "pytorch", training=True)
+    sd = omod.clone_state(model.state_dict())
+    loss_ref, pred_ref, g32 = omod.loss_and_grads(sd, fwd, x, tgt)
+    sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in model.state_dict().items()}
+    _, _, g64 = omod.loss_and_grads(sd64, fwd, x.double(), tgt.double())
+    model = model.cuda().train()
+    opt = Adam(model.parameters(), lr=1e-3).bind_arena(model.arena())
+    pred = model(x.cuda())
+    loss = JointsMSELoss(False)(pred, tgt.cuda(), None)
+    loss.backward()
+    got, want = pred.detach().cpu().numpy(), pred_ref.numpy()
+    assert got.shape == want.shape == (8, 21, 64, 64)
+    assert rel(got, want) < 1e-3, rel(got, want)
+    assert abs(float(loss.detach()) - loss_ref) < 1e-4 * abs(loss_ref)
+    assert np.array_equal(get_max_preds(got)[0], oracle_decode(want)[0])
+    num_h = num_c = den = 0.0
+    for k, p in model.named_parameters():
+        gh, gc, gt = p.grad.cpu().double().numpy(), g32[k].double().numpy(), g64[k].numpy()
+        num_h += ((gh - gt) ** 2).sum(); num_c += ((gc - gt) ** 2).sum(); den += (gt ** 2).sum()
+    l2_h, l2_c = (num_h / den) ** 0.5, (num_c / den) ** 0.5
+    print(f"C1 (R18, 256 x 256, bs 8, fp32): forward rel {rel(got, want):.2e}, gradient rel-L2 vs fp64 oracle HIP {l2_h:.2e} / CPU fp32 {l2_c:.2e}")
+    assert l2_h <= 3 * l2_c + 1e-5
+    opt.step()
+    adam = omod.AdamState(lr=1e-3)
+    adam.step(sd, g32)
+    torch.cuda.synchronize()
+    worst = max(float((p.detach().cpu() - sd[k]).abs().max()) for k, p in model.named_parameters())
+    assert worst <= 2e-3 + 1e-6, worst                               # Adam's first step moves an element by lr x sign(g)
+
+
 def test_c2_training_step_full_size_properties():
     """R50, 256 x 256, batch 64 (BASELINE.json configs[1]).  bf16, the benchmark's precision: the backward pass is EXACTLY
     linear in the heat-map gradient (2 * dheat -> 2 * every weight / BatchNorm gradient, bit for bit: every kernel of the

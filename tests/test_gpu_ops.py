@@ -207,6 +207,56 @@ def test_every_conv_kernel_configuration(case, precision, forced_plans):
         assert (256, 256) in tiles
 
 
+WIDE_CASES = [  # cin, cout, k, s, p, n, h, w, transposed -- at least 128 tiles of 256 x 256, which is where the form is offered
+    (256, 256, 3, 1, 1, 9, 61, 61, False),       # ragged pixel count: the last pixel tile is partial
+    (512, 256, 1, 1, 0, 8, 64, 64, False),
+    (128, 512, 3, 2, 1, 8, 96, 96, False),
+    (256, 256, 4, 2, 1, 8, 64, 64, True),        # the four sub-pixel phases of a transposed convolution as one launch
+]
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+@pytest.mark.parametrize("case", WIDE_CASES)
+def test_wide_wave_configurations(case, precision, forced_plans):
+    """The wide-wave form of the 256 x 256 tile (four waves, 128 x 128 per wave, ring depth written depth + 10:
+    igemm_ring_cfgs.h) on launches large enough to be offered it: forward and data gradient match PyTorch and agree BIT
+    FOR BIT with the 8-wave form of the same tile and with a 128 x 128 configuration."""
+    ConvNet, _ = _mods()
+    cin, cout, k, s_, p, n, h, w, tr = case
+    torch.manual_seed(11)
+    x = quant(torch.randn(n, cin, h, w), precision)
+    ref_m = nn.ConvTranspose2d(cin, cout, k, 2, 1, 0, bias=False) if tr else nn.Conv2d(cin, cout, k, s_, p, bias=False)
+    with torch.no_grad():
+        ref_m.weight.copy_(quant(ref_m.weight, precision))
+    xr = x.clone().requires_grad_(True)
+    ref = ref_m(xr)
+    dy = quant(torch.randn_like(ref), precision)
+    ref.backward(dy)
+    offered, results = set(), []
+    picks = [lambda c: 10 <= c[2] < 100 and c[3] == 128, lambda c: 10 <= c[2] < 100 and c[3] == 64 and c[2] == 13,
+             lambda c: 10 <= c[2] < 100 and c[2] == 14, lambda c: c[:2] == (256, 256) and c[2] < 10, lambda c: c[:2] == (128, 128)]
+    for sel in picks:
+        chosen = []
+
+        def pick(cands, sel=sel, chosen=chosen):
+            offered.update(c for c in cands if 10 <= c[2] < 100)
+            m_ = [c for c in cands if sel(c)]
+            c = m_[0] if m_ else cands[0]
+            chosen.append(c)
+            return c
+        forced_plans.force_cfg = pick
+        m = ConvNet(cin, cout, k, s_, p, bias=False, transposed=tr)
+        m.conv.load_state_dict(ref_m.state_dict())
+        out, dx, _ = _run_plan(m, x, lambda o: dy, precision)
+        assert rel_err(out, ref.detach()) < TOL[precision] and rel_err(dx, xr.grad) < TOL[precision], chosen
+        results.append((chosen, out, dx))
+    print(case, precision, "wide configurations offered:", sorted(offered), "| chosen:", [r[0] for r in results])
+    assert {c[2] for c in offered} >= {12, 13, 14} or cin * k * k < 256, offered
+    assert any(10 <= c[2] < 100 for c in results[0][0]), results[0][0]
+    for chosen, out, dx in results[1:]:
+        assert torch.equal(out, results[0][1]) and torch.equal(dx, results[0][2]), chosen
+
+
 def test_conv_tile_bn_statistics(forced_plans):
     """conv -> BN -> ReLU (+ residual) with the largest and the smallest tile forced: the tile's epilogue writes the BN
     partial sums (one slab row per pixel tile), so running statistics, BN parameter gradients and the data gradient must
@@ -281,19 +331,27 @@ def test_every_wgrad_kernel_plan(case, forced_plans):
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("bias", [False, True])
 @pytest.mark.parametrize("case", [(64, 32, 4, 2, 8, 8), (128, 64, 4, 1, 6, 10), (32, 32, 3, 1, 4, 4), (32, 16, 2, 1, 4, 4)])
-def test_deconv_fwd_bwd(case, precision):
+def test_deconv_fwd_bwd(case, bias, precision):
+    """Transposed convolution, forward / data gradient / weight gradient -- and with ``bias`` (DECONV_WITH_BIAS=True,
+    pose_resnet.py:149,227) the bias in the epilogue and its gradient from the NHWC channel-sum kernel (lh_channel_sum_nhwc)."""
     ConvNet, _ = _mods()
     cin, cout, k, n, h, w = case
     torch.manual_seed(3)
-    m = ConvNet(cin, cout, k, 2, 1, transposed=True)
+    m = ConvNet(cin, cout, k, 2, 1, bias=bias, transposed=True)
     x = torch.randn(n, cin, h, w)
     xq = quant(x, precision)
     wt = quant(m.conv.weight.detach().clone(), precision)
     wt.requires_grad_(True)
+    b = None
+    if bias:
+        with torch.no_grad():
+            m.conv.bias.uniform_(-1.0, 1.0)
+        b = m.conv.bias.detach().clone().requires_grad_(True)
     xr = xq.clone().requires_grad_(True)
     pad, opad = {4: (1, 0), 3: (1, 1), 2: (0, 0)}[k]
-    ref = F.conv_transpose2d(xr, wt, None, 2, pad, opad)
+    ref = F.conv_transpose2d(xr, wt, b, 2, pad, opad)
     torch.manual_seed(4)
     dy = torch.randn_like(ref)
     dyq = quant(dy, precision)
@@ -304,6 +362,8 @@ def test_deconv_fwd_bwd(case, precision):
     assert rel_err(out, ref.detach()) < tol
     assert rel_err(dx, xr.grad) < tol
     assert rel_err(grads["conv.weight"], wt.grad) < tol
+    if bias:
+        assert rel_err(grads["conv.bias"], b.grad) < 1e-5       # fp64 sums of the same (quantised) gradient values
 
 
 @pytest.mark.parametrize("mode", ["plain", "residual", "two_bn", "up", "pool"])

@@ -153,3 +153,32 @@ def test_init_weights_rules_of_both_factories(tmp_path):
     h.init_weights("")                                                        # no file requested: re-initialise only
     with pytest.raises(ValueError):
         h.init_weights(str(tmp_path / "missing.pth"))
+
+
+def test_tuning_file_is_versioned_and_tolerates_bad_lines(tmp_path, monkeypatch):
+    """The persisted kernel choices (engine.Plan._tune_cache_io): a file written by ANOTHER build of the kernel library
+    (first line = size + mtime of the .so) is ignored as a whole; unparsable lines of a matching file are skipped instead
+    of failing every Plan constructor; a save writes the stamp and only locally measured entries."""
+    from lighthand_amd.engine import Plan
+    path = tmp_path / "tune.txt"
+    monkeypatch.setenv("LH_TUNE_CACHE", str(path))
+    monkeypatch.setenv("LH_TUNE_DB", "0")
+    saved = dict(Plan._TUNE_CACHE), set(Plan._tune_measured), Plan._tune_file_loaded
+    try:
+        good = repr((("k", 1), (128, 128, 2, 64)))
+        path.write_text("# lib 1 2\n" + good + "\n")                               # another build's stamp
+        Plan._TUNE_CACHE.clear(); Plan._tune_measured.clear(); Plan._tune_file_loaded = False
+        Plan._tune_cache_io()
+        assert ("k", 1) not in Plan._TUNE_CACHE
+        path.write_text("# " + Plan._lib_stamp() + "\n" + good + "\nthis is not a tuple\n((\"k\", 2), (64,\n")
+        Plan._TUNE_CACHE.clear(); Plan._tune_measured.clear(); Plan._tune_file_loaded = False
+        Plan._tune_cache_io()
+        assert Plan._TUNE_CACHE == {("k", 1): (128, 128, 2, 64)} and Plan._tune_measured == {("k", 1)}
+        Plan._TUNE_CACHE[("k", 3)] = (64, 64, 2, 64)                                # not measured locally: a save must not write it
+        Plan._tune_cache_io(save=True)
+        lines = path.read_text().splitlines()
+        assert lines[0] == "# " + Plan._lib_stamp() and lines[1:] == [good]
+    finally:
+        Plan._TUNE_CACHE.clear(); Plan._TUNE_CACHE.update(saved[0])
+        Plan._tune_measured.clear(); Plan._tune_measured.update(saved[1])
+        Plan._tune_file_loaded = saved[2]

@@ -59,6 +59,22 @@ SHAPES = [
 ]
 
 
+if os.environ.get("LH_SWEEP_SET") == "c5":      # BASELINE.json configs[4]: R50 inference, 384 x 384, batch 256 (forward launches are what counts)
+    B = 256
+    SHAPES = [
+        ("c5 l1 3x3 64 @96", 64, 64, 3, 1, B, 96, 96, 0),
+        ("c5 l2 3x3 128 @48", 128, 128, 3, 1, B, 48, 48, 0),
+        ("c5 l3 3x3 256 @24", 256, 256, 3, 1, B, 24, 24, 0),
+        ("c5 l4 3x3 512 @12", 512, 512, 3, 1, B, 12, 12, 0),
+        ("c5 l3 1x1 1024->256 @24", 1024, 256, 1, 1, B, 24, 24, 0),
+        ("c5 l4 1x1 2048->512 @12", 2048, 512, 1, 1, B, 12, 12, 0),
+        ("c5 deconv0 2048->256 @12", 2048, 256, 4, 2, B, 12, 12, 1),
+        ("c5 deconv1 256->256 @24", 256, 256, 4, 2, B, 24, 24, 1),
+        ("c5 deconv2 256->256 @48", 256, 256, 4, 2, B, 48, 48, 1),
+    ]
+NBEST = int(os.environ.get("LH_SWEEP_NBEST", "4"))
+
+
 class Net(HipModule):
     def __init__(self, cin, cout, k, s, tr):
         super().__init__()
@@ -140,7 +156,7 @@ for name, cin, cout, k, s, n, h, w, tr in SHAPES:
         grand_best += best[0]
         bad = [r for r in res if not r[2]]
         print(f"{name:24s} {c.what[:26]:26s} default {tuple(cur)} {t_def:7.1f} us ({fl / t_def / 1e6:6.0f} TF/s) | best "
-              + "  ".join(f"{r[1]} {r[0]:.1f}" for r in res[:4]) + (f" | worst {res[-1][1]} {res[-1][0]:.1f}" if res else "")
+              + "  ".join(f"{r[1]} {r[0]:.1f}" for r in res[:NBEST]) + (f" | worst {res[-1][1]} {res[-1][0]:.1f}" if res else "")
               + (f" | MISMATCH {[r[1] for r in bad]}" if bad else "")
               + (" | best tiled " + "  ".join(f"{r[1][:4]} {r[0]:.1f}" for r in [r for r in res if r[1][2] != 1][:1])
                  + " | pointwise " + "  ".join(f"{r[1][:4]} {r[0]:.1f}" for r in res if r[1][2] == 1) if any(r[1][2] == 1 for r in res) else ""))

@@ -44,6 +44,21 @@ def main():
           f"{', '.join(f'{us(g):.1f} us at {us(a):.0f}' for g, a in sorted(gaps, reverse=True)[:5])}", file=out)
     mainq = max(qs, key=lambda q: len(qs[q]))
     order = sorted(seg, key=lambda r: int(r["Start_Timestamp"]))
+    # what borders the largest gaps: the kernels that ended last before each and the ones that started first after it
+    row = lambda r: (f"  q{r['Queue_Id']} {us(int(r['Start_Timestamp']) - t0):>9.1f} us  "
+                     f"{us(int(r['End_Timestamp']) - int(r['Start_Timestamp'])):>7.1f} us  {r['Kernel_Name'][:90]}")
+    for g, a in sorted(gaps, reverse=True)[:8]:
+        print(f"gap of {us(g):.1f} us at {us(a):.0f} us: the two kernels that ended last before it, the three that started first after it", file=out)
+        before = sorted((r for r in seg if int(r["End_Timestamp"]) - t0 <= a), key=lambda r: int(r["End_Timestamp"]))[-2:]
+        after = [r for r in order if int(r["Start_Timestamp"]) - t0 >= a + g][:3]
+        for r in before:
+            print(row(r), file=out)
+        print("    ...", file=out)
+        for r in after:
+            print(row(r), file=out)
+    print(f"the first 30 kernels of the step:", file=out)
+    for r in order[:30]:
+        print(row(r), file=out)
     print(f"the last 14 kernels of the step (queue {mainq} = the main stream's):", file=out)
     for r in order[-14:]:
         print(f"  q{r['Queue_Id']} {us(int(r['Start_Timestamp']) - t0):>9.1f} us  {us(int(r['End_Timestamp']) - int(r['Start_Timestamp'])):>7.1f} us  "
