@@ -2,7 +2,11 @@
 // elementwise op with its backward, and the 3x3/s2 max-pool -- all HBM-bound NHWC kernels:
 // one 16-byte chunk (8 x 16-bit or 4 x fp32 channels) per lane, per-channel vectors in fp32.
 #include "common.h"
+#ifndef LH_BN_EXP_DEFAULT
+#define LH_BN_EXP_DEFAULT 4      // measured (round 4): non-temporal loads of the BN inputs in the forward pass, -0.11 ms per R50 step
+#endif
 #include "multi.h"
+#include <type_traits>
 #include <vector>
 #include <algorithm>
 #include <stdlib.h>
@@ -332,7 +336,29 @@ extern "C" int lh_bn_eval_affine(const float* gamma, const float* beta, const fl
 }
 
 // ------------------------------------------------------------------------------------------------
+// Cache-policy / traversal experiments of the streaming BN passes (LH_BN_EXP, read once per process; speed only, results
+// do not depend on it): bit 0 = non-temporal loads for the LAST-USE reads of the backward apply passes (dout, x, out),
+// bit 1 = the apply passes walk the tensor back to front (what the reduce pass read last is re-read first), bit 2 =
+// non-temporal loads of the BN inputs in the forward pass, bit 3 = the forward pass walks back to front (the tail of the
+// convolution's output, written last, is read first).
+static int bn_exp_flags() {
+    static const int v = [] { const char* e = getenv("LH_BN_EXP"); return e ? atoi(e) : LH_BN_EXP_DEFAULT; }();
+    return v;
+}
+typedef unsigned int lh_u32x4 __attribute__((ext_vector_type(4)));
+template <bool NT> __device__ __forceinline__ uint4 ld16(const unsigned char* p) {
+    if constexpr (NT) {
+        const lh_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const lh_u32x4*>(p));
+        return uint4{v[0], v[1], v[2], v[3]};
+    } else {
+        return *reinterpret_cast<const uint4*>(p);
+    }
+}
+// index of round r of a grid-stride walk over `rounds` rounds, front to back or back to front
+__device__ __forceinline__ long walk_round(long r, long rounds, bool rev) { return rev ? rounds - 1 - r : r; }
+
 struct FuseArgs {
+    int exp;                     // bn_exp_flags() >> 2 (forward bits)
     const unsigned char* x[4];
     const float* scale[4];
     const float* shift[4];
@@ -436,12 +462,18 @@ __device__ __forceinline__ void fuse_fwd_flat_body(const FuseArgs& p, const int 
         else { fill_vec<EPC>(sc[t], 1.f); fill_vec<EPC>(sh[t], 0.f); }
     }
     const long stride = (long)nblk * 256;
-    for (long idx = (long)bid * 256 + threadIdx.x; idx < total; idx += stride) {
+    const long rounds = (total + stride - 1) / stride;
+    const bool rev = p.exp & 2;
+    auto body = [&](auto NTc) __attribute__((always_inline)) {
+    constexpr bool LNT = decltype(NTc)::value;
+    for (long rr = 0; rr < rounds; ++rr) {
+        const long idx = walk_round(rr, rounds, rev) * stride + (long)bid * 256 + threadIdx.x;
+        if (idx >= total) continue;
         float acc[EPC];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             float v[EPC];
-            unpack16<T>(*reinterpret_cast<const uint4*>(p.x[t] + idx * 16), v);
+            unpack16<T>(ld16<LNT>(p.x[t] + idx * 16), v);
             if (p.scale[t]) {
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) v[e] = v[e] * sc[t][e] + sh[t][e];
@@ -457,6 +489,8 @@ __device__ __forceinline__ void fuse_fwd_flat_body(const FuseArgs& p, const int 
         *reinterpret_cast<uint4*>(p.out + idx * 16) = u;
         if (p.mask) p.mask[idx] = positive_bits<T>(u);
     }
+    };
+    if (p.exp & 1) body(std::true_type{}); else body(std::false_type{});
 }
 template <typename T, int NT>
 __global__ __launch_bounds__(256) void fuse_fwd_flat_kernel(const FuseArgs p) { fuse_fwd_flat_body<T, NT>(p, blockIdx.x, gridDim.x); }
@@ -506,6 +540,7 @@ static int plan_fuse_fwd(const lh_fuse_desc* d, void* out, int n, int h, int w, 
     const long total = (long)n * h * w * (c / (16 / es));
     LH_REQUIRE(total < (1L << 31), "lh_fuse_fwd: tensor too large for 32-bit chunk indices");
     a.total = total;
+    a.exp = bn_exp_flags() >> 2;
     const int nchunk = c / (16 / es);
     bool flat = d->nterms <= 2 && (nchunk & (nchunk - 1)) == 0 && nchunk <= 256;
     for (int t = 0; t < d->nterms; ++t) flat = flat && a.log2up[t] == 0;
@@ -543,6 +578,7 @@ struct FuseBwdArgs {
     long count;                  // n * (h>>l) * (w>>l)
     long total;                  // 16-byte chunks of dx (flat apply kernel)
     int fold_rows;               // > 0: the flat apply pass folds partial[fold_rows][2][c] itself (no coefficient launch)
+    int exp;                     // bn_exp_flags() & 3 (backward bits)
 };
 
 template <typename T, int EPC>
@@ -838,11 +874,17 @@ __device__ __forceinline__ void fuse_bwd_apply_flat_body(const FuseBwdArgs& p, c
         }
     } else { fill_vec<EPC>(A, 1.f); fill_vec<EPC>(B, 0.f); fill_vec<EPC>(Cc, 0.f); }
     const long stride = (long)nblk * 256;
-    for (long idx = (long)bid * 256 + threadIdx.x; idx < total; idx += stride) {
+    const long rounds = (total + stride - 1) / stride;
+    const bool rev = p.exp & 2;
+    auto body = [&](auto NTc) __attribute__((always_inline)) {
+    constexpr bool LNT = decltype(NTc)::value;
+    for (long rr = 0; rr < rounds; ++rr) {
+        const long idx = walk_round(rr, rounds, rev) * stride + (long)bid * 256 + threadIdx.x;
+        if (idx >= total) continue;
         const long off = idx * 16;
         float g[EPC], xv[EPC];
-        unpack16<T>(*reinterpret_cast<const uint4*>(p.dout + off), g);
-        if (p.x) unpack16<T>(*reinterpret_cast<const uint4*>(p.x + off), xv);
+        unpack16<T>(ld16<LNT>(p.dout + off), g);
+        if (p.x) unpack16<T>(ld16<LNT>(p.x + off), xv);
         if (MASK_X) {
 #pragma unroll
             for (int e = 0; e < EPC; ++e) g[e] = (xv[e] * sc[e] + sh[e]) > 0.f ? g[e] : 0.f;
@@ -850,7 +892,7 @@ __device__ __forceinline__ void fuse_bwd_apply_flat_body(const FuseBwdArgs& p, c
             mask_by_bits<EPC>(p.mask[off >> 4], g);
         } else if (p.relu) {
             float o[EPC];
-            unpack16<T>(*reinterpret_cast<const uint4*>(p.out + off), o);
+            unpack16<T>(ld16<LNT>(p.out + off), o);
 #pragma unroll
             for (int e = 0; e < EPC; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
         }
@@ -867,6 +909,8 @@ __device__ __forceinline__ void fuse_bwd_apply_flat_body(const FuseBwdArgs& p, c
         }
         *dst = pack16<T>(g);
     }
+    };
+    if (p.exp & 1) body(std::true_type{}); else body(std::false_type{});
 }
 template <typename T, bool MASK_X>
 __global__ __launch_bounds__(256) void fuse_bwd_apply_flat_kernel(const FuseBwdArgs p) { fuse_bwd_apply_flat_body<T, MASK_X>(p, blockIdx.x, gridDim.x); }
@@ -897,6 +941,7 @@ struct FuseBwd2Args {
     long count;
     float* dgamma[2];
     float* dbeta[2];
+    int exp;                     // bn_exp_flags() & 3
 };
 
 template <typename T>
@@ -928,15 +973,21 @@ __device__ __forceinline__ void fuse_bwd_apply2_flat_body(const FuseBwd2Args& p,
         } else { fill_vec<EPC>(A[k], 1.f); fill_vec<EPC>(B[k], 0.f); fill_vec<EPC>(Cc[k], 0.f); }
     }
     const long stride = (long)nblk * 256;
-    for (long idx = (long)bid * 256 + threadIdx.x; idx < total; idx += stride) {
+    const long rounds = (total + stride - 1) / stride;
+    const bool rev = p.exp & 2;
+    auto body = [&](auto NTc) __attribute__((always_inline)) {
+    constexpr bool LNT = decltype(NTc)::value;
+    for (long rr = 0; rr < rounds; ++rr) {
+        const long idx = walk_round(rr, rounds, rev) * stride + (long)bid * 256 + threadIdx.x;
+        if (idx >= total) continue;
         const long off = idx * 16;
         float g[EPC];
-        unpack16<T>(*reinterpret_cast<const uint4*>(p.dout + off), g);
+        unpack16<T>(ld16<LNT>(p.dout + off), g);
         if (p.relu && p.mask) {
             mask_by_bits<EPC>(p.mask[idx], g);
         } else if (p.relu) {
             float o[EPC];
-            unpack16<T>(*reinterpret_cast<const uint4*>(p.out + off), o);
+            unpack16<T>(ld16<LNT>(p.out + off), o);
 #pragma unroll
             for (int e = 0; e < EPC; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
         }
@@ -946,7 +997,7 @@ __device__ __forceinline__ void fuse_bwd_apply2_flat_body(const FuseBwd2Args& p,
             float r[EPC];
             if (p.x[k]) {
                 float xv[EPC];
-                unpack16<T>(*reinterpret_cast<const uint4*>(p.x[k] + off), xv);
+                unpack16<T>(ld16<LNT>(p.x[k] + off), xv);
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) r[e] = A[k][e] * g[e] + B[k][e] * xv[e] + Cc[k][e];
             } else {
@@ -963,6 +1014,8 @@ __device__ __forceinline__ void fuse_bwd_apply2_flat_body(const FuseBwd2Args& p,
             *dst = pack16<T>(r);
         }
     }
+    };
+    if (p.exp & 1) body(std::true_type{}); else body(std::false_type{});
 }
 template <typename T>
 __global__ __launch_bounds__(256) void fuse_bwd_apply2_flat_kernel(const FuseBwd2Args p) { fuse_bwd_apply2_flat_body<T>(p, blockIdx.x, gridDim.x); }
@@ -1264,6 +1317,7 @@ static int plan_fuse_bwd(const lh_fuse_bwd_desc* d, int n, int h, int w, int c, 
         a.mask_from_x = (flat && d->relu && d->nterms == 1 && a.x && d->shift[t]) ? 1 : 0;
         if (a.mask_from_x) a.shift = d->shift[t];
         a.total = a.count * (c / (16 / es));
+        a.exp = bn_exp_flags() & 3;
         LH_REQUIRE((long)n * h * w * (c / (16 / es)) < (1L << 31), "lh_fuse_bwd: tensor too large for 32-bit chunk indices");
         if (a.x) {
             LH_REQUIRE(workspace && a.scale && a.mean && a.invstd, "lh_fuse_bwd: BN term %d lacks workspace/statistics", t);
@@ -1321,6 +1375,7 @@ static int plan_fuse_bwd(const lh_fuse_bwd_desc* d, int n, int h, int w, int c, 
         BnLaunch r;
         r.phase = 2;
         m2.total = (long)n * h * w * nchunk0;
+        m2.exp = bn_exp_flags() & 3;
         r.kind = K_FB_APPLY2;
         r.grid = flat_grid(m2.total);
         r.fb2 = m2;

@@ -60,6 +60,12 @@ template <typename T> __device__ __forceinline__ uint4 pack16(const float* f) {
     return v.u;
 }
 
+// 16-byte loads with the non-temporal cache policy (global_load_dwordx4 ... nt): last-use streams
+__device__ __forceinline__ float4 lh_ld_nt(const float4* p) {
+    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+    return float4{v[0], v[1], v[2], v[3]};
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

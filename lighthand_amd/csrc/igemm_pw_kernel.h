@@ -22,6 +22,10 @@
 #include "igemm_wave_epilogue.h"
 #include <stdlib.h>
 
+#ifndef LH_PW_NT
+#define LH_PW_NT 0          // debug builds only (-DLH_PW_NT=1): A/B of the cache policy of the operand-row loads
+#endif
+
 template <typename T, int BM, int KC, int PT, bool STATS>
 __global__ __launch_bounds__(256, 2) void igemm_pw_kernel(const IgemmArgs p) {
     // two operand register sets (the rows of tile n + 1 are requested before tile n is multiplied) where the register
@@ -107,7 +111,11 @@ __global__ __launch_bounds__(256, 2) void igemm_pw_kernel(const IgemmArgs p) {
             for (int kk = 0; kk < KS; ++kk) {
                 const unsigned char* src = (ok && kk * 32 + q * EPC < p.k_run) ? base + kk * 64 : p.zero;
                 if (LH_ABL & 4) B[j][kk] = uint4{(unsigned)(size_t)src, 1u, 2u, 3u};
-                else B[j][kk] = *reinterpret_cast<const uint4*>(src);
+                else if (LH_PW_NT) {                        // experiment: operand rows as non-temporal (read-once) loads
+                    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+                    const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(src));
+                    B[j][kk] = uint4{v[0], v[1], v[2], v[3]};
+                } else B[j][kk] = *reinterpret_cast<const uint4*>(src);
             }
         }
     };

@@ -1,5 +1,8 @@
 // Layout transforms, weight packs, heatmap target / loss / arg-max decode, fused Adam.
 #include "common.h"
+#ifndef LH_NT_ADAM
+#define LH_NT_ADAM 0         // debug builds only: the optimizer reads the gradient arena (its last use) with non-temporal loads
+#endif
 #include <stdarg.h>
 #include <stdio.h>
 
@@ -781,7 +784,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, flo
     const long nvec = numel / 4;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
         float4 pp = reinterpret_cast<float4*>(p)[i];
-        const float4 gg = reinterpret_cast<const float4*>(g)[i];
+        const float4 gg = LH_NT_ADAM ? lh_ld_nt(reinterpret_cast<const float4*>(g) + i) : reinterpret_cast<const float4*>(g)[i];
         float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
         float* P = &pp.x; const float* G = &gg.x; float* M = &mm.x; float* V = &vv.x;
 #pragma unroll

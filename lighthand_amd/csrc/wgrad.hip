@@ -12,6 +12,9 @@
 //  * split-K over pixels -> fp32 slabs [split][tap][o][i], folded (deterministically, in
 //    split order) into the reference-layout gradient by wgrad_reduce_kernel.
 #include "common.h"
+#ifndef LH_NT_WREDUCE
+#define LH_NT_WREDUCE 0      // debug builds only: the fold reads the split-K slabs (their last use) with non-temporal loads
+#endif
 #include <algorithm>
 #include <stdlib.h>
 
@@ -228,7 +231,7 @@ __device__ __forceinline__ void wgrad_reduce_body(const WreduceArgs& p, const in
         for (; sp + 8 <= p.nsplit; sp += 8) {
             float4 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = src[(long)(sp + u) * stride];
+            for (int u = 0; u < 8; ++u) v[u] = LH_NT_WREDUCE ? lh_ld_nt(src + (long)(sp + u) * stride) : src[(long)(sp + u) * stride];
 #pragma unroll
             for (int u = 0; u < 8; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
         }

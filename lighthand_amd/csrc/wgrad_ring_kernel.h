@@ -21,6 +21,13 @@
 //    the serial tail of one workgroup reading nsplit tiles costs more than the 5-8 us reduce launch it replaces at
 //    every split count this network uses, and its registers slowed the large tiles; removed.
 #pragma once
+// Debug builds only: cache-policy A/B of the operand streams (aux = 2 selects the non-temporal form of the LDS-DMA load)
+#ifndef LH_NT_WGRAD_X
+#define LH_NT_WGRAD_X 0
+#endif
+#ifndef LH_NT_WGRAD_DY
+#define LH_NT_WGRAD_DY 0
+#endif
 #include "common.h"
 #include "multi.h"
 
@@ -153,7 +160,7 @@ __device__ __forceinline__ void wgrad_ring_body(const WgradArgs& p, unsigned cha
 #pragma unroll
         for (int j = 0; j < NO; ++j) {
             const unsigned char* src = done + j * NWAVE * RPO < oleft ? osrc + (oadv + j * ostep) : zero;
-            if (!(LH_ABL & 4)) __builtin_amdgcn_global_load_lds((gbl_p)src, (lds_p)(st + (NWAVE * j + wave) * 1024), 16, 0, 0);
+            if (!(LH_ABL & 4)) __builtin_amdgcn_global_load_lds((gbl_p)src, (lds_p)(st + (NWAVE * j + wave) * 1024), 16, 0, LH_NT_WGRAD_DY ? 2 : 0);
         }
         int cn = xn, ca = xa, cb = xb;
 #pragma unroll
@@ -162,7 +169,7 @@ __device__ __forceinline__ void wgrad_ring_body(const WgradArgs& p, unsigned cha
             const bool ok = (int)(done + j * NWAVE * RPI < xleft) & (int)((unsigned)ih < (unsigned)p.hi) & (int)((unsigned)iw < (unsigned)p.wi);
             const int pix = (cn * p.hi + ih) * p.wi + iw;               // input pixel index (any value when !ok)
             const unsigned char* src = ok ? xsrc + (long)pix * xpix : zero;
-            if (!(LH_ABL & 4)) __builtin_amdgcn_global_load_lds((gbl_p)src, (lds_p)(st + KPS * RBO + (NWAVE * j + wave) * 1024), 16, 0, 0);
+            if (!(LH_ABL & 4)) __builtin_amdgcn_global_load_lds((gbl_p)src, (lds_p)(st + KPS * RBO + (NWAVE * j + wave) * 1024), 16, 0, LH_NT_WGRAD_X ? 2 : 0);
             if (j + 1 < NI) {                                           // on to instruction j + 1 (mixed-radix add: no division)
                 cb += jb; ca += ja; cn += jn;
                 if (cb >= p.wo) { cb -= p.wo; ++ca; }

@@ -211,12 +211,17 @@ def test_train_entry_point_takes_datasets(tmp_path, capsys, monkeypatch):
             return self.x[i], self.j[i]
 
     common = ["--root_path", str(tmp_path), "--batch_size", "8", "--epoch", "2", "--depth", "18", "--size", "64", "--precision", "bf16", "--reset"]
-    best = T.main(T.parse_args(common + ["--name", "ref"]), train_set=RefLayout(32, 1), val_set=RefLayout(8, 2))
+    # one loader worker instead of the reference's eight (src/utils/pre_argparser.py): every epoch forks the workers of both
+    # loaders from a process that holds a HIP context -- 64 forks took 170 of this suite's 420 s
+    args0 = T.parse_args(common + ["--name", "ref"])
+    args0.num_workers = 1
+    best = T.main(args0, train_set=RefLayout(32, 1), val_set=RefLayout(8, 2))
     assert np.isfinite(best) and "valid loss" in capsys.readouterr().out
     seen = []
     real = runtime.sample_color_jitter
     monkeypatch.setattr(runtime, "sample_color_jitter", lambda n, *a, mask=None, **k: (seen.append(mask.clone()), real(n, *a, mask=mask, **k))[1])
     args = T.parse_args(common + ["--name", "raw", "--ratio_of_aug", "0.25"])
+    args.num_workers = 1
     best = T.main(args, train_set=RawFrames(32, 3), val_set=RawFrames(8, 4))
     assert np.isfinite(best)
     assert len(seen) == 2 * 4 and all(m.dtype == torch.bool and m.numel() == 8 for m in seen)
@@ -394,9 +399,10 @@ def test_c5_r50_fp16_infer_384_graph_matches_oracle(static_kernel_choice):
     print(f"C5 parity: heatmap max err / peak {err:.3e}, peak {np.abs(want).max():.3f}, arg-max agreement {match:.4f}")
     assert got.shape == want.shape == (b, 21, 96, 96)
     assert np.abs(want).max() > 0.5                             # the network did learn peaks
-    assert err < 2e-2
+    # measured (round 4, static kernel choice, identical in two processes): err 2.14e-3, arg-max 210 / 210
+    assert err < 5e-3
     assert np.array_equal(preds, dec_h)                         # device decode == oracle rule on the same heatmaps
-    assert match >= 0.99
+    assert match >= 0.995                                       # at most one of the 210 joints
 
 
 def test_c2_r50_bf16_train_forward_matches_fp32_oracle(static_kernel_choice):
@@ -450,9 +456,10 @@ def test_c2_r50_bf16_train_forward_matches_fp32_oracle(static_kernel_choice):
           f"loss rel {lrel:.3e}")
     assert got.shape == want.shape == (b, 21, 64, 64)
     assert peak > 0.5                                           # the network did learn peaks
-    assert err < 5e-2 and rms < 2e-3
-    assert match >= 0.98
-    assert lrel < 5e-2
+    # measured (round 4, static kernel choice, identical in two processes): max 3.78e-2, RMS 6.7e-4, arg-max 168 / 168, loss 2.7e-2
+    assert err < 5e-2 and rms < 1e-3
+    assert match >= 0.99                                        # at most one of the 168 joints
+    assert lrel < 4e-2
 
 
 @pytest.mark.parametrize("precision", ["bf16", "fp16"])
@@ -516,14 +523,18 @@ def test_c4_hrnet_w32_bf16_train_forward_matches_fp32_oracle(precision, static_k
           f"arg-max equal {match:.4f}, within one pixel {near:.4f}, loss rel {lrel:.3e}")
     assert got.shape == want.shape == (b, 21, 64, 64)
     assert peak > 0.5                                           # the network did learn peaks
+    # measured (round 4, static kernel choice, identical in two processes) -- bounds = measured value + a margin for
+    # legitimate changes of rounding (a different summation order moves the 1 500-step trajectory):
+    #   fp16: RMS 1.5e-3, 99.9th percentile 2.0e-2, worst element 7.4e-2, equal 98.2 %, within one pixel 100 %, loss 1.4e-3
+    #   bf16: RMS 9.3e-3, 99.9th percentile 1.09e-1, worst element 5.6e-1, equal 90.5 %, within one pixel 96.4 %, loss 2.9e-2
     if precision == "fp16":
-        assert rms < 4e-3 and p999 < 5e-2
-        assert near >= 0.97
-        assert lrel < 5e-2
+        assert rms < 2.5e-3 and p999 < 3e-2 and err < 1.2e-1
+        assert near >= 0.99 and match >= 0.96
+        assert lrel < 5e-3
     else:
-        assert rms < 2e-2 and p999 < 2.5e-1
-        assert near >= 0.90
-        assert lrel < 1e-1
+        assert rms < 1.3e-2 and p999 < 1.5e-1 and err < 7.5e-1
+        assert near >= 0.94 and match >= 0.86
+        assert lrel < 5e-2
 
 
 def test_eval_tail_batch_runs_unpadded(tmp_path):
