@@ -322,6 +322,15 @@ int lh_fuse_bwd(const lh_fuse_bwd_desc* d, int n, int h, int w, int c, void* wor
 typedef struct { const lh_fuse_bwd_desc* d; int n, h, w, c; void* workspace; } lh_fuse_bwd_call;
 int lh_fuse_bwd_multi(const lh_fuse_bwd_call* calls, int n, int dtype, void* stream);
 
+/* The inference stem of SimpleBaseline-ResNet as ONE launch: maxpool(relu(bn1(conv1(x)))) -- conv1 = nn.Conv2d(3, 64, 7, 2, 3),
+ * bn1 in eval mode (running statistics folded into scale / shift), nn.MaxPool2d(3, 2, 1): src/modeling/simplebaseline/
+ * pose_resnet.py:151-156 and the first four lines of PoseResNet.forward.  img: the zero-padded NHWC4 image the engine's input
+ * transforms write ([n][hp][wp][4], image pixel (y, x) at (y + 3, x + 3)); wpack: the stem's weight pack (64 channels, one tap
+ * per kernel ROW, K run = 8 pixels x 4 channels); out = [n][ph][pw][64] with ph = (conv_h - 1) / 2 + 1.  relu must be 1 (the
+ * pool's padding is realised as zeros).  16-bit types.  Bit-identical to lh_igemm + lh_maxpool3x3s2_fwd on the same operands. */
+int lh_stem_pool(const void* img, int n, int hp, int wp, const void* wpack, const float* bias, const float* scale,
+                 const float* shift, void* out, int conv_h, int conv_w, int relu, int dtype, void* stream);
+
 /* nn.MaxPool2d(3, 2, 1): pose_resnet.py:156.  idx (uint8 [n][ho][wo][c]) keeps the window
  * position (first maximum in scan order, NaN propagates) for the backward pass; NULL when no backward pass follows. */
 int lh_maxpool3x3s2_fwd(const void* x, void* out, unsigned char* idx, int n, int h, int w, int c,

@@ -128,6 +128,7 @@ SIGNATURES = {
     "lh_fuse_bwd_multi": (_I, [C.POINTER(FuseBwdCall), _I, _I, _P]),
     "lh_fuse_bwd_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
     "lh_fuse_bwd": (_I, [C.POINTER(FuseBwdDesc), _I, _I, _I, _I, _P, _I, _P]),
+    "lh_stem_pool": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "lh_maxpool3x3s2_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "lh_maxpool3x3s2_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "lh_gaussian_target": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _P]),

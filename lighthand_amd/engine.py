@@ -338,6 +338,7 @@ class Plan:
     force_cfg = None
     force_wgrad = None
     fuse_head = True             # test hook: False keeps the inference head as separate launches (A/B against _fuse_head)
+    fuse_stem = True             # test hook: False keeps the inference stem as convolution + max-pool launches (A/B against _fuse_stem_pool)
     _tune_file_loaded = False
 
     _tune_measured = set()      # keys measured by this process or read from the user's cache file (what a save writes)
@@ -1797,8 +1798,40 @@ class Plan:
         self._producers.setdefault(id(out), []).extend(main)       # `out` is now written by these launches (see _fuse_head)
         return True
 
+    def _fuse_stem_pool(self, nd):
+        """Inference plans: `maxpool(relu(bn1(conv1(x))))` (pose_resnet.py:151-156 and the first lines of its forward) as ONE
+        launch (lh_stem_pool: direct 7x7 / stride 2 convolution with the weights in registers, the eval-mode BatchNorm
+        folded into its epilogue, the 3x3 / stride 2 maximum taken from the tile in LDS) -- the 64-channel convolution
+        output, the largest activation of the network, is never written.  Applies when the pool's input is produced by the
+        stem convolution alone (BatchNorm + ReLU already folded into it by _fold_eval_bn) and has no other reader."""
+        x, y = nd["x"], nd["y"]
+        if not Plan.fuse_stem or self.with_bwd or self.training or self.es != 2 or x.c != 64 or x.c_valid != 64:
+            return False
+        users = sum(1 for kind, n in self.nodes
+                    if (kind in ("conv", "deconv", "maxpool") and n["x"] is x) or (kind == "fuse" and any(a is x for a, _, _ in n["terms"]))
+                    or (kind == "output" and n["y"] is x))
+        prods = self._producers.get(id(x)) or []
+        if users != 1 or len(prods) != 1 or prods[0].fn is not self.lib.lh_igemm or not prods[0].what.endswith("stem fwd") or prods[0] not in self.fwd:
+            return False
+        call = prods[0]
+        a, ig, d = call.args, self._IG, call.keep
+        if (d.ntaps, d.k_run, d.sh, d.sw, d.cout, d.relu) != (7, 32, 2, 2, 64, 1) or a[ig["dst"]] != x.buf.data_ptr() or a[ig["addend"]] or a[ig["stats"]]:
+            return False
+        ybuf = self._act_buf(y)
+        fused = _Call(self.lib.lh_stem_pool, (a[ig["src"]], d.n, d.hi, d.wi, a[ig["pack"]], a[ig["bias"]], a[ig["scale"]], a[ig["shift"]],
+                                              ybuf.data_ptr(), d.ho, d.wo, 1, self.dt), "conv1 stem fwd + maxpool", keep=d)
+        fused.slane = call.slane
+        self.keep.append(call)
+        self.fwd[self.fwd.index(call)] = fused
+        self.profile_meta = [(w, fused if c is call else c, "stem_pool_kernel" if c is call else nm, fl,
+                              (nb - x.pixels * x.c * self.es + y.pixels * y.c * self.es) if c is call else nb) for w, c, nm, fl, nb in self.profile_meta]
+        self._producers[id(y)] = [fused]
+        return True
+
     def _c_maxpool(self, nd, blk):
         x, y = nd["x"], nd["y"]
+        if self._fuse_stem_pool(nd):
+            return
         xbuf, ybuf = self._act_buf(x), self._act_buf(y)
         idx = self._alloc(y.n, y.h, y.w, y.c, dtype=torch.uint8) if self.with_bwd else None     # window positions: only the backward pass reads them
         self.fwd.append(_Call(self.lib.lh_maxpool3x3s2_fwd, (xbuf.data_ptr(), ybuf.data_ptr(), _ptr(idx), x.n, x.h, x.w, x.c, self.dt), "maxpool fwd"))

@@ -404,3 +404,44 @@ def test_hrnet_branch_batching_is_bit_exact_and_cuts_launches(monkeypatch):
     d = (g_m - g_l).double()
     print("measured vs static kernel choice: heat-maps", rel(out_m.cpu().numpy(), out_l.cpu().numpy()), "gradients", float(d.norm() / g_l.double().norm()))
     assert float(d.norm() / g_l.double().norm()) < 5e-2
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+@pytest.mark.parametrize("shape", [(2, 256, 256), (3, 100, 132), (1, 64, 48), (5, 72, 200)])
+def test_fused_inference_stem_is_bit_identical_to_conv_then_pool(shape, precision):
+    """Inference plans run maxpool(relu(bn1(conv1(x)))) (pose_resnet.py:151-156) as ONE launch (lh_stem_pool: the 64-channel
+    convolution output is never written).  Same K order, same epilogue arithmetic, maximum over the rounded values: the
+    heat-maps must equal those of the plan that keeps convolution and max-pool apart BIT FOR BIT -- on full tiles, on ragged
+    sizes (partial 8 x 8 pooled tiles, odd convolution sizes) and with non-trivial running statistics -- and match the
+    oracle like any other eval-mode forward."""
+    from lighthand_amd.engine import Plan
+    from lighthand_amd.modeling.simplebaseline.pose_resnet import get_pose_net
+    from oracle import models as omod
+    n, h, w = shape
+    rng = np.random.RandomState(7)
+    x = torch.from_numpy(rng.randn(n, 3, h, w).astype(np.float32)).cuda()
+    outs, calls = [], []
+    for fuse in (True, False):
+        Plan.fuse_stem = fuse
+        try:
+            torch.manual_seed(21)
+            m = get_pose_net(resnet_cfg(18), True)
+            with torch.no_grad():                                      # running statistics away from (0, 1): the folded affine matters
+                m.bn1.running_mean.uniform_(-0.5, 0.5)
+                m.bn1.running_var.uniform_(0.5, 2.0)
+                m.bn1.weight.uniform_(0.5, 1.5)
+                m.bn1.bias.uniform_(-0.3, 0.3)
+            sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+            m = m.cuda().set_precision(precision).eval()
+            with torch.no_grad():
+                outs.append(m(x).clone())
+            plan = m.plan(n, h, w, training=False, backward=False)
+            calls.append([getattr(c, "what", "") for c in plan.fwd])
+        finally:
+            Plan.fuse_stem = True
+    assert any("stem fwd + maxpool" in c for c in calls[0]) and not any("maxpool fwd" in c for c in calls[0])
+    assert any("maxpool fwd" in c for c in calls[1])
+    assert torch.equal(outs[0], outs[1])
+    with torch.no_grad():
+        want = omod.pose_resnet_forward(sd, x.cpu(), 18, training=False).numpy()
+    assert rel(outs[0].cpu().numpy(), want) < (3e-2 if precision == "bf16" else 4e-3)
