@@ -111,8 +111,14 @@ static bool cfg_fits(const lh_igemm_desc* d, int dtype, const RingCfg& c) {
     if (c.bm > 64 && d->cout <= c.bm / 2) return false;               // (these three only multiply zeros / repeat a shallower ring)
     if (c.bp > 64 && M <= c.bp / 2) return false;
     if (ring_depth(c) > 2 && ring_depth(c) - 1 > stages) return false;
-    // the wide-wave tile pays for 256 x 256 of prologue / epilogue with one wave per SIMD: large launches only
-    if (ring_wide(c) && (((M + 255) / 256) * ((d->cout + 255) / 256) < 128 || stages < 4)) return false;
+    // the wide-wave tile pays for 256 x 256 of prologue / epilogue with one wave per SIMD: large launches only.  Measured 20-25 %
+    // SLOWER than the 8-wave form on every launch of C5 / C2 (profiles/r04_c5_deconv_what_holds_the_pipe.txt), so the tuner is
+    // not offered it unless LH_WIDE_TILES=1 (tests, experiments); an explicit cfg still runs it.
+    if (ring_wide(c)) {
+        const char* sw = getenv("LH_WIDE_TILES");                 // read per query (host side, planning time only)
+        const bool offer = sw && atoi(sw) != 0;
+        if (!offer || ((M + 255) / 256) * ((d->cout + 255) / 256) < 128 || stages < 4) return false;
+    }
     return true;
 }
 

@@ -140,6 +140,7 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemPoolArgs p)
                         const float v = fmaxf(acc[i][j] * sv[j] + bv[j], 0.f);
                         pk.e[j] = from_f<T>(inside ? v : 0.f);
                     }
+                    pk.u.x &= 0x7fff7fffu; pk.u.y &= 0x7fff7fffu;             // -0 -> +0 (see the maximum below)
                     *reinterpret_cast<uint2*>(ctile + idx * SP_CPITCH + (16 * i + 4 * q) * 2) = pk.u;
                 }
             }
@@ -152,19 +153,20 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemPoolArgs p)
             const int chunk = item & 7, pp = item >> 3;
             const int ppy = pp >> 3, ppx = pp & 7;
             const int oy = 8 * tyi + ppy, ox = 8 * txi + ppx;
-            float best[8];
+            // every stored value is >= +0 (ReLU; the sign bit is cleared at the store) or a NaN: the order of such 16-bit floats
+            // is the order of their bit patterns as unsigned integers, NaN patterns above every number -- the window maximum,
+            // with the framework's "a NaN wins" rule, is a packed unsigned 16-bit maximum (4 instructions per tap instead of ~40)
+            typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+            u16x8 best = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int ly = 2 * ppy + t / 3, lx = 2 * ppx + t % 3;
                 const unsigned char* src = ctile + (ly * SP_CT + lx) * SP_CPITCH + chunk * 16;
                 const uint2 lo = *reinterpret_cast<const uint2*>(src), hi = *reinterpret_cast<const uint2*>(src + 8);
-                float v[8];
-                unpack16<T>(uint4{lo.x, lo.y, hi.x, hi.y}, v);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) best[e] = (t == 0 || v[e] > best[e] || v[e] != v[e]) ? v[e] : best[e];   // NaN propagates (framework rule)
+                best = __builtin_elementwise_max(best, __builtin_bit_cast(u16x8, uint4{lo.x, lo.y, hi.x, hi.y}));
             }
             if (oy < p.ph && ox < p.pw)
-                *reinterpret_cast<uint4*>(p.out + (((long)b * p.ph + oy) * p.pw + ox) * 128 + chunk * 16) = pack16<T>(best);
+                *reinterpret_cast<uint4*>(p.out + (((long)b * p.ph + oy) * p.pw + ox) * 128 + chunk * 16) = __builtin_bit_cast(uint4, best);
         }
         // the next iteration's patch writes touch only `patch` (its reads ended at the barrier above); its tile writes come
         // after the next barrier, i.e. after every thread has finished these reads

@@ -207,6 +207,21 @@ def test_every_conv_kernel_configuration(case, precision, forced_plans):
         assert (256, 256) in tiles
 
 
+@pytest.fixture(scope="module")
+def wide_tiles_offered():
+    """The wide-wave configurations are compiled in but only offered to the tuner with LH_WIDE_TILES=1 (they lose to the 8-wave
+    tile everywhere: profiles/r04_c5_deconv_what_holds_the_pipe.txt).  The library reads the switch once per process, so the
+    library reads the switch at every candidate query."""
+    import os
+    old = os.environ.get("LH_WIDE_TILES")
+    os.environ["LH_WIDE_TILES"] = "1"
+    yield
+    if old is None:
+        os.environ.pop("LH_WIDE_TILES", None)
+    else:
+        os.environ["LH_WIDE_TILES"] = old
+
+
 WIDE_CASES = [  # cin, cout, k, s, p, n, h, w, transposed -- at least 128 tiles of 256 x 256, which is where the form is offered
     (256, 256, 3, 1, 1, 9, 61, 61, False),       # ragged pixel count: the last pixel tile is partial
     (512, 256, 1, 1, 0, 8, 64, 64, False),
@@ -217,7 +232,7 @@ WIDE_CASES = [  # cin, cout, k, s, p, n, h, w, transposed -- at least 128 tiles 
 
 @pytest.mark.parametrize("precision", ["bf16", "fp16"])
 @pytest.mark.parametrize("case", WIDE_CASES)
-def test_wide_wave_configurations(case, precision, forced_plans):
+def test_wide_wave_configurations(case, precision, forced_plans, wide_tiles_offered):
     """The wide-wave form of the 256 x 256 tile (four waves, 128 x 128 per wave, ring depth written depth + 10:
     igemm_ring_cfgs.h) on launches large enough to be offered it: forward and data gradient match PyTorch and agree BIT
     FOR BIT with the 8-wave form of the same tile and with a 128 x 128 configuration."""
