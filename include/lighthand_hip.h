@@ -282,6 +282,12 @@ typedef struct {
     int relu;
     void* relu_mask;            /* optional output: one byte per 16-byte chunk of `out`, bit e = (element e > 0); lets the
                                  * backward pass read n*h*w*c/8 mask bytes instead of the whole stored activation */
+    const lh_bn_finalize_call* fin[4];
+                                /* optional, per term: the BatchNorm finalize of that term (batch statistics -> scale / shift /
+                                 * saved mean / invstd / running statistics: what lh_bn_finalize does) has NOT run yet and is part
+                                 * of this call.  Small tensors fold the statistics slab inside the elementwise launch itself
+                                 * (one launch instead of two on the dependency chain of every BatchNorm); otherwise the call
+                                 * launches the finalize first.  fin[t]->scale / ->shift must equal scale[t] / shift[t]. */
 } lh_fuse_desc;
 int lh_fuse_fwd(const lh_fuse_desc* d, void* out, int n, int h, int w, int c, int dtype, void* stream);
 /* Multi-problem forms (pose_hrnet.py:139-185, 247-265: the same layer position of the 2-4 parallel branches of a

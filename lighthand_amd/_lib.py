@@ -24,9 +24,16 @@ class IgemmDesc(C.Structure):
                 ("relu", C.c_int), ("dh", C.c_byte * 64), ("dw", C.c_byte * 64), ("cfg", C.c_int * 8)]
 
 
+class BnFinalizeCall(C.Structure):     # lh_bn_finalize_multi / lh_fuse_desc.fin
+    _fields_ = [("stats", C.c_void_p), ("rows", C.c_int), ("count", C.c_int), ("c", C.c_int), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+                ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("num_batches_tracked", C.c_void_p), ("momentum", C.c_float),
+                ("eps", C.c_float), ("scale", C.c_void_p), ("shift", C.c_void_p), ("save_mean", C.c_void_p), ("save_invstd", C.c_void_p)]
+
+
 class FuseDesc(C.Structure):
     _fields_ = [("x", C.c_void_p * 4), ("scale", C.c_void_p * 4), ("shift", C.c_void_p * 4),
-                ("log2up", C.c_int * 4), ("nterms", C.c_int), ("relu", C.c_int), ("relu_mask", C.c_void_p)]
+                ("log2up", C.c_int * 4), ("nterms", C.c_int), ("relu", C.c_int), ("relu_mask", C.c_void_p),
+                ("fin", C.POINTER(BnFinalizeCall) * 4)]
 
 
 class FuseBwdDesc(C.Structure):
@@ -54,12 +61,6 @@ class FuseFwdCall(C.Structure):        # lh_fuse_fwd_multi
 
 class FuseBwdCall(C.Structure):        # lh_fuse_bwd_multi
     _fields_ = [("d", C.POINTER(FuseBwdDesc)), ("n", C.c_int), ("h", C.c_int), ("w", C.c_int), ("c", C.c_int), ("workspace", C.c_void_p)]
-
-
-class BnFinalizeCall(C.Structure):     # lh_bn_finalize_multi
-    _fields_ = [("stats", C.c_void_p), ("rows", C.c_int), ("count", C.c_int), ("c", C.c_int), ("gamma", C.c_void_p), ("beta", C.c_void_p),
-                ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("num_batches_tracked", C.c_void_p), ("momentum", C.c_float),
-                ("eps", C.c_float), ("scale", C.c_void_p), ("shift", C.c_void_p), ("save_mean", C.c_void_p), ("save_invstd", C.c_void_p)]
 
 
 class Head(C.Structure):

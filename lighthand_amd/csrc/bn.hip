@@ -359,6 +359,11 @@ __device__ __forceinline__ long walk_round(long r, long rounds, bool rev) { retu
 
 struct FuseArgs {
     int exp;                     // bn_exp_flags() >> 2 (forward bits)
+    // slice kernel only (fuse_fwd_slice_body): the BatchNorm finalize of terms 0 / 1 runs inside the launch (has_fin bit t)
+    FinalizeArgs fin[2];
+    int has_fin;
+    int slice_ppg;               // pixels per workgroup of a channel slice
+    int slice_w;                 // channels per slice (64 | 32)
     const unsigned char* x[4];
     const float* scale[4];
     const float* shift[4];
@@ -501,10 +506,149 @@ __global__ __launch_bounds__(256) void fuse_fwd_flat_multi_kernel(const LhMulti<
     fuse_fwd_flat_body<T, NT>(m.a[i], bid, nblk);
 }
 
+// Channel-slice form for SMALL tensors: BatchNorm finalize + apply as ONE launch.  A workgroup owns 64 channels of a range
+// of pixels; it first folds the statistics slab of ITS 64 channels ([rows][2][c] partial sums the convolution epilogues
+// wrote: rows x 512 bytes, four row lanes per channel, fp64, fixed order), derives mean / invstd / scale / shift like
+// bn_finalize_fused_body (the workgroups of pixel group 0 also store them for the backward pass and update the running
+// statistics), then streams its pixels: 128 contiguous bytes per pixel and term.  One launch instead of two on the
+// dependency chain of every BatchNorm of stages 3-4 and of HRNet's branches, whose tensors are a few MB: the separate
+// finalize launch was 5-6 us of pure launch + fold latency in front of an 8 us elementwise pass.
+template <typename T, int NT>
+__device__ __forceinline__ void fuse_fwd_slice_body(const FuseArgs& p, const int bid, const int nblk) {
+    constexpr int EPC = 16 / sizeof(T);
+    const int SW = p.slice_w;                         // channels per slice: 64, or 32 for 32-channel tensors (HRNet's widest-resolution branch)
+    const int CPS = SW / EPC;                         // 16-byte chunks per slice
+    const int PL = 256 / CPS;                         // pixel lanes
+    const int NP = 256 / SW;                          // row lanes of the fold
+    __shared__ double red[2][16][64];
+    __shared__ float scsh[NT][2][64];
+    const int nslices = p.c / SW;
+    const int slice = bid % nslices, grp = bid / nslices;
+    const int cbase = slice * SW;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (!((p.has_fin >> t) & 1)) {
+            if (threadIdx.x < SW) {
+                scsh[t][0][threadIdx.x] = p.scale[t] ? p.scale[t][cbase + threadIdx.x] : 1.f;
+                scsh[t][1][threadIdx.x] = p.scale[t] ? p.shift[t][cbase + threadIdx.x] : 0.f;
+            }
+            continue;
+        }
+        const FinalizeArgs& f = p.fin[t];
+        const float* slab = (const float*)f.slab;
+        // The fold is arithmetically THE SAME as bn_finalize_fused_body's (slab_totals_then: 16 row lanes per channel with its
+        // grouping of eight / four rows, lanes summed in ascending order), so a node gets bit-identical statistics whether its
+        // finalize runs in this launch or as a launch of its own (a merged multi-problem call may decide differently from
+        // the same call on its own).  A thread takes the row lanes part, part + NP, ... of its channel.
+        const int ch = threadIdx.x % SW, part = threadIdx.x / SW;
+        const long cc = f.c;
+        const float* col = slab + cbase + ch;
+        if (t) __syncthreads();                       // the previous term's partial sums have been consumed
+        for (int rl = part; rl < 16; rl += NP) {
+            double a = 0.0, b = 0.0;
+            int r = rl;
+            for (; r + 112 < f.rows; r += 128) {
+                float av[8], bv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { av[u] = col[((long)(r + 16 * u) * 2) * cc]; bv[u] = col[((long)(r + 16 * u) * 2 + 1) * cc]; }
+                a += (((double)av[0] + (double)av[1]) + ((double)av[2] + (double)av[3])) + (((double)av[4] + (double)av[5]) + ((double)av[6] + (double)av[7]));
+                b += (((double)bv[0] + (double)bv[1]) + ((double)bv[2] + (double)bv[3])) + (((double)bv[4] + (double)bv[5]) + ((double)bv[6] + (double)bv[7]));
+            }
+            for (; r + 48 < f.rows; r += 64) {
+                const float a0 = col[((long)r * 2) * cc], b0 = col[((long)r * 2 + 1) * cc];
+                const float a1 = col[((long)(r + 16) * 2) * cc], b1 = col[((long)(r + 16) * 2 + 1) * cc];
+                const float a2 = col[((long)(r + 32) * 2) * cc], b2 = col[((long)(r + 32) * 2 + 1) * cc];
+                const float a3 = col[((long)(r + 48) * 2) * cc], b3 = col[((long)(r + 48) * 2 + 1) * cc];
+                a += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+                b += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
+            }
+            for (; r < f.rows; r += 16) {
+                a += (double)col[((long)r * 2) * cc];
+                b += (double)col[((long)r * 2 + 1) * cc];
+            }
+            red[0][rl][ch] = a;
+            red[1][rl][ch] = b;
+        }
+        __syncthreads();
+        if (threadIdx.x < SW) {
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s0 += red[0][i][ch]; s1 += red[1][i][ch]; }
+            const int gc = cbase + ch, count = f.count;
+            const double mean = s0 / count;
+            double var = s1 / count - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float invstd = (float)(1.0 / sqrt(var + (double)f.eps));
+            const float g = f.gamma ? f.gamma[gc] : 1.f, be = f.beta ? f.beta[gc] : 0.f;
+            const float sc = g * invstd, sh = be - (float)mean * sc;
+            scsh[t][0][ch] = sc;
+            scsh[t][1][ch] = sh;
+            if (grp == 0) {                           // one workgroup per slice publishes (same values in every group)
+                f.scale[gc] = sc;
+                f.shift[gc] = sh;
+                if (f.smean) f.smean[gc] = (float)mean;
+                if (f.sinv) f.sinv[gc] = invstd;
+                if (f.rmean) f.rmean[gc] = (1.f - f.momentum) * f.rmean[gc] + f.momentum * (float)mean;
+                if (f.rvar) {
+                    const double unb = count > 1 ? var * ((double)count / (count - 1)) : var;
+                    f.rvar[gc] = (1.f - f.momentum) * f.rvar[gc] + f.momentum * (float)unb;
+                }
+            }
+        }
+        if (bid == 0 && threadIdx.x == 0 && f.nbt) *f.nbt += 1;
+    }
+    __syncthreads();
+    const int chunk = threadIdx.x % CPS, plane = threadIdx.x / CPS;
+    float sc[NT][EPC], sh[NT][EPC];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) { sc[t][e] = scsh[t][0][chunk * EPC + e]; sh[t][e] = scsh[t][1][chunk * EPC + e]; }
+    const long P = p.total / (p.c / EPC);             // pixels
+    const long p0 = (long)grp * p.slice_ppg;
+    long p1 = p0 + p.slice_ppg;
+    if (p1 > P) p1 = P;
+    const int nchunk = p.c / EPC;
+    auto body = [&](auto NTc) __attribute__((always_inline)) {
+        constexpr bool LNT = decltype(NTc)::value;
+        for (long px = p0 + plane; px < p1; px += PL) {
+            const long idx = px * nchunk + slice * CPS + chunk;
+            float acc[EPC];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                float v[EPC];
+                unpack16<T>(ld16<LNT>(p.x[t] + idx * 16), v);
+                if (p.scale[t]) {
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) v[e] = v[e] * sc[t][e] + sh[t][e];
+                }
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) acc[e] = t == 0 ? v[e] : acc[e] + v[e];
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) acc[e] = fmaxf(acc[e], 0.f);
+            }
+            const uint4 u = pack16<T>(acc);
+            *reinterpret_cast<uint4*>(p.out + idx * 16) = u;
+            if (p.mask) p.mask[idx] = positive_bits<T>(u);
+        }
+    };
+    if (p.exp & 1) body(std::true_type{}); else body(std::false_type{});
+}
+template <typename T, int NT>
+__global__ __launch_bounds__(256) void fuse_fwd_slice_kernel(const FuseArgs p) { fuse_fwd_slice_body<T, NT>(p, blockIdx.x, gridDim.x); }
+template <typename T, int NT>
+__global__ __launch_bounds__(256) void fuse_fwd_slice_multi_kernel(const LhMulti<FuseArgs> m) {
+    int bid, nblk;
+    const int i = lh_multi_pick(m, bid, nblk);
+    fuse_fwd_slice_body<T, NT>(m.a[i], bid, nblk);
+}
+
 // ---- launch records: a C-ABI call is first PLANNED into the kernel launches it consists of (kind, grid, argument block),
 // then run -- one record as a plain launch, the records of several independent calls that agree in kind as one
 // multi-problem launch (multi.h).
-enum BnKind { K_FF_GEN, K_FF_FLAT1, K_FF_FLAT2, K_FB_REDUCE_GEN, K_FB_REDUCE_FLAT, K_FB_REDUCE_FLAT_X, K_FB_COEF, K_FB_APPLY_GEN,
+enum BnKind { K_FF_GEN, K_FF_FLAT1, K_FF_FLAT2, K_FF_SLICE1, K_FF_SLICE2, K_FB_REDUCE_GEN, K_FB_REDUCE_FLAT, K_FB_REDUCE_FLAT_X, K_FB_COEF, K_FB_APPLY_GEN,
               K_FB_APPLY_FLAT, K_FB_APPLY_FLAT_X, K_FB_APPLY2 };
 struct FuseBwdArgs;
 struct FuseBwd2Args;
@@ -519,7 +663,10 @@ static int flat_grid(long total) {
     return (int)(g > 2048 ? 2048 : (g < 1 ? 1 : g));
 }
 
-static int plan_fuse_fwd(const lh_fuse_desc* d, void* out, int n, int h, int w, int c, int dtype, FuseArgs* ap, int* kind, int* grid_out) {
+// pre_fin (out): bit t set when term t carries a BatchNorm finalize (lh_fuse_desc.fin) that the planned kernel does NOT run
+// itself -- the caller launches it first.  allow_slice = false plans the streaming kernels only.
+static int plan_fuse_fwd(const lh_fuse_desc* d, void* out, int n, int h, int w, int c, int dtype, FuseArgs* ap, int* kind, int* grid_out,
+                         int* pre_fin = nullptr, bool allow_slice = true) {
     LH_REQUIRE(d && out && d->nterms >= 1 && d->nterms <= 4, "lh_fuse_fwd: bad descriptor");
     const int es = lh_dtype_size(dtype);
     LH_REQUIRE(es > 0 && c % (16 / es) == 0, "lh_fuse_fwd: c %d not a multiple of the 16-byte chunk", c);
@@ -544,6 +691,40 @@ static int plan_fuse_fwd(const lh_fuse_desc* d, void* out, int n, int h, int w, 
     const int nchunk = c / (16 / es);
     bool flat = d->nterms <= 2 && (nchunk & (nchunk - 1)) == 0 && nchunk <= 256;
     for (int t = 0; t < d->nterms; ++t) flat = flat && a.log2up[t] == 0;
+    a.has_fin = 0; a.slice_ppg = 0; a.slice_w = 0;
+    int fin_mask = 0, rows_max = 0;
+    for (int t = 0; t < d->nterms; ++t) {
+        const lh_bn_finalize_call* f = d->fin[t];
+        if (!f) continue;
+        LH_REQUIRE(pre_fin, "lh_fuse_fwd: this entry point does not take a descriptor with a pending finalize");
+        LH_REQUIRE(f->stats && f->rows > 0 && f->count > 0 && f->c == c && f->scale == d->scale[t] && f->shift == d->shift[t] && f->scale && f->shift,
+                   "lh_fuse_fwd: term %d: the pending finalize must produce this term's scale / shift (c %d vs %d)", t, f->c, c);
+        fin_mask |= 1 << t;
+        rows_max = f->rows > rows_max ? f->rows : rows_max;
+    }
+    // small tensors: finalize + apply as ONE launch (fuse_fwd_slice_body) -- < 256 slab rows (the 16-lane fold of the finalize
+    // kernel, whose arithmetic the slice kernel reproduces; a workgroup folds rows x 2 x 64 floats), <= 48 MB per tensor, channel
+    // slices of 64 (or the whole 32-channel row)
+    static const bool slice_on = !(getenv("LH_BN_SLICE") && atoi(getenv("LH_BN_SLICE")) == 0);
+    const int sw = c % 64 == 0 ? 64 : (c == 32 ? 32 : 0);
+    if (flat && fin_mask && allow_slice && slice_on && sw && rows_max < LH_FOLD_WIDE_ROWS && total * 16 <= (48L << 20)) {
+        const long P = (long)n * h * w;
+        const int pl = 256 / (sw / (16 / es));
+        long ppg = 8L * rows_max > 256 ? 8L * rows_max : 256;
+        ppg = (ppg + pl - 1) / pl * pl;
+        const long G = (P + ppg - 1) / ppg;
+        a.has_fin = fin_mask; a.slice_ppg = (int)ppg; a.slice_w = sw;
+        for (int t = 0; t < d->nterms && t < 2; ++t) {
+            const lh_bn_finalize_call* f = d->fin[t];
+            if (f) a.fin[t] = finalize_args(f->stats, f->rows, f->count, f->c, f->gamma, f->beta, f->running_mean, f->running_var,
+                                            f->num_batches_tracked, f->momentum, f->eps, f->scale, f->shift, f->save_mean, f->save_invstd);
+        }
+        *grid_out = (int)(G * (c / sw));
+        *kind = d->nterms == 1 ? K_FF_SLICE1 : K_FF_SLICE2;
+        if (pre_fin) *pre_fin = 0;
+        return LH_OK;
+    }
+    if (pre_fin) *pre_fin = fin_mask;
     if (flat) {
         *grid_out = flat_grid(total);      // >= 4 chunks per thread
         *kind = d->nterms == 1 ? K_FF_FLAT1 : K_FF_FLAT2;
@@ -1115,6 +1296,8 @@ static int bn_run(const BnLaunch* const* L, int n, int dtype, hipStream_t s) {
         case K_FF_GEN: LH_DISPATCH_DTYPE(dtype, T, BN_RUN((fuse_fwd_kernel<T>), (fuse_fwd_multi_kernel<T>), ff, FuseArgs)); break;
         case K_FF_FLAT1: LH_DISPATCH_DTYPE(dtype, T, BN_RUN((fuse_fwd_flat_kernel<T, 1>), (fuse_fwd_flat_multi_kernel<T, 1>), ff, FuseArgs)); break;
         case K_FF_FLAT2: LH_DISPATCH_DTYPE(dtype, T, BN_RUN((fuse_fwd_flat_kernel<T, 2>), (fuse_fwd_flat_multi_kernel<T, 2>), ff, FuseArgs)); break;
+        case K_FF_SLICE1: LH_DISPATCH_DTYPE(dtype, T, BN_RUN((fuse_fwd_slice_kernel<T, 1>), (fuse_fwd_slice_multi_kernel<T, 1>), ff, FuseArgs)); break;
+        case K_FF_SLICE2: LH_DISPATCH_DTYPE(dtype, T, BN_RUN((fuse_fwd_slice_kernel<T, 2>), (fuse_fwd_slice_multi_kernel<T, 2>), ff, FuseArgs)); break;
         case K_FB_REDUCE_GEN: LH_DISPATCH_DTYPE(dtype, T, BN_RUN((fuse_bwd_reduce_kernel<T>), (fuse_bwd_reduce_multi_kernel<T>), fb, FuseBwdArgs)); break;
         case K_FB_REDUCE_FLAT: LH_DISPATCH_DTYPE(dtype, T, BN_RUN((fuse_bwd_reduce_flat_kernel<T, false>), (fuse_bwd_reduce_flat_multi_kernel<T, false>), fb, FuseBwdArgs)); break;
         case K_FB_REDUCE_FLAT_X: LH_DISPATCH_DTYPE(dtype, T, BN_RUN((fuse_bwd_reduce_flat_kernel<T, true>), (fuse_bwd_reduce_flat_multi_kernel<T, true>), fb, FuseBwdArgs)); break;
@@ -1256,9 +1439,20 @@ static int bn_run_calls(const std::vector<std::vector<BnLaunch>>& plans, int dty
     return LH_OK;
 }
 
+// the pending finalizes of a descriptor that the planned kernel does not run itself: launched first (one multi-problem launch)
+static int run_pending_finalizes(const std::vector<lh_bn_finalize_call>& fins, void* stream) {
+    return fins.empty() ? LH_OK : lh_bn_finalize_multi(fins.data(), (int)fins.size(), stream);
+}
+
 extern "C" int lh_fuse_fwd(const lh_fuse_desc* d, void* out, int n, int h, int w, int c, int dtype, void* stream) {
     BnLaunch r;
-    const int rc = plan_fuse_fwd(d, out, n, h, w, c, dtype, &r.ff, &r.kind, &r.grid);
+    int pre = 0;
+    int rc = plan_fuse_fwd(d, out, n, h, w, c, dtype, &r.ff, &r.kind, &r.grid, &pre);
+    if (rc) return rc;
+    std::vector<lh_bn_finalize_call> fins;
+    for (int t = 0; t < d->nterms; ++t)
+        if ((pre >> t) & 1) fins.push_back(*d->fin[t]);
+    rc = run_pending_finalizes(fins, stream);
     if (rc) return rc;
     const BnLaunch* L[1] = {&r};
     return bn_run(L, 1, dtype, (hipStream_t)stream);
@@ -1267,11 +1461,26 @@ extern "C" int lh_fuse_fwd(const lh_fuse_desc* d, void* out, int n, int h, int w
 extern "C" int lh_fuse_fwd_multi(const lh_fuse_fwd_call* calls, int n, int dtype, void* stream) {
     LH_REQUIRE(calls && n >= 1, "lh_fuse_fwd_multi: bad arguments");
     std::vector<std::vector<BnLaunch>> plans(n, std::vector<BnLaunch>(1));
-    for (int i = 0; i < n; ++i) {
-        BnLaunch& r = plans[i][0];
-        const int rc = plan_fuse_fwd(calls[i].d, calls[i].out, calls[i].n, calls[i].h, calls[i].w, calls[i].c, dtype, &r.ff, &r.kind, &r.grid);
-        if (rc) return rc;
+    std::vector<lh_bn_finalize_call> fins;
+    // the calls merge into one launch only when they plan the SAME kernel: the in-launch finalize is used when every call
+    // takes it, else none does (their finalizes then run first, as one multi-problem launch)
+    for (int pass = 0; pass < 2; ++pass) {
+        fins.clear();
+        bool same = true;
+        for (int i = 0; i < n; ++i) {
+            BnLaunch& r = plans[i][0];
+            int pre = 0;
+            const int rc = plan_fuse_fwd(calls[i].d, calls[i].out, calls[i].n, calls[i].h, calls[i].w, calls[i].c, dtype, &r.ff, &r.kind, &r.grid,
+                                         &pre, pass == 0);
+            if (rc) return rc;
+            for (int t = 0; t < calls[i].d->nterms; ++t)
+                if ((pre >> t) & 1) fins.push_back(*calls[i].d->fin[t]);
+            same = same && r.kind == plans[0][0].kind;
+        }
+        if (same || pass == 1) break;
     }
+    const int rc = run_pending_finalizes(fins, stream);
+    if (rc) return rc;
     return bn_run_calls(plans, dtype, (hipStream_t)stream);
 }
 

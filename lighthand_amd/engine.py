@@ -1682,11 +1682,15 @@ class Plan:
             P = self.params
             if self.training:
                 assert a.stats is not None, f"BN {bn} input has no statistics slab"
-                self.fwd.append(_Call(self.lib.lh_bn_finalize, (
+                # the finalize (batch statistics -> scale / shift / saved mean, invstd / running statistics) travels WITH the
+                # elementwise call (lh_fuse_desc.fin): small tensors run both as one launch, the others launch it first
+                fin = _lib.BnFinalizeCall(
                     a.stats.data_ptr(), a.stats_rows, a.pixels, c, P[bn + ".weight"].data_ptr(), P[bn + ".bias"].data_ptr(),
                     P[bn + ".running_mean"].data_ptr(), P[bn + ".running_var"].data_ptr(),
                     _ptr(P.get(bn + ".num_batches_tracked")), BN_MOMENTUM, BN_EPS,
-                    st["scale"].data_ptr(), st["shift"].data_ptr(), st["mean"].data_ptr(), st["invstd"].data_ptr()), bn + " finalize"))
+                    st["scale"].data_ptr(), st["shift"].data_ptr(), st["mean"].data_ptr(), st["invstd"].data_ptr())
+                self.keep.append(fin)
+                fd.fin[i] = C.pointer(fin)
             else:
                 self.fwd.append(_Call(self.lib.lh_bn_eval_affine, (
                     P[bn + ".weight"].data_ptr(), P[bn + ".bias"].data_ptr(), P[bn + ".running_mean"].data_ptr(),
