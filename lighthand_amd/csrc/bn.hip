@@ -544,28 +544,41 @@ __device__ __forceinline__ void fuse_fwd_slice_body(const FuseArgs& p, const int
         const long cc = f.c;
         const float* col = slab + cbase + ch;
         if (t) __syncthreads();                       // the previous term's partial sums have been consumed
-        for (int rl = part; rl < 16; rl += NP) {
-            double a = 0.0, b = 0.0;
-            int r = rl;
-            for (; r + 112 < f.rows; r += 128) {
-                float av[8], bv[8];
+        // <= 128 rows (the planner's rule): a row lane holds at most eight rows.  ALL rows of the thread's row lanes are
+        // requested before the first sum (one memory round trip instead of one per lane), then summed in that order.
+        constexpr int MAXL = 8;                       // row lanes per thread at most (SW = 32: 256 / 32 = 8 parts -> 2 lanes; SW = 64: 4)
+        float av[MAXL / 2][8], bv[MAXL / 2][8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { av[u] = col[((long)(r + 16 * u) * 2) * cc]; bv[u] = col[((long)(r + 16 * u) * 2 + 1) * cc]; }
-                a += (((double)av[0] + (double)av[1]) + ((double)av[2] + (double)av[3])) + (((double)av[4] + (double)av[5]) + ((double)av[6] + (double)av[7]));
-                b += (((double)bv[0] + (double)bv[1]) + ((double)bv[2] + (double)bv[3])) + (((double)bv[4] + (double)bv[5]) + ((double)bv[6] + (double)bv[7]));
+        for (int k = 0; k < MAXL / 2; ++k) {
+            const int rl = part + k * NP;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int r = rl + 16 * u;
+                // every lane issues every load (rows past the slab re-read row 0; they are never summed): a load under a
+                // runtime condition would be branched around and waited for one at a time
+                const long rr = (rl < 16 && r < f.rows) ? r : 0;
+                av[k][u] = col[(rr * 2) * cc];
+                bv[k][u] = col[(rr * 2 + 1) * cc];
             }
-            for (; r + 48 < f.rows; r += 64) {
-                const float a0 = col[((long)r * 2) * cc], b0 = col[((long)r * 2 + 1) * cc];
-                const float a1 = col[((long)(r + 16) * 2) * cc], b1 = col[((long)(r + 16) * 2 + 1) * cc];
-                const float a2 = col[((long)(r + 32) * 2) * cc], b2 = col[((long)(r + 32) * 2 + 1) * cc];
-                const float a3 = col[((long)(r + 48) * 2) * cc], b3 = col[((long)(r + 48) * 2 + 1) * cc];
-                a += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
-                b += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
+        }
+#pragma unroll
+        for (int k = 0; k < MAXL / 2; ++k) {
+            const int rl = part + k * NP;
+            if (rl >= 16) continue;
+            double a = 0.0, b = 0.0;
+            int u0 = 0;
+            if (rl + 112 < f.rows) {
+                a += (((double)av[k][0] + (double)av[k][1]) + ((double)av[k][2] + (double)av[k][3])) + (((double)av[k][4] + (double)av[k][5]) + ((double)av[k][6] + (double)av[k][7]));
+                b += (((double)bv[k][0] + (double)bv[k][1]) + ((double)bv[k][2] + (double)bv[k][3])) + (((double)bv[k][4] + (double)bv[k][5]) + ((double)bv[k][6] + (double)bv[k][7]));
+                u0 = 8;
+            } else if (rl + 48 < f.rows) {
+                a += ((double)av[k][0] + (double)av[k][1]) + ((double)av[k][2] + (double)av[k][3]);
+                b += ((double)bv[k][0] + (double)bv[k][1]) + ((double)bv[k][2] + (double)bv[k][3]);
+                u0 = 4;
             }
-            for (; r < f.rows; r += 16) {
-                a += (double)col[((long)r * 2) * cc];
-                b += (double)col[((long)r * 2 + 1) * cc];
-            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (u >= u0 && rl + 16 * u < f.rows) { a += (double)av[k][u]; b += (double)bv[k][u]; }
             red[0][rl][ch] = a;
             red[1][rl][ch] = b;
         }
@@ -702,15 +715,17 @@ static int plan_fuse_fwd(const lh_fuse_desc* d, void* out, int n, int h, int w, 
         fin_mask |= 1 << t;
         rows_max = f->rows > rows_max ? f->rows : rows_max;
     }
-    // small tensors: finalize + apply as ONE launch (fuse_fwd_slice_body) -- < 256 slab rows (the 16-lane fold of the finalize
-    // kernel, whose arithmetic the slice kernel reproduces; a workgroup folds rows x 2 x 64 floats), <= 48 MB per tensor, channel
+    // small tensors: finalize + apply as ONE launch (fuse_fwd_slice_body) -- <= 128 slab rows (the 16-lane fold of the finalize
+    // kernel, whose arithmetic the slice kernel reproduces with all its rows in flight at once; a workgroup folds rows x 2 x 64 floats), <= 48 MB per tensor, channel
     // slices of 64 (or the whole 32-channel row)
-    static const bool slice_on = !(getenv("LH_BN_SLICE") && atoi(getenv("LH_BN_SLICE")) == 0);
+    // MEASURED SLOWER (round 4: R50 step 9.67-9.69 ms with it vs 9.59 without, HRNet unchanged): the fold every workgroup
+    // repeats (rows x 512 bytes + two barriers) costs more than the 5.4 us finalize launch it removes.  Off unless LH_BN_SLICE=1.
+    static const bool slice_on = getenv("LH_BN_SLICE") && atoi(getenv("LH_BN_SLICE")) != 0;
     const int sw = c % 64 == 0 ? 64 : (c == 32 ? 32 : 0);
-    if (flat && fin_mask && allow_slice && slice_on && sw && rows_max < LH_FOLD_WIDE_ROWS && total * 16 <= (48L << 20)) {
+    if (flat && fin_mask && allow_slice && slice_on && sw && rows_max <= 128 && total * 16 <= (48L << 20)) {
         const long P = (long)n * h * w;
         const int pl = 256 / (sw / (16 / es));
-        long ppg = 8L * rows_max > 256 ? 8L * rows_max : 256;
+        long ppg = 4L * rows_max > 128 ? 4L * rows_max : 128;       // payload of a workgroup >= 2 x the statistics it folds
         ppg = (ppg + pl - 1) / pl * pl;
         const long G = (P + ppg - 1) / ppg;
         a.has_fin = fin_mask; a.slice_ppg = (int)ppg; a.slice_w = sw;

@@ -414,8 +414,9 @@ class Plan:
                         cls._tune_measured.add(kv[0])
         # the shipped database: choices measured on MI355X for the benchmark configurations (tools/make_tune_db.sh);
         # entries are validated against the compiled-in configurations when used, anything else is measured on the fly
-        db = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tune_db_gfx950.txt")
-        if os.path.isfile(db) and os.environ.get("LH_TUNE_DB", "1") != "0":
+        sw = os.environ.get("LH_TUNE_DB", "1")                 # 0 = ignore the database, a path = use that file instead (experiments)
+        db = sw if sw not in ("0", "1") else os.path.join(os.path.dirname(os.path.abspath(__file__)), "tune_db_gfx950.txt")
+        if os.path.isfile(db) and sw != "0":
             for line in open(db):
                 kv = cls._parse_tune_line(line) if line.strip() and not line.startswith("#") else None
                 if kv is not None:
