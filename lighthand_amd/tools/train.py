@@ -222,8 +222,11 @@ def main(args, train_set=None, val_set=None):
     val_kind, val_hw = _sample_kind(val_set)
     train_set = _WithAugFlag(train_set, args.ratio_of_aug)
     workers = args.num_workers if not isinstance(train_set.base, SyntheticHands) else 0
-    train_loader = torch.utils.data.DataLoader(train_set, batch_size=args.batch_size, shuffle=True, drop_last=True, pin_memory=True, num_workers=workers)
-    val_loader = torch.utils.data.DataLoader(val_set, batch_size=args.batch_size, shuffle=False, drop_last=True, pin_memory=True, num_workers=workers)
+    # persistent workers: a worker is forked from THIS process, which by the first epoch holds a HIP context and hundreds of
+    # GB of mappings (~20 s per fork measured on the GPU box) -- fork them once per loader, not once per epoch
+    kw = dict(batch_size=args.batch_size, drop_last=True, pin_memory=True, num_workers=workers, persistent_workers=workers > 0)
+    train_loader = torch.utils.data.DataLoader(train_set, shuffle=True, **kw)
+    val_loader = torch.utils.data.DataLoader(val_set, shuffle=False, **kw)
 
     model = build_model(args).cuda().set_precision(args.precision)
     best_loss, epo, count, opt_state = np.inf, 0, 0, None

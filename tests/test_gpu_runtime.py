@@ -211,17 +211,18 @@ def test_train_entry_point_takes_datasets(tmp_path, capsys, monkeypatch):
             return self.x[i], self.j[i]
 
     common = ["--root_path", str(tmp_path), "--batch_size", "8", "--epoch", "2", "--depth", "18", "--size", "64", "--precision", "bf16", "--reset"]
-    # one loader worker instead of the reference's eight (src/utils/pre_argparser.py): every epoch forks the workers of both
-    # loaders from a process that holds a HIP context -- 64 forks took 170 of this suite's 420 s
+    # loaders without worker processes (the reference uses eight, src/utils/pre_argparser.py): every epoch forks the workers of
+    # both loaders from a process that holds a HIP context and hundreds of GB of mappings -- ~20 s per fork, 180 of this
+    # suite's 435 s with even one worker per loader
     args0 = T.parse_args(common + ["--name", "ref"])
-    args0.num_workers = 1
+    args0.num_workers = 0
     best = T.main(args0, train_set=RefLayout(32, 1), val_set=RefLayout(8, 2))
     assert np.isfinite(best) and "valid loss" in capsys.readouterr().out
     seen = []
     real = runtime.sample_color_jitter
     monkeypatch.setattr(runtime, "sample_color_jitter", lambda n, *a, mask=None, **k: (seen.append(mask.clone()), real(n, *a, mask=mask, **k))[1])
     args = T.parse_args(common + ["--name", "raw", "--ratio_of_aug", "0.25"])
-    args.num_workers = 1
+    args.num_workers = 0
     best = T.main(args, train_set=RawFrames(32, 3), val_set=RawFrames(8, 4))
     assert np.isfinite(best)
     assert len(seen) == 2 * 4 and all(m.dtype == torch.bool and m.numel() == 8 for m in seen)

@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/refresh
 rm -rf $O && mkdir -p $O
 export LH_TUNE_CACHE=$PWD/$O/tune_cache.txt
-R=${LH_ROUND:-r03}
+R=${LH_ROUND:-r04}
 timeout -k 10 900 python bench.py > $O/bench.json 2> $O/bench.err
 tail -c 600 $O/bench.json
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o $R -- python3 bench.py --no-cpu-baseline --no-extra > $O/stats.log 2>&1
@@ -18,9 +18,9 @@ timeout -k 10 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv 
 timeout -k 10 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-extra > $O/pmc_write.log 2>&1
 timeout -k 10 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --output-format csv -d $O/pmc_mfma -o m -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-extra > $O/pmc_mfma.log 2>&1
 timeout -k 10 300 python tools/layer_profile.py > $O/layers.txt 2>&1
-echo "[refresh] C4 share: HRNet-W32 bs32"
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_hrnet -o h -- python3 bench.py --hrnet-width 32 --batch 32 --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-extra > $O/stats_hrnet.log 2>&1
-timeout -k 10 300 python tools/layer_profile.py --hrnet-width 32 --batch 32 > $O/layers_hrnet.txt 2>&1
+echo "[refresh] C4 share: HRNet-W32 bs32, fp16 + static loss scale (the timed dtype since round 4)"
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_hrnet -o h -- python3 bench.py --hrnet-width 32 --batch 32 --precision fp16 --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-extra > $O/stats_hrnet.log 2>&1
+timeout -k 10 300 python tools/layer_profile.py --hrnet-width 32 --batch 32 --precision fp16 > $O/layers_hrnet.txt 2>&1
 echo "[refresh] C5: R50 384x384 bs256 fp16 inference"
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c5 -o c -- python3 bench.py --infer-only --size 384 --batch 256 --precision fp16 --steps 10 --warmup 3 > $O/stats_c5.log 2>&1
 timeout -k 10 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_c5 -o f -- python3 bench.py --infer-only --size 384 --batch 256 --precision fp16 --steps 2 --warmup 1 > $O/pmc_fetch_c5.log 2>&1
