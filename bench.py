@@ -33,7 +33,7 @@ WORK = {
     ("hrnet32", 256): (20.388, 61.107, 107.2, 321.5),
     ("hrnet48", 256): (41.846, 125.483, 142.9, 428.7),
 }
-PMC_FILE = "r03_pmc_traffic.json"      # per-kernel HBM bytes from the committed rocprofv3 --pmc passes (tools/pmc_traffic.py)
+PMC_FILE = "r04_pmc_traffic.json"      # per-kernel HBM bytes from the committed rocprofv3 --pmc passes (tools/pmc_traffic.py)
 TRAIN_GFLOP_PER_IMG = 43.128
 FWD_GFLOP_PER_IMG = 14.479
 PEAK_BF16_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA
@@ -410,7 +410,7 @@ def main():
                     out["roofline"]["traffic"] = pmc[name]["read_bytes_per_launch"] + pmc[name]["write_bytes_per_launch"]
                     out["roofline"]["traffic_source"] = "committed profile (profiles/%s), not measured in this run" % PMC_FILE
                     out["roofline"]["traffic_note"] = ("bytes per launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, corrected per the "
-                                                       "MI355X guide), profiles/r03_pmc_hbm_traffic.txt")
+                                                       "MI355X guide), profiles/r04_pmc_hbm_traffic.txt")
             except (OSError, ValueError, KeyError):
                 pass
             out["roofline"].update({"kernel": name, "launches_per_train_step": agg[name]["launches"], "avg_launch_ms": round(avg_ms, 4),
@@ -419,7 +419,7 @@ def main():
                                     "event_pair_overhead_us": round(agg[name]["gap_ms"] / max(agg[name]["launches"], 1) * 1e3, 2),
                                     "note": "average over every launch of this kernel in the process (train-step and inference-graph launches, "
                                             "weighted by how often each ran), HIP events on the launch stream minus half the measured empty-pair "
-                                            "time: comparable with the AverageNs of rocprofv3 --kernel-trace --stats (profiles/r03_bench_kernel_stats.csv)"})
+                                            "time: comparable with the AverageNs of rocprofv3 --kernel-trace --stats (profiles/r04_bench_kernel_stats.csv)"})
             # the largest FAMILY of the step: the BatchNorm / ReLU backward (reduce + coefficient fold + apply kernels per call)
             fam = agg.get("fuse_bwd(all kernels)")
             if fam and fam["ms"] > 0:
