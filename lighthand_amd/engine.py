@@ -488,7 +488,8 @@ class Plan:
         library's static default."""
         if os.environ.get("LH_AUTOTUNE", "1") == "0":
             return
-        if self._forced is not None and role in self._forced and len(descs) == 1:     # member of a batch group: the group's choice
+        if (self._forced is not None and role in self._forced and len(descs) == 1
+                and self._forced["member"] not in self._forced.get("solo", ())):          # member of a batch group: the group's choice
             for d in descs:
                 d.cfg[0], d.cfg[1], d.cfg[2], d.cfg[3] = self._forced[role]
             return
@@ -869,6 +870,9 @@ class Plan:
                 gid = self._n_groups
                 self._forced = self._tune_group([self.nodes[i][1] for i in item]) if self.nodes[item[0]][0] == "conv" else None
                 group_forced[item[0]] = self._forced
+            split = bool(self._forced and self._forced.get("lanes"))     # some members launch beside the merged rest, on lanes of their own
+            if split:
+                self.fwd.append(_Marker("fork"))
             for j, i in enumerate(item):
                 (kind, nd), lane = self.nodes[i], self.node_lanes[i]
                 if self._forced is not None:
@@ -876,14 +880,17 @@ class Plan:
                 blk = []
                 n0 = len(self.fwd)
                 getattr(self, "_c_" + kind)(nd, blk)
+                alone = self._forced is not None and j in self._forced.get("solo", ())
                 for k, c in enumerate(self.fwd[n0:]):
-                    c.slane = lane
-                    if gid is not None and isinstance(c, _Call):
+                    c.slane = self._forced["lanes"].get(j, lane) if split else lane
+                    if gid is not None and isinstance(c, _Call) and not alone:
                         c.mtag = (gid, "f", j, k)
                 out_act = nd.get("y", nd.get("out")) if isinstance(nd, dict) else nd
                 if out_act is not None:
                     self._ready[id(out_act)] = len(self.fwd)      # list position from which this activation is complete
                 bwd_blocks[i] = blk
+            if split:
+                self.fwd.append(_Marker("join"))
             self._forced = None
         # backward list: node blocks in reverse order; accumulate flags resolved in that order
         if self._pack_items:       # every weight pack of the model is rebuilt by ONE launch
@@ -945,6 +952,9 @@ class Plan:
                 flush_lanes = []
                 self._emit_group = len(item)
                 self._forced = group_forced.get(item[0])          # the data gradients are tuned while the blocks are emitted
+                split = bool(self._forced and self._forced.get("lanes"))
+                if split:
+                    self.bwd.append(_Marker("fork"))
                 for j, i in enumerate(item):
                     (kind, nd), blk, lane = self.nodes[i], bwd_blocks[i], self.node_lanes[i]
                     self._cur_lane = lane
@@ -957,9 +967,10 @@ class Plan:
                     w0 = len(self._pending()["calls"]) if self.wgrad_group > 0 else 0
                     for emit in blk:
                         emit()
+                    alone = self._forced is not None and j in self._forced.get("solo", ())
                     for k, c in enumerate(self.bwd[n0:]):
-                        c.slane = lane
-                        if gid is not None and isinstance(c, _Call):
+                        c.slane = self._forced["lanes"].get(j, lane) if split else lane
+                        if gid is not None and isinstance(c, _Call) and not alone:
                             c.mtag = (gid, "b", j, k)
                     if gid is not None and self.wgrad_group > 0:
                         for k, c in enumerate(self._pending()["calls"][w0:]):
@@ -984,6 +995,8 @@ class Plan:
                                 names += [bn + ".weight", bn + ".bias"]
                     if names:
                         self.bwd_marks.append((len(self.bwd), names))
+                if split:
+                    self.bwd.append(_Marker("join"))
                 self._forced = None
                 for lane in dict.fromkeys(flush_lanes):
                     self._cur_lane = lane
@@ -1115,11 +1128,31 @@ class Plan:
         descs = [self._conv_descs(nd) for nd in nds]
         forced = {"member": 0}
         es = self.es
+        # Experiment (LH_SOLO_DIRECT=1; round 4): members the direct 3x3 kernel takes (C_in = 32 / 64 per tap: HRNet's two
+        # high-resolution branches) leave the merged launch and run on their own, each on a stream lane of its own BESIDE the
+        # merged launch of the remaining members.  MEASURED SLOWER: HRNet-W32 bs 32 15.2-15.3 ms vs 13.1 ms -- the fork / join of
+        # the lanes at every layer position (224 more launches and as many cross-stream edges in the graph) costs about 10 us
+        # per position, more than the shorter kernels save.  Off by default.
+        solo = []
+        if os.environ.get("LH_SOLO_DIRECT", "0") == "1" and len(nds) >= 2:
+            for j, (df, dg) in enumerate(descs):
+                buf = (C.c_int * (5 * 64))()
+                n = self.lib.lh_igemm_candidates(C.byref(df), self.dt, buf, 64)
+                if any(buf[5 * i + 2] == 100 for i in range(n)) and dg is not None:
+                    solo.append(j)
+            if len(solo) > 3:
+                solo = []
+        lanes, rest = {}, [j for j in range(len(nds)) if j not in solo]
+        for k, j in enumerate(solo):
+            lanes[j] = k + 1 if rest else k            # without a remainder the first direct member stays on the main lane
+        if solo and len(rest) == 1:
+            solo = solo + rest                         # a lone remaining member is tuned (and launched) on its own too
+        forced["solo"], forced["lanes"] = tuple(solo), lanes
         for role, idx in (("fwd", 0), ("dgrad", 1)):
-            ds = [d[idx] for d in descs]
+            ds = [d[idx] for j, d in enumerate(descs) if j not in solo]
             if any(d is None for d in ds):
                 continue
-            with_stats = role == "fwd" and self.training and all(id(nd["y"]) in self._bn_inputs for nd in nds)
+            with_stats = role == "fwd" and self.training and all(id(nd["y"]) in self._bn_inputs for j, nd in enumerate(nds) if j not in solo)
             key = ("g", role, self.dt, with_stats) + tuple(self._desc_key(d) for d in ds)
             common = None
             for d in ds:
