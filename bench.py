@@ -451,14 +451,6 @@ def main():
             extra["r50_infer_256_bs64_two_in_flight"] = {"images_per_s": round(args.batch * 2 * args.steps / (time.perf_counter() - t2), 1),
                                                          "in_flight": 2, "dtype": args.precision}
             del pipe
-            # ONE batch as two half-batches in flight inside one graph (runtime.InferSplitStep): eval-mode samples are independent,
-            # results identical to InferStep's; the latency form of the pipeline above
-            from lighthand_amd.runtime import InferSplitStep
-            sp = InferSplitStep(model, args.batch, args.size, args.size, parts=2)
-            dts = timed_replays(lambda: sp(images), 5, args.steps)
-            extra["r50_infer_256_bs64_split2"] = {"images_per_s": round(args.batch / dts, 1), "ms_per_batch": round(dts * 1e3, 3), "parts": 2,
-                                                  "dtype": args.precision}
-            del sp
             # configs[3], one GPU's share.  Timed dtype: fp16 with the static loss scale (TrainStep default 1024) -- BASELINE.json
             # names no dtype for this configuration, and HRNet's heat-maps are 8x closer to the fp32 oracle in fp16 than in
             # bf16 at the same speed (tests/test_gpu_runtime.py::test_c4_...); bf16 is reported beside it

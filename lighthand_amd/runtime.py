@@ -307,68 +307,6 @@ class InferStep:
         return self.preds
 
 
-class InferSplitStep:
-    """ONE batch as ``parts`` independent sub-batches in flight inside one captured graph (a stream and an InferStep per
-    part): the latency form of ``InferPipeline``.  In eval mode every sample is independent (BatchNorm uses the running
-    statistics, folded into the convolutions), so the results are those of ``InferStep`` bit for bit; the stage 3-4 launches
-    of a 64-image batch are single waves of tiles whose latencies the other half's launches fill (R50, 256x256, bs 64, bf16:
-    see DESIGN.md section 5).  Same call surface as ``InferStep``: ``step(images) -> preds``, ``.preds``, ``.maxvals``."""
-
-    def __init__(self, model, batch, height, width, parts=2, input_u8=None):
-        if parts < 1 or batch % parts:
-            raise ValueError(f"batch {batch} does not split into {parts} equal parts")
-        self.parts, self.sub = parts, batch // parts
-        self.steps = [InferStep(model, self.sub, height, width, bn_train=False, use_graph=False, input_u8=input_u8, slot=100 + i)
-                      for i in range(parts)]
-        ref = self.steps[0]
-        dev = ref.preds.device
-        self.preds = torch.zeros(batch, ref.preds.shape[1], 2, dtype=torch.float32, device=dev)
-        self.maxvals = torch.zeros(batch, ref.preds.shape[1], 1, dtype=torch.float32, device=dev)
-        for i, st in enumerate(self.steps):                      # every part decodes straight into its slice of the batch's outputs
-            st.preds = self.preds[i * self.sub:(i + 1) * self.sub]
-            st.maxvals = self.maxvals[i * self.sub:(i + 1) * self.sub]
-        self.streams = [torch.cuda.Stream() for _ in range(parts)]
-        self.graph = None
-
-    @property
-    def heatmaps(self):
-        return torch.cat([st.heatmaps for st in self.steps], 0)
-
-    def refresh_weights(self):
-        for st in self.steps:
-            st.refresh_weights()
-
-    def _enqueue(self):
-        main = torch.cuda.current_stream()
-        ev = main.record_event()
-        for st, s in zip(self.steps, self.streams):
-            s.wait_event(ev)
-            with torch.cuda.stream(s):
-                st._enqueue()
-        for s in self.streams:
-            main.wait_stream(s)
-
-    def __call__(self, images=None):
-        if images is not None:
-            for i, st in enumerate(self.steps):
-                st.images.copy_(images[i * self.sub:(i + 1) * self.sub], non_blocking=True)
-        for st in self.steps:
-            if not st._packed:
-                st.refresh_weights()
-        if self.graph is None:
-            warm = torch.cuda.Stream()
-            warm.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(warm):
-                self._enqueue()
-            torch.cuda.current_stream().wait_stream(warm)
-            torch.cuda.synchronize()
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self._enqueue()
-        self.graph.replay()
-        return self.preds
-
-
 class InferPipeline:
     """``depth`` batches in flight: one InferStep (own activation buffers, weight packs and captured graph) per slot, each on
     a stream of its own.  The stage 3-4 launches of one batch are latency-bound chains of one wave of tiles; a second batch

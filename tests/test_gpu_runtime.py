@@ -956,26 +956,3 @@ def test_bench_gpus_2_starts_two_ranks():
                         "--batch", "4", "--size", "128", "--no-cpu-baseline", "--no-roofline", "--no-extra"],
                        env=env1, capture_output=True, text=True, timeout=600)
     assert r.returncode != 0
-
-
-def test_infer_split_step_equals_infer_step():
-    """runtime.InferSplitStep (one batch as two or four sub-batches in flight inside one captured graph): key points and
-    confidences equal InferStep's bit for bit (eval-mode samples are independent), on replays too, with float and uint8 input."""
-    from lighthand_amd.modeling.simplebaseline.pose_resnet import get_pose_net
-    from lighthand_amd.runtime import InferSplitStep, InferStep
-    torch.manual_seed(5)
-    model = get_pose_net(resnet_cfg(18), True).cuda().set_precision("bf16").eval()
-    b, h, w = 8, 128, 96
-    ref = InferStep(model, b, h, w)
-    for parts in (2, 4):
-        sp = InferSplitStep(model, b, h, w, parts=parts)
-        for seed in (1, 2, 3):
-            x = torch.randn(b, 3, h, w, device="cuda", generator=torch.Generator(device="cuda").manual_seed(seed))
-            want_p, want_m = ref(x).clone(), ref.maxvals.clone()
-            got_p = sp(x)
-            torch.cuda.synchronize()
-            assert torch.equal(got_p, want_p) and torch.equal(sp.maxvals, want_m), (parts, seed)
-        assert torch.equal(sp.heatmaps, ref.heatmaps)
-    frames = torch.randint(0, 256, (b, 100, 80, 3), dtype=torch.uint8, device="cuda")
-    ref8, sp8 = InferStep(model, b, h, w, input_u8=(100, 80)), InferSplitStep(model, b, h, w, parts=2, input_u8=(100, 80))
-    assert torch.equal(sp8(frames), ref8(frames))
