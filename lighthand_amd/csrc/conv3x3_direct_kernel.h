@@ -24,9 +24,10 @@
 #include "igemm_wave_epilogue.h"
 #include <stdlib.h>
 
+// The kernel proper for workgroup `b` of its launch (plain launch: the block index; the mixed multi-problem launch of
+// igemm_mixed_kernel.h: the index inside the problem the workgroup belongs to).  512 threads.
 template <typename T, int C, bool STATS>
-__global__ __launch_bounds__(512, 2) void conv3x3_direct_kernel(const IgemmArgs p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void conv3x3_direct_body(const IgemmArgs& p, unsigned char* smem, const int b) {
     constexpr int ES = sizeof(T);
     static_assert(ES == 2 && (C == 32 || C == 64), "16-bit element types, 32 or 64 input channels per tap");
     constexpr int BM = 64, TH = 16, TW = 16, PH = TH + 2, PW = TW + 2;
@@ -51,7 +52,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_direct_kernel(const IgemmArgs 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4, pl = lane & 15;
     const int CB = p.pw_cb, G = p.pw_g;
-    const int b = blockIdx.x;
     const int cblk = (b >> 3) % CB;
     const int g = (b & 7) + 8 * ((b >> 3) / CB);
     // swizzle: slot s of row r holds chunk s ^ f(r); f repeats every 16 rows and makes 16 consecutive rows x one chunk hit
@@ -209,6 +209,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_direct_kernel(const IgemmArgs 
         __syncthreads();
         wave_stats_row<BM, NWAVE>(s1, s2, reinterpret_cast<float*>(smem), p.stats ? p.stats + (long)g * 2 * p.cout : nullptr, cblk, p.cout, tid);
     }
+}
+
+template <typename T, int C, bool STATS>
+__global__ __launch_bounds__(512, 2) void conv3x3_direct_kernel(const IgemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    conv3x3_direct_body<T, C, STATS>(p, smem, blockIdx.x);
 }
 
 static inline int lh_d3_lds_bytes(int c) {

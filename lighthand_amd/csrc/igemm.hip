@@ -412,9 +412,15 @@ static int igemm_impl(const lh_igemm_desc* d, const void* in, const void* wpack,
         a.head_j = head->n_out; a.head_wstride = (int)head->w_row_bytes;
     }
     if (prep_args) {            // lh_igemm_multi: hand the argument block back instead of launching
-        LH_REQUIRE(ring && rc_.depth >= 2 && rc_.depth < LH_WIDE_DEPTH, "lh_igemm_multi: problem does not run on the LDS-DMA ring kernel (its cfg must name a tiled configuration)");
-        lh_tap_grid(d, &a.tw, &a.dh0, &a.dhs, &a.dw0, &a.dws);
-        a.kspt = (d->k_run * es + rc_.kb - 1) / rc_.kb;
+        LH_REQUIRE(ring && ((rc_.depth >= 2 && rc_.depth < LH_WIDE_DEPTH) || rc_.depth == 100),
+                   "lh_igemm_multi: problem does not run on the LDS-DMA ring kernel or the direct 3x3 kernel (its cfg must name a tiled or the direct configuration)");
+        if (rc_.depth == 100) {                     // direct 3x3 member of a mixed launch (igemm_mixed_kernel.h): its persistent grid
+            a.pw_cb = (d->cout + 63) / 64;
+            a.pw_g = lh_d3_rows(d);
+        } else {
+            lh_tap_grid(d, &a.tw, &a.dh0, &a.dhs, &a.dw0, &a.dws);
+            a.kspt = (d->k_run * es + rc_.kb - 1) / rc_.kb;
+        }
         *prep_args = a;
         *prep_cfg = rc_;
         return LH_OK;
@@ -458,30 +464,65 @@ extern "C" int lh_igemm_multi(const lh_igemm_call* calls, int n, int dtype, void
         const int cnt = n - i0 < LH_MULTI_MAX ? n - i0 : LH_MULTI_MAX;
         LhMulti<IgemmArgs> m;
         IgemmArgs tmp[LH_MULTI_MAX];
-        RingCfg cfg0 = {0, 0, 0, 0};
+        RingCfg cfgs[LH_MULTI_MAX];
+        RingCfg cfg0 = {0, 0, 0, 0};                 // the tiled configuration of the call (its ring members share it)
+        int ndirect = 0;
         m.n = cnt; m.first[0] = 0;
         for (int i = 0; i < cnt; ++i) {
             const lh_igemm_call& q = calls[i0 + i];
-            RingCfg c;
             const int rc = igemm_impl(q.d, q.in, q.wpack, q.out, q.addend, q.addend_mask, q.bias, q.scale, q.shift, q.stats, dtype, stream,
-                                      nullptr, nullptr, &tmp[i], &c);
+                                      nullptr, nullptr, &tmp[i], &cfgs[i]);
             if (rc) return rc;
-            if (i == 0) cfg0 = c;
+            const RingCfg& c = cfgs[i];
+            if (c.depth == 100) { ++ndirect; continue; }
+            if (cfg0.bm == 0) cfg0 = c;
             LH_REQUIRE(c.bm == cfg0.bm && c.bp == cfg0.bp && c.depth == cfg0.depth && c.kb == cfg0.kb,
-                       "lh_igemm_multi: problem %d runs tile %dx%d depth %d kb %d, problem 0 %dx%d depth %d kb %d -- one configuration per call",
+                       "lh_igemm_multi: problem %d runs tile %dx%d depth %d kb %d, another %dx%d depth %d kb %d -- one tiled configuration per call",
                        i0 + i, c.bm, c.bp, c.depth, c.kb, cfg0.bm, cfg0.bp, cfg0.depth, cfg0.kb);
         }
         // longest K loop first: workgroups are dispatched in grid order, so the problem whose tiles take longest must not
-        // be the one that starts last (the launch ends with its last tile)
+        // be the one that starts last (the launch ends with its last tile); the direct members' workgroups (a few tiles each,
+        // no dependent stages) come last
         int order[LH_MULTI_MAX];
         for (int i = 0; i < cnt; ++i) order[i] = i;
-        std::stable_sort(order, order + cnt, [&](int x, int y) { return tmp[x].ntaps * tmp[x].kspt > tmp[y].ntaps * tmp[y].kspt; });
-        for (int i = 0; i < cnt; ++i) {
-            m.a[i] = tmp[order[i]];
-            m.first[i + 1] = m.first[i] + ceil_div(m.a[i].M, cfg0.bp) * ceil_div(m.a[i].cout, cfg0.bm);
+        std::stable_sort(order, order + cnt, [&](int x, int y) {
+            const int kx = cfgs[x].depth == 100 ? -1 : tmp[x].ntaps * tmp[x].kspt, ky = cfgs[y].depth == 100 ? -1 : tmp[y].ntaps * tmp[y].kspt;
+            return kx > ky;
+        });
+        if (ndirect == 0) {
+            for (int i = 0; i < cnt; ++i) {
+                m.a[i] = tmp[order[i]];
+                m.first[i + 1] = m.first[i] + ceil_div(m.a[i].M, cfg0.bp) * ceil_div(m.a[i].cout, cfg0.bm);
+            }
+            const int rc = cnt == 1 ? lh_igemm_ring_launch(m.a[0], cfg0, dtype, (hipStream_t)stream)
+                                    : lh_igemm_ring_multi_launch(m, cfg0, dtype, (hipStream_t)stream);
+            if (rc) return rc;
+            continue;
         }
-        const int rc = cnt == 1 ? lh_igemm_ring_launch(m.a[0], cfg0, dtype, (hipStream_t)stream)
-                                : lh_igemm_ring_multi_launch(m, cfg0, dtype, (hipStream_t)stream);
+        if (cnt == 1) {                              // a lone direct problem: its own kernel
+            const int rc = lh_igemm_ring_launch(tmp[0], cfgs[0], dtype, (hipStream_t)stream);
+            if (rc) return rc;
+            continue;
+        }
+        // mixed launch (igemm_mixed_kernel.h): direct 3x3 bodies beside the 64 x 128 ring tile
+        if (cfg0.bm == 0) cfg0 = RingCfg{64, 128, 2, 64};
+        LH_REQUIRE(cfg0.bm == 64 && cfg0.bp == 128, "lh_igemm_multi: direct 3x3 problems share a launch with the 64 x 128 tile only (got %dx%d)", cfg0.bm, cfg0.bp);
+        int kinds[LH_MULTI_MAX] = {0, 0, 0, 0};
+        bool stats = false, stats_all = true;
+        for (int i = 0; i < cnt; ++i) {
+            const int j = order[i];
+            m.a[i] = tmp[j];
+            if (cfgs[j].depth == 100) {
+                kinds[i] = cfgs[j].kb;
+                m.first[i + 1] = m.first[i] + m.a[i].pw_g * m.a[i].pw_cb;
+                stats = stats || m.a[i].stats != nullptr;
+                stats_all = stats_all && m.a[i].stats != nullptr;
+            } else {
+                m.first[i + 1] = m.first[i] + ceil_div(m.a[i].M, cfg0.bp) * ceil_div(m.a[i].cout, cfg0.bm);
+            }
+        }
+        LH_REQUIRE(!stats || stats_all, "lh_igemm_multi: the direct 3x3 problems of one call must all (or none) write BatchNorm statistics");
+        const int rc = lh_igemm_mixed_multi_launch(m, kinds, cfg0, dtype, stats, (hipStream_t)stream);
         if (rc) return rc;
     }
     return LH_OK;

@@ -1,0 +1,4 @@
+// bf16 instantiations of the mixed multi-problem convolution launch (see igemm_mixed_inst.h).
+#define LH_T bf16
+#define LH_FN lh_mixed_multi_launch_bf16
+#include "igemm_mixed_inst.h"

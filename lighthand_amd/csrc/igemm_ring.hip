@@ -20,6 +20,9 @@ int lh_ring_launch_f16_wide(const IgemmArgs& a, const RingCfg& c, hipStream_t s)
 int lh_ring_launch_f32(const IgemmArgs& a, const RingCfg& c, hipStream_t s);
 int lh_ring_multi_launch_bf16(const LhMulti<IgemmArgs>& m, const RingCfg& c, hipStream_t s);
 int lh_ring_multi_launch_f16(const LhMulti<IgemmArgs>& m, const RingCfg& c, hipStream_t s);
+struct MixedKinds { int k[LH_MULTI_MAX]; };
+int lh_mixed_multi_launch_bf16(const LhMulti<IgemmArgs>& m, const MixedKinds& kt, const RingCfg& c, bool stats, hipStream_t s);
+int lh_mixed_multi_launch_f16(const LhMulti<IgemmArgs>& m, const MixedKinds& kt, const RingCfg& c, bool stats, hipStream_t s);
 int lh_pw_launch_bf16(const IgemmArgs& a, const RingCfg& c, hipStream_t s);
 int lh_pw_launch_f16(const IgemmArgs& a, const RingCfg& c, hipStream_t s);
 int lh_d3_launch_bf16(const IgemmArgs& a, const RingCfg& c, hipStream_t s);
@@ -377,6 +380,27 @@ int lh_igemm_ring_multi_launch(LhMulti<IgemmArgs>& m, const RingCfg& c, int dtyp
     if (rc == 1) {
         lh_set_error("igemm_ring_multi: no multi-problem kernel for tile %dx%d depth %d kb %d dtype %d (4-wave tiles, 16-bit types)",
                      c.bm, c.bp, c.depth, c.kb, dtype);
+        return LH_ERR_UNSUPPORTED;
+    }
+    return rc;
+}
+
+// direct 3x3 bodies and ring-tile bodies in one grid (igemm_mixed_kernel.h); kinds[i] = channels per tap of a direct member, 0 = ring
+int lh_igemm_mixed_multi_launch(LhMulti<IgemmArgs>& m, const int* kinds, const RingCfg& c, int dtype, bool stats, hipStream_t s) {
+    const unsigned char* z = zero_page();
+    unsigned char* dp = dump_page();
+    if (!z || !dp) {
+        lh_set_error("igemm_mixed_multi: cannot resolve the zero page on this device");
+        return LH_ERR_HIP;
+    }
+    MixedKinds kt;
+    for (int i = 0; i < LH_MULTI_MAX; ++i) kt.k[i] = i < m.n ? kinds[i] : 0;
+    for (int i = 0; i < m.n; ++i) { m.a[i].zero = z; m.a[i].dump = dp; }
+    int rc = 1;
+    if (dtype == LH_BF16) rc = lh_mixed_multi_launch_bf16(m, kt, c, stats, s);
+    else if (dtype == LH_F16) rc = lh_mixed_multi_launch_f16(m, kt, c, stats, s);
+    if (rc == 1) {
+        lh_set_error("igemm_mixed_multi: no mixed kernel for ring depth %d kb %d dtype %d (64 x 128 tile, 16-bit types)", c.depth, c.kb, dtype);
         return LH_ERR_UNSUPPORTED;
     }
     return rc;

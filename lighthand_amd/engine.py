@@ -488,10 +488,12 @@ class Plan:
         library's static default."""
         if os.environ.get("LH_AUTOTUNE", "1") == "0":
             return
-        if (self._forced is not None and role in self._forced and len(descs) == 1
-                and self._forced["member"] not in self._forced.get("solo", ())):          # member of a batch group: the group's choice
+        if self._forced is not None and role in self._forced and len(descs) == 1:     # member of a batch group: the group's choice
+            choice = self._forced[role]
+            if isinstance(choice, list):              # mixed launch: a configuration per member (direct 3x3 | the shared tile)
+                choice = choice[self._forced["member"]]
             for d in descs:
-                d.cfg[0], d.cfg[1], d.cfg[2], d.cfg[3] = self._forced[role]
+                d.cfg[0], d.cfg[1], d.cfg[2], d.cfg[3] = choice
             return
         lead = max(descs, key=lambda d: d.ntaps)
         if lead.ntaps == 0:
@@ -870,9 +872,6 @@ class Plan:
                 gid = self._n_groups
                 self._forced = self._tune_group([self.nodes[i][1] for i in item]) if self.nodes[item[0]][0] == "conv" else None
                 group_forced[item[0]] = self._forced
-            split = bool(self._forced and self._forced.get("lanes"))     # some members launch beside the merged rest, on lanes of their own
-            if split:
-                self.fwd.append(_Marker("fork"))
             for j, i in enumerate(item):
                 (kind, nd), lane = self.nodes[i], self.node_lanes[i]
                 if self._forced is not None:
@@ -880,17 +879,14 @@ class Plan:
                 blk = []
                 n0 = len(self.fwd)
                 getattr(self, "_c_" + kind)(nd, blk)
-                alone = self._forced is not None and j in self._forced.get("solo", ())
                 for k, c in enumerate(self.fwd[n0:]):
-                    c.slane = self._forced["lanes"].get(j, lane) if split else lane
-                    if gid is not None and isinstance(c, _Call) and not alone:
+                    c.slane = lane
+                    if gid is not None and isinstance(c, _Call):
                         c.mtag = (gid, "f", j, k)
                 out_act = nd.get("y", nd.get("out")) if isinstance(nd, dict) else nd
                 if out_act is not None:
                     self._ready[id(out_act)] = len(self.fwd)      # list position from which this activation is complete
                 bwd_blocks[i] = blk
-            if split:
-                self.fwd.append(_Marker("join"))
             self._forced = None
         # backward list: node blocks in reverse order; accumulate flags resolved in that order
         if self._pack_items:       # every weight pack of the model is rebuilt by ONE launch
@@ -952,9 +948,6 @@ class Plan:
                 flush_lanes = []
                 self._emit_group = len(item)
                 self._forced = group_forced.get(item[0])          # the data gradients are tuned while the blocks are emitted
-                split = bool(self._forced and self._forced.get("lanes"))
-                if split:
-                    self.bwd.append(_Marker("fork"))
                 for j, i in enumerate(item):
                     (kind, nd), blk, lane = self.nodes[i], bwd_blocks[i], self.node_lanes[i]
                     self._cur_lane = lane
@@ -967,10 +960,9 @@ class Plan:
                     w0 = len(self._pending()["calls"]) if self.wgrad_group > 0 else 0
                     for emit in blk:
                         emit()
-                    alone = self._forced is not None and j in self._forced.get("solo", ())
                     for k, c in enumerate(self.bwd[n0:]):
-                        c.slane = self._forced["lanes"].get(j, lane) if split else lane
-                        if gid is not None and isinstance(c, _Call) and not alone:
+                        c.slane = lane
+                        if gid is not None and isinstance(c, _Call):
                             c.mtag = (gid, "b", j, k)
                     if gid is not None and self.wgrad_group > 0:
                         for k, c in enumerate(self._pending()["calls"][w0:]):
@@ -995,8 +987,6 @@ class Plan:
                                 names += [bn + ".weight", bn + ".bias"]
                     if names:
                         self.bwd_marks.append((len(self.bwd), names))
-                if split:
-                    self.bwd.append(_Marker("join"))
                 self._forced = None
                 for lane in dict.fromkeys(flush_lanes):
                     self._cur_lane = lane
@@ -1128,31 +1118,11 @@ class Plan:
         descs = [self._conv_descs(nd) for nd in nds]
         forced = {"member": 0}
         es = self.es
-        # Experiment (LH_SOLO_DIRECT=1; round 4): members the direct 3x3 kernel takes (C_in = 32 / 64 per tap: HRNet's two
-        # high-resolution branches) leave the merged launch and run on their own, each on a stream lane of its own BESIDE the
-        # merged launch of the remaining members.  MEASURED SLOWER: HRNet-W32 bs 32 15.2-15.3 ms vs 13.1 ms -- the fork / join of
-        # the lanes at every layer position (224 more launches and as many cross-stream edges in the graph) costs about 10 us
-        # per position, more than the shorter kernels save.  Off by default.
-        solo = []
-        if os.environ.get("LH_SOLO_DIRECT", "0") == "1" and len(nds) >= 2:
-            for j, (df, dg) in enumerate(descs):
-                buf = (C.c_int * (5 * 64))()
-                n = self.lib.lh_igemm_candidates(C.byref(df), self.dt, buf, 64)
-                if any(buf[5 * i + 2] == 100 for i in range(n)) and dg is not None:
-                    solo.append(j)
-            if len(solo) > 3:
-                solo = []
-        lanes, rest = {}, [j for j in range(len(nds)) if j not in solo]
-        for k, j in enumerate(solo):
-            lanes[j] = k + 1 if rest else k            # without a remainder the first direct member stays on the main lane
-        if solo and len(rest) == 1:
-            solo = solo + rest                         # a lone remaining member is tuned (and launched) on its own too
-        forced["solo"], forced["lanes"] = tuple(solo), lanes
         for role, idx in (("fwd", 0), ("dgrad", 1)):
-            ds = [d[idx] for j, d in enumerate(descs) if j not in solo]
+            ds = [d[idx] for d in descs]
             if any(d is None for d in ds):
                 continue
-            with_stats = role == "fwd" and self.training and all(id(nd["y"]) in self._bn_inputs for j, nd in enumerate(nds) if j not in solo)
+            with_stats = role == "fwd" and self.training and all(id(nd["y"]) in self._bn_inputs for nd in nds)
             key = ("g", role, self.dt, with_stats) + tuple(self._desc_key(d) for d in ds)
             common = None
             for d in ds:
@@ -1160,10 +1130,36 @@ class Plan:
                 n = self.lib.lh_igemm_candidates(C.byref(d), self.dt, buf, 64)
                 c = {tuple(buf[5 * i:5 * i + 4]) for i in range(n)}
                 common = c if common is None else common & c
-            cands = sorted(c for c in (common or ()) if 2 <= c[2] < 100 and (c[0], c[1]) in self._MULTI_TILES)
+            cands = sorted(c + (0,) for c in (common or ()) if 2 <= c[2] < 100 and (c[0], c[1]) in self._MULTI_TILES)
+            # MIXED launches (igemm_mixed_kernel.h; experiment, LH_MIXED=1): the members the direct 3x3 kernel takes (C = 32 / 64
+            # per tap: HRNet's two high-resolution branches) run its body inside the merged grid, the others the 64 x 128 ring
+            # tile -- whose stage size the 64-byte K run of the 32-channel member no longer dictates.  Candidate = (tile
+            # configuration of the ring members, 1).  MEASURED (round 4, HRNet-W32 bs 32 fp16, tuned from scratch): the tuner
+            # prefers the mixed form in 3 of 26 groups, step 13.30-13.35 vs 13.27 ms -- the direct body's 156 KB of LDS leave
+            # one workgroup per CU for the whole grid (832 workgroups = 3.25 rounds); off by default.
+            direct = []
+            for d in ds:
+                buf = (C.c_int * (5 * 64))()
+                n = self.lib.lh_igemm_candidates(C.byref(d), self.dt, buf, 64)
+                direct.append(next((tuple(buf[5 * i:5 * i + 4]) for i in range(n) if buf[5 * i + 2] == 100), None))
+            if os.environ.get("LH_MIXED", "0") == "1" and any(direct) and len(ds) >= 2:
+                rest = None
+                for d, dc in zip(ds, direct):
+                    if dc is None:
+                        buf = (C.c_int * (5 * 64))()
+                        n = self.lib.lh_igemm_candidates(C.byref(d), self.dt, buf, 64)
+                        c = {tuple(buf[5 * i:5 * i + 4]) for i in range(n)}
+                        rest = c if rest is None else rest & c
+                ring = sorted(c for c in rest if (c[0], c[1]) == (64, 128) and 2 <= c[2] < 10) if rest is not None else [(64, 128, 2, 64)]
+                cands += [c + (1,) for c in ring]
             hit = Plan._TUNE_CACHE.get(key)
+            if hit is not None and len(hit) == 4:
+                hit = tuple(hit) + (0,)               # entries of earlier rounds: one tiled configuration for all members
             if hit is not None and hit not in cands:
                 hit = None
+
+            def per_member(cfg):
+                return [dc if (cfg[4] and dc is not None) else cfg[:4] for dc in direct]
             if hit is None and cands:
                 arr = (_lib.IgemmCall * len(ds))()
                 warm = []
@@ -1183,8 +1179,8 @@ class Plan:
                     check(self.lib.lh_igemm_multi(arr, len(ds), self.dt, sp), "group autotune lh_igemm_multi")
                 best = None
                 for cfg in cands:
-                    for d in ds:
-                        d.cfg[0], d.cfg[1], d.cfg[2], d.cfg[3] = cfg
+                    for d, mc in zip(ds, per_member(cfg)):
+                        d.cfg[0], d.cfg[1], d.cfg[2], d.cfg[3] = mc
                     run()
                     t = self._timed_cold(run, warm, Plan.tune_iters())
                     if best is None or t < best[0]:
@@ -1193,7 +1189,7 @@ class Plan:
                 Plan._TUNE_CACHE[key] = hit
                 Plan._tune_measured.add(key)
             if hit is not None:
-                forced[role] = hit
+                forced[role] = per_member(hit) if hit[4] else hit[:4]
         # weight gradient: common (tile, stage rows, ring depth); per member the plan with the fewest workgroups -- the batch
         # fills the machine, a member need not
         if self.with_bwd:
@@ -1276,9 +1272,11 @@ class Plan:
                     cfg = (C.c_int * 5)()
                     check(lib.lh_igemm_config(c.args[0], self.dt, cfg), "lh_igemm_config")
                     cfgs.add(tuple(cfg[:4]))
-                cfg = next(iter(cfgs))
-                if len(cfgs) != 1 or not 2 <= cfg[2] < 100 or (cfg[0], cfg[1]) not in self._MULTI_TILES:
+                ring = {c for c in cfgs if c[2] != 100}
+                if len(ring) > 1 or any(not 2 <= c[2] < 10 or (c[0], c[1]) not in self._MULTI_TILES for c in ring):
                     return None
+                if len(ring) != len(cfgs) and any((c[0], c[1]) != (64, 128) for c in ring):
+                    return None                 # direct 3x3 members share a launch with the 64 x 128 tile only (igemm_mixed_kernel.h)
                 arr = (_lib.IgemmCall * n)()
                 for i, c in enumerate(calls):
                     a = c.args
