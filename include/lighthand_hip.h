@@ -394,6 +394,14 @@ int lh_keypoint_metrics(const float* pred, const float* gt, int gt_stride, int b
  * is scratch for the bias-corrected step size evaluated in fp64 like the reference's Python. */
 int lh_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long numel,
                  const double* hyper, int* step, float* derived, float grad_scale, void* stream);
+/* The two halves of lh_adam_step, for an update applied SLICE BY SLICE while the backward pass still runs (a gradient
+ * bucket's parameters are updated as soon as the bucket is final / all-reduced; torch.optim.Adam's update is elementwise,
+ * so the result is bit-identical to one lh_adam_step over the whole range): lh_adam_tick once per iteration (step += 1,
+ * derived = bias-corrected step size ...), then lh_adam_apply per slice -- pointers advanced to the slice, which must
+ * start on a 16-byte boundary. */
+int lh_adam_tick(const double* hyper, int* step, float* derived, void* stream);
+int lh_adam_apply(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long numel, const float* derived,
+                  float grad_scale, void* stream);
 
 /* Bias gradient of the head's 1x1 convolution (pose_resnet.py:169-175; loss.backward()): out[c] = sum over n, h, w of an
  * NCHW fp32 gradient.  fp64 partials in a fixed order (deterministic).  workspace >= lh_channel_sum_workspace_bytes(c). */

@@ -151,6 +151,8 @@ SIGNATURES = {
     "lh_comm_destroy": (_I, [_P]),
     "lh_cast_f32_bf16": (_I, [_P, _P, _L, _I, _P]),
     "lh_adam_step": (_I, [_P, _P, _P, _P, _L, _P, _P, _P, _F, _P]),
+    "lh_adam_tick": (_I, [_P, _P, _P, _P]),
+    "lh_adam_apply": (_I, [_P, _P, _P, _P, _L, _P, _F, _P]),
 }
 
 _lib = None

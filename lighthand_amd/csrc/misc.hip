@@ -807,17 +807,30 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, flo
         }
 }
 
+extern "C" int lh_adam_tick(const double* hyper, int* step, float* derived, void* stream) {
+    LH_REQUIRE(hyper && step && derived, "lh_adam_tick: null pointer");
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, hyper, step, derived);
+    LH_LAUNCH_CHECK("adam_tick launch");
+    return LH_OK;
+}
+
+extern "C" int lh_adam_apply(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long numel, const float* derived,
+                             float grad_scale, void* stream) {
+    LH_REQUIRE(param && grad && exp_avg && exp_avg_sq && derived && numel > 0, "lh_adam_apply: bad arguments");
+    LH_REQUIRE((((size_t)param | (size_t)grad | (size_t)exp_avg | (size_t)exp_avg_sq) & 15) == 0, "lh_adam_apply: slices must start on 16-byte boundaries");
+    const long nvec = numel / 4;
+    const int grid = (int)((nvec + 255) / 256 > 2048 ? 2048 : ((nvec + 255) / 256 < 1 ? 1 : (nvec + 255) / 256));
+    hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, numel, derived, grad_scale);
+    LH_LAUNCH_CHECK("adam launch");
+    return LH_OK;
+}
+
 extern "C" int lh_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long numel,
                             const double* hyper, int* step, float* derived, float grad_scale, void* stream) {
     LH_REQUIRE(param && grad && exp_avg && exp_avg_sq && hyper && step && derived && numel > 0, "lh_adam_step: bad arguments");
-    hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, s, hyper, step, derived);
-    const long nvec = numel / 4;
-    const int grid = (int)((nvec + 255) / 256 > 2048 ? 2048 : ((nvec + 255) / 256 < 1 ? 1 : (nvec + 255) / 256));
-    hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq, numel,
-                       (const float*)derived, grad_scale);
-    LH_LAUNCH_CHECK("adam launch");
-    return LH_OK;
+    const int rc = lh_adam_tick(hyper, step, derived, stream);
+    if (rc) return rc;
+    return lh_adam_apply(param, grad, exp_avg, exp_avg_sq, numel, derived, grad_scale, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ head bias gradient

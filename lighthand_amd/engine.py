@@ -1935,16 +1935,20 @@ class Plan:
         self._pack_event = side.record_event()
         return side_work is not None
 
-    def _run_lanes(self, calls, stream):
+    def _run_lanes(self, calls, stream, hooks=None):
         """Launch `calls` with the independent branch chains (stream lane > 0) on side streams: a lane's first launch
         after a fork waits for the fork's event on the main stream, the join makes the main stream wait for every lane
         used since; outside fork/join regions (and at the end of the slice) everything is ordered on the main stream.
-        Works eagerly and under hipGraph capture (the side streams join the capture through the events)."""
+        Works eagerly and under hipGraph capture (the side streams join the capture through the events).
+        hooks: {i: fn(events)} -- before calls[i] is launched, fn receives events that cover everything launched so far
+        (main stream + every side stream used): work that only needs calls[:i] hangs off them without stalling any lane."""
         main = torch.cuda.current_stream()
         assert main.cuda_stream == stream, "lanes need the launch stream to be torch's current stream"
         ev, forked, used = None, set(), set()
         wev, wused = {}, set()                 # weight-gradient side streams: pending event per stream, streams used
-        for c in calls:
+        for ci, c in enumerate(calls):
+            if hooks and ci in hooks:
+                hooks[ci]([main.record_event()] + [self._lane_streams[L].record_event() for L in sorted(used | wused)])
             if isinstance(c, _Marker):
                 if c.kind == "packjoin":
                     if self._pack_event is not None:
@@ -2011,12 +2015,17 @@ class Plan:
                 self._pack_late(stream)              # no side streams in this plan: the late group runs in place
                 self._pack_late = None
 
-    def run_backward(self, stream, lo=0, hi=None):
-        """Run bwd[lo:hi] (a segment of the backward list: data-parallel plans replay it bucket by bucket)."""
+    def run_backward(self, stream, lo=0, hi=None, hooks=None):
+        """Run bwd[lo:hi] (a segment of the backward list: data-parallel plans replay it bucket by bucket).
+        hooks: {index in the backward list: fn(events)}, called when everything before that index has been launched, with
+        events that cover it (TrainStep: the Adam update of the parameters whose gradients are final by then)."""
         calls = self.bwd[lo:hi]
+        hooks = {i - lo: f for i, f in hooks.items() if lo <= i < (len(self.bwd) if hi is None else hi)} if hooks else None
         if self.use_lanes:
-            return self._run_lanes(calls, stream)
-        for c in calls:
+            return self._run_lanes(calls, stream, hooks)
+        for ci, c in enumerate(calls):
+            if hooks and ci in hooks:
+                hooks[ci]([torch.cuda.current_stream().record_event()])
             if not isinstance(c, _Marker):
                 c(stream)
 

@@ -77,6 +77,37 @@ class Adam(torch.optim.Optimizer):
             st["hyper"].copy_(torch.tensor(host, dtype=torch.float64))
             st["host"] = host
 
+    # -- the arena update in slices (runtime.TrainStep: a gradient bucket's parameters are updated as soon as the bucket is
+    #    final, under the rest of the backward pass).  tick() once per iteration, then apply_slice() per bucket; elementwise,
+    #    hence bit-identical to step().
+    def sliceable(self):
+        return self._flat is not None and len(self.param_groups) == 1
+
+    def _flat_state(self):
+        arena = self._flat
+        st = self._group_state(0, arena.device, 0)
+        s = self.state.setdefault("flat", {})
+        if "exp_avg" not in s:
+            s["exp_avg"] = torch.zeros_like(arena.flat)
+            s["exp_avg_sq"] = torch.zeros_like(arena.flat)
+        return arena, st, s
+
+    @torch.no_grad()
+    def tick(self, stream):
+        arena, st, s = self._flat_state()
+        self._sync_hyper(st, self.param_groups[0])
+        check(_lib.load().lh_adam_tick(st["hyper"].data_ptr(), st["step"].data_ptr(), st["derived"].data_ptr(), stream), "lh_adam_tick")
+
+    @torch.no_grad()
+    def apply_slice(self, start, stop, grad_scale, stream):
+        arena, st, s = self._flat_state()
+        if not (0 <= start < stop <= arena.numel) or start % 4:
+            raise _lib.LightHandError(f"Adam.apply_slice: bad slice [{start}, {stop}) of {arena.numel}")
+        off = 4 * start
+        check(_lib.load().lh_adam_apply(arena.flat.data_ptr() + off, arena.flat_grad.data_ptr() + off, s["exp_avg"].data_ptr() + off,
+                                        s["exp_avg_sq"].data_ptr() + off, stop - start, st["derived"].data_ptr(), float(grad_scale), stream),
+              "lh_adam_apply")
+
     @torch.no_grad()
     def step(self, closure=None, grad_scale=1.0):
         loss = closure() if closure is not None else None

@@ -163,7 +163,8 @@ def plan_buckets(marks, offsets, total, bucket_bytes=32 << 20):
 
 
 class GradSync:
-    """Launches one all-reduce per gradient bucket on a side stream and lets Adam wait for all."""
+    """Launches one all-reduce per gradient bucket on a side stream; the optimizer waits for all of them (or updates each
+    bucket's parameters right behind its all-reduce: launch(after=...))."""
 
     def __init__(self, world_size=None, bucket_bytes=32 << 20, group=None, compress=None, comm=None):
         """compress='bf16': every bucket travels as bfloat16 (half the bytes per xGMI link; the sum is formed in bf16 by
@@ -189,10 +190,16 @@ class GradSync:
             self._segments = plan_buckets(plan.bwd_marks, offsets, plan.arena_numel, self.bucket_bytes)
         return self._segments
 
-    def launch(self, flat_grad, bucket):
+    def launch(self, flat_grad, bucket, after=None):
+        """All-reduce flat_grad[start:stop] on the side stream.  after(stream): work to enqueue on that stream right behind
+        the collective (TrainStep: the Adam update of the bucket's parameters); device tensors only."""
         start, stop = bucket
         view = flat_grad[start:stop]
+        if after is not None and not (self.cuda and view.is_cuda):
+            raise ValueError("GradSync.launch(after=...) needs device gradients")
         if self.world_size == 1:
+            if after is not None:
+                after(torch.cuda.current_stream().cuda_stream)
             return
         if self.cuda and view.is_cuda:
             ev = torch.cuda.Event()
@@ -213,6 +220,8 @@ class GradSync:
                     _lib.check(lib.lh_cast_f32_bf16(view.data_ptr(), half.data_ptr(), stop - start, 1, sp), "lh_cast_f32_bf16")
                 else:
                     reduce_(view)
+                if after is not None:
+                    after(self.stream.cuda_stream)
                 done = torch.cuda.Event()
                 done.record(self.stream)
             self._pending.append(done)

@@ -86,6 +86,13 @@ class TrainStep:
         self.loss_scale = float(loss_scale)
         self._loss_scale_dev = torch.tensor([self.loss_scale], dtype=torch.float32, device=dev) if self.loss_scale != 1.0 else None
         self.grad_scale /= self.loss_scale
+        # LH_ADAM_SLICES=1: Adam slice by slice under the backward pass (Adam.apply_slice) -- the parameters of a gradient
+        # bucket are updated as soon as the bucket is final (data parallel: right behind its all-reduce), on a side stream.
+        # Bit-identical, and measured SLOWER on one GPU (9.73-9.80 vs 9.61-9.63 ms: a 1 GB stream through HBM and the
+        # Infinity Cache under the backward kernels costs more than the 0.15 ms tail it removes), hence off by default.
+        self.adam_slices = os.environ.get("LH_ADAM_SLICES", "0") == "1" and hasattr(self.optimizer, "sliceable") and self.optimizer.sliceable()
+        self._adam_stream = torch.cuda.Stream() if self.adam_slices and grad_sync is None else None
+        self._adam_segs = None
         self.graphs = None
         self.use_graph = use_graph
         self.heat_scale = float(height // out.shape[2])               # x4 of method.py:157
@@ -125,8 +132,37 @@ class TrainStep:
     def _enqueue_all(self):
         stream = torch.cuda.current_stream().cuda_stream
         self._fwd_loss(stream)
-        self.plan.run_backward(stream)
-        self.optimizer.step(grad_scale=self.grad_scale)
+        if not self.adam_slices:
+            self.plan.run_backward(stream)
+            self.optimizer.step(grad_scale=self.grad_scale)
+            return
+        # the backward list runs as ONE pass; where a slice of the arena has all its gradients, its update starts on the
+        # side stream behind events of every stream used so far (nothing waits for it until the end of the step)
+        from . import parallel
+        if self._adam_segs is None:
+            mb = float(os.environ.get("LH_ADAM_SLICE_MB", "24"))
+            self._adam_segs = parallel.plan_buckets(self.plan.bwd_marks, self.plan.arena_offsets, self.plan.arena_numel, int(mb * (1 << 20)))
+        main, side, opt = torch.cuda.current_stream(), self._adam_stream, self.optimizer
+        opt.tick(stream)
+
+        def update(buckets):
+            def fn(events):
+                for e in events:
+                    side.wait_event(e)
+                for b in buckets:
+                    opt.apply_slice(b[0], b[1], self.grad_scale, side.cuda_stream)
+            return fn
+        nb = len(self.plan.bwd)
+        early = [(end, b) for i, (_, end, b) in enumerate(self._adam_segs) if b is not None and end < nb and i + 1 < len(self._adam_segs)]
+        tail = [b for i, (_, end, b) in enumerate(self._adam_segs) if b is not None and not (end < nb and i + 1 < len(self._adam_segs))]
+        at = {}
+        for end, b in early:
+            at.setdefault(end, []).append(b)
+        self.plan.run_backward(stream, hooks={end: update(bs) for end, bs in at.items()})
+        for b in tail:
+            opt.apply_slice(b[0], b[1], self.grad_scale, stream)
+        if early:
+            main.wait_event(side.record_event())
 
     def _capture(self):
         """One graph for the whole step; with gradient synchronisation through torch.distributed one graph per backward
@@ -161,22 +197,36 @@ class TrainStep:
                 stream = torch.cuda.current_stream().cuda_stream
                 if i == 0:
                     self._fwd_loss(stream)
+                    if self.adam_slices:
+                        self.optimizer.tick(stream)
                 self.plan.run_backward(stream, lo, hi)
             self.graphs.append((g, bucket))
+        if self.adam_slices:                   # every bucket's update rides behind its all-reduce: nothing left but the join
+            self.graphs.append((None, "adam"))
+            return
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             self.optimizer.step(grad_scale=self.grad_scale)
         self.graphs.append((g, "adam"))
 
+    def _update_after(self, bucket):
+        """Data parallel: the Adam update of a bucket's parameters, enqueued behind the bucket's all-reduce."""
+        if not self.adam_slices:
+            return None
+        return lambda s: self.optimizer.apply_slice(bucket[0], bucket[1], self.grad_scale, s)
+
     def _eager_synced(self):
         stream = torch.cuda.current_stream().cuda_stream
         self._fwd_loss(stream)
+        if self.adam_slices:
+            self.optimizer.tick(stream)
         for lo, hi, bucket in self.grad_sync.segments(self.plan):
             self.plan.run_backward(stream, lo, hi)
             if bucket is not None:
-                self.grad_sync.launch(self.arena.flat_grad, bucket)
+                self.grad_sync.launch(self.arena.flat_grad, bucket, after=self._update_after(bucket))
         self.grad_sync.wait_all()
-        self.optimizer.step(grad_scale=self.grad_scale)
+        if not self.adam_slices:
+            self.optimizer.step(grad_scale=self.grad_scale)
 
     def _optimizer_snapshot(self):
         """Adam moments and device step counters as they are BEFORE the warm-up / capture iterations: a resumed run
@@ -241,9 +291,10 @@ class TrainStep:
             for g, bucket in self.graphs:
                 if bucket == "adam":
                     self.grad_sync.wait_all()
-                g.replay()
+                if g is not None:
+                    g.replay()
                 if bucket is not None and bucket != "adam":
-                    self.grad_sync.launch(self.arena.flat_grad, bucket)
+                    self.grad_sync.launch(self.arena.flat_grad, bucket, after=self._update_after(bucket))
         self.steps += 1
         return self.loss
 

@@ -88,10 +88,12 @@ def test_data_parallel_semantics_emulated_on_one_gpu(monkeypatch):
             super().__init__(world_size=2, bucket_bytes=2 << 20)
             self.peer, self.launched = peer_grad, []
 
-        def launch(self, flat_grad, bucket):
+        def launch(self, flat_grad, bucket, after=None):
             s, e = bucket
             flat_grad[s:e] += self.peer[s:e]           # what all_reduce(SUM) over 2 ranks leaves behind
             self.launched.append(bucket)
+            if after is not None:                      # the bucket's Adam update rides behind its all-reduce
+                after(torch.cuda.current_stream().cuda_stream)
 
     for use_graph, group in ((False, None), (True, None), (True, "4"), (True, "0")):
         if group is None:
@@ -337,6 +339,36 @@ for tag in ('r50', 'hrnet32'):
     out.append(hashlib.sha256(m.arena().flat.cpu().numpy().tobytes()).hexdigest())
 print('SHA ' + ' '.join(out))
 """
+
+
+def test_sliced_adam_is_bit_identical_to_one_update(static_kernel_choice, monkeypatch):
+    """LH_ADAM_SLICES=1: the arena is updated slice by slice while the backward pass still runs (lh_adam_tick once, then
+    lh_adam_apply per finished gradient bucket on a side stream; data parallel: behind each bucket's all-reduce).  Adam is
+    elementwise: weights and moments after three steps equal those of the single lh_adam_step launch bit for bit."""
+    from lighthand_amd import parallel
+    from lighthand_amd.runtime import TrainStep
+    x, j = _batch(4, 64, 5)
+
+    def run(sliced, sync):
+        monkeypatch.setenv("LH_ADAM_SLICES", "1" if sliced else "0")
+        monkeypatch.setenv("LH_ADAM_SLICE_MB", "2")
+        m = _model(seed=77)
+        step = TrainStep(m, 4, 64, 64, lr=1e-3, grad_sync=parallel.GradSync(world_size=1, bucket_bytes=2 << 20) if sync else None)
+        assert step.adam_slices == sliced
+        for _ in range(3):
+            loss = step(x, j)
+        torch.cuda.synchronize()
+        if sliced and not sync:
+            assert len(step._adam_segs) >= 2, step._adam_segs      # weight gradients finish in deferred groups: R18 gives two cuts
+        st = step.optimizer.state["flat"]
+        return float(loss), m.arena().flat.clone(), st["exp_avg"].clone(), st["exp_avg_sq"].clone(), int(step.optimizer._dev[0]["step"])
+
+    want = run(False, False)
+    for sync in (False, True):
+        got = run(True, sync)
+        assert got[0] == want[0] and got[4] == want[4] == 3
+        for a, b in zip(got[1:4], want[1:4]):
+            assert torch.equal(a, b)
 
 
 def test_static_choice_training_is_bit_reproducible_across_processes(static_kernel_choice):
