@@ -24,6 +24,19 @@
 #include "igemm_wave_epilogue.h"
 #include <stdlib.h>
 
+// One LDS-DMA instruction as inline asm: 64 lanes x 16 bytes from `src` (per lane) to LDS address `lds` (wave-uniform) +
+// 16 * lane.  Why not __builtin_amdgcn_global_load_lds: a ds_read the COMPILER sees after an LDS-DMA it cannot disambiguate
+// from makes it wait for that DMA (s_waitcnt vmcnt(0)) -- in this kernel after every patch piece requested between the
+// MFMA steps, the memory latency exposed six times per tile, and at the top of every tile for the previous tile's output
+// stores.  With the DMA invisible to the compiler the kernel's own counted waits are the only ones (the compiler's counts
+// for its own loads then under-count the operations in flight, which only makes its waits stronger).
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"      // m0 is a reserved register: it is exactly what the instruction reads, and nothing else in these kernels uses it
+__device__ __forceinline__ void d3_lds_dma16(const unsigned char* src, unsigned lds) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+
 // The kernel proper for workgroup `b` of its launch (plain launch: the block index; the mixed multi-problem launch of
 // igemm_mixed_kernel.h: the index inside the problem the workgroup belongs to).  512 threads.
 template <typename T, int C, bool STATS>
@@ -51,6 +64,7 @@ __device__ __forceinline__ void conv3x3_direct_body(const IgemmArgs& p, unsigned
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4, pl = lane & 15;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
     const int CB = p.pw_cb, G = p.pw_g;
     const int cblk = (b >> 3) % CB;
     const int g = (b & 7) + 8 * ((b >> 3) / CB);
@@ -70,7 +84,7 @@ __device__ __forceinline__ void conv3x3_direct_body(const IgemmArgs& p, unsigned
             const int c = (lane % SL) ^ fswz(row);
             const int grow = cblk * BM + row;
             const unsigned char* src = grow < prow_lim ? p.w + (((long)grow * 9 + tap) * p.kpad + c * 8) * ES : p.zero;
-            if (!(LH_ABL & 4)) __builtin_amdgcn_global_load_lds((gbl_void_p)src, (lds_void_p)(smem + tap * (BM * ROWB) + r0 * ROWB), 16, 0, 0);
+            if (!(LH_ABL & 4)) d3_lds_dma16(src, lds_base + tap * (BM * ROWB) + r0 * ROWB);
         }
         float* cst = reinterpret_cast<float*>(smem + OFF_CST);
         for (int c = tid; c < BM; c += 64 * NWAVE) {
@@ -117,8 +131,8 @@ __device__ __forceinline__ void conv3x3_direct_body(const IgemmArgs& p, unsigned
         const int iy = fy0 + ppy[j], ix = fx0 + ppx[j];
         const bool ok = flive & ((unsigned)iy < (unsigned)p.hi) & ((unsigned)ix < (unsigned)p.wi);
         const unsigned char* src = ok ? fbase + iy * row_stride + (long)ix * pix_stride + pch[j] : p.zero;
-        unsigned char* dst = smem + OFF_PATCH + buf * PATCH + (NWAVE * j + wave) * 1024;
-        if (!(LH_ABL & 4) && ppy[j] >= 0) __builtin_amdgcn_global_load_lds((gbl_void_p)src, (lds_void_p)dst, 16, 0, 0);   // lanes past the patch: masked off
+        const unsigned dst = lds_base + OFF_PATCH + buf * PATCH + (NWAVE * j + wave) * 1024;
+        if (!(LH_ABL & 4) && ppy[j] >= 0) d3_lds_dma16(src, dst);   // lanes past the patch: masked off
     };
     // fragment addresses.  A (weights): row = 16 i + pl of tap t: t * BM * ROWB + i * 16 * ROWB + pl * ROWB + ((c ^ f(pl)) << 4).
     // B (pixels): the wave's two image rows are patch rows 2 wave + j + dy (dy = 0..2), pixel column pl + dx.
@@ -138,7 +152,11 @@ __device__ __forceinline__ void conv3x3_direct_body(const IgemmArgs& p, unsigned
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's share of the weights and of the first patch has landed
     int buf = 0;
     for (; t < ntile; t += G, buf ^= 1) {
-        __syncthreads();                                          // patch t: everyone's share; and everyone is done with the other buffer
+        // patch t: everyone's share has landed (counted vmcnt below / before the loop), and everyone is done with the other
+        // buffer.  A RAW barrier: __syncthreads() waits for vmcnt(0), i.e. for the previous tile's output stores to retire.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
         tile_origin(t + G);
         const unsigned char* patch = smem + OFF_PATCH + buf * PATCH;
         f32x4 acc[4][PT];
@@ -192,7 +210,11 @@ __device__ __forceinline__ void conv3x3_direct_body(const IgemmArgs& p, unsigned
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             continue;
         }
-        if (ALIAS) __syncthreads();                               // every wave is done reading patch t: its buffer becomes the staging area
+        if (ALIAS) {                                              // every wave is done reading patch t: its buffer becomes the staging area
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
         unsigned char* stg = (ALIAS ? smem + OFF_PATCH + buf * PATCH : smem + OFF_STG) + wave * STG;
         const int n = t / (ty_n * tx_n), rem = t - n * (ty_n * tx_n);
         const int oy0 = (rem / tx_n) * TH + PT * wave, ox0 = (rem % tx_n) * TW;
