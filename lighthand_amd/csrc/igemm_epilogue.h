@@ -9,6 +9,33 @@
 #define LH_ABL 0
 #endif
 
+// LDS bytes of the epilogue: the [BP][BM] tile (row pitch BM * ES + 8), the fused head's 32 weight rows where it exists,
+// and the per-channel bias / scale / shift of the tile's BM channels (3 * BM floats).
+template <typename T, int BM, int BP, bool HEAD> constexpr int lh_epi_lds_bytes() {
+    return BP * (BM * (int)sizeof(T) + 8) + (HEAD ? 32 * (BM * (int)sizeof(T) + 16) : 0) + 3 * BM * 4;
+}
+
+// The tile's per-channel constants, fetched by the workgroup in ONE round trip into LDS at `cst` ([3][BM] floats: value to
+// add, factor, -- both already combined as the epilogue applies them): every thread loads (index clamped, dropped by a
+// select).  Per-lane loads under `channel < cout` conditions are branched around and waited for one by one: 2 * CT dependent
+// L2 round trips per wave, 8 us of the 256 x 256 tile's epilogue in eval-mode plans (round 4).
+template <int BM, int NT>
+__device__ __forceinline__ void igemm_epilogue_consts(const IgemmArgs& p, float* cst, int c0, int tid) {
+    const int cmax = p.cout - 1;
+    for (int c = tid; c < BM; c += NT) {
+        const int gc = c0 + c, gk = gc < cmax ? gc : cmax;
+        const bool ok = gc < p.cout;
+        const float b = p.bias ? p.bias[gk] : 0.f, sc = p.scale ? p.scale[gk] : 1.f, sh = p.scale ? p.shift[gk] : 0.f;   // wave-uniform conditions
+        float bv = (p.bias && ok) ? b : 0.f, sv = 1.f;
+        if (p.scale) {                      // out = acc * scale + shift (+ bias * scale folded by the host if both are given)
+            sv = ok ? sc : 1.f;
+            bv = bv * sv + (ok ? sh : 0.f);
+        }
+        cst[c] = sv;
+        cst[BM + c] = bv;
+    }
+}
+
 template <typename T, int BM, int BP, int WC, int WP>
 __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, unsigned char* smem, f32x4 (&acc)[BM / WC / 16][BP / WP / 16],
                                                int pblk, int cblk, int tid, int lane, int wc, int wp, int hw,
@@ -29,27 +56,23 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, unsigned char
         return;
     }
     __syncthreads();
+    float* cst = reinterpret_cast<float*>(smem + BP * RS);
+    const bool affine = p.bias || p.scale;              // wave-uniform: training-mode forward / gradient launches carry neither
+    if (affine) {
+        igemm_epilogue_consts<BM, 64 * WC * WP>(p, cst, cblk * BM, tid);
+        __syncthreads();
+    }
     {
         const int q = lane >> 4, pl = lane & 15;
 #pragma unroll
         for (int i = 0; i < CT; ++i) {
             const int col = wc * TC + i * 16 + q * 4;
-            float bv[4] = {0.f, 0.f, 0.f, 0.f}, sv[4] = {1.f, 1.f, 1.f, 1.f};
-            if (p.bias) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int gc = cblk * BM + col + r;
-                    bv[r] = gc < p.cout ? p.bias[gc] : 0.f;
-                }
+            float4 s4 = float4{1.f, 1.f, 1.f, 1.f}, b4 = float4{0.f, 0.f, 0.f, 0.f};
+            if (affine) {
+                s4 = *reinterpret_cast<const float4*>(cst + col);
+                b4 = *reinterpret_cast<const float4*>(cst + BM + col);
             }
-            if (p.scale) {                      // out = acc * scale + shift (+ bias * scale folded by the host if both are given)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int gc = cblk * BM + col + r;
-                    sv[r] = gc < p.cout ? p.scale[gc] : 1.f;
-                    bv[r] = bv[r] * sv[r] + (gc < p.cout ? p.shift[gc] : 0.f);
-                }
-            }
+            const float sv[4] = {s4.x, s4.y, s4.z, s4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
             for (int j = 0; j < PT; ++j) {
                 const int pr = wp * TP + j * 16 + pl;
@@ -112,10 +135,11 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, unsigned char
         opx[k] = (m < p.M && col_ok) ? opix : -1;
         ad[k] = uint4{0u, 0u, 0u, 0u};
         mbits[k] = 0xffu;
-        if (p.addend && opx[k] >= 0) {
-            const long eoff = (long)((unsigned long)(unsigned)opx[k] * (unsigned)p.out_pix_stride) + col0;
-            ad[k] = *reinterpret_cast<const uint4*>(p.addend + eoff * ES);
-            if (p.addend_mask) mbits[k] = p.addend_mask[eoff / EPC];    // addend = upstream gradient, gated by the activation's ReLU mask
+        if (p.addend) {                                  // wave-uniform; rows with nothing to store read the zero page (every lane loads)
+            const bool ok = opx[k] >= 0;
+            const long eoff = (long)((unsigned long)(unsigned)(ok ? opx[k] : 0) * (unsigned)p.out_pix_stride) + col0;
+            ad[k] = *reinterpret_cast<const uint4*>(ok ? p.addend + eoff * ES : p.zero);
+            if (p.addend_mask) mbits[k] = *(ok ? p.addend_mask + eoff / EPC : p.zero);    // addend = upstream gradient, gated by the activation's ReLU mask
         }
     }
 #pragma unroll
@@ -190,19 +214,16 @@ __device__ __forceinline__ void igemm_epilogue_head(const IgemmArgs& p, unsigned
     static_assert(ES == 2 && BP % (16 * NW) == 0 && BM % 32 == 0, "head epilogue: 16-bit types, whole pixel tiles per wave");
     unsigned char* hw_lds = smem + BP * RS;
     __syncthreads();
+    float* cst = reinterpret_cast<float*>(hw_lds + 32 * HS);
+    igemm_epilogue_consts<BM, NT>(p, cst, 0, tid);      // one round trip for the tile's per-channel constants (see above)
+    __syncthreads();
     {
         const int q = lane >> 4, pl = lane & 15;
 #pragma unroll
         for (int i = 0; i < CT; ++i) {
             const int col = wc * TC + i * 16 + q * 4;
-            float bv[4], sv[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int gc = col + r;
-                const bool ok = gc < p.cout;
-                sv[r] = (p.scale && ok) ? p.scale[gc] : 1.f;
-                bv[r] = ((p.bias && ok) ? p.bias[gc] : 0.f) * sv[r] + ((p.scale && ok) ? p.shift[gc] : 0.f);
-            }
+            const float4 s4 = *reinterpret_cast<const float4*>(cst + col), b4 = *reinterpret_cast<const float4*>(cst + BM + col);
+            const float sv[4] = {s4.x, s4.y, s4.z, s4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
             for (int j = 0; j < PT; ++j) {
                 const int pr = wp * TP + j * 16 + pl;

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(512, 2) void igemm_mixed_multi_kernel(const LhMulti
 
 template <typename T, int D, int KB>
 static int launch_mixed(const LhMulti<IgemmArgs>& m, const MixedKinds& kt, bool stats, hipStream_t s) {
-    constexpr int ring = D * (64 + 128) * KB, epi = 128 * (64 * 2 + 8);
+    constexpr int ring = D * (64 + 128) * KB, epi = lh_epi_lds_bytes<T, 64, 128, false>();
     int lds = ring > epi ? ring : epi;
     for (int i = 0; i < m.n; ++i)
         if (kt.k[i]) { const int l = lh_d3_lds_bytes(kt.k[i]); lds = l > lds ? l : lds; }

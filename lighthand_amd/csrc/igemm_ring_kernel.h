@@ -351,7 +351,7 @@ template <typename T, int BM, int BP, int WC, int WP, int D, int KB>
 static int launch_ring(const IgemmArgs& a, hipStream_t s) {
     constexpr int ES = sizeof(T);
     constexpr int ring = D * (BM + BP) * KB;
-    constexpr int epi = BP * (BM * ES + 8) + ((BM == 256 && BP == 256 && ES == 2) ? 32 * (BM * ES + 16) : 0);   // + the fused head's weights
+    constexpr int epi = lh_epi_lds_bytes<T, BM, BP, (BM == 256 && BP == 256 && ES == 2)>();   // tile + the fused head's weights + per-channel constants
     constexpr int lds = ring > epi ? ring : epi;
     static_assert(lds <= 160 * 1024, "LDS budget");
     if (lds > 64 * 1024) {
@@ -373,9 +373,8 @@ static int launch_ring(const IgemmArgs& a, hipStream_t s) {
 
 template <typename T, int BM, int BP, int WC, int WP, int D, int KB>
 static int launch_ring_multi(const LhMulti<IgemmArgs>& m, hipStream_t s) {
-    constexpr int ES = sizeof(T);
     constexpr int ring = D * (BM + BP) * KB;
-    constexpr int epi = BP * (BM * ES + 8);
+    constexpr int epi = lh_epi_lds_bytes<T, BM, BP, false>();
     constexpr int lds = ring > epi ? ring : epi;
     static_assert(lds <= 160 * 1024, "LDS budget");
     if (lds > 64 * 1024) {

@@ -111,9 +111,12 @@ __device__ __forceinline__ void wgrad_ring_body(const WgradArgs& p, unsigned cha
     // work item w = (split, tap, tile), tile fastest: every XCD gets a contiguous range of pixel splits with all their
     // taps and tiles, which re-read the same dy / x rows from that XCD's L2 instead of the Infinity Cache
     const int w = p.xcd ? lh_xcd_remap(bid, nblk) : bid;
-    const int tile = w % p.tiles, tap = (w / p.tiles) % p.ntaps, split = w / (p.tiles * p.ntaps);
+    const int tile = w % p.tiles, tap = __builtin_amdgcn_readfirstlane((w / p.tiles) % p.ntaps), split = w / (p.tiles * p.ntaps);
     const int otile = tile / p.i_tiles, itile = tile % p.i_tiles;
-    const int dh = p.dh[tap], dw = p.dw[tap];
+    // the tap offsets come out of the argument block through a VECTOR load (dynamic index): consume them here -- left to the
+    // compiler their first use lands behind the first LDS-DMA instructions, and the s_waitcnt vmcnt(0) in front of it waits
+    // for those too (one memory latency per workgroup, in launches of 10-30 us per workgroup)
+    const int dh = __builtin_amdgcn_readfirstlane((int)p.dh[tap]), dw = __builtin_amdgcn_readfirstlane((int)p.dw[tap]);
     const int hw = p.ho * p.wo;
     const long m_begin = (long)split * p.steps_per_split * KPS;
     long m_end = m_begin + (long)p.steps_per_split * KPS;
