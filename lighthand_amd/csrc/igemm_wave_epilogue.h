@@ -56,7 +56,7 @@ __device__ __forceinline__ void wave_epilogue(const IgemmArgs& p, f32x4 (&acc)[B
             if (p.addend) {                                 // every lane loads (masked lanes: the zero page): fixed instruction count
                 const long eoff = opix[k] * p.out_pix_stride + col0;
                 ad[k] = *reinterpret_cast<const uint4*>(opix[k] >= 0 ? p.addend + eoff * ES : p.zero);
-                if (p.addend_mask) mb[k] = opix[k] >= 0 ? p.addend_mask[eoff / EPC] : (unsigned char)0;
+                if (p.addend_mask) mb[k] = *(opix[k] >= 0 ? p.addend_mask + eoff / EPC : p.zero);     // every lane loads
             }
         }
 #pragma unroll
