@@ -159,6 +159,24 @@ typedef struct {
 int lh_igemm(const lh_igemm_desc* d, const void* in, const void* wpack, void* out,
              const void* addend, const void* addend_mask, const float* bias, const float* scale, const float* shift,
              float* stats, int dtype, void* stream);
+/* A data-gradient launch whose OUTPUT is the gradient of an activation a = relu(BN(x)) (x = the forward convolution's raw
+ * output, BN in training mode: pose_resnet.py:60-66 and what loss.backward() does with them) can do the first half of that
+ * BatchNorm's backward pass on the tile it holds: it stores g = dout * (x * scale + shift > 0) -- the ReLU-gated gradient
+ * -- instead of dout, and writes the per-block partial sums { sum g, sum g * (x - mean) * invstd } per channel into `partial`
+ * (fp32 [rows][2][cout], rows = lh_igemm_stats_rows: the layout of the forward statistics).  lh_fuse_bwd then takes them
+ * (lh_fuse_bwd_desc.pre_partial / pre_rows) and skips its own reduce pass over dout and x: one read of dout, one launch
+ * less per BatchNorm.  x has the layout of this launch's output (same pixel stride).  Tiled LDS-DMA configurations only
+ * (lh_igemm_config: ring depth 2..9); LH_ERR_UNSUPPORTED otherwise. */
+typedef struct {
+    const void* x;
+    const float* mean;
+    const float* invstd;
+    const float* scale;
+    const float* shift;
+    float* partial;
+} lh_bn_bwd_gate;
+int lh_igemm_gated(const lh_igemm_desc* d, const void* in, const void* wpack, void* out, const void* addend, const void* addend_mask,
+                   const lh_bn_bwd_gate* gate, int dtype, void* stream);
 /* Phase batching: 2..4 lh_igemm launches that share input, output tensor, sizes and epilogue and differ only in weight
  * pack, tap list and output placement (ooh, oow) -- the sub-pixel phases of a 4x4/s2 transposed convolution
  * (pose_resnet.py:194-232) or of a stride-2 convolution's data gradient -- as ONE grid.  Phases may have zero taps
@@ -320,6 +338,9 @@ typedef struct {
     const void* relu_mask;      /* mask bits written by lh_fuse_fwd; when set, `out` is not read and may be NULL */
     int strips_cap;             /* 0 = default (512): upper bound on the strips of the streaming reduce pass = rows of the
                                  * partial-sum slab; 256 is the measured choice for nodes that share lh_fuse_bwd_multi launches */
+    const float* pre_partial;   /* single BN term under a ReLU whose dout was written by lh_igemm_gated: dout is already the gated
+                                 * gradient and these are its partial sums [pre_rows][2][c] -- no reduce pass, no mask */
+    int pre_rows;
 } lh_fuse_bwd_desc;
 size_t lh_fuse_bwd_workspace_bytes(int n, int h, int w, int c);
 int lh_fuse_bwd(const lh_fuse_bwd_desc* d, int n, int h, int w, int c, void* workspace,

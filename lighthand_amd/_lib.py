@@ -41,7 +41,12 @@ class FuseBwdDesc(C.Structure):
                 ("shift", C.c_void_p * 4), ("save_mean", C.c_void_p * 4), ("save_invstd", C.c_void_p * 4), ("dx", C.c_void_p * 4),
                 ("dgamma", C.c_void_p * 4), ("dbeta", C.c_void_p * 4), ("log2up", C.c_int * 4),
                 ("accumulate", C.c_int * 4), ("nterms", C.c_int), ("relu", C.c_int),
-                ("relu_mask", C.c_void_p), ("strips_cap", C.c_int)]
+                ("relu_mask", C.c_void_p), ("strips_cap", C.c_int), ("pre_partial", C.c_void_p), ("pre_rows", C.c_int)]
+
+
+class BnBwdGate(C.Structure):          # lh_igemm_gated
+    _fields_ = [("x", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p),
+                ("partial", C.c_void_p)]
 
 
 class IgemmCall(C.Structure):          # one entry of lh_igemm_multi = the arguments of lh_igemm
@@ -111,6 +116,7 @@ SIGNATURES = {
     "lh_wgrad_tile": (_I, [C.POINTER(IgemmDesc), _I, _I, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "lh_wgrad_candidates": (_I, [C.POINTER(IgemmDesc), _I, _I, _I, C.POINTER(_I), _I]),
     "lh_igemm_stats_rows": (_I, [C.POINTER(IgemmDesc), _I]),
+    "lh_igemm_gated": (_I, [C.POINTER(IgemmDesc), _P, _P, _P, _P, _P, C.POINTER(BnBwdGate), _I, _P]),
     "lh_wgrad_slab_bytes": (_SZ, [C.POINTER(IgemmDesc), _I, _I, _I]),
     "lh_wgrad": (_I, [C.POINTER(IgemmDesc), _P, _P, _I, _I, _I, _P, _I, _P]),
     "lh_wgrad_rowfold": (_I, [C.POINTER(IgemmDesc), _I, _P, _P, _I, _I, _P, _I, _P]),

@@ -1537,8 +1537,15 @@ static int plan_fuse_bwd(const lh_fuse_bwd_desc* d, int n, int h, int w, int c, 
         a.shift = nullptr;
         const int nchunk = c / (16 / es);
         const bool flat = a.l == 0 && (nchunk & (nchunk - 1)) == 0 && nchunk <= 256;
+        // dout written by lh_igemm_gated: already the gated gradient, its partial sums come with it
+        const bool pre = d->pre_partial != nullptr;
+        if (pre) {
+            LH_REQUIRE(d->nterms == 1 && d->relu && a.x && d->pre_rows >= 1 && a.l == 0, "lh_fuse_bwd: pre_partial takes ONE BatchNorm term under a ReLU");
+            a.relu = 0;
+            a.out = nullptr; a.mask = nullptr;
+        }
         // single BN term under the ReLU: the mask is sign(x*scale+shift), no need to read the stored activation
-        a.mask_from_x = (flat && d->relu && d->nterms == 1 && a.x && d->shift[t]) ? 1 : 0;
+        a.mask_from_x = (!pre && flat && d->relu && d->nterms == 1 && a.x && d->shift[t]) ? 1 : 0;
         if (a.mask_from_x) a.shift = d->shift[t];
         a.total = a.count * (c / (16 / es));
         a.exp = bn_exp_flags() & 3;
@@ -1549,7 +1556,10 @@ static int plan_fuse_bwd(const lh_fuse_bwd_desc* d, int n, int h, int w, int c, 
             // small tensors (HRNet's branches): few enough strips that the apply pass folds them itself; a strip must stay
             // short (<= 64 KiB of the operand), else the reduce pass would lose the workgroups it streams with
             bool fold_in_apply = false;
-            if (flat && c <= 256 && getenv("LH_FOLD_IN_APPLY") == nullptr) {
+            if (pre) {
+                strips = d->pre_rows;
+                fold_in_apply = flat && c <= 256 && getenv("LH_FOLD_IN_APPLY") == nullptr && strips * 2 * c <= LH_FOLD_IN_APPLY_FLOATS;
+            } else if (flat && c <= 256 && getenv("LH_FOLD_IN_APPLY") == nullptr) {
                 int rps2;
                 const long s2 = fuse_bwd_strips(a.count, &rps2, (int)std::min<long>(d->strips_cap >= 16 ? d->strips_cap : 512, LH_FOLD_IN_APPLY_FLOATS / (2 * c)));
                 if (s2 * 2 * c <= LH_FOLD_IN_APPLY_FLOATS && (long)rps2 * c * es <= 65536) {
@@ -1559,17 +1569,20 @@ static int plan_fuse_bwd(const lh_fuse_bwd_desc* d, int n, int h, int w, int c, 
                 }
             }
             a.partial = (float*)((unsigned char*)workspace + (size_t)t * term_bytes);
-            const long slab_floats = strips * 2 * c;
+            const long slab_floats = pre ? 0 : strips * 2 * c;      // pre: the slab is the caller's, the workspace holds the scratch only
             double* scratch = (double*)(a.partial + ((slab_floats + 3) & ~3L));
+            if (pre) a.partial = const_cast<float*>(d->pre_partial);
             double* totals = scratch + (long)ceil_div(strips, 256) * 2 * c;
             a.totals = totals;
             a.coef = (float*)(totals + 2 * c) + (size_t)(merge2 ? t : 0) * 2 * c;   // merging keeps one coefficient block per term
-            BnLaunch r;
-            r.kind = flat ? (a.mask_from_x ? K_FB_REDUCE_FLAT_X : K_FB_REDUCE_FLAT) : K_FB_REDUCE_GEN;
-            r.grid = (int)strips;
-            r.phase = 0;
-            r.fb = a;
-            v.push_back(r);
+            if (!pre) {
+                BnLaunch r;
+                r.kind = flat ? (a.mask_from_x ? K_FB_REDUCE_FLAT_X : K_FB_REDUCE_FLAT) : K_FB_REDUCE_GEN;
+                r.grid = (int)strips;
+                r.phase = 0;
+                r.fb = a;
+                v.push_back(r);
+            }
             if (fold_in_apply) {
                 if (merge2) { m2.fold_slab[t] = a.partial; m2.fold_rows[t] = (int)strips; m2.dgamma[t] = a.dgamma; m2.dbeta[t] = a.dbeta; }
                 else a.fold_rows = (int)strips;

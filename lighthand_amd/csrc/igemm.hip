@@ -345,7 +345,7 @@ struct PhaseSet {                 // lh_igemm_phases: the other descriptors / pa
 static int igemm_impl(const lh_igemm_desc* d, const void* in, const void* wpack, void* out,
                       const void* addend, const void* addend_mask, const float* bias, const float* scale, const float* shift, float* stats,
                       int dtype, void* stream, const PhaseSet* phases = nullptr, const lh_head* head = nullptr,
-                      IgemmArgs* prep_args = nullptr, RingCfg* prep_cfg = nullptr) {
+                      IgemmArgs* prep_args = nullptr, RingCfg* prep_cfg = nullptr, const lh_bn_bwd_gate* gate = nullptr) {
     LH_REQUIRE(d && in && wpack && (out || head), "lh_igemm: null pointer");
     const int es = lh_dtype_size(dtype);
     LH_REQUIRE(es > 0, "lh_igemm: bad dtype %d", dtype);
@@ -366,6 +366,13 @@ static int igemm_impl(const lh_igemm_desc* d, const void* in, const void* wpack,
     a.scale = scale; a.shift = shift;
     LH_REQUIRE((scale == nullptr) == (shift == nullptr), "lh_igemm: scale and shift must come together");
     a.head_w = nullptr; a.head_bias = nullptr; a.head_out = nullptr; a.head_j = 0; a.head_wstride = 0;
+    a.gx = nullptr; a.gmean = a.ginv = a.gscale = a.gshift = nullptr;
+    if (gate) {
+        LH_REQUIRE(gate->x && gate->mean && gate->invstd && gate->scale && gate->shift && gate->partial, "lh_igemm_gated: null pointer in the gate");
+        LH_REQUIRE(!bias && !scale && !d->relu && !phases && !head, "lh_igemm_gated: a data gradient carries no bias / affine / ReLU / phases");
+        a.gx = (const unsigned char*)gate->x; a.gmean = gate->mean; a.ginv = gate->invstd; a.gscale = gate->scale; a.gshift = gate->shift;
+        a.stats = gate->partial;
+    }
     a.n = d->n; a.hi = d->hi; a.wi = d->wi; a.in_pix_stride = d->in_pix_stride; a.k_run = d->k_run;
     a.kspt = (d->k_run * es + 63) / 64;
     a.kpad = (d->k_run * es + 127) / 128 * (128 / es);
@@ -425,6 +432,10 @@ static int igemm_impl(const lh_igemm_desc* d, const void* in, const void* wpack,
         *prep_cfg = rc_;
         return LH_OK;
     }
+    if (gate && !(ring && rc_.depth >= 2 && rc_.depth < 10 && es == 2)) {
+        lh_set_error("lh_igemm_gated: the launch does not run on a tiled LDS-DMA configuration (ring depth %d)", ring ? rc_.depth : 0);
+        return LH_ERR_UNSUPPORTED;
+    }
     if (ring) {
         lh_tap_grid(d, &a.tw, &a.dh0, &a.dhs, &a.dw0, &a.dws);
         a.kspt = (d->k_run * es + rc_.kb - 1) / rc_.kb;
@@ -453,6 +464,12 @@ extern "C" int lh_igemm(const lh_igemm_desc* d, const void* in, const void* wpac
                         const void* addend, const void* addend_mask, const float* bias, const float* scale, const float* shift,
                         float* stats, int dtype, void* stream) {
     return igemm_impl(d, in, wpack, out, addend, addend_mask, bias, scale, shift, stats, dtype, stream);
+}
+
+extern "C" int lh_igemm_gated(const lh_igemm_desc* d, const void* in, const void* wpack, void* out, const void* addend, const void* addend_mask,
+                              const lh_bn_bwd_gate* gate, int dtype, void* stream) {
+    LH_REQUIRE(gate, "lh_igemm_gated: null gate");
+    return igemm_impl(d, in, wpack, out, addend, addend_mask, nullptr, nullptr, nullptr, nullptr, dtype, stream, nullptr, nullptr, nullptr, nullptr, gate);
 }
 
 // n independent convolutions that share ONE kernel configuration (every descriptor's cfg names the same tiled

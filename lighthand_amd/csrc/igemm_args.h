@@ -14,6 +14,13 @@ struct IgemmArgs {
     const float* scale;      // optional per-output-channel affine applied to the fp32 accumulator (eval-mode BN fold)
     const float* shift;
     float* stats;
+    // BatchNorm-backward gate (lh_igemm_gated): the launch's output is the gradient of relu(BN(gx)); the epilogue stores the
+    // gated gradient and `stats` receives { sum g, sum g * xhat } instead of { sum v, sum v^2 }
+    const unsigned char* gx;
+    const float* gmean;
+    const float* ginv;
+    const float* gscale;
+    const float* gshift;
     // Fused 1x1 head (lh_igemm_phases_head, 256 x 256 tile only): the tile -- after affine + ReLU -- is multiplied by
     // head_w [>= 32 rows][cout] (K-major pack rows of the 1x1 convolution, rows >= head_j zero) inside the epilogue and
     // only head_out[n][j][OH][OW] (fp32) is written; `out` is not touched

@@ -122,7 +122,17 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, unsigned char
     static_assert(BP % RPP == 0, "rows per thread");
     int opx[NR];                                      // output pixel of row k, -1: nothing to store
     uint4 ad[NR];
+    uint4 xd[NR];                                     // BatchNorm-backward gate (lh_igemm_gated): the BN input at the output position
     unsigned mbits[NR];
+    // gate constants of this thread's EPC channels (every thread loads, index clamped)
+    float gmean[EPC], ginv[EPC], gsc[EPC], gsh[EPC];
+    if (p.gx) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const int gk = col0 + e < p.cout ? col0 + e : p.cout - 1;
+            gmean[e] = p.gmean[gk]; ginv[e] = p.ginv[gk]; gsc[e] = p.gscale[gk]; gsh[e] = p.gshift[gk];
+        }
+    }
 #pragma unroll
     for (int k = 0; k < NR; ++k, m += RPP) {
         int opix = m;
@@ -140,6 +150,12 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, unsigned char
             const long eoff = (long)((unsigned long)(unsigned)(ok ? opx[k] : 0) * (unsigned)p.out_pix_stride) + col0;
             ad[k] = *reinterpret_cast<const uint4*>(ok ? p.addend + eoff * ES : p.zero);
             if (p.addend_mask) mbits[k] = *(ok ? p.addend_mask + eoff / EPC : p.zero);    // addend = upstream gradient, gated by the activation's ReLU mask
+        }
+        xd[k] = uint4{0u, 0u, 0u, 0u};
+        if (p.gx) {
+            const bool ok = opx[k] >= 0;
+            const long eoff = (long)((unsigned long)(unsigned)(ok ? opx[k] : 0) * (unsigned)p.out_pix_stride) + col0;
+            xd[k] = *reinterpret_cast<const uint4*>(ok ? p.gx + eoff * ES : p.zero);
         }
     }
 #pragma unroll
@@ -170,7 +186,20 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, unsigned char
             }
             u = pack16<T>(v);
         }
-        if (stats) {
+        if (p.gx) {
+            // the stored value is the gradient of relu(BN(x)): gate it with the activation's sign (recomputed from x as the
+            // BN-backward kernels do, bn.hip fuse_bwd_reduce_flat_body<MASK_X>) and take its share of the BatchNorm-backward sums
+            float g[EPC], xv[EPC];
+            unpack16<T>(u, g);
+            unpack16<T>(xd[k], xv);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                g[e] = (xv[e] * gsc[e] + gsh[e]) > 0.f ? g[e] : 0.f;
+                s1[e] += g[e];
+                s2[e] += g[e] * (xv[e] - gmean[e]) * ginv[e];
+            }
+            u = pack16<T>(g);
+        } else if (stats) {
             float sv[EPC];
             unpack16<T>(u, sv);
 #pragma unroll

@@ -650,7 +650,28 @@ class Plan:
             return
         for dd, pk in zip(descs, packs):
             self._tune([dd], addend=kind, role="dgrad")
-            self._igemm(self.bwd, dd, dy, pk, dx, addend, None, None, what, addend_mask=amask)
+            # (networks with parallel branches: not gated -- their batch groups would not be, and a plan must compute the
+            #  same sums whether its branches run as groups or on stream lanes)
+            gi = self._gate_info.get(id(x)) if (self.bn_gate and first and len(descs) == 1 and self.n_lanes == 1 and self.es == 2) else None
+            cfg = (C.c_int * 5)()
+            if gi is not None and len(self._uses.get(id(x), [])) == 1 and x.c == x.c_valid and x.pixels * x.c * self.es <= self.bn_gate_bytes and \
+                    self.lib.lh_igemm_config(C.byref(dd), self.dt, cfg) == 0 and 2 <= cfg[2] < 10:
+                # x = relu(BN(raw)) with this convolution as its only consumer: the launch stores the ReLU-gated gradient
+                # and the BatchNorm-backward partial sums of its tile (the node's backward skips its reduce pass)
+                rows = self.lib.lh_igemm_stats_rows(C.byref(dd), self.dt)
+                partial = self._alloc(rows * 2 * x.c, dtype=torch.float32)
+                st = gi["st"]
+                gate = _lib.BnBwdGate(gi["raw"].buf.data_ptr(), st["mean"].data_ptr(), st["invstd"].data_ptr(), st["scale"].data_ptr(),
+                                      st["shift"].data_ptr(), partial.data_ptr())
+                self.keep += [dd, gate]
+                c = _Call(self.lib.lh_igemm_gated, (C.byref(dd), _ptr(dy), _ptr(pk), _ptr(dx), _ptr(addend), _ptr(amask), C.byref(gate), self.dt),
+                          what + " + BN-backward gate")
+                c.keep = dd
+                c.ig = dict(src=1, dst=3, addend=4, addend_mask=5)
+                self.bwd.append(c)
+                self._gated[id(x)] = (partial, rows)
+            else:
+                self._igemm(self.bwd, dd, dy, pk, dx, addend, None, None, what, addend_mask=amask)
             yield dd, dd.ntaps
 
     def _patch(self, call, relu=None, **ptrs):
@@ -853,6 +874,12 @@ class Plan:
         self._bn_inputs = consumers_bn
         self._nwrites = {}
         self._masked_addend = {}           # id(activation) -> (dout, relu mask bits) a later data-gradient launch adds
+        # BatchNorm-backward gate (lh_igemm_gated): id(activation a = relu(BN(x))) -> what the data gradient that writes a.grad
+        # needs (recorded by _c_fuse), and id(a) -> (partial sums, rows) once such a launch has been planned (read by the node's
+        # backward, which then skips its reduce pass).  LH_BN_GATE=0: off.
+        self._gate_info, self._gated = {}, {}
+        self.bn_gate = os.environ.get("LH_BN_GATE", "1") != "0"
+        self.bn_gate_bytes = float(os.environ.get("LH_BN_GATE_MAX_MB", "9")) * (1 << 20)
         # consumers of every activation in forward order: (kind, node) -- backward visits them in reverse
         self._uses = {}
         for kind, nd in self.nodes:
@@ -1737,6 +1764,8 @@ class Plan:
         if relu and self.with_bwd and len(terms) > 1:
             relu_bits = self._alloc(out.pixels * c // (16 // self.es), dtype=torch.uint8)
             fd.relu_mask = relu_bits.data_ptr()
+        if self.training and self.with_bwd and relu and len(terms) == 1 and terms[0][1] is not None and terms[0][2] == 0:
+            self._gate_info[id(out)] = dict(raw=terms[0][0], st=bn_state[0])
         self.fwd.append(_Call(self.lib.lh_fuse_fwd, (C.byref(fd), obuf.data_ptr(), out.n, out.h, out.w, c, self.dt), "fuse fwd"))
         self.profile_meta.append(("fwd", self.fwd[-1], "fuse_fwd(all kernels)", 0.0, (sum(a.pixels for a, _, _ in terms) + out.pixels) * c * self.es))
         if not self.with_bwd:
@@ -1749,6 +1778,9 @@ class Plan:
             bd.relu_mask = relu_bits.data_ptr() if relu_bits is not None else None
             bd.nterms, bd.relu = len(terms), int(relu)
             bd.strips_cap = 256 if self._emit_group > 1 else 0      # nodes of a batch group share their launches
+            pre = self._gated.get(id(out))
+            if pre is not None:                                     # dout was written by lh_igemm_gated: gated, with its partial sums
+                bd.pre_partial, bd.pre_rows = pre[0].data_ptr(), pre[1]
             for i, (a, bn, l) in enumerate(terms):
                 bd.log2up[i] = l
                 if not a.needs_grad:

@@ -290,6 +290,39 @@ def test_gradients_well_conditioned_case_at_1e3(tag):
     assert np.median(eh) <= 2 * np.median(ec) + 1e-5
 
 
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_bn_backward_gate_in_the_data_gradient_matches_the_separate_reduce_pass(precision, monkeypatch):
+    """lh_igemm_gated: the data gradient that writes the gradient of a = relu(BN(x)) stores the ReLU-gated gradient and the
+    BatchNorm-backward partial sums of its tiles; the node's backward then runs without its reduce pass (loss.backward()
+    through `out = self.relu(self.bn2(self.conv2(out)))`, pose_resnet.py:60-66).  Same model, same batch, gate on / off:
+    the launches change (gated data gradients appear, as many reduce passes disappear), the whole-model gradient agrees to
+    the rounding of the 16-bit activations gradients (the fp32 partial sums are formed in another order: a few gradients
+    round to the neighbouring 16-bit value)."""
+    from lighthand_amd import _lib
+    from lighthand_amd.heatmap import JointsMSELoss
+    lib = _lib.load()
+    rng = np.random.RandomState(5)
+    x = torch.from_numpy(rng.randn(4, 3, 128, 128).astype(np.float32)).cuda()
+    tgt = torch.from_numpy(rng.rand(4, 21, 32, 32).astype(np.float32)).cuda()
+    grads, gated = {}, {}
+    for gate in ("0", "1"):
+        monkeypatch.setenv("LH_BN_GATE", gate)
+        monkeypatch.setenv("LH_AUTOTUNE", "0")
+        torch.manual_seed(11)
+        model, _ = _build("r50")
+        model.load_state_dict(_trained_like(model.state_dict()))
+        model = model.cuda().set_precision(precision).train()
+        pred = model(x)
+        JointsMSELoss(False)(pred, tgt, None).backward()
+        plan = model.plan(4, 128, 128, training=True, backward=True)
+        gated[gate] = sum(1 for c in plan.bwd if getattr(c, "fn", None) is lib.lh_igemm_gated)
+        grads[gate] = torch.cat([p.grad.flatten().double() for p in model.parameters()]).cpu()
+    assert gated["0"] == 0 and gated["1"] >= 10, gated          # R50: most bn1 / bn2 nodes sit in front of a tiled data gradient
+    err = float((grads["1"] - grads["0"]).norm() / grads["0"].norm())
+    print(f"{precision}: {gated['1']} gated data gradients; whole-model gradient, gate on vs off: rel-L2 {err:.3e}")
+    assert err < 2e-2, err          # measured 5e-4 (bf16), 6e-3 (fp16 without a loss scale: the small gradients sit near its subnormal range)
+
+
 def test_c2_r50_bf16_gradients_vs_fp32_oracle():
     """The timed configuration's arithmetic (R50, bf16 activations / weight packs, fp32 accumulation and fp32 master
     gradients) against the fp32 CPU oracle, whole-model dL/dtheta at batch 8, 128 x 128, on the well-conditioned
