@@ -432,7 +432,7 @@ static int igemm_impl(const lh_igemm_desc* d, const void* in, const void* wpack,
         *prep_cfg = rc_;
         return LH_OK;
     }
-    if (gate && !(ring && rc_.depth >= 2 && rc_.depth < 10 && es == 2)) {
+    if (gate && !(ring && ((rc_.depth >= 2 && rc_.depth < 10) || (rc_.depth >= LH_DENSE_DEPTH && rc_.depth < LH_DENSE_DEPTH + 10)) && es == 2)) {
         lh_set_error("lh_igemm_gated: the launch does not run on a tiled LDS-DMA configuration (ring depth %d)", ring ? rc_.depth : 0);
         return LH_ERR_UNSUPPORTED;
     }

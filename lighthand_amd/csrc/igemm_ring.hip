@@ -17,6 +17,8 @@ int lh_ring_launch_f16_mid(const IgemmArgs& a, const RingCfg& c, hipStream_t s);
 int lh_ring_launch_f16_small(const IgemmArgs& a, const RingCfg& c, hipStream_t s);
 int lh_ring_launch_bf16_wide(const IgemmArgs& a, const RingCfg& c, hipStream_t s);
 int lh_ring_launch_f16_wide(const IgemmArgs& a, const RingCfg& c, hipStream_t s);
+int lh_ring_launch_bf16_dense(const IgemmArgs& a, const RingCfg& c, hipStream_t s);
+int lh_ring_launch_f16_dense(const IgemmArgs& a, const RingCfg& c, hipStream_t s);
 int lh_ring_launch_f32(const IgemmArgs& a, const RingCfg& c, hipStream_t s);
 int lh_ring_multi_launch_bf16(const LhMulti<IgemmArgs>& m, const RingCfg& c, hipStream_t s);
 int lh_ring_multi_launch_f16(const LhMulti<IgemmArgs>& m, const RingCfg& c, hipStream_t s);
@@ -37,6 +39,9 @@ static const RingCfg kCfg16[] = {
 #define X(BM, BP, WC, WP, D, KB) {BM, BP, D + LH_WIDE_DEPTH, KB},
     LH_RING_CFGS_WIDE(X)
 #undef X
+#define X(BM, BP, WC, WP, D, KB) {BM, BP, D + LH_DENSE_DEPTH, KB},
+    LH_RING_CFGS_DENSE(X)
+#undef X
 };
 static const RingCfg kCfg32[] = {
 #define X(BM, BP, WC, WP, D, KB) {BM, BP, D, KB},
@@ -56,9 +61,10 @@ static void cfg_table(int dtype, const RingCfg** t, int* n) {
     else { *t = kCfg16; *n = (int)(sizeof(kCfg16) / sizeof(RingCfg)); }
 }
 
-// ring depth of a tiled configuration (the wide-wave form carries it as depth + LH_WIDE_DEPTH)
-static inline int ring_depth(const RingCfg& c) { return c.depth >= LH_WIDE_DEPTH && c.depth < 100 ? c.depth - LH_WIDE_DEPTH : c.depth; }
-static inline bool ring_wide(const RingCfg& c) { return c.depth >= LH_WIDE_DEPTH && c.depth < 100; }
+// ring depth of a tiled configuration (the wide-wave form carries it as depth + LH_WIDE_DEPTH, the dense-wave forms as depth + LH_DENSE_DEPTH)
+static inline int ring_depth(const RingCfg& c) { return c.depth >= 100 ? c.depth : c.depth % 10 == 0 ? 10 : c.depth % 10; }
+static inline bool ring_wide(const RingCfg& c) { return c.depth >= LH_WIDE_DEPTH && c.depth < LH_DENSE_DEPTH; }
+static inline bool ring_dense(const RingCfg& c) { return c.depth >= LH_DENSE_DEPTH && c.depth < LH_DENSE_DEPTH + 10; }
 
 static bool cfg_exists(int dtype, const RingCfg& c) {
     const RingCfg* t; int n;
@@ -117,6 +123,13 @@ static bool cfg_fits(const lh_igemm_desc* d, int dtype, const RingCfg& c) {
     // the wide-wave tile pays for 256 x 256 of prologue / epilogue with one wave per SIMD: large launches only.  Measured 20-25 %
     // SLOWER than the 8-wave form on every launch of C5 / C2 (profiles/r04_c5_deconv_what_holds_the_pipe.txt), so the tuner is
     // not offered it unless LH_WIDE_TILES=1 (tests, experiments); an explicit cfg still runs it.
+    // dense-wave forms: for launches that leave a CU with at most two workgroups of the tile (LH_DENSE_TILES=0: not offered)
+    if (ring_dense(c)) {
+        const char* sw = getenv("LH_DENSE_TILES");
+        if (sw && atoi(sw) == 0) return false;
+        const long wgs = ((M + c.bp - 1) / c.bp) * ((d->cout + c.bm - 1) / c.bm);
+        if (wgs > 512) return false;
+    }
     if (ring_wide(c)) {
         const char* sw = getenv("LH_WIDE_TILES");                 // read per query (host side, planning time only)
         const bool offer = sw && atoi(sw) != 0;
@@ -346,12 +359,14 @@ int lh_igemm_ring_launch(const IgemmArgs& a0, const RingCfg& c, int dtype, hipSt
             if (rc == 1) rc = lh_ring_launch_bf16_mid(a, c, s);
             if (rc == 1) rc = lh_ring_launch_bf16_small(a, c, s);
             if (rc == 1) rc = lh_ring_launch_bf16_wide(a, c, s);
+            if (rc == 1) rc = lh_ring_launch_bf16_dense(a, c, s);
             break;
         case LH_F16:
             rc = lh_ring_launch_f16_big(a, c, s);
             if (rc == 1) rc = lh_ring_launch_f16_mid(a, c, s);
             if (rc == 1) rc = lh_ring_launch_f16_small(a, c, s);
             if (rc == 1) rc = lh_ring_launch_f16_wide(a, c, s);
+            if (rc == 1) rc = lh_ring_launch_f16_dense(a, c, s);
             break;
         case LH_F32:
             rc = lh_ring_launch_f32(a, c, s);

@@ -655,7 +655,7 @@ class Plan:
             gi = self._gate_info.get(id(x)) if (self.bn_gate and first and len(descs) == 1 and self.n_lanes == 1 and self.es == 2) else None
             cfg = (C.c_int * 5)()
             if gi is not None and len(self._uses.get(id(x), [])) == 1 and x.c == x.c_valid and x.pixels * x.c * self.es <= self.bn_gate_bytes and \
-                    self.lib.lh_igemm_config(C.byref(dd), self.dt, cfg) == 0 and 2 <= cfg[2] < 10:
+                    self.lib.lh_igemm_config(C.byref(dd), self.dt, cfg) == 0 and (2 <= cfg[2] < 10 or 20 <= cfg[2] < 30):
                 # x = relu(BN(raw)) with this convolution as its only consumer: the launch stores the ReLU-gated gradient
                 # and the BatchNorm-backward partial sums of its tile (the node's backward skips its reduce pass)
                 rows = self.lib.lh_igemm_stats_rows(C.byref(dd), self.dt)
@@ -734,7 +734,10 @@ class Plan:
             if depth == 100:
                 return f"conv3x3_direct_kernel<{t}, {kb}, {'true' if stats else 'false'}>"
             wc, wp = {(256, 256): (2, 4), (128, 256): (2, 2), (128, 128): (2, 2), (128, 64): (4, 1), (64, 128): (1, 4), (64, 64): (2, 2)}[(bm, bp)]
-            if 10 <= depth < 100:               # the wide-wave form of the 256 x 256 tile (four waves, igemm_ring_cfgs.h)
+            if 20 <= depth < 30:                # the dense-wave forms (eight waves on the 4-wave tiles, igemm_ring_cfgs.h)
+                wc, wp = {(128, 128): (2, 4), (128, 64): (4, 2), (64, 128): (2, 4), (64, 64): (2, 4)}[(bm, bp)]
+                depth -= 20
+            elif 10 <= depth < 20:              # the wide-wave form of the 256 x 256 tile (four waves)
                 wc, wp, depth = 2, 2, depth - 10
             if depth:
                 return f"igemm_ring_kernel<{t}, {bm}, {bp}, {wc}, {wp}, {depth}, {kb}>"
@@ -1157,7 +1160,7 @@ class Plan:
                 n = self.lib.lh_igemm_candidates(C.byref(d), self.dt, buf, 64)
                 c = {tuple(buf[5 * i:5 * i + 4]) for i in range(n)}
                 common = c if common is None else common & c
-            cands = sorted(c + (0,) for c in (common or ()) if 2 <= c[2] < 100 and (c[0], c[1]) in self._MULTI_TILES)
+            cands = sorted(c + (0,) for c in (common or ()) if 2 <= c[2] < 10 and (c[0], c[1]) in self._MULTI_TILES)      # 4-wave tiled forms (the multi-problem kernels)
             # MIXED launches (igemm_mixed_kernel.h; experiment, LH_MIXED=1): the members the direct 3x3 kernel takes (C = 32 / 64
             # per tap: HRNet's two high-resolution branches) run its body inside the merged grid, the others the 64 x 128 ring
             # tile -- whose stage size the 64-byte K run of the 32-channel member no longer dictates.  Candidate = (tile
