@@ -431,12 +431,22 @@ def test_hrnet_branch_batching_is_bit_exact_and_cuts_launches(monkeypatch):
     out_l, g_l = run(lanes, (lanes.fwd, lanes.bwd))
     assert torch.equal(out_s, out_l) and torch.equal(g_s, g_l)
     # measured vs static kernel choice: two equally valid bf16 evaluations (different tiles -> different BN partial-sum rows
-    # -> last-bit differences of the statistics and of bf16 roundings downstream); on well-conditioned weights they stay
-    # at the bf16 level
+    # -> last-bit differences of the statistics and of bf16 roundings downstream).  The heat-maps stay at the bf16 level;
+    # the GRADIENT of this network in bf16 does not: a last-bit difference in the forward pass moves the early layers'
+    # gradients by tens of percent (both plans sit 0.29 from the fp32 plan's gradient, and 0.2 from each other as soon as
+    # their tiles differ; round 4, DESIGN.md section 4 -- which is why C4 is timed in fp16).  What a kernel choice must NOT
+    # do is move the plan further from the fp32 gradient than the static choice is.
     assert rel(out_m.cpu().numpy(), out_l.cpu().numpy()) < 3e-2
+    model.set_precision("fp32")
+    model._lh_plans.clear()
+    ref = model.plan(b, h, w, training=True, backward=True)
+    _, g_f = run(ref, (ref.fwd, ref.bwd))
+    e_m = float((g_m.double() - g_f.double()).norm() / g_f.double().norm())
+    e_l = float((g_l.double() - g_f.double()).norm() / g_f.double().norm())
     d = (g_m - g_l).double()
-    print("measured vs static kernel choice: heat-maps", rel(out_m.cpu().numpy(), out_l.cpu().numpy()), "gradients", float(d.norm() / g_l.double().norm()))
-    assert float(d.norm() / g_l.double().norm()) < 5e-2
+    print("measured vs static kernel choice: heat-maps", rel(out_m.cpu().numpy(), out_l.cpu().numpy()), "gradients", float(d.norm() / g_l.double().norm()),
+          f"; bf16 gradient vs the fp32 plan: measured {e_m:.3f}, static {e_l:.3f}")
+    assert e_m < 1.1 * e_l + 0.01, (e_m, e_l)
 
 
 @pytest.mark.parametrize("precision", ["bf16", "fp16"])

@@ -72,6 +72,26 @@ if os.environ.get("LH_SWEEP_SET") == "c5":      # BASELINE.json configs[4]: R50 
         ("c5 deconv1 256->256 @24", 256, 256, 4, 2, B, 24, 24, 1),
         ("c5 deconv2 256->256 @48", 256, 256, 4, 2, B, 48, 48, 1),
     ]
+if os.environ.get("LH_SWEEP_SET") == "hrsmall":  # HRNet-W32 at the size of tests/test_gpu_model.py (batch 4, 128 x 96): ragged tiles, tiny K
+    B = 4
+    SHAPES = [
+        ("stem conv2 3x3s2 64 @64x48", 64, 64, 3, 2, B, 64, 48, 0),
+        ("transition1.0 3x3 256->32 @32x24", 256, 32, 3, 1, B, 32, 24, 0),
+        ("transition1.1 3x3s2 256->64 @32x24", 256, 64, 3, 2, B, 32, 24, 0),
+        ("fuse 3x3s2 32->64 @32x24", 32, 64, 3, 2, B, 32, 24, 0),
+        ("fuse 3x3s2 32->32 @32x24", 32, 32, 3, 2, B, 32, 24, 0),
+        ("fuse 3x3s2 64->128 @16x12", 64, 128, 3, 2, B, 16, 12, 0),
+        ("fuse 3x3s2 128->256 @8x6", 128, 256, 3, 2, B, 8, 6, 0),
+        ("transition3 3x3s2 128->256 @8x6", 128, 256, 3, 2, B, 8, 6, 0),
+        ("b0 3x3 32 @32x24", 32, 32, 3, 1, B, 32, 24, 0),
+        ("b1 3x3 64 @16x12", 64, 64, 3, 1, B, 16, 12, 0),
+        ("b2 3x3 128 @8x6", 128, 128, 3, 1, B, 8, 6, 0),
+        ("b3 3x3 256 @4x3", 256, 256, 3, 1, B, 4, 3, 0),
+        ("fuse 1x1 64->32 @16x12", 64, 32, 1, 1, B, 16, 12, 0),
+        ("fuse 1x1 256->32 @4x3", 256, 32, 1, 1, B, 4, 3, 0),
+        ("layer1 1x1 64->256 @32x24", 64, 256, 1, 1, B, 32, 24, 0),
+        ("layer1 3x3 64 @32x24", 64, 64, 3, 1, B, 32, 24, 0),
+    ]
 NBEST = int(os.environ.get("LH_SWEEP_NBEST", "4"))
 
 
