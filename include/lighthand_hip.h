@@ -364,6 +364,14 @@ int lh_maxpool3x3s2_fwd(const void* x, void* out, unsigned char* idx, int n, int
                         int dtype, void* stream);
 int lh_maxpool3x3s2_bwd(const void* dout, const unsigned char* idx, void* dx, int n, int h, int w,
                         int c, int dtype, void* stream);
+/* maxpool(relu(bn(x))) of the training stem (pose_resnet.py:153-156: bn1, relu, maxpool) as ONE pass: x is the RAW BatchNorm
+ * input, scale / shift the training-mode affine lh_bn_finalize derived from the batch statistics; every tap is
+ * relu(x * scale + shift) rounded to the run precision -- the value lh_fuse_fwd would have stored -- so out and idx are
+ * bit-identical to lh_fuse_fwd followed by lh_maxpool3x3s2_fwd, and the activation between them (the largest of the
+ * network) is never written: the backward pass does not need it (lh_maxpool3x3s2_bwd works from idx, lh_fuse_bwd
+ * recomputes the ReLU mask from x). */
+int lh_bn_relu_maxpool3x3s2_fwd(const void* x, const float* scale, const float* shift, void* out, unsigned char* idx, int n,
+                                int h, int w, int c, int dtype, void* stream);
 
 /* ------------------------------------------------------------------ heatmap target / loss / decode */
 /* CustomDataset.generate_target: src/tools/dataset.py:165-212.  joints fp32 [b][j][jstride]

@@ -1641,9 +1641,12 @@ extern "C" int lh_fuse_bwd_multi(const lh_fuse_bwd_call* calls, int n, int dtype
 }
 
 // ------------------------------------------------------------------------------------------------
-template <typename T>
+// BN = true: x is the RAW BatchNorm input and every tap becomes relu(x * scale + shift), rounded to T as lh_fuse_fwd would
+// have stored it, before it enters the maximum (lh_bn_relu_maxpool3x3s2_fwd: the activation between the BatchNorm and the
+// pool is never written).
+template <typename T, bool BN>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* x, T* out, unsigned char* idx, int n, int h, int w,
-                                                          int c, int ho, int wo) {
+                                                          int c, int ho, int wo, const float* scale, const float* shift) {
     constexpr int EPC = 16 / sizeof(T);
     const int nchunk = c / EPC;
     const long total = (long)n * ho * wo * nchunk;
@@ -1671,11 +1674,18 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* x, T* out, un
         float best[EPC];
         unsigned char bi[EPC];
         bool any = false;
+        float sc[EPC], sh[EPC];
+        if constexpr (BN) { load_vec<EPC>(scale + ch * EPC, sc); load_vec<EPC>(shift + ch * EPC, sh); }
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             if (!ok[t]) continue;
             float v[EPC];
             unpack16<T>(raw[t], v);
+            if constexpr (BN) {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) v[e] = fmaxf(v[e] * sc[e] + sh[e], 0.f);
+                unpack16<T>(pack16<T>(v), v);        // the rounding of the stored activation
+            }
             if (!any) {                              // first tap inside the image (scan order)
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) { best[e] = v[e]; bi[e] = (unsigned char)t; }
@@ -1756,9 +1766,24 @@ extern "C" int lh_maxpool3x3s2_fwd(const void* x, void* out, unsigned char* idx,
     const long total = (long)n * ho * wo * (c / (16 / es));
     LH_REQUIRE((long)n * h * w * (c / (16 / es)) < (1L << 31), "lh_maxpool3x3s2_fwd: tensor too large for 32-bit chunk indices");
     const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
-    LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((maxpool_fwd_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                                                   (const T*)x, (T*)out, idx, n, h, w, c, ho, wo));
+    LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((maxpool_fwd_kernel<T, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                                                   (const T*)x, (T*)out, idx, n, h, w, c, ho, wo, nullptr, nullptr));
     LH_LAUNCH_CHECK("maxpool_fwd launch");
+    return LH_OK;
+}
+
+extern "C" int lh_bn_relu_maxpool3x3s2_fwd(const void* x, const float* scale, const float* shift, void* out, unsigned char* idx, int n,
+                                           int h, int w, int c, int dtype, void* stream) {
+    LH_REQUIRE(x && scale && shift && out && n > 0 && h > 0 && w > 0, "lh_bn_relu_maxpool3x3s2_fwd: bad arguments");
+    const int es = lh_dtype_size(dtype);
+    LH_REQUIRE(es > 0 && c % (16 / es) == 0, "lh_bn_relu_maxpool3x3s2_fwd: c %d not a multiple of the 16-byte chunk", c);
+    const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
+    const long total = (long)n * ho * wo * (c / (16 / es));
+    LH_REQUIRE((long)n * h * w * (c / (16 / es)) < (1L << 31), "lh_bn_relu_maxpool3x3s2_fwd: tensor too large for 32-bit chunk indices");
+    const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((maxpool_fwd_kernel<T, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                                                   (const T*)x, (T*)out, idx, n, h, w, c, ho, wo, scale, shift));
+    LH_LAUNCH_CHECK("bn_relu_maxpool_fwd launch");
     return LH_OK;
 }
 

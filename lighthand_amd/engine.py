@@ -881,6 +881,7 @@ class Plan:
         # needs (recorded by _c_fuse), and id(a) -> (partial sums, rows) once such a launch has been planned (read by the node's
         # backward, which then skips its reduce pass).  LH_BN_GATE=0: off.
         self._gate_info, self._gated = {}, {}
+        self._bnrelu_info = {}             # id(a = relu(BN(x))) -> its lh_fuse_fwd call and BN state (training plans; _c_maxpool)
         self.bn_gate = os.environ.get("LH_BN_GATE", "1") != "0"
         self.bn_gate_bytes = float(os.environ.get("LH_BN_GATE_MAX_MB", "9")) * (1 << 20)
         # consumers of every activation in forward order: (kind, node) -- backward visits them in reverse
@@ -1770,6 +1771,9 @@ class Plan:
         if self.training and self.with_bwd and relu and len(terms) == 1 and terms[0][1] is not None and terms[0][2] == 0:
             self._gate_info[id(out)] = dict(raw=terms[0][0], st=bn_state[0])
         self.fwd.append(_Call(self.lib.lh_fuse_fwd, (C.byref(fd), obuf.data_ptr(), out.n, out.h, out.w, c, self.dt), "fuse fwd"))
+        if self.training and relu and len(terms) == 1 and terms[0][1] is not None and terms[0][2] == 0 and relu_bits is None:
+            # what a max-pool that follows needs to take this node's elementwise pass over (_c_maxpool)
+            self._bnrelu_info[id(out)] = dict(raw=terms[0][0], st=bn_state[0], call=self.fwd[-1], fin=fd.fin[0])
         self.profile_meta.append(("fwd", self.fwd[-1], "fuse_fwd(all kernels)", 0.0, (sum(a.pixels for a, _, _ in terms) + out.pixels) * c * self.es))
         if not self.with_bwd:
             return
@@ -1905,7 +1909,26 @@ class Plan:
             return
         xbuf, ybuf = self._act_buf(x), self._act_buf(y)
         idx = self._alloc(y.n, y.h, y.w, y.c, dtype=torch.uint8) if self.with_bwd else None     # window positions: only the backward pass reads them
-        self.fwd.append(_Call(self.lib.lh_maxpool3x3s2_fwd, (xbuf.data_ptr(), ybuf.data_ptr(), _ptr(idx), x.n, x.h, x.w, x.c, self.dt), "maxpool fwd"))
+        bi = self._bnrelu_info.get(id(x)) if os.environ.get("LH_BN_POOL", "1") != "0" else None
+        nchunk = x.c * self.es // 16
+        if bi is not None and len(self._uses.get(id(x), [])) == 1 and self.fwd and self.fwd[-1] is bi["call"] and x.c == x.c_valid \
+                and nchunk & (nchunk - 1) == 0 and nchunk <= 256:            # (the flat BN-backward kernels: they take the mask from raw)
+            # x = relu(BN(raw)) feeds this pool alone (the training stem, pose_resnet.py:153-156): the pool reads RAW, applies the
+            # BatchNorm affine + ReLU per tap (rounded as the stored activation would be: bit-identical pooled values and
+            # positions) and x -- the largest activation of the network -- is never written: the backward pass works from
+            # idx (pool) and recomputes the ReLU mask from raw (lh_fuse_bwd), it never reads x
+            self.fwd.pop()
+            self.profile_meta = [m for m in self.profile_meta if m[1] is not bi["call"]]
+            st = bi["st"]
+            if bi["fin"]:                                           # the finalize that travelled with the elementwise call: a launch of its own
+                arr = (_lib.BnFinalizeCall * 1)(bi["fin"].contents)
+                self.keep.append(arr)
+                self.fwd.append(_Call(self.lib.lh_bn_finalize_multi, (arr, 1), "bn finalize"))
+            self.fwd.append(_Call(self.lib.lh_bn_relu_maxpool3x3s2_fwd, (bi["raw"].buf.data_ptr(), st["scale"].data_ptr(), st["shift"].data_ptr(),
+                                                                          ybuf.data_ptr(), _ptr(idx), x.n, x.h, x.w, x.c, self.dt), "bn + relu + maxpool fwd"))
+            self.profile_meta.append(("fwd", self.fwd[-1], "maxpool_fwd_kernel(bn)", 0.0, (x.pixels * x.c + y.pixels * y.c) * self.es))
+        else:
+            self.fwd.append(_Call(self.lib.lh_maxpool3x3s2_fwd, (xbuf.data_ptr(), ybuf.data_ptr(), _ptr(idx), x.n, x.h, x.w, x.c, self.dt), "maxpool fwd"))
         if not self.with_bwd:
             return
 

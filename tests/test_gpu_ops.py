@@ -465,6 +465,40 @@ def test_maxpool_ties_route_to_first():
     assert torch.equal(dx.permute(0, 3, 1, 2).cpu(), xr.grad)
 
 
+@pytest.mark.parametrize("shape", [(3, 64, 34, 30), (2, 128, 17, 23), (1, 64, 8, 8)])
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_bn_relu_pool_as_one_pass_matches_the_two_launches(shape, dtype):
+    """lh_bn_relu_maxpool3x3s2_fwd -- maxpool(relu(bn(x))) of the training stem as one pass over the RAW BatchNorm input
+    (pose_resnet.py:153-156): pooled values AND window positions equal lh_fuse_fwd's stored activation (mul, add, max in
+    fp32, one rounding) followed by lh_maxpool3x3s2_fwd, bit for bit, on ragged sizes with ties (post-ReLU zeros); the plain
+    pool agrees with PyTorch's, NaNs included."""
+    from lighthand_amd import _lib
+    lib = _lib.load()
+    n, c, h, w = shape
+    td = {"bf16": torch.bfloat16, "fp16": torch.float16}[dtype]
+    dt = {"bf16": _lib.LH_BF16, "fp16": _lib.LH_F16}[dtype]
+    torch.manual_seed(4)
+    raw = torch.randn(n, h, w, c).to(td).cuda()
+    scale = (0.5 + torch.rand(c)).cuda()
+    shift = (0.3 * torch.randn(c)).cuda()
+    v = raw.float() * scale + shift
+    act = torch.where(v > 0, v, torch.zeros_like(v)).to(td)               # what lh_fuse_fwd stores
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    s = torch.cuda.current_stream().cuda_stream
+    out, idx = torch.empty(n, ho, wo, c, dtype=td, device="cuda"), torch.empty(n, ho, wo, c, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.lh_maxpool3x3s2_fwd(act.data_ptr(), out.data_ptr(), idx.data_ptr(), n, h, w, c, dt, s))
+    out2, idx2 = torch.empty_like(out), torch.empty_like(idx)
+    _lib.check(lib.lh_bn_relu_maxpool3x3s2_fwd(raw.data_ptr(), scale.data_ptr(), shift.data_ptr(), out2.data_ptr(), idx2.data_ptr(), n, h, w, c, dt, s))
+    act_nan = act.clone()
+    act_nan[0, 3, 5, :7] = float("nan")
+    out3, idx3 = torch.empty_like(out), torch.empty_like(idx)
+    _lib.check(lib.lh_maxpool3x3s2_fwd(act_nan.data_ptr(), out3.data_ptr(), idx3.data_ptr(), n, h, w, c, dt, s))
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2) and torch.equal(idx, idx2)
+    ref = F.max_pool2d(act_nan.float().permute(0, 3, 1, 2).cpu(), 3, 2, 1).permute(0, 2, 3, 1)
+    assert torch.equal(torch.nan_to_num(out3.float().cpu(), nan=-7.0), torch.nan_to_num(ref, nan=-7.0))
+
+
 def test_gaussian_target_matches_oracle_and_golden(golden_dir):
     from lighthand_amd.heatmap import render_targets, generate_target
     from oracle.heatmap import generate_target as oracle_target
