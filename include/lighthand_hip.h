@@ -358,6 +358,15 @@ int lh_fuse_bwd_multi(const lh_fuse_bwd_call* calls, int n, int dtype, void* str
 int lh_stem_pool(const void* img, int n, int hp, int wp, const void* wpack, const float* bias, const float* scale,
                  const float* shift, void* out, int conv_h, int conv_w, int relu, int dtype, void* stream);
 
+/* The TRAINING stem: conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False) alone (pose_resnet.py:151-152; bn1 runs on batch statistics),
+ * same operands as lh_stem_pool (padded NHWC4 image, the stem's weight pack), on the same direct kernel form: out =
+ * [n][conv_h][conv_w][64] raw convolution output (bit-identical to lh_igemm on that pack), stats = fp32
+ * [lh_stem_conv_rows(n, conv_h, conv_w)][2][64] per-workgroup sums / sums of squares of the stored values for lh_bn_finalize.
+ * 16-bit types. */
+int lh_stem_conv_rows(int n, int conv_h, int conv_w);
+int lh_stem_conv(const void* img, int n, int hp, int wp, const void* wpack, void* out, float* stats, int conv_h, int conv_w,
+                 int dtype, void* stream);
+
 /* nn.MaxPool2d(3, 2, 1): pose_resnet.py:156.  idx (uint8 [n][ho][wo][c]) keeps the window
  * position (first maximum in scan order, NaN propagates) for the backward pass; NULL when no backward pass follows. */
 int lh_maxpool3x3s2_fwd(const void* x, void* out, unsigned char* idx, int n, int h, int w, int c,

@@ -136,6 +136,8 @@ SIGNATURES = {
     "lh_fuse_bwd_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
     "lh_fuse_bwd": (_I, [C.POINTER(FuseBwdDesc), _I, _I, _I, _I, _P, _I, _P]),
     "lh_stem_pool": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "lh_stem_conv_rows": (_I, [_I, _I, _I]),
+    "lh_stem_conv": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _P]),
     "lh_maxpool3x3s2_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "lh_maxpool3x3s2_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "lh_bn_relu_maxpool3x3s2_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

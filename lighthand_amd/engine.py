@@ -1590,13 +1590,28 @@ class Plan:
         d = _desc(x.n, hp, wp, 4, kr, y.h, y.w, s, s, y.c, y.h, y.w, 1, 1, 0, 0, y.c, rows)
         ybuf = self._act_buf(y)
         stats_ptr = None
-        self._tune([d], with_stats=id(y) in self._bn_inputs and self.training)
-        if id(y) in self._bn_inputs and self.training:
-            self._stats_for(y, [d])
-            stats_ptr = y.stats
         flops = 2.0 * y.pixels * cout * 3 * k * k
-        self._igemm(self.fwd, d, img, pack, ybuf, None, bias, stats_ptr, nd["w"] + " stem fwd", produces=y)
-        self.profile_meta.append(("fwd", self.fwd[-1], self._kname(d), flops, (x.pixels * 4 + y.pixels * y.c) * self.es))
+        direct = (self.training and id(y) in self._bn_inputs and self.es == 2 and (k, s, p, cout, y.c) == (7, 2, 3, 64, 64) and bias is None
+                  and os.environ.get("LH_STEM_DIRECT", "1") != "0")
+        if direct:
+            # training stem (pose_resnet.py:151-152) on the direct kernel: weights in registers, a tile's input patch in LDS,
+            # raw convolution output + one statistics row per workgroup (stem_pool.hip, lh_stem_conv)
+            rows_ = self.lib.lh_stem_conv_rows(x.n, y.h, y.w)
+            y.stats = self._alloc((self.lib.lh_bn_stats_slab_bytes(rows_, y.c) + 3) // 4, dtype=torch.float32)
+            y.stats_rows = rows_
+            self.keep.append(d)
+            c_ = _Call(self.lib.lh_stem_conv, (img.data_ptr(), x.n, hp, wp, pack.data_ptr(), ybuf.data_ptr(), y.stats.data_ptr(), y.h, y.w, self.dt),
+                       nd["w"] + " stem fwd (direct)")
+            self.fwd.append(c_)
+            self._producers.setdefault(id(y), []).append(c_)
+            self.profile_meta.append(("fwd", self.fwd[-1], "stem_conv_kernel", flops, (x.pixels * 4 + y.pixels * y.c) * self.es))
+        else:
+            self._tune([d], with_stats=id(y) in self._bn_inputs and self.training)
+            if id(y) in self._bn_inputs and self.training:
+                self._stats_for(y, [d])
+                stats_ptr = y.stats
+            self._igemm(self.fwd, d, img, pack, ybuf, None, bias, stats_ptr, nd["w"] + " stem fwd", produces=y)
+            self.profile_meta.append(("fwd", self.fwd[-1], self._kname(d), flops, (x.pixels * 4 + y.pixels * y.c) * self.es))
         if not self.with_bwd:
             return
         # 16-bit runs: all k kernel rows in ONE pass (lh_wgrad_rowfold: dy is read once per input tile, not once per row);

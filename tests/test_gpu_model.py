@@ -291,6 +291,42 @@ def test_gradients_well_conditioned_case_at_1e3(tag):
 
 
 @pytest.mark.parametrize("precision", ["bf16", "fp16"])
+@pytest.mark.parametrize("shape", [(3, 72, 104), (2, 256, 256)])
+def test_direct_training_stem_matches_the_tiled_kernel(precision, shape, monkeypatch):
+    """lh_stem_conv -- conv1 of a training plan on the direct kernel (weights in registers, input patch in LDS; pose_resnet.py:
+    151-152) -- writes the convolution output of the tiled kernel BIT FOR BIT (ragged tiles included) and statistics rows
+    whose totals are its column sums; the first training-mode heat-maps agree to the rounding the statistics' summation
+    order allows."""
+    from lighthand_amd import _lib
+    lib = _lib.load()
+    b, h, w = shape
+    rng = np.random.RandomState(8)
+    x = torch.from_numpy(rng.randn(b, 3, h, w).astype(np.float32)).cuda()
+    got = {}
+    for direct in ("0", "1"):
+        monkeypatch.setenv("LH_STEM_DIRECT", direct)
+        monkeypatch.setenv("LH_AUTOTUNE", "0")
+        torch.manual_seed(11)
+        model, _ = _build("r18")
+        model = model.cuda().set_precision(precision).train()
+        plan = model.plan(b, h, w, training=True, backward=True)            # (a plan with a backward pass keeps every activation)
+        n_direct = sum(1 for c in plan.fwd if getattr(c, "fn", None) is lib.lh_stem_conv)
+        assert n_direct == int(direct)
+        out = plan.forward(x).detach().clone()
+        torch.cuda.synchronize()
+        stem = [nd for kind, nd in plan.nodes if kind == "conv"][0]["y"]                 # conv1: the first convolution of the graph
+        rows = stem.stats_rows
+        st = stem.stats[:rows * 2 * 64].view(rows, 2, 64).double().sum(0)
+        got[direct] = (stem.buf.clone(), st.clone(), out)
+    assert torch.equal(got["0"][0], got["1"][0])
+    conv = got["1"][0].double()
+    want = torch.stack([conv.reshape(-1, 64).sum(0), (conv * conv).reshape(-1, 64).sum(0)])
+    assert torch.allclose(got["1"][1], want, rtol=1e-5, atol=1e-3), float((got["1"][1] - want).abs().max())
+    assert torch.allclose(got["0"][1], got["1"][1], rtol=1e-5, atol=1e-3)
+    assert rel(got["0"][2].cpu().numpy(), got["1"][2].cpu().numpy()) < 2e-2
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
 def test_bn_backward_gate_in_the_data_gradient_matches_the_separate_reduce_pass(precision, monkeypatch):
     """lh_igemm_gated: the data gradient that writes the gradient of a = relu(BN(x)) stores the ReLU-gated gradient and the
     BatchNorm-backward partial sums of its tiles; the node's backward then runs without its reduce pass (loss.backward()
