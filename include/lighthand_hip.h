@@ -373,6 +373,12 @@ int lh_maxpool3x3s2_fwd(const void* x, void* out, unsigned char* idx, int n, int
                         int dtype, void* stream);
 int lh_maxpool3x3s2_bwd(const void* dout, const unsigned char* idx, void* dx, int n, int h, int w,
                         int c, int dtype, void* stream);
+/* lh_maxpool3x3s2_bwd whose output dx is the gradient of a = relu(BN(gate->x)) (the training stem: the pool follows bn1 + relu):
+ * stores the ReLU-gated gradient and one row of BatchNorm-backward partial sums per workgroup (gate->partial: fp32
+ * [lh_maxpool3x3s2_bwd_gated_rows][2][c]), for lh_fuse_bwd's pre_partial -- see lh_igemm_gated.  16-bit types. */
+int lh_maxpool3x3s2_bwd_gated_rows(int n, int h, int w, int c, int dtype);
+int lh_maxpool3x3s2_bwd_gated(const void* dout, const unsigned char* idx, void* dx, const lh_bn_bwd_gate* gate, int n, int h, int w,
+                              int c, int dtype, void* stream);
 /* maxpool(relu(bn(x))) of the training stem (pose_resnet.py:153-156: bn1, relu, maxpool) as ONE pass: x is the RAW BatchNorm
  * input, scale / shift the training-mode affine lh_bn_finalize derived from the batch statistics; every tap is
  * relu(x * scale + shift) rounded to the run precision -- the value lh_fuse_fwd would have stored -- so out and idx are

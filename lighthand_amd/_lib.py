@@ -141,6 +141,8 @@ SIGNATURES = {
     "lh_maxpool3x3s2_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "lh_maxpool3x3s2_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "lh_bn_relu_maxpool3x3s2_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "lh_maxpool3x3s2_bwd_gated_rows": (_I, [_I, _I, _I, _I, _I]),
+    "lh_maxpool3x3s2_bwd_gated": (_I, [_P, _P, _P, C.POINTER(BnBwdGate), _I, _I, _I, _I, _I, _P]),
     "lh_gaussian_target": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _P]),
     "lh_gaussian_target_alt": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _P]),
     "lh_mse_workspace_bytes": (_SZ, [_L]),

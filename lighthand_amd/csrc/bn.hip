@@ -1711,12 +1711,31 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* x, T* out, un
     }
 }
 
-template <typename T>
+// GATE = true (lh_maxpool3x3s2_bwd_gated): dx is the gradient of a = relu(BN(gx)); the pass stores the ReLU-gated gradient
+// and writes the BatchNorm-backward partial sums { sum g, sum g * xhat } of its elements, one row per workgroup (what
+// lh_igemm_gated does for a data gradient): lh_fuse_bwd then runs without its reduce pass.  Needs a power-of-two number of
+// 16-byte chunks per pixel <= 256 (a thread keeps its chunk over the grid-stride loop).
+struct PoolGate {
+    const unsigned char* x;
+    const float* mean;
+    const float* invstd;
+    const float* scale;
+    const float* shift;
+    float* partial;
+};
+template <typename T, bool GATE>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* dout, const unsigned char* idx, T* dx, int n, int h,
-                                                          int w, int c, int ho, int wo) {
+                                                          int w, int c, int ho, int wo, const PoolGate gt) {
     constexpr int EPC = 16 / sizeof(T);
     const int nchunk = c / EPC;
     const long total = (long)n * h * w * nchunk;
+    float gmean[EPC], ginv[EPC], gsc[EPC], gsh[EPC], s1[EPC], s2[EPC];
+    if constexpr (GATE) {
+        const int chunk = threadIdx.x & (nchunk - 1);
+        load_vec<EPC>(gt.mean + chunk * EPC, gmean); load_vec<EPC>(gt.invstd + chunk * EPC, ginv);
+        load_vec<EPC>(gt.scale + chunk * EPC, gsc); load_vec<EPC>(gt.shift + chunk * EPC, gsh);
+        fill_vec<EPC>(s1, 0.f); fill_vec<EPC>(s2, 0.f);
+    }
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const unsigned iu = (unsigned)i;             // 32-bit index arithmetic (total < 2^31, checked by the launcher)
         const unsigned pix = iu / (unsigned)nchunk;
@@ -1753,7 +1772,32 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* dout, const u
             for (int e = 0; e < EPC; ++e)
                 if (((pk[k][e >> 2] >> (8 * (e & 3))) & 0xffu) == (unsigned)code[k]) g[e] += d[e];
         }
+        if constexpr (GATE) {
+            float xv[EPC];
+            unpack16<T>(*reinterpret_cast<const uint4*>(gt.x + i * 16), xv);
+            unpack16<T>(pack16<T>(g), g);            // the gradient as the ungated pass stores it
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                g[e] = (xv[e] * gsc[e] + gsh[e]) > 0.f ? g[e] : 0.f;
+                s1[e] += g[e];
+                s2[e] += g[e] * (xv[e] - gmean[e]) * ginv[e];
+            }
+        }
         *reinterpret_cast<uint4*>(dx + i * EPC) = pack16<T>(g);
+    }
+    if constexpr (GATE) {
+        __shared__ float red[256 * EPC * 2];
+        const int lanes = 256 / nchunk, chunk = threadIdx.x & (nchunk - 1), rl = threadIdx.x / nchunk;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) { red[((rl * nchunk + chunk) * EPC + e) * 2] = s1[e]; red[((rl * nchunk + chunk) * EPC + e) * 2 + 1] = s2[e]; }
+        __syncthreads();
+        float* row = gt.partial + (long)blockIdx.x * 2 * c;
+        for (int t = threadIdx.x; t < c; t += 256) {
+            float a = 0.f, b = 0.f;
+            for (int k = 0; k < lanes; ++k) { a += red[((k * nchunk) * EPC + t) * 2]; b += red[((k * nchunk) * EPC + t) * 2 + 1]; }
+            row[t] = a;
+            row[c + t] = b;
+        }
     }
 }
 
@@ -1796,8 +1840,36 @@ extern "C" int lh_maxpool3x3s2_bwd(const void* dout, const unsigned char* idx, v
     const long total = (long)n * h * w * (c / (16 / es));
     LH_REQUIRE(total < (1L << 31), "lh_maxpool3x3s2_bwd: tensor too large for 32-bit chunk indices");
     const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
-    LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                                                   (const T*)dout, idx, (T*)dx, n, h, w, c, ho, wo));
+    LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((maxpool_bwd_kernel<T, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                                                   (const T*)dout, idx, (T*)dx, n, h, w, c, ho, wo, PoolGate{}));
     LH_LAUNCH_CHECK("maxpool_bwd launch");
+    return LH_OK;
+}
+
+// rows of the partial-sum slab lh_maxpool3x3s2_bwd_gated writes (= its grid)
+extern "C" int lh_maxpool3x3s2_bwd_gated_rows(int n, int h, int w, int c, int dtype) {
+    const int es = lh_dtype_size(dtype);
+    if (es <= 0 || c % (16 / es)) return 0;
+    const long total = (long)n * h * w * (c / (16 / es));
+    return (int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
+}
+
+extern "C" int lh_maxpool3x3s2_bwd_gated(const void* dout, const unsigned char* idx, void* dx, const lh_bn_bwd_gate* gate, int n, int h,
+                                         int w, int c, int dtype, void* stream) {
+    LH_REQUIRE(dout && dx && idx && gate && n > 0 && h > 0 && w > 0, "lh_maxpool3x3s2_bwd_gated: bad arguments");
+    LH_REQUIRE(gate->x && gate->mean && gate->invstd && gate->scale && gate->shift && gate->partial, "lh_maxpool3x3s2_bwd_gated: null pointer in the gate");
+    const int es = lh_dtype_size(dtype);
+    LH_REQUIRE(es == 2 && c % 8 == 0, "lh_maxpool3x3s2_bwd_gated: 16-bit types, c %d a multiple of 8", c);
+    const int nchunk = c / 8;
+    LH_REQUIRE((nchunk & (nchunk - 1)) == 0 && nchunk <= 256, "lh_maxpool3x3s2_bwd_gated: c / 8 = %d must be a power of two <= 256", nchunk);
+    const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
+    const long total = (long)n * h * w * nchunk;
+    LH_REQUIRE(total < (1L << 31), "lh_maxpool3x3s2_bwd_gated: tensor too large for 32-bit chunk indices");
+    const int grid = lh_maxpool3x3s2_bwd_gated_rows(n, h, w, c, dtype);
+    PoolGate g;
+    g.x = (const unsigned char*)gate->x; g.mean = gate->mean; g.invstd = gate->invstd; g.scale = gate->scale; g.shift = gate->shift; g.partial = gate->partial;
+    if (dtype == LH_BF16) hipLaunchKernelGGL((maxpool_bwd_kernel<bf16, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)dout, idx, (bf16*)dx, n, h, w, c, ho, wo, g);
+    else hipLaunchKernelGGL((maxpool_bwd_kernel<f16, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const f16*)dout, idx, (f16*)dx, n, h, w, c, ho, wo, g);
+    LH_LAUNCH_CHECK("maxpool_bwd_gated launch");
     return LH_OK;
 }

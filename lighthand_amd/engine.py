@@ -1950,7 +1950,22 @@ class Plan:
         def emit():
             dy, dx = self._act_grad(y), self._act_grad(x)
             assert self._first_write(x), "maxpool input gradient must be produced by the pool alone"
-            self.bwd.append(_Call(self.lib.lh_maxpool3x3s2_bwd, (dy.data_ptr(), idx.data_ptr(), dx.data_ptr(), x.n, x.h, x.w, x.c, self.dt), "maxpool bwd"))
+            gi = self._gate_info.get(id(x)) if (self.bn_gate and self.n_lanes == 1 and self.es == 2 and os.environ.get("LH_POOL_GATE", "1") != "0") else None
+            nch = x.c * self.es // 16
+            if gi is not None and len(self._uses.get(id(x), [])) == 1 and x.c == x.c_valid and nch & (nch - 1) == 0 and nch <= 256:
+                # x = relu(BN(raw)) with the pool as its only reader: the pool's backward stores the ReLU-gated gradient and the
+                # BatchNorm-backward partial sums (the node's backward skips its reduce pass), as lh_igemm_gated does for convolutions
+                rows = self.lib.lh_maxpool3x3s2_bwd_gated_rows(x.n, x.h, x.w, x.c, self.dt)
+                partial = self._alloc(rows * 2 * x.c, dtype=torch.float32)
+                st = gi["st"]
+                gate = _lib.BnBwdGate(gi["raw"].buf.data_ptr(), st["mean"].data_ptr(), st["invstd"].data_ptr(), st["scale"].data_ptr(),
+                                      st["shift"].data_ptr(), partial.data_ptr())
+                self.keep.append(gate)
+                self.bwd.append(_Call(self.lib.lh_maxpool3x3s2_bwd_gated, (dy.data_ptr(), idx.data_ptr(), dx.data_ptr(), C.byref(gate), x.n, x.h, x.w, x.c,
+                                                                         self.dt), "maxpool bwd + BN-backward gate"))
+                self._gated[id(x)] = (partial, rows)
+            else:
+                self.bwd.append(_Call(self.lib.lh_maxpool3x3s2_bwd, (dy.data_ptr(), idx.data_ptr(), dx.data_ptr(), x.n, x.h, x.w, x.c, self.dt), "maxpool bwd"))
         blk.append(emit)
 
     def use_uint8_input(self, hs, ws, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225), jitter=False):
