@@ -56,6 +56,9 @@ template <> struct MmaR<float> {
 // Debug-only ablation builds (tools/ablate.sh): -DLH_ABL=<bits>  1 = drop the MFMAs, 2 = drop the fragment reads,
 // 4 = drop the LDS-DMA loads, 8 = drop the epilogue (the K loop is pruned with it), 16 = keep the epilogue but drop its
 // global stores, 32 = drop the epilogue but keep every accumulator live.  Results are garbage; only the timing is of interest.  Never set in the product build.
+#ifndef LH_PRIO
+#define LH_PRIO 0      // debug builds only (s_setprio around the MFMA block of a K slice; measured)
+#endif
 #ifndef LH_ABL
 #define LH_ABL 0
 #endif
@@ -239,6 +242,7 @@ __device__ __forceinline__ void igemm_ring_body(const IgemmArgs& p, unsigned cha
         const unsigned ca = offA[kk] + so, cb = offB[kk] + so;
         uint4 F[NR];
         static_for<0, NR>([&](auto r) { rd(r, F[decltype(r)::value], ca, cb); });
+        if (LH_PRIO) __builtin_amdgcn_s_setprio(LH_PRIO);      // experiment: the wave in its MFMA phase issues ahead of its SIMD partner
         static_for<0, CT>([&](auto Ic) {
             constexpr int i = decltype(Ic)::value;
             // the reads younger than weight fragment i may stay in flight (LDS returns in order); the scheduling barrier in
@@ -250,6 +254,7 @@ __device__ __forceinline__ void igemm_ring_body(const IgemmArgs& p, unsigned cha
             for (int j = 0; j < PT; ++j)
                 if (!(LH_ABL & 1)) MmaR<T>::run(F[PT + i], F[j], acc[i][j]);
         });
+        if (LH_PRIO) __builtin_amdgcn_s_setprio(0);
     };
 
     // The wide-wave form (one wave per SIMD, 128 x 128 per wave): no partner wave covers this wave's stalls, so the stage is
