@@ -56,6 +56,9 @@ template <> struct MmaR<float> {
 // Debug-only ablation builds (tools/ablate.sh): -DLH_ABL=<bits>  1 = drop the MFMAs, 2 = drop the fragment reads,
 // 4 = drop the LDS-DMA loads, 8 = drop the epilogue (the K loop is pruned with it), 16 = keep the epilogue but drop its
 // global stores, 32 = drop the epilogue but keep every accumulator live.  Results are garbage; only the timing is of interest.  Never set in the product build.
+#ifndef LH_PREREAD
+#define LH_PREREAD 0   // debug builds only: both K slices' fragment reads of a 128-byte stage issued up front (measured neutral)
+#endif
 #ifndef LH_PRIO
 #define LH_PRIO 0      // debug builds only (s_setprio around the MFMA block of a K slice; measured)
 #endif
@@ -318,6 +321,27 @@ __device__ __forceinline__ void igemm_ring_body(const IgemmArgs& p, unsigned cha
         }
         // the refill goes into the slot of stage s - 1, whose reads every wave retired before the barrier
         if (!late && issued < S) issue();
+        if constexpr (LH_PREREAD && KSUB == 2 && NR <= 8) {
+            // experiment: the fragment reads of BOTH K slices of the stage up front (a second fragment register set), the
+            // second slice's read latency under the first slice's MFMAs
+            uint4 F0[NR], F1[NR];
+            static_for<0, NR>([&](auto r) { rd(r, F0[decltype(r)::value], offA[0] + so, offB[0] + so); });
+            static_for<0, NR>([&](auto r) { rd(r, F1[decltype(r)::value], offA[1] + so, offB[1] + so); });
+            static_for<0, CT>([&](auto Ic) {
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NR + CT - 1 - decltype(Ic)::value) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_group(Ic, F0);
+            });
+            if (late && issued < S) issue();
+            static_for<0, CT>([&](auto Ic) {
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(CT - 1 - decltype(Ic)::value) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_group(Ic, F1);
+            });
+            continue;
+        }
         step(ic<0>{}, so);
         if constexpr (KSUB == 2) {
             if (late && issued < S) issue();
