@@ -123,12 +123,11 @@ static bool cfg_fits(const lh_igemm_desc* d, int dtype, const RingCfg& c) {
     // the wide-wave tile pays for 256 x 256 of prologue / epilogue with one wave per SIMD: large launches only.  Measured 20-25 %
     // SLOWER than the 8-wave form on every launch of C5 / C2 (profiles/r04_c5_deconv_what_holds_the_pipe.txt), so the tuner is
     // not offered it unless LH_WIDE_TILES=1 (tests, experiments); an explicit cfg still runs it.
-    // dense-wave forms: for launches that leave a CU with at most two workgroups of the tile (LH_DENSE_TILES=0: not offered)
+    // dense-wave forms (LH_DENSE_TILES=0: not offered).  Built for launches that leave a CU one workgroup; measured 2-9 % ahead
+    // on larger launches as well (two co-resident workgroups = four waves per SIMD), so every launch is offered them
     if (ring_dense(c)) {
         const char* sw = getenv("LH_DENSE_TILES");
         if (sw && atoi(sw) == 0) return false;
-        const long wgs = ((M + c.bp - 1) / c.bp) * ((d->cout + c.bm - 1) / c.bm);
-        if (wgs > 512) return false;
     }
     if (ring_wide(c)) {
         const char* sw = getenv("LH_WIDE_TILES");                 // read per query (host side, planning time only)
