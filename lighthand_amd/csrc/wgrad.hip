@@ -386,16 +386,17 @@ extern "C" int lh_wgrad_candidates(const lh_igemm_desc* d, int n_out, int n_in, 
         if (!wcfg_fits(c, n_out, n_in)) continue;
         const long tiles = (long)((n_out + c.bo - 1) / c.bo) * ((n_in + c.bi - 1) / c.bi) * d->ntaps;
         const long stages = ((long)d->n * d->ho * d->wo + c.kps - 1) / c.kps;
-        int seen[8], nseen = 0;
+        int seen[12], nseen = 0;
         const long targets[5] = {256, 512, 1024, 2048, 4096};
-        for (int t = 0; t < 8 && k < max; ++t) {
+        const bool big = c.bo * c.bi >= 256 * 256;
+        for (int t = 0; t < (big ? 8 : 11) && k < max; ++t) {
             int ns, sps;
             if (t < 5) {
                 wgrad_splits(d, n_out, n_in, c.bo, c.bi, c.kps, targets[t], &ns, &sps);
             } else {
-                // the 8-wave tile runs one workgroup per CU: also offer the split counts that fill the 256 CUs exactly
-                // once, twice, three times (a 257th workgroup would run alone in a second round)
-                if (c.bo * c.bi < 256 * 256) break;
+                // also offer the split counts that fill the 256 CUs exactly once, twice, ... (the 8-wave tile runs one workgroup
+                // per CU: 1 - 3 rounds; the 4-wave tiles two to four per CU: 1 - 6 x 256 workgroups): the targets above round the
+                // split count UP, and a launch of 576 workgroups on 512 slots runs a second round for its last 64
                 const long fill = 256L * (t - 4) / tiles;
                 if (fill < 1 || fill > 0xffff) continue;
                 sps = (int)((stages + fill - 1) / fill);

@@ -578,8 +578,8 @@ class Plan:
             return
         key = ("w", self.dt, self._desc_key(d), n_out, n_in, dy_stride) + tuple(tag)
         hit = Plan._TUNE_CACHE.get(key) if Plan.force_wgrad is None else None
-        buf = (C.c_int * (5 * 128))()
-        n = self.lib.lh_wgrad_candidates(C.byref(d), n_out, n_in, self.dt, buf, 128)
+        buf = (C.c_int * (5 * 320))()
+        n = self.lib.lh_wgrad_candidates(C.byref(d), n_out, n_in, self.dt, buf, 320)
         cands = [tuple(buf[5 * i:5 * i + 5]) for i in range(n)]
         if hit is not None and hit != (0, 0, 0) and hit not in [c[:3] for c in cands]:
             hit = None
@@ -1227,8 +1227,8 @@ class Plan:
             per, common = [], None
             for (d, _), nd in zip(descs, nds):
                 y, wt = nd["y"], self.params[nd["w"] + ".weight"]
-                buf = (C.c_int * (5 * 128))()
-                n = self.lib.lh_wgrad_candidates(C.byref(d), y.c, wt.shape[1], self.dt, buf, 128)
+                buf = (C.c_int * (5 * 320))()
+                n = self.lib.lh_wgrad_candidates(C.byref(d), y.c, wt.shape[1], self.dt, buf, 320)
                 cs = [tuple(buf[5 * i:5 * i + 5]) for i in range(n)]
                 per.append(cs)
                 keys = {(c[0], c[1], (c[2] >> 16) & 255, (c[2] >> 24) & 255) for c in cs if c[0] <= 128 and c[1] <= 128}

@@ -148,8 +148,8 @@ for name, cin, cout, k, s, n, h, w, tr in SHAPES:
         ds = descs_of(c)
         lead = max(ds, key=lambda d: d.ntaps)
         out_t = plan.out_act.buf if c in plan.fwd else plan.in_act.grad
-        buf = (C.c_int * (5 * 128))()
-        nc = lib.lh_igemm_candidates(C.byref(lead), plan.dt, buf, 128)
+        buf = (C.c_int * (5 * 320))()
+        nc = lib.lh_igemm_candidates(C.byref(lead), plan.dt, buf, 320)
         cands = [tuple(buf[5 * i:5 * i + 5]) for i in range(nc)]
         for d in ds:
             for i in range(5):
@@ -188,8 +188,8 @@ for name, cin, cout, k, s, n, h, w, tr in SHAPES:
     for cw in wcalls:
         d = cw.args[0]._obj
         n_out, n_in = cw.args[5], cw.args[6]
-        buf = (C.c_int * (5 * 128))()
-        nc = lib.lh_wgrad_candidates(C.byref(d), n_out, n_in, plan.dt, buf, 128)
+        buf = (C.c_int * (5 * 320))()
+        nc = lib.lh_wgrad_candidates(C.byref(d), n_out, n_in, plan.dt, buf, 320)
         cands = [tuple(buf[5 * i:5 * i + 5]) for i in range(nc)]
         ws = torch.zeros((max([c[4] for c in cands] + [0]) + 2) << 20, dtype=torch.uint8, device="cuda")
         wa = list(cw.args)
