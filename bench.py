@@ -33,7 +33,8 @@ WORK = {
     ("hrnet32", 256): (20.388, 61.107, 107.2, 321.5),
     ("hrnet48", 256): (41.846, 125.483, 142.9, 428.7),
 }
-PMC_FILE = "r04_pmc_traffic.json"      # per-kernel HBM bytes from the committed rocprofv3 --pmc passes (tools/pmc_traffic.py)
+PMC_FILE = "r05_pmc_traffic.json"      # per-kernel HBM bytes from the committed rocprofv3 --pmc passes (tools/pmc_traffic.py)
+STATS_FILE = "r05_bench_kernel_stats.csv"   # rocprofv3 --kernel-trace --stats of this same command (profiles/README.md)
 TRAIN_GFLOP_PER_IMG = 43.128
 FWD_GFLOP_PER_IMG = 14.479
 PEAK_BF16_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA
@@ -177,6 +178,26 @@ def kernel_roofline(flops, nbytes, ms, es=2):
             "mfma_frac": round(t_mfma / ms, 4), "hbm_frac": round(t_hbm / ms, 4)}
 
 
+def profile_average_ns(stats_csv, kernel):
+    """AverageNs of `kernel` (bench.py's demangled name) in a rocprofv3 --stats kernel table, or None."""
+    import csv
+    import re
+    types = {"DF16b": "__bf16", "DF16_": "_Float16", "f": "float"}
+    try:
+        rows = list(csv.DictReader(open(stats_csv)))
+    except OSError:
+        return None
+    for r in rows:
+        nm = r.get("Name", "")
+        m = re.match(r"_Z\d+([A-Za-z_0-9]+?)I(DF16b|DF16_|f)((?:Li\d+E)*)E", nm)
+        if m:
+            ints = re.findall(r"Li(\d+)E", m.group(3))
+            nm = m.group(1) + "<" + ", ".join([types[m.group(2)]] + ints) + ">"
+        if nm == kernel or nm.replace(" ", "") == kernel.replace(" ", ""):
+            return float(r["AverageNs"])
+    return None
+
+
 def cpu_baseline(depth, size, batch, seconds_budget=25.0, cores=None):
     """The oracle (plain PyTorch fp32 on the host cores) running the same training step on a
     bounded sample of the workload."""
@@ -263,6 +284,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra configurations (HRNet-W32 training, R50 384x384 fp16 inference)")
+    ap.add_argument("--train-only", action="store_true",
+                    help="training replays only (no inference graph, no per-launch profile, no extra configurations): the process the "
+                         "PMC passes of tools/refresh_profiles.sh count a training step's HBM bytes on")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -343,6 +367,29 @@ def main():
     loss_val = float(step.loss)
     ms = elapsed / args.steps * 1e3
     value = world * args.batch * args.steps / elapsed
+    # what the gradient exchange costs the step: the same ranks, the same step, with the collectives stubbed out
+    # (GradSync.stub: stream hand-over, staging and the per-bucket Adam launches stay).  Default transport only -- the
+    # single-graph transport (--comm lh) holds its collectives inside the captured graph.
+    exposed = None
+    if world > 1 and sync is not None and args.comm == "torch":
+        def timed(k):
+            barrier()
+            t_ = time.perf_counter()
+            for _ in range(k):
+                step()
+            barrier()
+            dt_ = torch.tensor([time.perf_counter() - t_], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(dt_, op=torch.distributed.ReduceOp.MAX)
+            return float(dt_) / k * 1e3
+        k2 = max(2, min(args.steps, 30))
+        with_ms = timed(k2)
+        sync.stub = True
+        for _ in range(2):
+            step()
+        stub_ms = timed(k2)
+        sync.stub = False
+        exposed = {"allreduce_exposed_ms": round(with_ms - stub_ms, 3), "ms_per_step_with_collectives": round(with_ms, 3),
+                   "ms_per_step_collectives_stubbed": round(stub_ms, 3), "steps": k2}
 
     out = {
         "metric": METRIC, "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps,
@@ -355,6 +402,7 @@ def main():
         "ms_per_step_median": round(median_ms, 3), "ranks_seen": ranks_seen,
         "dist_backend": torch.distributed.get_backend() if world > 1 else None,
         "loss_after": round(loss_val, 6),
+        "allreduce_exposed_ms": exposed["allreduce_exposed_ms"] if exposed else None, "allreduce_exposed": exposed,
         "train_tflops": round(value * (TRAIN_GFLOP_PER_IMG if (args.depth, args.size) == (50, 256) else 0) / 1e3, 1),
     }
     wkey = (f"hrnet{args.hrnet_width}" if args.hrnet_width else f"r{args.depth}", args.size)
@@ -363,7 +411,7 @@ def main():
     out["step_roofline"] = step_roofline(wkey, True, value / world, es)
     out["c_abi_calls_per_step"] = sum(1 for c in step.plan.packs + step.plan.fwd + step.plan.bwd if hasattr(c, "fn")) + 4
 
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.train_only:
         # eval-mode forward + decode throughput (the "infer" half of the metric)
         torch.cuda.synchronize()
         inf = InferStep(model, args.batch, args.size, args.size)
@@ -402,17 +450,46 @@ def main():
             # governing roof per launch = max(T_mfma, T_hbm) of its algorithmic FLOPs and bytes; both fractions reported
             out["roofline"] = kernel_roofline(d["flops"] / d["launches"], d["bytes"] / d["launches"], avg_ms, es_)
             out["roofline"]["traffic"] = None
-            # HBM bytes per launch of that kernel from the committed PMC passes of this same command
-            # (profiles/README.md; tools/pmc_traffic.py applies the guide's KiB unit and gfx950 FETCH_SIZE x2 correction)
+            # HBM bytes per launch of that kernel from the committed PMC passes of this same command (profiles/README.md;
+            # tools/pmc_traffic.py applies the guide's KiB unit and gfx950 FETCH_SIZE x2 correction).  A committed figure is
+            # attached only while the profile still describes the kernels of THIS build: the profile's average duration of the
+            # kernel (rocprofv3 --kernel-trace --stats of the same command) must lie within 10 % of the live HIP-event average.
+            headline = args.depth == 50 and args.batch == 64 and args.size == 256 and args.precision == "bf16"
+            prof_dir = os.path.join(ROOT, "profiles")
+            pmc = {}
             try:
-                pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", PMC_FILE)))
-                if name in pmc and args.depth == 50 and args.batch == 64 and args.size == 256 and args.precision == "bf16":
+                pmc = json.load(open(os.path.join(prof_dir, PMC_FILE)))
+            except (OSError, ValueError):
+                out["roofline"]["traffic_source"] = "none: profiles/%s is missing or unreadable" % PMC_FILE
+            if pmc and not headline:
+                out["roofline"]["traffic_source"] = "none: the committed PMC passes describe the headline configuration only"
+            elif pmc and name not in pmc:
+                out["roofline"]["traffic_source"] = "none: profiles/%s has no row for this kernel (the dominant kernel changed since the profile)" % PMC_FILE
+            elif pmc:
+                prof_ns = profile_average_ns(os.path.join(prof_dir, STATS_FILE), name)
+                if prof_ns is None:
+                    out["roofline"]["traffic_source"] = "none: profiles/%s has no row for this kernel" % STATS_FILE
+                elif abs(prof_ns * 1e-6 - avg_ms) > 0.10 * avg_ms:
+                    out["roofline"]["traffic_source"] = ("none: the committed profile no longer describes this kernel (AverageNs %.0f in profiles/%s "
+                                                         "vs %.0f ns live: more than 10 %% apart)" % (prof_ns, STATS_FILE, avg_ms * 1e6))
+                else:
                     out["roofline"]["traffic"] = pmc[name]["read_bytes_per_launch"] + pmc[name]["write_bytes_per_launch"]
-                    out["roofline"]["traffic_source"] = "committed profile (profiles/%s), not measured in this run" % PMC_FILE
+                    out["roofline"]["profile_avg_launch_ms"] = round(prof_ns * 1e-6, 4)
+                    out["roofline"]["traffic_source"] = ("committed profile (profiles/%s; its AverageNs for this kernel is within 10 %% of the live "
+                                                         "average), not measured in this run" % PMC_FILE)
                     out["roofline"]["traffic_note"] = ("bytes per launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, corrected per the "
-                                                       "MI355X guide), profiles/r04_pmc_hbm_traffic.txt")
-            except (OSError, ValueError, KeyError):
-                pass
+                                                       "MI355X guide), profiles/%s" % PMC_FILE.replace("traffic.json", "hbm_traffic.txt"))
+            # the waste ratio of the WHOLE training step: fabric bytes (PMC read + write over one step of a --train-only process)
+            # over SURVEY 8(d)'s algorithmic bytes
+            st = pmc.get("__train_step__") if headline else None
+            alg = WORK[("r50", 256)][3] * 1e6 * args.batch
+            out["roofline"]["step_traffic"] = ({"bytes": int(st["bytes"]), "read_bytes": int(st["read_bytes"]), "write_bytes": int(st["write_bytes"]),
+                                                "algorithmic_bytes": int(alg), "over_algorithmic": round(st["bytes"] / alg, 3),
+                                                "source": "committed profile (profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                                          "`bench.py --train-only`, all kernels of %d training steps / %d), not measured in this run"
+                                                          % (PMC_FILE, st["steps"], st["steps"])} if st else
+                                               {"bytes": None, "over_algorithmic": None, "algorithmic_bytes": int(alg),
+                                                "source": "none: profiles/%s has no __train_step__ entry for this configuration" % PMC_FILE})
             out["roofline"].update({"kernel": name, "launches_per_train_step": agg[name]["launches"], "avg_launch_ms": round(avg_ms, 4),
                                     "flops_per_launch": int(d["flops"] / d["launches"]), "algorithmic_bytes_per_launch": int(d["bytes"] / d["launches"]),
                                     "share_of_profiled_ms": round(d["ms"] / tot, 3),
@@ -427,6 +504,16 @@ def main():
                 fr.update({"family": "fuse_bwd (fuse_bwd_reduce* + fuse_bwd_coef_fused + fuse_bwd_apply*)", "calls_per_train_step": fam["launches"],
                            "ms_per_train_step": round(fam["ms"], 3), "algorithmic_bytes_per_step": int(fam["bytes"]),
                            "share_of_profiled_ms": round(fam["ms"] / sum(v["ms"] for v in agg.values()), 3)})
+                # `frac` above is against the family's OWN pass count (five tensor passes per BatchNorm node), NOT a roofline fraction
+                # in SURVEY 8(d)'s sense: 8(d) charges the BatchNorm backward one re-read of y per BatchNorm term, everything
+                # else these kernels move is traffic a perfect fusion would not have
+                b8 = getattr(step.plan, "bn_bwd_8d_bytes", 0.0)
+                if b8 > 0:
+                    fr["section_8d_bytes_per_step"] = int(b8)
+                    fr["over_section_8d"] = round(fam["bytes"] / b8, 2)
+                    fr["frac_of_section_8d_roof"] = round(b8 / (PEAK_HBM_GBS * 1e9) * 1e3 / fam["ms"], 4)
+                    fr["note"] = ("frac = the family's own algorithmic bytes (5 passes per BatchNorm node) over the HBM peak; "
+                                  "frac_of_section_8d_roof = the bytes SURVEY 8(d) charges to it (one re-read of y) over the HBM peak")
                 out["roofline_family"] = fr
             out["kernel_breakdown_ms"] = {k: [round(v["ms"], 3), v["launches"],
                                               round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] else None]

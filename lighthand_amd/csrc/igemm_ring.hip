@@ -7,6 +7,7 @@
 #include "igemm_ring_cfgs.h"
 #include "igemm_pw_cfgs.h"
 #include <stdlib.h>
+#include <cstdlib>
 #include <mutex>
 
 int lh_ring_launch_bf16_big(const IgemmArgs& a, const RingCfg& c, hipStream_t s);
@@ -325,6 +326,27 @@ static const unsigned char* zero_page() {
     return ptr[dev];
 }
 
+// The buffer form of the tiled kernel's operand path (igemm_ring_kernel.h) addresses a tile's pixels with 32-bit offsets
+// relative to the first image the tile touches, and marks masked lanes with offset 2^31: everything a tile can reach --
+// the images a tile of `bp` pixels spans, the tap window in front of them, a weight block -- must stay below 2^31 bytes.
+static int lh_ring_offsets_fit(const IgemmArgs& a, int bm, int bp, int es) {
+    const long ipix = (long)a.in_pix_stride * es, img = (long)a.hi * a.wi * ipix;
+    const long hw = (long)a.ho * a.wo > 0 ? (long)a.ho * a.wo : 1;
+    long reach = (bp / hw + 2) * img;
+    for (int ph = 0; ph < (a.nphase > 1 ? a.nphase : 1); ++ph) {
+        const int ntaps = a.nphase > 1 ? a.ph_ntaps[ph] : a.ntaps, tw = a.nphase > 1 ? a.ph_tw[ph] : a.tw;
+        const int dh0 = a.nphase > 1 ? a.ph_dh0[ph] : a.dh0, dhs = a.nphase > 1 ? a.ph_dhs[ph] : a.dhs;
+        const int dw0 = a.nphase > 1 ? a.ph_dw0[ph] : a.dw0, dws = a.nphase > 1 ? a.ph_dws[ph] : a.dws;
+        const int th = tw > 0 ? (ntaps + tw - 1) / tw : 1;
+        const long shift = ((long)(std::abs(dh0) + std::abs(dhs) * th) * a.wi + std::abs(dw0) + std::abs(dws) * tw) * ipix;
+        LH_REQUIRE(reach + 2 * shift + (long)a.k_run * es + 256 < (1L << 31) && (long)bm * ntaps * a.kpad * es < (1L << 31),
+                   "igemm_ring: a %d-pixel tile of this launch reaches %ld bytes of input (%d x %d pixels of %ld bytes per image, tap window %ld) "
+                   "or %ld bytes of weights: more than the 2 GiB a workgroup's buffer descriptor addresses",
+                   bp, reach + 2 * shift, a.hi, a.wi, ipix, shift, (long)bm * ntaps * a.kpad * es);
+    }
+    return LH_OK;
+}
+
 int lh_igemm_ring_launch(const IgemmArgs& a0, const RingCfg& c, int dtype, hipStream_t s) {
     IgemmArgs a = a0;
     a.zero = zero_page();
@@ -352,6 +374,7 @@ int lh_igemm_ring_launch(const IgemmArgs& a0, const RingCfg& c, int dtype, hipSt
         }
         return rc;
     }
+    if (int e = lh_ring_offsets_fit(a, c.bm, c.bp, dtype == LH_F32 ? 4 : 2)) return e;
     switch (dtype) {
         case LH_BF16:
             rc = lh_ring_launch_bf16_big(a, c, s);
@@ -388,6 +411,8 @@ int lh_igemm_ring_multi_launch(LhMulti<IgemmArgs>& m, const RingCfg& c, int dtyp
         return LH_ERR_HIP;
     }
     for (int i = 0; i < m.n; ++i) { m.a[i].zero = z; m.a[i].dump = dump_page(); }
+    for (int i = 0; i < m.n; ++i)
+        if (int e = lh_ring_offsets_fit(m.a[i], c.bm, c.bp, 2)) return e;
     int rc = 1;
     if (dtype == LH_BF16) rc = lh_ring_multi_launch_bf16(m, c, s);
     else if (dtype == LH_F16) rc = lh_ring_multi_launch_f16(m, c, s);
@@ -410,6 +435,9 @@ int lh_igemm_mixed_multi_launch(LhMulti<IgemmArgs>& m, const int* kinds, const R
     MixedKinds kt;
     for (int i = 0; i < LH_MULTI_MAX; ++i) kt.k[i] = i < m.n ? kinds[i] : 0;
     for (int i = 0; i < m.n; ++i) { m.a[i].zero = z; m.a[i].dump = dp; }
+    for (int i = 0; i < m.n; ++i)
+        if (kinds[i] == 0)
+            if (int e = lh_ring_offsets_fit(m.a[i], c.bm, c.bp, 2)) return e;
     int rc = 1;
     if (dtype == LH_BF16) rc = lh_mixed_multi_launch_bf16(m, kt, c, stats, s);
     else if (dtype == LH_F16) rc = lh_mixed_multi_launch_f16(m, kt, c, stats, s);

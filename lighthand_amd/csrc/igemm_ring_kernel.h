@@ -12,8 +12,8 @@
 //    The LDS image of a 16-row group is row-major, [row][KB/16 slots], and the bank swizzle is a permutation of the
 //    slots INSIDE a row applied to the per-lane source: slot s of row r holds chunk s ^ f(r), f(r) = r >> 2 (KB = 64)
 //    or r >> 1 (KB = 128), which makes the 16 rows x one chunk of a ds_read_b128 quarter-wave hit all 64 banks once;
-//  * rows that fall into the zero padding (or past k_run / past the last pixel) read a 16-byte zero page instead, so
-//    every lane issues every load and the vmcnt bookkeeping is exact;
+//  * rows that fall into the zero padding (or past k_run / past the last pixel) fetch zeros (an out-of-range buffer
+//    offset, below), so every lane issues every load and the vmcnt bookkeeping is exact;
 //  * fragment pipeline: a logical step (one MFMA K slice of 64 bytes) reads PT pixel fragments then CT weight fragments
 //    (ds_read_b128, inline asm: the compiler cannot tell LDS-DMA writes from these reads and would drain the ring in
 //    front of every one) and retires them with a LADDER of counted s_waitcnt lgkmcnt: the MFMAs of weight-row tile i
@@ -22,8 +22,15 @@
 //  * a stage of KB = 128 bytes carries two logical steps per barrier; in the 8-wave tile the two waves of a SIMD issue
 //    their LDS-DMA at DIFFERENT points of the stage (waves 0-3 before the first step, waves 4-7 between the two), so
 //    one wave's address arithmetic runs under its partner's MFMAs instead of both stalling the matrix pipe together;
-//  * the per-load address work is a bit test of a per-lane tap mask, one compare against a per-lane K limit, one
-//    64-bit add and a select against the zero page (a kernel argument).
+//  * BUFFER FORM of the operand path (round 5; tools/ingest_ladder.hip: the per-load vector address work -- tap-mask bit
+//    test, K-limit compare, 64-bit add, select against a zero page -- cost 1.3-3.4 us of this loop's 21 us on the stage-3
+//    3x3 layer): the loads are `buffer_load_dwordx4 ... offen lds` through ONE descriptor per operand and workgroup.  A
+//    lane's 32-bit offset is fixed for the whole launch; everything that changes per stage (tap, K step) is wave-uniform
+//    and travels in the SGPR offset, so a load costs NO vector instruction.  A lane whose tap falls outside the image (or
+//    whose chunk lies past the K run) carries an out-of-range offset instead: the descriptor's range check makes the
+//    load write ZEROS to LDS (probed: tools/probes/buffer_lds_oob.hip; the SGPR offset is part of the check).  The
+//    choice in-range / out-of-range is remade once per TAP (per stage only when the K run is not a whole number of
+//    stages).  Every lane still issues every load, so the vmcnt bookkeeping stays exact.
 #pragma once
 #include "common.h"
 #include "igemm_args.h"
@@ -97,6 +104,7 @@ template <int L, int MAXS> __device__ __forceinline__ void wait_stages(int stage
 // multi-problem kernel (multi.h) the index inside the problem the workgroup belongs to.
 template <typename T, int BM, int BP, int WC, int WP, int D, int KB>
 __device__ __forceinline__ void igemm_ring_body(const IgemmArgs& p, unsigned char* smem, const int bid, const int nblk) {
+#if defined(__HIP_DEVICE_COMPILE__)      // the buffer builtins exist in the device pass only
     constexpr int ES = sizeof(T);
     constexpr int EPC = 16 / ES;
     constexpr int KSTEP = KB / ES;                    // elements per ring stage (KB bytes per row)
@@ -136,13 +144,28 @@ __device__ __forceinline__ void igemm_ring_body(const IgemmArgs& p, unsigned cha
     const int pblk = w / CB, cblk = w - pblk * CB;
     const int hw = p.ho * p.wo;
 
-    // ---- per-lane source bookkeeping.  Instruction q = NWAVE*j + wave of a stage fills (16-row group, part) =
+    // ---- per-lane source bookkeeping (buffer form).  Instruction q = NWAVE*j + wave of a stage fills (16-row group, part) =
     //      (q / H, q % H); this lane supplies slot lane % SL of row (q % H) * RPI + lane / SL, i.e. chunk slot ^ f(row).
-    //      Everything that depends on the lane is folded ONCE into a 64-bit byte offset (tap (0,0), k = 0), a bit mask
-    //      of the taps that fall inside the image and a K limit; per stage only wave-uniform values are added.
-    long pbase[NX];
+    //      The activation descriptor starts `shift` bytes in front of the first image this tile touches (shift >= the most
+    //      negative tap offset, so the SGPR offset shift + tap offset + K offset is never negative); a lane's offset is its
+    //      pixel (tap (0,0), k = 0) relative to that image.
+    constexpr unsigned OOR = 0x80000000u;   // an offset no descriptor of this kernel covers (records < 2^31: lh_ring_offsets_fit)
+    const int th = (ntaps + tw - 1) / tw;
+    const long ipix = (long)p.in_pix_stride * ES;
+    const long shift = ((long)((dh0 < 0 ? -dh0 : dh0) + (dhs < 0 ? -dhs : dhs) * th) * p.wi + (dw0 < 0 ? -dw0 : dw0) + (dws < 0 ? -dws : dws) * tw) * ipix;
+    const long img_bytes = (long)p.hi * p.wi * ipix;
+    const int m_first = pblk * BP < p.M ? pblk * BP : p.M - 1;
+    const int n_first = m_first / hw;
+    const long in_off = (long)n_first * img_bytes - shift;
+    const long in_rec = (long)p.n * img_bytes - in_off + 16;   // + 16: a chunk that straddles the end of the K run may straddle the tensor's end (those elements meet zero weights)
+    const auto rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + in_off), 0, (int)(in_rec < 0x7fffffffL ? in_rec : 0x7fffffffL), 0x00020000);
+    const long kpad = p.kpad;
+    const long w_off = (long)cblk * BM * ntaps * kpad * ES;
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)(wgt + w_off), 0, (int)((long)BM * ntaps * kpad * ES), 0x00020000);
+    unsigned pvoff[NX], cvoff[NX];          // the lane's offset; what it issues for the current tap (pvoff or OOR)
     unsigned tmask[NX];                     // bit t set when tap t of this lane's pixel lies inside the image
     int klim[NX];                           // chunk is inside the K run while (stage K base) < klim
+    const bool kfull = p.k_run % KSTEP == 0;   // every chunk of every stage lies inside the K run: klim never bites
 #pragma unroll
     for (int j = 0; j < NX; ++j) {
         const int q = NWAVE * j + wave;
@@ -151,11 +174,11 @@ __device__ __forceinline__ void igemm_ring_body(const IgemmArgs& p, unsigned cha
         const int row = g * 16 + lrow;
         const int m = pblk * BP + row;
         const bool ok = m < p.M;
-        const int mm = ok ? m : 0;
+        const int mm = ok ? m : m_first;
         const int n = mm / hw, rem = mm - n * hw;
         const int a = rem / p.wo, b = rem - a * p.wo;
         const int ih0 = a * p.sh, iw0 = b * p.sw;
-        pbase[j] = ((long)(n * p.hi * p.wi + ih0 * p.wi + iw0) * p.in_pix_stride + c * EPC) * ES;
+        pvoff[j] = (unsigned)(((long)((n - n_first) * p.hi * p.wi + ih0 * p.wi + iw0) * p.in_pix_stride + c * EPC) * ES);
         klim[j] = p.k_run - c * EPC;        // > 0 for every chunk of the first stage
         unsigned tm = 0;
         int t = 0;
@@ -163,51 +186,55 @@ __device__ __forceinline__ void igemm_ring_body(const IgemmArgs& p, unsigned cha
             for (int tjj = 0, dw = dw0; tjj < tw; ++tjj, dw += dws, ++t)
                 if (ok && (unsigned)(ih0 + dh) < (unsigned)p.hi && (unsigned)(iw0 + dw) < (unsigned)p.wi) tm |= 1u << t;
         tmask[j] = tm;
+        cvoff[j] = (tm & 1u) ? pvoff[j] : OOR;
     }
-    const long kpad = p.kpad;
-    const unsigned char* wsrc[NW];
+    unsigned wvoff[NW];
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
         const int q = NWAVE * j + wave;
         const int g = q / H, lrow = (q % H) * RPI + lane / SL;
         const int c = (lane % SL) ^ ((lrow / (16 / SL)) & (SL - 1));
         const int row = g * 16 + lrow;
-        wsrc[j] = wgt + ((long)(cblk * BM + row) * ntaps * kpad + c * EPC) * ES;
+        wvoff[j] = (unsigned)(((long)row * ntaps * kpad + c * EPC) * ES);
     }
-    const unsigned char* zero = p.zero;                  // 16 zero bytes: what a lane outside the image / K run fetches
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
 
     // stage index -> (tap, kc) is tracked incrementally; `woff` is the byte offset of the stage inside a weight
-    // row (stages are contiguous there), `toff` the activation byte offset of the tap + K step.
+    // row (stages are contiguous there), the activation's SGPR offset = shift + tap offset + K offset.
     int itap = 0, ikc = 0, tj = 0, cdh = dh0, cdw = dw0;
     int issued = 0, islot = 0;
-    long woff = 0;
+    int woff = 0;
     auto issue = [&]() {
         unsigned char* st = smem + islot * STAGE;
 #pragma unroll
         for (int j = 0; j < NW; ++j) {
             const int q = NWAVE * j + wave;
             if (!(LH_ABL & 4))
-                __builtin_amdgcn_global_load_lds((gbl_void_p)(wsrc[j] + woff), (lds_void_p)(st + (q / H) * GB + (q % H) * 1024), 16, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_p)(st + (q / H) * GB + (q % H) * 1024), 16, wvoff[j], woff, 0, 0);
         }
         const int kbase = ikc * KSTEP;
-        const unsigned char* tsrc = p.in + ((long)(cdh * p.wi + cdw) * p.in_pix_stride + kbase) * ES;
+        const int soff = (int)(shift + ((long)(cdh * p.wi + cdw) * p.in_pix_stride + kbase) * ES);
 #pragma unroll
         for (int j = 0; j < NX; ++j) {
             const int q = NWAVE * j + wave;
-            const bool ok = (int)((tmask[j] >> itap) & 1u) & (int)(kbase < klim[j]);
-            const unsigned char* src = ok ? tsrc + pbase[j] : zero;            // select: every lane issues the load
             if (!(LH_ABL & 4))
-                __builtin_amdgcn_global_load_lds((gbl_void_p)src, (lds_void_p)(st + BM * KB + (q / H) * GB + (q % H) * 1024), 16, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void_p)(st + BM * KB + (q / H) * GB + (q % H) * 1024), 16, cvoff[j], soff, 0, 0);
         }
         ++issued;
         if (++islot == D) islot = 0;
         woff += KB;
+        bool retap = false;
         if (++ikc == p.kspt) {
             ikc = 0; ++itap;
-            woff = (long)itap * kpad * ES;
+            woff = (int)((long)itap * kpad * ES);
             cdw += dws;
             if (++tj == tw) { tj = 0; cdw = dw0; cdh += dhs; }
+            retap = true;
+        }
+        if (retap || !kfull) {                // the next stage's in-range / out-of-range choice (wave-uniform branch)
+            const int kb2 = ikc * KSTEP;
+#pragma unroll
+            for (int j = 0; j < NX; ++j) cvoff[j] = (((tmask[j] >> itap) & 1u) != 0 && kb2 < klim[j]) ? pvoff[j] : OOR;
         }
     };
 
@@ -355,6 +382,7 @@ __device__ __forceinline__ void igemm_ring_body(const IgemmArgs& p, unsigned cha
         }
     }
     igemm_epilogue<T, BM, BP, WC, WP>(p, smem, acc, pblk, cblk, tid, lane, wc, wp, hw, ooh, oow, stats);
+#endif
 }
 
 // waves per SIMD the register budget is sized for: 2, except the wide-wave form of the 256 x 256 tile (four waves holding

@@ -480,6 +480,17 @@ class Plan:
             self._tune_bufs[name] = t
         return t
 
+    _MAX_CANDS = 320          # one size for every lh_igemm_candidates buffer (the 16-bit table holds ~60 entries per launch)
+
+    def _igemm_candidates(self, desc):
+        """(buffer of 5 ints per candidate, count) of the configurations compiled in for this launch; a list that fills the
+        buffer would have been cut short silently, so that is an error."""
+        buf = (C.c_int * (5 * Plan._MAX_CANDS))()
+        n = self.lib.lh_igemm_candidates(C.byref(desc), self.dt, buf, Plan._MAX_CANDS)
+        if not 0 <= n < Plan._MAX_CANDS:
+            raise _lib.LightHandError(f"lh_igemm_candidates returned {n} entries for a buffer of {Plan._MAX_CANDS}")
+        return buf, n
+
     def _tune(self, descs, with_stats=False, addend=None, role=None):
         """Measured kernel choice (cdna guide: measure, don't guess): time every compiled-in configuration that fits
         this launch (lh_igemm_candidates) on scratch operands of the real size and write the fastest into the
@@ -502,8 +513,7 @@ class Plan:
         # times the bytes of a plain one, which shifts the best tile
         key = (self.dt, with_stats) + tuple(self._desc_key(d) for d in descs) + ((addend,) if addend else ())
         hit = Plan._TUNE_CACHE.get(key) if Plan.force_cfg is None else None
-        buf = (C.c_int * (5 * 64))()
-        n = self.lib.lh_igemm_candidates(C.byref(lead), self.dt, buf, 64)
+        buf, n = self._igemm_candidates(lead)
         cands = [tuple(buf[5 * i:5 * i + 4]) for i in range(n)]
         if len(descs) > 1:
             cands = [c for c in cands if c[2] not in (1, 100)]  # the persistent kernels take single launches only
@@ -1157,8 +1167,7 @@ class Plan:
             key = ("g", role, self.dt, with_stats) + tuple(self._desc_key(d) for d in ds)
             common = None
             for d in ds:
-                buf = (C.c_int * (5 * 64))()
-                n = self.lib.lh_igemm_candidates(C.byref(d), self.dt, buf, 64)
+                buf, n = self._igemm_candidates(d)
                 c = {tuple(buf[5 * i:5 * i + 4]) for i in range(n)}
                 common = c if common is None else common & c
             cands = sorted(c + (0,) for c in (common or ()) if 2 <= c[2] < 10 and (c[0], c[1]) in self._MULTI_TILES)      # 4-wave tiled forms (the multi-problem kernels)
@@ -1170,15 +1179,13 @@ class Plan:
             # one workgroup per CU for the whole grid (832 workgroups = 3.25 rounds); off by default.
             direct = []
             for d in ds:
-                buf = (C.c_int * (5 * 64))()
-                n = self.lib.lh_igemm_candidates(C.byref(d), self.dt, buf, 64)
+                buf, n = self._igemm_candidates(d)
                 direct.append(next((tuple(buf[5 * i:5 * i + 4]) for i in range(n) if buf[5 * i + 2] == 100), None))
             if os.environ.get("LH_MIXED", "0") == "1" and any(direct) and len(ds) >= 2:
                 rest = None
                 for d, dc in zip(ds, direct):
                     if dc is None:
-                        buf = (C.c_int * (5 * 64))()
-                        n = self.lib.lh_igemm_candidates(C.byref(d), self.dt, buf, 64)
+                        buf, n = self._igemm_candidates(d)
                         c = {tuple(buf[5 * i:5 * i + 4]) for i in range(n)}
                         rest = c if rest is None else rest & c
                 ring = sorted(c for c in rest if (c[0], c[1]) == (64, 128) and 2 <= c[2] < 10) if rest is not None else [(64, 128, 2, 64)]
@@ -1306,8 +1313,11 @@ class Plan:
                 ring = {c for c in cfgs if c[2] != 100}
                 if len(ring) > 1 or any(not 2 <= c[2] < 10 or (c[0], c[1]) not in self._MULTI_TILES for c in ring):
                     return None
-                if len(ring) != len(cfgs) and any((c[0], c[1]) != (64, 128) for c in ring):
-                    return None                 # direct 3x3 members share a launch with the 64 x 128 tile only (igemm_mixed_kernel.h)
+                if len(ring) != len(cfgs) and (os.environ.get("LH_MIXED", "0") != "1" or any((c[0], c[1]) != (64, 128) for c in ring)):
+                    # direct 3x3 members share a launch with the 64 x 128 tile only (igemm_mixed_kernel.h), and only when the
+                    # mixed launch was asked for: members tuned one by one may pick the direct kernel in a default build, where
+                    # the mixed kernel (measured slower) must not run -- they are launched one by one instead
+                    return None
                 arr = (_lib.IgemmCall * n)()
                 for i, c in enumerate(calls):
                     a = c.args
@@ -1460,8 +1470,7 @@ class Plan:
         descs = call.keep
         lead = max(descs, key=lambda dd: dd.ntaps)
         if (lead.cfg[0], lead.cfg[1]) != (256, 256):           # the head lives in the 256 x 256 tile's epilogue
-            buf = (C.c_int * (5 * 64))()
-            n = self.lib.lh_igemm_candidates(C.byref(lead), self.dt, buf, 64)
+            buf, n = self._igemm_candidates(lead)
             big = [tuple(buf[5 * i:5 * i + 4]) for i in range(n) if (buf[5 * i], buf[5 * i + 1]) == (256, 256)]
             if not big:
                 return False
@@ -1837,6 +1846,8 @@ class Plan:
             n_dx = sum(1 for i in range(len(terms)) if bd.dx[i])
             passes = (2 * (1 + n_bn) if n_bn else 1) + n_dx
             self.profile_meta.append(("bwd", self.bwd[-1], "fuse_bwd(all kernels)", 0.0, float(passes) * out.pixels * c * self.es))
+            # what SURVEY 8(d)'s traffic model itself charges to the BatchNorm backward: ONE re-read of y per BatchNorm term
+            self.bn_bwd_8d_bytes = getattr(self, "bn_bwd_8d_bytes", 0.0) + float(n_bn) * out.pixels * c * self.es
         blk.append(emit)
 
     def _next_writer_is_conv(self, a, nd):

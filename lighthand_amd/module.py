@@ -136,14 +136,19 @@ class HipModule(nn.Module):
         """slot: plans of the same shape with different slots own separate activation buffers and weight packs (several
         batches in flight on different streams: runtime.InferPipeline).
         owner: a step object that REWIRES or replays its plan on its own (runtime.InferStep with uint8 input or on a
-        pipeline stream, runtime.TrainStep) names itself here and gets a plan of its own: ``model(x)`` keeps the
-        (shape, mode) plan without an owner, whose input is always the float NCHW image and whose buffers no
-        asynchronous replay touches."""
+        pipeline stream, runtime.TrainStep) names itself here and gets a plan of its own, which the module does NOT keep
+        (it lives and dies with the step): ``model(x)`` keeps the (shape, mode) plan without an owner, whose input is
+        always the float NCHW image and whose buffers no asynchronous replay touches."""
         training = self.training if training is None else training
         backward = training if backward is None else backward
         self.arena()
-        key = (n, h, w, self._lh_precision, training, backward, wgrad_bucket_bytes) + ((slot,) if slot else ()) \
-            + ((("owner", owner),) if owner is not None else ())
+        if owner is not None:
+            # never cached: the step holds the only reference, so dropping the step frees the plan's activation buffers,
+            # weight packs and workspaces (a cached owner plan per InferStep made device memory grow without bound)
+            p = Plan(self, n, h, w, self._lh_precision, training=training, backward=backward, wgrad_bucket_bytes=wgrad_bucket_bytes)
+            p.generation = 0
+            return p
+        key = (n, h, w, self._lh_precision, training, backward, wgrad_bucket_bytes) + ((slot,) if slot else ())
         p = self._lh_plans.get(key)
         if p is None:
             p = Plan(self, n, h, w, self._lh_precision, training=training, backward=backward, wgrad_bucket_bytes=wgrad_bucket_bytes)

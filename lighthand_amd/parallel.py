@@ -183,6 +183,9 @@ class GradSync:
         self.stream = torch.cuda.Stream() if self.cuda else None
         self._pending = []
         self._segments = None
+        # measurement only (bench.py allreduce_exposed_ms): with stub = True launch() keeps its stream hand-over, the bf16
+        # staging and the `after` work but skips the collective itself -- the step then costs what it would with a free wire
+        self.stub = False
 
     def segments(self, plan):
         if self._segments is None:
@@ -206,7 +209,7 @@ class GradSync:
             ev.record(torch.cuda.current_stream())
             self.stream.wait_event(ev)
             with torch.cuda.stream(self.stream):
-                reduce_ = self.comm.all_reduce_sum_ if self.comm is not None else \
+                reduce_ = (lambda t: None) if self.stub else self.comm.all_reduce_sum_ if self.comm is not None else \
                     (lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group))
                 if self.compress == "bf16":
                     half = self._staging.get(bucket)

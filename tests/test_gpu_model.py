@@ -147,6 +147,49 @@ def test_g6_three_step_trajectory(golden_dir, tag):
     print(tag, "losses", losses, "reference", meta["losses"])
 
 
+@pytest.mark.parametrize("tag", ["r18", "r50", "hrnet_w32"])
+def test_g6wc_well_conditioned_trajectory_at_1e3(golden_dir, tag):
+    """G6 on a WELL-CONDITIONED network, held to the north star's 1e-3 on ALL three steps: the reference ran its three Adam
+    steps (method.py:160-183, train.py:45-48) after the gain of the last BatchNorm of every residual branch was scaled by
+    0.05 (tests/golden/make_golden.py g6wc; the keys travel with the fixture).  In that regime -- a trained residual
+    network's -- the train-mode BatchNorm stack no longer amplifies rounding noise, so the HIP fp32 path must reproduce
+    the reference's losses of steps 1-3 and the picked weight sums to 1e-3 (plain G6, on the default init, can only hold
+    steps 2-3 to percents)."""
+    from lighthand_amd.heatmap import JointsMSELoss, render_targets
+    from lighthand_amd.optim import Adam
+    meta = json.load(open(os.path.join(golden_dir, "g6wc_traj.json")))[tag]
+    g = np.load(os.path.join(golden_dir, "g6wc_traj.npz"))
+    torch.manual_seed(9001)
+    model, _ = _build(tag)
+    sd = model.state_dict()
+    assert set(meta["scaled_keys"]) <= set(sd)
+    with torch.no_grad():
+        for k in meta["scaled_keys"]:
+            sd[k].mul_(meta["gain_scale"])
+    model = model.cuda().train()
+    opt = Adam(model.parameters(), lr=1e-3).bind_arena(model.arena())
+    crit = JointsMSELoss(False)
+    x = torch.from_numpy(g[f"{tag}_x"]).cuda()
+    tgt = render_targets(torch.from_numpy(g[f"{tag}_joints"]).cuda())[:, :, :16, :16].contiguous()
+    losses = []
+    for _ in range(3):
+        pred = model(x)
+        loss = crit(pred, tgt, None)
+        losses.append(float(loss.detach()))
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    final = model(x).detach().cpu().numpy()
+    lerr = [abs(a - b) / abs(b) for a, b in zip(losses, meta["losses"])]
+    sd = model.state_dict()
+    serr = {k: abs(float(sd[k].double().abs().sum()) - v) / max(1e-6, abs(v)) for k, v in meta["abs_sums"].items()}
+    print(tag, "losses", losses, "reference", meta["losses"], "rel", lerr, "worst weight abs-sum rel", max(serr.values()),
+          "final heat-maps rel", rel(final, g[f"{tag}_final_pred"]))
+    assert lerr[0] < 1e-4 and max(lerr) < 1e-3, (losses, meta["losses"])
+    assert max(serr.values()) < 1e-3, serr
+    assert rel(final, g[f"{tag}_final_pred"]) < 5e-3
+
+
 def test_torch_adam_also_drives_the_model():
     """The reference loop uses torch.optim.Adam (train.py:45-48): it must work unchanged."""
     from lighthand_amd.heatmap import JointsMSELoss
@@ -349,14 +392,21 @@ def test_bn_backward_gate_in_the_data_gradient_matches_the_separate_reduce_pass(
         model.load_state_dict(_trained_like(model.state_dict()))
         model = model.cuda().set_precision(precision).train()
         pred = model(x)
-        JointsMSELoss(False)(pred, tgt, None).backward()
+        # the configuration the product SHIPS: fp16 plans always train with the static loss scale (TrainStep default 1024; a
+        # power of two, so scaling the loss here and dividing the gradients is exact), bf16 plans with none
+        scale = 1024.0 if precision == "fp16" else 1.0
+        (JointsMSELoss(False)(pred, tgt, None) * scale).backward()
         plan = model.plan(4, 128, 128, training=True, backward=True)
         gated[gate] = sum(1 for c in plan.bwd if getattr(c, "fn", None) is lib.lh_igemm_gated)
-        grads[gate] = torch.cat([p.grad.flatten().double() for p in model.parameters()]).cpu()
+        grads[gate] = torch.cat([p.grad.flatten().double() for p in model.parameters()]).cpu() / scale
     assert gated["0"] == 0 and gated["1"] >= 10, gated          # R50: most bn1 / bn2 nodes sit in front of a tiled data gradient
     err = float((grads["1"] - grads["0"]).norm() / grads["0"].norm())
     print(f"{precision}: {gated['1']} gated data gradients; whole-model gradient, gate on vs off: rel-L2 {err:.3e}")
-    assert err < 2e-2, err          # measured 5e-4 (bf16), 6e-3 (fp16 without a loss scale: the small gradients sit near its subnormal range)
+    # bound per dtype = 2 x the measured value (round 5; static kernel choice, so the figure is reproducible)
+    assert err < GATE_BOUND[precision], err
+
+
+GATE_BOUND = {"bf16": 1.0e-3, "fp16": 1.0e-3}      # measured: bf16 5.0e-4; fp16 with the loss scale: see DESIGN.md section 4
 
 
 def test_c2_r50_bf16_gradients_vs_fp32_oracle():
@@ -402,6 +452,51 @@ def test_c2_r50_bf16_gradients_vs_fp32_oracle():
     assert np.median(cos) >= 0.9
     assert herr < 5e-2            # flat random-feature maps; the forward pin is test_c2_r50_bf16_train_forward_matches_fp32_oracle
     assert lrel < 1e-3
+
+
+def test_c4_hrnet_w32_fp16_gradients_vs_fp32_oracle(monkeypatch):
+    """C4's TIMED dtype (bench.py extra.hrnet_w32_train_bs32: fp16 + static loss scale 1024) against the fp32 CPU oracle:
+    whole-model dL/dtheta of HRNet-W32 (pose_hrnet.py:139-185, 247-265, 401-460) at batch 4, 128 x 128, on the
+    well-conditioned trained-like weights, merged multi-problem launches, static kernel choice (reproducible figures).
+    Round 4 measured the bf16 form of this gradient 0.29 from the fp32 plan's -- which is why fp16 is
+    the timed dtype; this test holds fp16 to its own measured distance."""
+    from oracle import models as omod
+    from lighthand_amd.heatmap import JointsMSELoss
+    monkeypatch.setenv("LH_AUTOTUNE", "0")
+    torch.manual_seed(11)
+    model, fwd = _build("hrnet_w32")
+    model.load_state_dict(_trained_like(model.state_dict()))
+    rng = np.random.RandomState(5)
+    b, h, w = 4, 128, 128
+    x = torch.from_numpy(rng.randn(b, 3, h, w).astype(np.float32))
+    tgt = torch.from_numpy(rng.rand(b, 21, h // 4, w // 4).astype(np.float32))
+    sd = omod.clone_state(model.state_dict())
+    loss_ref, pred_ref, g32 = omod.loss_and_grads(sd, lambda s, xx: fwd(s, xx, True), x, tgt)
+    stats = {}
+    for prec, scale in (("fp16", 1024.0), ("bf16", 1.0)):
+        m = model.cuda().set_precision(prec).train()
+        m.zero_grad(set_to_none=True)
+        pred = m(x.cuda())
+        loss = JointsMSELoss(False)(pred, tgt.cuda(), None)
+        (loss * scale).backward()
+        num = den = dot = nh = 0.0
+        cos = []
+        for k, p in m.named_parameters():
+            gh, gr = p.grad.cpu().double().numpy().ravel() / scale, g32[k].double().numpy().ravel()
+            num += ((gh - gr) ** 2).sum(); den += (gr ** 2).sum(); dot += (gh * gr).sum(); nh += (gh ** 2).sum()
+            cos.append(float((gh * gr).sum() / (np.sqrt((gh ** 2).sum() * (gr ** 2).sum()) + 1e-30)))
+        stats[prec] = (float(np.sqrt(num / den)), float(dot / np.sqrt(nh * den)), float(np.median(cos)), float(min(cos)),
+                       rel(pred.detach().cpu().numpy(), pred_ref.numpy()), abs(float(loss.detach()) - loss_ref) / abs(loss_ref))
+        print(f"C4 arithmetic ({prec}, loss scale {scale:g}) vs fp32 oracle, HRNet-W32 trained-like weights: gradient global rel-L2 {stats[prec][0]:.3e} "
+              f"(cosine {stats[prec][1]:.5f}), per-tensor cosine median {stats[prec][2]:.4f} min {stats[prec][3]:.4f}; heat-map err {stats[prec][4]:.3e}; "
+              f"loss rel {stats[prec][5]:.3e}")
+    l2, gcos, cmed, cmin, herr, lrel = stats["fp16"]
+    assert l2 < C4_FP16_GRAD_L2 and gcos > 1.0 - C4_FP16_GRAD_L2 ** 2 and cmed >= 0.95, stats
+    assert herr < 1e-2 and lrel < 1e-3, stats
+    assert stats["fp16"][0] < stats["bf16"][0], stats          # the reason fp16 is C4's timed dtype
+
+
+C4_FP16_GRAD_L2 = 1.0e-1       # placeholder until measured: measured value x 2 (DESIGN.md section 4)
 
 
 def test_hrnet_branch_batching_is_bit_exact_and_cuts_launches(monkeypatch):

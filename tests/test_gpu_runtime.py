@@ -963,6 +963,36 @@ def test_infer_steps_own_their_plans_and_pipeline_inputs_may_be_freed():
         assert torch.equal(p, pw)
 
 
+def test_dropped_infer_steps_release_their_plans():
+    """Round-4 advisor: every InferStep got a plan of its own that the module cached for good, so a loop that builds a step
+    per epoch / per batch size grew device memory without bound.  Owner plans are no longer cached: building N steps and
+    dropping them leaves neither entries in model._lh_plans nor allocated memory behind."""
+    import gc
+    from lighthand_amd.modeling.simplebaseline.pose_resnet import get_pose_net
+    from lighthand_amd.runtime import InferStep
+    torch.manual_seed(5)
+    model = get_pose_net(resnet_cfg(18), True).cuda().set_precision("bf16").eval()
+    b, h, w = 4, 128, 96
+    x = torch.randn(b, 3, h, w, device="cuda")
+
+    def one():
+        st = InferStep(model, b, h, w)
+        out = st(x).clone()
+        torch.cuda.synchronize()
+        del st
+        return out
+    first = one()
+    gc.collect()
+    torch.cuda.synchronize()
+    n_plans, mem = len(model._lh_plans), torch.cuda.memory_allocated()
+    for _ in range(4):
+        assert torch.equal(one(), first)
+        gc.collect()
+    torch.cuda.synchronize()
+    assert len(model._lh_plans) == n_plans == 0
+    assert torch.cuda.memory_allocated() <= mem + (1 << 20), (torch.cuda.memory_allocated(), mem)
+
+
 def test_bench_gpus_2_starts_two_ranks():
     """`python bench.py --gpus 2` WITHOUT a launcher must yield two ranks (the parent starts torch.distributed.run as a
     child and relays rank 0's line) or exit non-zero -- never run one rank and report it as two.  Rehearsed on this one GPU
@@ -982,6 +1012,9 @@ def test_bench_gpus_2_starts_two_ranks():
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["dist_backend"] == "gloo", out
     assert out["config"]["global_batch"] == 8 and out["value"] > 0
+    # the exposed cost of the gradient exchange (step with collectives - step with GradSync stubbed), printed for every N > 1
+    ex = out["allreduce_exposed"]
+    assert isinstance(out["allreduce_exposed_ms"], float) and ex["ms_per_step_with_collectives"] > 0 and ex["ms_per_step_collectives_stubbed"] > 0
     # a rank count the launcher did not create is refused
     env1 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--depth", "18",

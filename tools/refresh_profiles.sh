@@ -10,12 +10,12 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/refresh
 rm -rf $O && mkdir -p $O
 export LH_TUNE_CACHE=$PWD/$O/tune_cache.txt
-R=${LH_ROUND:-r04}
+R=${LH_ROUND:-r05}
 timeout -k 10 900 python bench.py > $O/bench.json 2> $O/bench.err
 tail -c 600 $O/bench.json
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o $R -- python3 bench.py --no-cpu-baseline --no-extra > $O/stats.log 2>&1
-timeout -k 10 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-extra > $O/pmc_fetch.log 2>&1
-timeout -k 10 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-extra > $O/pmc_write.log 2>&1
+timeout -k 10 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --train-only > $O/pmc_fetch.log 2>&1
+timeout -k 10 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --train-only > $O/pmc_write.log 2>&1
 timeout -k 10 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --output-format csv -d $O/pmc_mfma -o m -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-extra > $O/pmc_mfma.log 2>&1
 timeout -k 10 300 python tools/layer_profile.py > $O/layers.txt 2>&1
 echo "[refresh] C4 share: HRNet-W32 bs32, fp16 + static loss scale (the timed dtype since round 4)"
