@@ -274,7 +274,8 @@ def g6wc_trajectory():
 
     rec, meta = {}, {}
 
-    def run(tag, build, hm_size):
+    def run(tag, build, hm_size, threads=8, record=True):
+        torch.set_num_threads(threads)
         torch.manual_seed(9001)
         model = build()
         model.train()
@@ -305,6 +306,15 @@ def g6wc_trajectory():
         pick += [k for k in keys if "deconv_layers.6" in k or "stage2.0.fuse_layers.1.0.0.0" in k][:1]
         pick += scaled[:2] + scaled[-2:]
         pick = list(dict.fromkeys(pick))
+        if not record:
+            # the SAME reference trajectory with one CPU thread (other summation orders inside its convolutions / BatchNorms):
+            # how far the reference is from itself -- the floor under any second implementation's distance
+            meta[tag]["losses_one_thread"] = losses
+            meta[tag]["abs_sums_one_thread"] = {k: float(sd[k].double().abs().sum()) for k in pick}
+            meta[tag]["final_pred_self_rel"] = float(np.abs(model(x).detach().numpy() - rec[f"{tag}_final_pred"]).max()
+                                                      / np.abs(rec[f"{tag}_final_pred"]).max())
+            print("G6wc", tag, "one thread", losses)
+            return
         meta[tag] = {"losses": losses, "scaled_keys": scaled, "gain_scale": 0.05,
                      "sums": {k: float(sd[k].double().sum()) for k in pick},
                      "abs_sums": {k: float(sd[k].double().abs().sum()) for k in pick}}
@@ -313,9 +323,11 @@ def g6wc_trajectory():
         rec[f"{tag}_final_pred"] = model(x).detach().numpy()
         print("G6wc", tag, losses, len(scaled), "gains scaled")
 
-    run("r18", lambda: get_pose_net(resnet_cfg(18), True), 16)
-    run("r50", lambda: get_pose_net(resnet_cfg(50), True), 16)
-    run("hrnet_w32", lambda: get_hrnet(hrnet_cfg(32), True), 16)
+    for tag, build in (("r18", lambda: get_pose_net(resnet_cfg(18), True)), ("r50", lambda: get_pose_net(resnet_cfg(50), True)),
+                       ("hrnet_w32", lambda: get_hrnet(hrnet_cfg(32), True))):
+        run(tag, build, 16)
+        run(tag, build, 16, threads=1, record=False)
+    torch.set_num_threads(8)
     np.savez_compressed(os.path.join(OUT, "g6wc_traj.npz"), **rec)
     with open(os.path.join(OUT, "g6wc_traj.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)

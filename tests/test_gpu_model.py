@@ -179,10 +179,10 @@ def test_g6wc_well_conditioned_trajectory_at_1e3(golden_dir, tag):
         opt.zero_grad()
         loss.backward()
         opt.step()
-    final = model(x).detach().cpu().numpy()
     lerr = [abs(a - b) / abs(b) for a, b in zip(losses, meta["losses"])]
     sd = model.state_dict()
     serr = {k: abs(float(sd[k].double().abs().sum()) - v) / max(1e-6, abs(v)) for k, v in meta["abs_sums"].items()}
+    final = model(x).detach().cpu().numpy()            # (a fourth forward: after the sums, as in the fixture's generator)
     print(tag, "losses", losses, "reference", meta["losses"], "rel", lerr, "worst weight abs-sum rel", max(serr.values()),
           "final heat-maps rel", rel(final, g[f"{tag}_final_pred"]))
     assert lerr[0] < 1e-4 and max(lerr) < 1e-3, (losses, meta["losses"])

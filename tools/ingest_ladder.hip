@@ -39,7 +39,7 @@ struct Args {
     const unsigned char* zero;   // 16 zero bytes
     const unsigned char* lin;    // 256 x 64 KiB
     float* sink;
-    unsigned long long* stamps;  // [nwg][3]
+    unsigned long long* stamps;  // [nwg][5]: realtime t0 t1 t2, shader clock c1 c2
     int n, h, wd, c, cout;
 };
 
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void ladder_kernel(const Args p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wc = wave / WP, wp = wave % WP;
     const int bid = blockIdx.x, nblk = gridDim.x;
-    unsigned long long t0 = 0, t1 = 0, t2 = 0;
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, c1 = 0, c2 = 0;
     if (tid == 0) t0 = wall_clock64();
     const int w = xcd_remap(bid, nblk);
     const int pblk = w / 2, cblk = w % 2;
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void ladder_kernel(const Args p) {
         for (int j = 0; j < PT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int S = ntaps * kspt;
-    if (tid == 0) t1 = wall_clock64();
+    if (tid == 0) { t1 = wall_clock64(); c1 = clock64(); }
 #pragma unroll
     for (int s = 0; s < D - 1; ++s)
         if (issued < S) issue();
@@ -203,6 +203,7 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void ladder_kernel(const Args p) {
     }
     auto rd = [](auto Rc, uint4& dst, unsigned base_a, unsigned base_b) {
         constexpr int r = decltype(Rc)::value;
+        if constexpr ((ADD & 16) != 0) { dst = uint4{base_a | 0x3c003c00u, base_b | 0x3c003c00u, 0x3c013c02u + r, 0x3c033c04u}; return; }
         if constexpr (r < PT) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(base_b), "n"(r * GB));
         else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(base_a), "n"((r - PT) * GB));
     };
@@ -259,6 +260,45 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void ladder_kernel(const Args p) {
                 for (int j = 0; j < PT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, F[PT + i]), __builtin_bit_cast(bf16x8, F[j]), acc[i][j], 0, 0, 0);
         };
+        // ADD bit 5 (32): the same loop with the next slice's reads SPREAD between this slice's MFMA groups (NR / CT reads behind
+        // every group but the last) instead of in one burst in front of them
+        auto mm_rd = [&](uint4 (&F)[NR], uint4 (&G)[NR], auto KKc, unsigned so) {
+            constexpr int kk = decltype(KKc)::value;
+            const unsigned ca = offA[kk] + so, cb = offB[kk] + so;
+            constexpr int PERG = (NR + CT - 2) / (CT - 1);
+            static_for<0, CT>([&](auto Ic) {
+                constexpr int i = decltype(Ic)::value;
+#pragma unroll
+                for (int j = 0; j < PT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, F[PT + i]), __builtin_bit_cast(bf16x8, F[j]), acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<i * PERG, ((i + 1) * PERG < NR ? (i + 1) * PERG : NR)>([&](auto r) { rd(r, G[decltype(r)::value], ca, cb); });
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        };
+        if constexpr ((ADD & 32) != 0) {
+            wait_stages<L, D - 2>(issued - 1);
+            if (SYNC == 0) __builtin_amdgcn_s_barrier();
+            if (issued < S) issue();
+            rdall(FA, ic<0>{}, 0u);
+            for (int s = 0; s < S; ++s) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                mm_rd(FA, FB, ic<1>{}, (unsigned)(cslot * STAGE));          // slice 0's MFMAs, slice 1's reads between them
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                if (s + 1 < S) {
+                    wait_stages<L, D - 2>(issued - 2 - s);
+                    if (SYNC == 0) __builtin_amdgcn_s_barrier();
+                    if (issued < S) issue();
+                    if (++cslot == D) cslot = 0;
+                    mm_rd(FB, FA, ic<0>{}, (unsigned)(cslot * STAGE));      // slice 1's MFMAs, the next stage's first reads between them
+                } else {
+                    mm(FB);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
         wait_stages<L, D - 2>(issued - 1);
         if (SYNC == 0) __builtin_amdgcn_s_barrier();
         if (issued < S) issue();
@@ -286,6 +326,7 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void ladder_kernel(const Args p) {
             mm(FB);
             __builtin_amdgcn_sched_barrier(0);
         }
+        }
     } else
     for (int s = 0; s < S; ++s) {
         wait_stages<L, D - 2>(issued - 1 - s);
@@ -306,8 +347,8 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void ladder_kernel(const Args p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-        t2 = wall_clock64();
-        p.stamps[bid * 3] = t0; p.stamps[bid * 3 + 1] = t1; p.stamps[bid * 3 + 2] = t2;
+        t2 = wall_clock64(); c2 = clock64();
+        p.stamps[bid * 5] = t0; p.stamps[bid * 5 + 1] = t1; p.stamps[bid * 5 + 2] = t2; p.stamps[bid * 5 + 3] = c1; p.stamps[bid * 5 + 4] = c2;
     }
     float v = 0.f;
 #pragma unroll
@@ -323,7 +364,21 @@ __global__ void copy_kernel(const uint4* __restrict__ a, uint4* __restrict__ b, 
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) b[i] = a[i];
 }
 
+// L2 warm-up kernels for the cache-state experiment: every XCD (blocks b, b + 8, ... share one) reads the WHOLE weight pack / its
+// own eighth of the pixel rows (the conv's work-item order: XCD x owns pixel tiles [16 x, 16 x + 16) of the 128)
+__global__ void touch_kernel(const uint4* __restrict__ w, long nw, const uint4* __restrict__ in, long nin_per_xcd, int what, unsigned* sink) {
+    const int xcd = blockIdx.x & 7, sub = blockIdx.x >> 3, nsub = gridDim.x >> 3;
+    unsigned acc = 0;
+    if (what & 1)
+        for (long i = (long)sub * blockDim.x + threadIdx.x; i < nw; i += (long)nsub * blockDim.x) acc ^= w[i].x;
+    if (what & 2)
+        for (long i = (long)sub * blockDim.x + threadIdx.x; i < nin_per_xcd; i += (long)nsub * blockDim.x) acc ^= in[(long)xcd * nin_per_xcd + i].x;
+    if (acc == 0x12345u) sink[0] = acc;
+}
+
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+static bool g_more_states = false;     // + producer state followed by an L2 warm-up of the weights (L2w), the pixel rows (L2x), both (L2wx)
 
 int main(int argc, char** argv) {
     const int reps = argc > 1 ? atoi(argv[1]) : 12;
@@ -333,7 +388,7 @@ int main(int argc, char** argv) {
     float* sink; unsigned long long* stamps;
     CK(hipMalloc(&in_raw, in_bytes + 2 * guard)); CK(hipMalloc(&twin, in_bytes)); CK(hipMalloc(&wgt, w_bytes));
     CK(hipMalloc(&zero, 256)); CK(hipMalloc(&lin, (size_t)NWG * 65536)); CK(hipMalloc(&flush, 512u << 20));
-    CK(hipMalloc(&sink, NWG * 512 * 4)); CK(hipMalloc(&stamps, NWG * 3 * 8));
+    CK(hipMalloc(&sink, NWG * 512 * 4)); CK(hipMalloc(&stamps, NWG * 5 * 8));
     {   // random bit patterns of ordinary bf16 magnitude (zero operands clock higher)
         std::vector<unsigned short> hbuf((in_bytes + 2 * guard) / 2);
         unsigned s = 12345u;
@@ -345,34 +400,38 @@ int main(int argc, char** argv) {
         CK(hipMemset(zero, 0, 256));
     }
     Args a{in_raw + guard, wgt, zero, lin, sink, stamps, N, H, W, C, COUT};
-    std::vector<unsigned long long> hs(NWG * 3);
+    std::vector<unsigned long long> hs(NWG * 5);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
 
     printf("# rung / ring / waves / sync                    state     span us   loop us  prologue us  GB/s per CU (loop)   wall us (events)\n");
     auto measure = [&](const char* name, auto launch) {
-        for (int state = 0; state < 3; ++state) {
-            std::vector<double> span, loop, pro, wall;
+        for (int state = 0; state < (g_more_states ? 6 : 3); ++state) {
+            std::vector<double> span, loop, pro, wall, ghz;
             for (int r = 0; r < reps + 2; ++r) {
                 if (state >= 1) CK(hipMemsetAsync(flush, r, 512u << 20, 0));
-                if (state == 2) hipLaunchKernelGGL(copy_kernel, dim3(2048), dim3(256), 0, 0, (const uint4*)twin, (uint4*)(in_raw + guard), (long)(in_bytes / 16));
+                if (state >= 2) hipLaunchKernelGGL(copy_kernel, dim3(2048), dim3(256), 0, 0, (const uint4*)twin, (uint4*)(in_raw + guard), (long)(in_bytes / 16));
+                if (state >= 3) hipLaunchKernelGGL(touch_kernel, dim3(256), dim3(256), 0, 0, (const uint4*)wgt, (long)(w_bytes / 16), (const uint4*)(in_raw + guard),
+                                                   (long)(in_bytes / 16 / 8), state - 2, (unsigned*)sink);
                 CK(hipEventRecord(e0, 0));
                 launch();
                 CK(hipEventRecord(e1, 0));
                 CK(hipEventSynchronize(e1));
                 float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
-                CK(hipMemcpy(hs.data(), stamps, NWG * 3 * 8, hipMemcpyDeviceToHost));
+                CK(hipMemcpy(hs.data(), stamps, NWG * 5 * 8, hipMemcpyDeviceToHost));
                 if (r < 2) continue;
-                unsigned long long mn = ~0ull, mx = 0; double lp = 0, pr = 0;
+                unsigned long long mn = ~0ull, mx = 0; double lp = 0, pr = 0, cy = 0;
                 for (int i = 0; i < NWG; ++i) {
-                    mn = std::min(mn, hs[i * 3]); mx = std::max(mx, hs[i * 3 + 2]);
-                    lp += (double)(hs[i * 3 + 2] - hs[i * 3 + 1]); pr += (double)(hs[i * 3 + 1] - hs[i * 3]);
+                    mn = std::min(mn, hs[i * 5]); mx = std::max(mx, hs[i * 5 + 2]);
+                    lp += (double)(hs[i * 5 + 2] - hs[i * 5 + 1]); pr += (double)(hs[i * 5 + 1] - hs[i * 5]);
+                    cy += (double)(hs[i * 5 + 4] - hs[i * 5 + 3]);
                 }
+                ghz.push_back(cy / (lp * 10.0));            // shader cycles per ns over the loop (s_memtime / s_memrealtime at 100 MHz)
                 span.push_back((mx - mn) * 0.01); loop.push_back(lp / NWG * 0.01); pro.push_back(pr / NWG * 0.01); wall.push_back(ms * 1e3);
             }
             auto med = [](std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
             const double l = med(loop);
-            printf("%-48s %-9s %7.2f  %7.2f  %7.2f      %7.1f              %7.2f\n", name, state == 0 ? "warm" : state == 1 ? "cold" : "producer",
-                   med(span), l, med(pro), 36.0 * 32768 / l / 1e3, med(wall));
+            printf("%-48s %-9s %7.2f  %7.2f  %7.2f      %7.1f              %7.2f   %5.2f GHz  %5.0f cyc/stage\n", name, state == 0 ? "warm" : state == 1 ? "cold" : state == 2 ? "producer" : state == 3 ? "prod+L2w" : state == 4 ? "prod+L2x" : "prod+L2wx",
+                   med(span), l, med(pro), 36.0 * 32768 / l / 1e3, med(wall), med(ghz), l * 1e3 * med(ghz) / 36.0);
         }
         fflush(stdout);
     };
@@ -380,7 +439,8 @@ int main(int argc, char** argv) {
         CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ladder_kernel<NWAVE, D, SRC, ADD, SYNC>), hipFuncAttributeMaxDynamicSharedMemorySize, D * STAGE)); \
         measure(NAME, [&]() { hipLaunchKernelGGL((ladder_kernel<NWAVE, D, SRC, ADD, SYNC>), dim3(NWG), dim3(64 * NWAVE), D * STAGE, 0, a); }); }
 
-    const bool second = argc > 2 && atoi(argv[2]) == 2;
+    const bool second = argc > 2 && atoi(argv[2]) >= 2;
+    g_more_states = argc > 2 && atoi(argv[2]) == 3;
     if (!second) {
     RUN(8, 3, 0, 0, 0, "R0 linear private region      D3 8w barrier")
     RUN(8, 3, 1, 0, 0, "R1 real rows, centre tap      D3 8w barrier")
@@ -400,24 +460,30 @@ int main(int argc, char** argv) {
     RUN(4, 4, 3, 3, 0, "R5                            D4 4w barrier")
     RUN(4, 3, 0, 3, 0, "R0 + reads + MFMAs            D3 4w barrier")
     } else {
-    // second sitting: which part of R0+reads+MFMAs -> R5 (16.3 -> 20.6 us warm) is the per-load vector address work?
+    // later sittings: what the complete loop is made of, the buffer form, pipelined stage loops
+    if (g_more_states) {
+        RUN(8, 3, 4, 0, 0, "B3 buffer form, DMA only      D3 8w barrier")
+        RUN(8, 3, 4, 3, 0, "B5 buffer form + reads + MFMA D3 8w barrier")
+        RUN(8, 3, 4, 43, 0, "I5 buffer form, reads spread            D3 8w")
+        RUN(4, 3, 4, 43, 0, "I5 buffer form, reads spread            D3 4w")
+        return 0;
+    }
     RUN(8, 3, 5, 3, 0, "no DMA: reads + MFMAs only    D3 8w barrier")
+    RUN(8, 3, 5, 3, 1, "no DMA: reads + MFMAs only    D3 8w no barrier")
     RUN(8, 3, 3, 3, 0, "R5 global_load_lds, masked    D3 8w barrier")
-    RUN(8, 3, 2, 3, 0, "R2 + reads + MFMAs (no mask)  D3 8w barrier")
     RUN(8, 3, 4, 0, 0, "B3 buffer form, DMA only      D3 8w barrier")
     RUN(8, 3, 4, 3, 0, "B5 buffer form + reads + MFMA D3 8w barrier")
-    RUN(8, 3, 4, 7, 0, "B5 + DMA between MFMA groups  D3 8w barrier")
-    RUN(8, 4, 4, 3, 0, "B5 buffer form + reads + MFMA D4 8w barrier")
     RUN(4, 3, 5, 3, 0, "no DMA: reads + MFMAs only    D3 4w barrier")
     RUN(4, 3, 4, 3, 0, "B5 buffer form + reads + MFMA D3 4w barrier")
-    // third: the software-pipelined stage loop (reads one K slice ahead, barrier in mid-stage)
-    RUN(8, 3, 5, 11, 0, "P  no DMA, pipelined reads     D3 8w barrier")
-    RUN(8, 3, 4, 11, 0, "P5 buffer form, pipelined      D3 8w barrier")
-    RUN(8, 4, 4, 11, 0, "P5 buffer form, pipelined      D4 8w barrier")
-    RUN(8, 3, 3, 11, 0, "P5 global_load_lds masked, pipelined D3 8w")
-    RUN(4, 3, 5, 11, 0, "P  no DMA, pipelined reads     D3 4w barrier")
-    RUN(4, 3, 4, 11, 0, "P5 buffer form, pipelined      D3 4w barrier")
-    RUN(4, 4, 4, 11, 0, "P5 buffer form, pipelined      D4 4w barrier")
+    RUN(8, 3, 5, 11, 0, "P  no DMA, reads a slice ahead (burst)  D3 8w")
+    RUN(8, 3, 4, 11, 0, "P5 buffer form, reads a slice ahead     D3 8w")
+    RUN(8, 3, 5, 43, 0, "I  no DMA, reads ahead, SPREAD between MFMA groups D3 8w")
+    RUN(8, 3, 5, 43, 1, "I  the same, no barrier                 D3 8w")
+    RUN(8, 3, 4, 43, 0, "I5 buffer form, reads spread            D3 8w")
+    RUN(8, 4, 4, 43, 0, "I5 buffer form, reads spread            D4 8w")
+    RUN(4, 3, 5, 43, 0, "I  no DMA, reads spread                 D3 4w")
+    RUN(4, 3, 4, 43, 0, "I5 buffer form, reads spread            D3 4w")
+    RUN(4, 4, 4, 43, 0, "I5 buffer form, reads spread            D4 4w")
     }
     return 0;
 }
