@@ -358,6 +358,19 @@ int lh_fuse_bwd_multi(const lh_fuse_bwd_call* calls, int n, int dtype, void* str
 int lh_stem_pool(const void* img, int n, int hp, int wp, const void* wpack, const float* bias, const float* scale,
                  const float* shift, void* out, int conv_h, int conv_w, int relu, int dtype, void* stream);
 
+/* The inference BOTTLENECK of the first ResNet stage as ONE launch (round 5):
+ *   out = relu( bn3(conv3( relu(bn2(conv2( relu(bn1(conv1(x))) ))) )) + residual )
+ * conv1 = 1x1 (cin -> 64), conv2 = 3x3 / stride 1 / pad 1 (64 -> 64), conv3 = 1x1 (64 -> 256), the BatchNorms in eval mode folded
+ * into per-channel scale / shift (lh_bn_eval_affine): Bottleneck.forward, src/modeling/simplebaseline/pose_resnet.py:61-99, for the
+ * blocks with stride 1 (pytorch and caffe style alike).  x = [n][h][w][cin], residual and out = [n][h][w][256] (residual = x for an
+ * identity shortcut, the projection's output otherwise; out may alias neither).  w1 / w2 / w3: the weight packs lh_pack_weight makes
+ * for those three convolutions (K-major rows, taps in (r, s) order).  16-bit types.  Only x and the residual are read and out is
+ * written -- the two 64-channel intermediates stay in LDS.  Bit-identical to the three lh_igemm launches with the same folds. */
+typedef struct { int n, h, w, cin, mid, cout; } lh_bottleneck_desc;
+int lh_bottleneck_infer(const lh_bottleneck_desc* d, const void* x, const void* w1, const void* w2, const void* w3,
+                        const float* s1, const float* b1, const float* s2, const float* b2, const float* s3, const float* b3,
+                        const void* residual, void* out, int dtype, void* stream);
+
 /* The TRAINING stem: conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False) alone (pose_resnet.py:151-152; bn1 runs on batch statistics),
  * same operands as lh_stem_pool (padded NHWC4 image, the stem's weight pack), on the same direct kernel form: out =
  * [n][conv_h][conv_w][64] raw convolution output (bit-identical to lh_igemm on that pack), stats = fp32

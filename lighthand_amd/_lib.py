@@ -68,6 +68,10 @@ class FuseBwdCall(C.Structure):        # lh_fuse_bwd_multi
     _fields_ = [("d", C.POINTER(FuseBwdDesc)), ("n", C.c_int), ("h", C.c_int), ("w", C.c_int), ("c", C.c_int), ("workspace", C.c_void_p)]
 
 
+class BottleneckDesc(C.Structure):   # lh_bottleneck_infer
+    _fields_ = [("n", C.c_int), ("h", C.c_int), ("w", C.c_int), ("cin", C.c_int), ("mid", C.c_int), ("cout", C.c_int)]
+
+
 class Head(C.Structure):
     _fields_ = [("w", C.c_void_p), ("w_row_bytes", C.c_size_t), ("bias", C.c_void_p), ("out", C.c_void_p), ("n_out", C.c_int)]
 
@@ -136,6 +140,7 @@ SIGNATURES = {
     "lh_fuse_bwd_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
     "lh_fuse_bwd": (_I, [C.POINTER(FuseBwdDesc), _I, _I, _I, _I, _P, _I, _P]),
     "lh_stem_pool": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "lh_bottleneck_infer": (_I, [C.POINTER(BottleneckDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "lh_stem_conv_rows": (_I, [_I, _I, _I]),
     "lh_stem_conv": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _P]),
     "lh_maxpool3x3s2_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -1,0 +1,356 @@
+// Inference bottleneck as ONE launch (round 5): the stride-1 residual block of the first ResNet stage in eval mode,
+//
+//   out = relu( bn3(conv3( relu(bn2(conv2( relu(bn1(conv1(x))) ))) )) + residual )        (reference: src/modeling/simplebaseline/
+//                                                                                           pose_resnet.py:61-99, Bottleneck.forward)
+//
+// with conv1 = 1x1 (CIN -> 64), conv2 = 3x3 / s1 / p1 (64 -> 64), conv3 = 1x1 (64 -> 256), every BatchNorm folded into a
+// per-channel scale / shift (running statistics).  Launched one by one these three convolutions move 4.8 GB per block at
+// BASELINE.json configs[4] (R50, 384 x 384, batch 256, fp16: the block's 1.2 GB input is read by conv1 and again as the
+// residual, the 0.3 GB intermediates are written and read back); here only the block input is read and the block output
+// written -- the 64-channel intermediates never leave LDS.
+//
+//  * A persistent workgroup (8 waves, one per CU: 152 KB of LDS) walks over 16 x 16 output tiles.  Per tile:
+//      P1  conv1 on the (16+2) x (16+2) haloed patch -> LDS patch [324 pixels][64 ch] (positions outside the image = 0: they are
+//          conv2's zero padding, not relu(shift));
+//      P2  conv2, the nine taps as nine offsets into that patch (conv3x3_direct_kernel.h's layout and swizzle) -> LDS [256][64],
+//          wave-private: a wave writes the two image rows it owns and is the only reader of them in P3;
+//      P3  conv3 (+ bn3 + residual + ReLU) through the per-wave epilogue of igemm_wave_epilogue.h (full-line NHWC stores).
+//  * EVERYTHING that comes from memory -- the input patch in 32-channel chunks, and the three weight tensors -- arrives through
+//    ONE ring of three 25 KB stages filled by LDS-DMA, as a continuous stream of stages that runs ahead of the phases and
+//    across tile boundaries:   per tile  CIN/32 x { input chunk [324][32] + W1 chunk [64][32] },  3 x { W2 taps 3g..3g+2 },
+//    2 x { W3 rows 128h..128h+127 }.   One raw s_barrier per stage; counted vmcnt (every wave issues the same number of DMA
+//    instructions per stage kind: surplus ones copy the zero page into a dump kilobyte).
+//  * K order of every convolution = that of the tiled kernels (tap-major, K ascending in 32-element MFMA slices), the
+//    epilogue arithmetic that of igemm_wave_epilogue.h: the block output is BIT-IDENTICAL to the three launches
+//    (tests/test_gpu_ops.py::test_fused_inference_bottleneck_is_bit_identical).
+#pragma once
+#include "igemm_ring_kernel.h"
+#include "igemm_wave_epilogue.h"
+#include "conv3x3_direct_kernel.h"
+
+struct BottleneckArgs {
+    IgemmArgs p3;                 // what the shared wave epilogue reads: out, out_pix_stride, cout, relu, addend (= residual), zero, dump
+    const unsigned char* x;       // block input  [n][h][w][cin]
+    const unsigned char* w1;      // packs (lh_pack_weight layout): [64 pad 128][1][kpad1], [64 pad 128][9][64], [256][1][64]
+    const unsigned char* w2;
+    const unsigned char* w3;
+    const float* s1; const float* b1; const float* s2; const float* b2; const float* s3; const float* b3;
+    int n, h, w, cin, kpad1, grid;
+};
+
+template <typename T>
+__device__ __forceinline__ void bottleneck_infer_body(const BottleneckArgs& a, unsigned char* smem) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int ES = sizeof(T);
+    static_assert(ES == 2, "16-bit element types");
+    constexpr int MID = 64, COUT = 256, TH = 16, TW = 16, PH = 18, PW = 18, NPIX = PH * PW, NWAVE = 8;
+    constexpr int NG1 = (NPIX + 15) / 16;                         // 21 pixel groups of conv1
+    constexpr int PATCH = NPIX * MID * ES;                        // 41,472
+    constexpr int MID2 = TH * TW * MID * ES;                      // 32,768
+    constexpr int IN_CH = NPIX * 64;                              // input chunk: 324 rows of 64 bytes (32 channels)
+    constexpr int IN_INST = (IN_CH + 1023) / 1024;                // 21 LDS-DMA instructions (16 rows each; the last one 4 rows)
+    constexpr int IN_PAD = IN_INST * 1024;                        // the last instruction's rows past the patch land in [IN_CH, IN_PAD): W1 sits behind them
+    constexpr int SLOT = IN_PAD + 4096;                           // 25,600 >= 24,576 (three W2 taps) >= 16,384 (half of W3)
+    constexpr int OFF_PATCH = 0, OFF_MID2 = PATCH, OFF_RING = PATCH + MID2, OFF_DUMP = OFF_RING + 3 * SLOT, OFF_CST = OFF_DUMP + 1024;
+    constexpr int NI1 = 4, NI2 = 3, NI3 = 2;                      // DMA instructions per wave and stage kind (25 / 24 / 16 real ones)
+    constexpr int RS = 64 * ES + 8, STG = 2 * 16 * RS;            // staging patch of the per-wave epilogue (32 rows x 64 channels)
+    static_assert(NWAVE * STG <= PATCH, "the epilogue's staging lives in the conv1 patch");
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, pl = lane & 15;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const int NK1 = a.cin / 32;                                   // conv1 K chunks = S1 stages per tile
+    const int SPT = NK1 + 5;                                      // stages per tile
+    const int H = a.h, W = a.w;
+    const int tx_n = (W + TW - 1) / TW, ty_n = (H + TH - 1) / TH;
+    const int ntile = a.n * ty_n * tx_n;
+    const int G = a.grid, b = blockIdx.x;
+    const int my_tiles = b < ntile ? (ntile - b + G - 1) / G : 0;
+    const long total = (long)my_tiles * SPT;                      // stages of this workgroup's stream
+    const long pixb = (long)a.cin * ES, rowb = (long)W * pixb, imgb = (long)H * rowb;
+
+    // per-channel constants -> LDS: [s1 b1 | s2 b2 | s3 b3 of channels 0..127 | s3 b3 of channels 128..255]
+    float* cst = reinterpret_cast<float*>(smem + OFF_CST);
+    for (int c = tid; c < 64; c += 64 * NWAVE) {
+        cst[c] = a.s1[c]; cst[64 + c] = a.b1[c]; cst[128 + c] = a.s2[c]; cst[192 + c] = a.b2[c];
+    }
+    for (int c = tid; c < COUT; c += 64 * NWAVE) {                // conv3: per half of 128 channels [scale | shift] (wave_epilogue<.., 128, ..>)
+        cst[256 + (c >> 7) * 256 + (c & 127)] = a.s3[c];
+        cst[256 + (c >> 7) * 256 + 128 + (c & 127)] = a.b3[c];
+    }
+
+    // ---- the stage stream: issue cursor
+    long issued = 0;
+    int i_tile = b, i_k = 0, i_slot = 0;                          // tile of the stage being issued, its index inside the tile
+    int iy0 = 0, ix0 = 0;
+    const unsigned char* ibase = a.x;
+    auto tile_origin = [&](int tile, int& y0, int& x0, int& n) {
+        n = tile / (ty_n * tx_n);
+        const int rem = tile - n * (ty_n * tx_n);
+        y0 = (rem / tx_n) * TH;
+        x0 = (rem % tx_n) * TW;
+    };
+    {
+        int n0;
+        tile_origin(i_tile < ntile ? i_tile : 0, iy0, ix0, n0);
+        ibase = a.x + n0 * imgb;
+    }
+    auto dump_dma = [&]() { d3_lds_dma16(a.p3.zero, lds_base + OFF_DUMP); };
+    auto issue = [&]() {
+        const unsigned slot = lds_base + OFF_RING + i_slot * SLOT;
+        if (i_k < NK1) {                                          // S1: input chunk (rows of 64 B, 16 rows per instruction) + W1 chunk
+#pragma unroll
+            for (int j = 0; j < NI1; ++j) {
+                const int inst = NWAVE * j + wave;
+                if (inst < IN_INST) {
+                    const int pp = inst * 16 + (lane >> 2);
+                    const int c = (lane & 3) ^ ((pp >> 2) & 3);
+                    const int py = pp / PW, px = pp - py * PW;
+                    const int iy = iy0 - 1 + py, ix = ix0 - 1 + px;
+                    const bool ok = (pp < NPIX) & ((unsigned)iy < (unsigned)H) & ((unsigned)ix < (unsigned)W);
+                    const unsigned char* src = ok ? ibase + iy * rowb + ix * pixb + i_k * 64 + c * 16 : a.p3.zero;
+                    d3_lds_dma16(src, slot + inst * 1024);
+                } else if (inst < IN_INST + 4) {
+                    const int r = (inst - IN_INST) * 16 + (lane >> 2);
+                    const int c = (lane & 3) ^ ((r >> 2) & 3);
+                    d3_lds_dma16(a.w1 + ((long)r * a.kpad1 + i_k * 32 + c * 8) * ES, slot + IN_PAD + (inst - IN_INST) * 1024);
+                } else dump_dma();
+            }
+        } else if (i_k < NK1 + 3) {                               // S2: three taps of W2, [tap][64 rows][128 B]
+            const int g = i_k - NK1;
+#pragma unroll
+            for (int j = 0; j < NI2; ++j) {
+                const int inst = NWAVE * j + wave;                // 0 .. 23: tap tt = inst / 8, rows 8 (inst % 8) ..
+                const int tt = inst >> 3, r = (inst & 7) * 8 + (lane >> 3);
+                const int c = (lane & 7) ^ ((r >> 1) & 7);
+                d3_lds_dma16(a.w2 + (((long)r * 9 + 3 * g + tt) * 64 + c * 8) * ES, slot + inst * 1024);
+            }
+        } else {                                                  // S3: half of W3, [128 rows][128 B]
+            const int hh = i_k - NK1 - 3;
+#pragma unroll
+            for (int j = 0; j < NI3; ++j) {
+                const int inst = NWAVE * j + wave;                // 0 .. 15: rows 8 inst ..
+                const int r = inst * 8 + (lane >> 3);
+                const int c = (lane & 7) ^ ((r >> 1) & 7);
+                d3_lds_dma16(a.w3 + ((long)(128 * hh + r) * 64 + c * 8) * ES, slot + inst * 1024);
+            }
+        }
+        ++issued;
+        if (++i_slot == 3) i_slot = 0;
+        if (++i_k == SPT) {
+            i_k = 0;
+            i_tile += G;
+            int n0;
+            tile_origin(i_tile < ntile ? i_tile : 0, iy0, ix0, n0);
+            ibase = a.x + n0 * imgb;
+        }
+    };
+    // DMA instructions per wave of the stage `k` positions behind the issue cursor (what may stay in flight)
+    auto ni_of = [&](int k_in_tile) { return k_in_tile < NK1 ? NI1 : k_in_tile < NK1 + 3 ? NI2 : NI3; };
+
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (total > 0) issue();
+    if (total > 1) issue();
+
+    // ---- consume cursor
+    long done = 0;                                                // stages consumed so far
+    int c_slot = 0;
+    // stage `done` has landed for this wave: the stages issued after it may stay in flight (at most two, their instruction
+    // counts depend on their kind); then the barrier: everyone's share has landed AND everyone is done with stage done - 1
+    // The output stores of the per-wave epilogue (8 per half tile and wave: wave_epilogue stores from every lane in every pass)
+    // are YOUNGER than the stages that were in flight when they were issued: the waits that follow leave them in flight too
+    // (`stores` = how many of them may still be behind the stage waited for).
+    auto stage_wait = [&](int k_in_tile, int stores) {
+        const long ahead = issued - 1 - done;                     // 1 in the steady state, 0 on the last stage of the stream
+        const int allow = (ahead >= 1 ? ni_of((k_in_tile + 1) % SPT) : 0) + stores;
+        switch (allow) {                                          // 0, 2, 3, 4 (+ 8 or 16): immediates
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+            case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+            case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+            case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+            case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+            case 19: asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); break;
+            case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (issued < total) issue();                              // into the slot of stage done - 1
+    };
+    auto stage_done = [&]() {
+        ++done;
+        if (++c_slot == 3) c_slot = 0;
+    };
+
+    const int ng1 = wave < NG1 - 2 * NWAVE ? 3 : 2;               // conv1 pixel groups of this wave: gq = wave, wave + 8 (, wave + 16)
+    for (int t = b; t < ntile; t += G) {
+        int y0, x0, n;
+        tile_origin(t, y0, x0, n);
+        // ================= P1: conv1 over the haloed patch, K in 32-channel stages
+        f32x4 acc1[4][3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < NK1; ++k) {
+            stage_wait(k, t != b ? (k == 0 ? 16 : k == 1 ? 8 : 0) : 0);
+            const unsigned char* st = smem + OFF_RING + c_slot * SLOT;
+            uint4 A[4], B[3];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 16 * i + pl;
+                A[i] = *reinterpret_cast<const uint4*>(st + IN_PAD + r * 64 + ((q ^ ((r >> 2) & 3)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int pp = 16 * (wave + 8 * j) + pl;
+                if (j < ng1) B[j] = *reinterpret_cast<const uint4*>(st + pp * 64 + ((q ^ ((pp >> 2) & 3)) << 4));
+                else B[j] = uint4{0u, 0u, 0u, 0u};
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    if (j < 2 || ng1 == 3) MmaR<T>::run(A[i], B[j], acc1[i][j]);
+            stage_done();
+        }
+        // conv1 epilogue: bn1 + ReLU -> patch [pp][64 ch] (swizzled by pp); positions outside the image are conv2's zero padding
+        {
+            unsigned char* patch = smem + OFF_PATCH;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                if (j >= ng1) continue;
+                const int pp = 16 * (wave + 8 * j) + pl;
+                const int py = pp / PW, px = pp - py * PW;
+                const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+                const bool inside = ((unsigned)iy < (unsigned)H) & ((unsigned)ix < (unsigned)W);
+                if (pp < NPIX) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int col = 16 * i + 4 * q;
+                        const float4 sv = *reinterpret_cast<const float4*>(cst + col);
+                        const float4 bv = *reinterpret_cast<const float4*>(cst + 64 + col);
+                        union { uint2 u; T e[4]; } pk;
+                        pk.e[0] = from_f<T>(fmaxf(to_f<T>(from_f<T>(acc1[i][j][0] * sv.x + bv.x)), 0.f));
+                        pk.e[1] = from_f<T>(fmaxf(to_f<T>(from_f<T>(acc1[i][j][1] * sv.y + bv.y)), 0.f));
+                        pk.e[2] = from_f<T>(fmaxf(to_f<T>(from_f<T>(acc1[i][j][2] * sv.z + bv.z)), 0.f));
+                        pk.e[3] = from_f<T>(fmaxf(to_f<T>(from_f<T>(acc1[i][j][3] * sv.w + bv.w)), 0.f));
+                        if (!inside) pk.u = uint2{0u, 0u};
+                        const int chunk = col >> 3;                           // 16-byte slot of these four channels
+                        *reinterpret_cast<uint2*>(patch + pp * 128 + ((chunk ^ ((pp >> 1) & 7)) << 4) + (col & 7) * ES) = pk.u;
+                    }
+                }
+            }
+        }
+        // ================= P2: conv2, three taps per stage; the wave owns image rows 2 wave, 2 wave + 1 of the tile
+        f32x4 acc2[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int g = 0; g < 3; ++g) {
+            stage_wait(NK1 + g, 0);                               // (g == 0: also "every wave's part of the patch is written")
+            const unsigned char* st = smem + OFF_RING + c_slot * SLOT;
+            const unsigned char* patch = smem + OFF_PATCH;
+#pragma unroll
+            for (int tt = 0; tt < 3; ++tt) {
+                const int dy = g, dx = tt;                        // tap 3 g + tt = (dy, dx) of the 3 x 3 window, row-major
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    uint4 A[4], B[2];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = 16 * i + pl;
+                        A[i] = *reinterpret_cast<const uint4*>(st + tt * 8192 + r * 128 + (((4 * kk + q) ^ ((r >> 1) & 7)) << 4));
+                    }
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int pp = (2 * wave + j + dy) * PW + dx + pl;
+                        B[j] = *reinterpret_cast<const uint4*>(patch + pp * 128 + (((4 * kk + q) ^ ((pp >> 1) & 7)) << 4));
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) MmaR<T>::run(A[i], B[j], acc2[i][j]);
+                }
+            }
+            stage_done();
+        }
+        // conv2 epilogue: bn2 + ReLU -> mid2 rows of THIS wave's 32 pixels (wave-private: written and read by this wave only)
+        {
+            unsigned char* mid = smem + OFF_MID2 + wave * (32 * 128);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int col = 16 * i + 4 * q, r = 16 * j + pl;
+                    const float4 sv = *reinterpret_cast<const float4*>(cst + 128 + col);
+                    const float4 bv = *reinterpret_cast<const float4*>(cst + 192 + col);
+                    union { uint2 u; T e[4]; } pk;
+                    pk.e[0] = from_f<T>(fmaxf(to_f<T>(from_f<T>(acc2[i][j][0] * sv.x + bv.x)), 0.f));
+                    pk.e[1] = from_f<T>(fmaxf(to_f<T>(from_f<T>(acc2[i][j][1] * sv.y + bv.y)), 0.f));
+                    pk.e[2] = from_f<T>(fmaxf(to_f<T>(from_f<T>(acc2[i][j][2] * sv.z + bv.z)), 0.f));
+                    pk.e[3] = from_f<T>(fmaxf(to_f<T>(from_f<T>(acc2[i][j][3] * sv.w + bv.w)), 0.f));
+                    *reinterpret_cast<uint2*>(mid + r * 128 + (((col >> 3) ^ ((r >> 1) & 7)) << 4) + (col & 7) * ES) = pk.u;
+                }
+        }
+        // ================= P3: conv3 in two halves of 128 output channels (one W3 stage each); B fragments = this wave's mid2 rows.
+        // Each half goes straight through bn3 + residual + ReLU and out (64 accumulator registers instead of 128); the staging
+        // patch of the epilogue = the conv1 patch, which every wave left before the barrier of the first W3 stage.
+        uint4 Bm[2][2];
+        {
+            const unsigned char* mid = smem + OFF_MID2 + wave * (32 * 128);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int r = 16 * j + pl;
+                    Bm[kk][j] = *reinterpret_cast<const uint4*>(mid + r * 128 + (((4 * kk + q) ^ ((r >> 1) & 7)) << 4));
+                }
+        }
+        for (int hh = 0; hh < 2; ++hh) {
+            stage_wait(NK1 + 3 + hh, hh == 1 ? 8 : 0);
+            const unsigned char* st = smem + OFF_RING + c_slot * SLOT;
+            f32x4 acc3[8][2];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc3[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int r = 16 * i + pl;
+                    const uint4 A = *reinterpret_cast<const uint4*>(st + r * 128 + (((4 * kk + q) ^ ((r >> 1) & 7)) << 4));
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) MmaR<T>::run(A, Bm[kk][j], acc3[i][j]);
+                }
+            }
+            stage_done();
+            unsigned char* stg = smem + OFF_PATCH + wave * STG;
+            float s1d[1][8], s2d[1][8];
+            const int oy0 = y0 + 2 * wave;
+            wave_epilogue<T, 128, 2, false>(a.p3, acc3, stg, cst + 256 + hh * 256, hh, lane, [&](int row) {
+                const int y = oy0 + (row >> 4), x = x0 + (row & 15);
+                return (y < H && x < W) ? ((long)n * H + y) * W + x : -1L;
+            }, s1d, s2d);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+
+template <typename T>
+__global__ __launch_bounds__(512, 2) void bottleneck_infer_kernel(const BottleneckArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bottleneck_infer_body<T>(a, smem);
+}
+
+static inline int lh_bottleneck_lds_bytes() { return 18 * 18 * 64 * 2 + 16 * 16 * 64 * 2 + 3 * (21 * 1024 + 4096) + 1024 + (128 + 128 + 512) * 4; }

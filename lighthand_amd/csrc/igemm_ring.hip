@@ -347,6 +347,9 @@ static int lh_ring_offsets_fit(const IgemmArgs& a, int bm, int bp, int es) {
     return LH_OK;
 }
 
+const unsigned char* lh_ring_zero_page() { return zero_page(); }      // bottleneck_infer.hip
+unsigned char* lh_ring_dump_page() { return dump_page(); }
+
 int lh_igemm_ring_launch(const IgemmArgs& a0, const RingCfg& c, int dtype, hipStream_t s) {
     IgemmArgs a = a0;
     a.zero = zero_page();

@@ -339,6 +339,7 @@ class Plan:
     force_wgrad = None
     fuse_head = True             # test hook: False keeps the inference head as separate launches (A/B against _fuse_head)
     fuse_stem = True             # test hook: False keeps the inference stem as convolution + max-pool launches (A/B against _fuse_stem_pool)
+    fuse_bottleneck = os.environ.get("LH_FUSE_BOTTLENECK", "1") != "0"    # False keeps the stage-1 bottlenecks of inference plans as three launches (A/B against _fuse_bottleneck)
     _tune_file_loaded = False
 
     _tune_measured = set()      # keys measured by this process or read from the user's cache file (what a save writes)
@@ -1897,6 +1898,69 @@ class Plan:
         for c in main:
             self._patch(c, relu=relu, dst=obuf, addend=addend, scale=st0["scale"].data_ptr(), shift=st0["shift"].data_ptr())
         self._producers.setdefault(id(out), []).extend(main)       # `out` is now written by these launches (see _fuse_head)
+        if len(terms) == 2 and relu:
+            self._fuse_bottleneck(terms[0][0], out)
+        return True
+
+    def _fuse_bottleneck(self, y3, out):
+        """Inference plans: a stride-1 bottleneck of the first ResNet stage (pose_resnet.py:61-99: conv1 1x1 -> bn1 -> relu ->
+        conv2 3x3 -> bn2 -> relu -> conv3 1x1 -> bn3, + residual, relu; 64 mid channels, 256 out) as ONE launch
+        (lh_bottleneck_infer): only the block input and the residual are read and the block output written, the 64-channel
+        intermediates stay in LDS -- 2.4 instead of 4.8 GB per identity block at configs[4].  Called when the block's last
+        node has just been folded into conv3's epilogue (_fold_eval_bn); walks back conv3 <- conv2 <- conv1 and replaces the
+        three launches when every link is what the kernel implements.  The projection shortcut of the stage's first block
+        stays a launch of its own (its output is the residual)."""
+        if not Plan.fuse_bottleneck or self.with_bwd or self.training or self.es != 2:
+            return False
+        conv_of = lambda act: next((n for kind, n in self.nodes if kind == "conv" and n["y"] is act), None)
+        users = lambda act: sum(1 for kind, n in self.nodes
+                                if (kind in ("conv", "deconv", "maxpool") and n["x"] is act) or (kind == "fuse" and any(a is act for a, _, _ in n["terms"]))
+                                or (kind == "output" and n["y"] is act))
+        n3 = conv_of(y3)
+        if n3 is None or (n3["k"], n3["s"], n3["p"]) != (1, 1, 0) or n3["bias"]:
+            return False
+        a2 = n3["x"]                                   # relu(bn2(conv2)): written by conv2's launch since its node was folded
+        p2 = self._producers.get(id(a2)) or []
+        n2 = conv_of(next((t[0] for kind, n in self.nodes if kind == "fuse" and n["out"] is a2 for t in n["terms"]), None))
+        if len(p2) != 1 or n2 is None or (n2["k"], n2["s"], n2["p"]) != (3, 1, 1) or n2["bias"] or users(a2) != 1:
+            return False
+        a1 = n2["x"]
+        p1 = self._producers.get(id(a1)) or []
+        n1 = conv_of(next((t[0] for kind, n in self.nodes if kind == "fuse" and n["out"] is a1 for t in n["terms"]), None))
+        if len(p1) != 1 or n1 is None or (n1["k"], n1["s"], n1["p"]) != (1, 1, 0) or n1["bias"] or users(a1) != 1:
+            return False
+        p3 = self._producers.get(id(y3)) or []
+        if len(p3) != 1:
+            return False
+        c1, c2, c3 = p1[0], p2[0], p3[0]
+        lib, ig = self.lib, self._IG
+        if any(c.fn is not lib.lh_igemm or c not in self.fwd or self._in_closed_region(c) for c in (c1, c2, c3)):
+            return False
+        x = n1["x"]
+        d1, d2, d3 = c1.keep, c2.keep, c3.keep
+        ok = (d1.cout == 64 and d2.cout == 64 and d3.cout == 256 and d2.k_run == 64 and d3.k_run == 64 and d1.k_run == x.c and x.c % 32 == 0
+              and 64 <= x.c <= 1024 and d1.in_pix_stride == x.c and d2.in_pix_stride == 64 and d3.in_pix_stride == 64
+              and d1.relu == 1 and d2.relu == 1 and d3.relu == 1 and (d1.ho, d1.wo) == (x.h, x.w) and (d3.ho, d3.wo) == (x.h, x.w))
+        a1_, a2_, a3_ = c1.args, c2.args, c3.args
+        ok = ok and all(a[ig["scale"]] and a[ig["shift"]] and not a[ig["bias"]] and not a[ig["stats"]] and not a[ig["addend_mask"]] for a in (a1_, a2_, a3_))
+        ok = ok and not a1_[ig["addend"]] and not a2_[ig["addend"]] and a3_[ig["addend"]] and a1_[ig["src"]] == x.buf.data_ptr()
+        ok = ok and a3_[ig["dst"]] not in (a1_[ig["src"]], a3_[ig["addend"]])
+        if not ok:
+            return False
+        bd = _lib.BottleneckDesc(x.n, x.h, x.w, x.c, 64, 256)
+        fused = _Call(lib.lh_bottleneck_infer, (C.byref(bd), a1_[ig["src"]], a1_[ig["pack"]], a2_[ig["pack"]], a3_[ig["pack"]],
+                                                a1_[ig["scale"]], a1_[ig["shift"]], a2_[ig["scale"]], a2_[ig["shift"]], a3_[ig["scale"]], a3_[ig["shift"]],
+                                                a3_[ig["addend"]], a3_[ig["dst"]], self.dt), c1.what.replace("conv1 fwd", "bottleneck fwd (conv1 + conv2 + conv3 + residual)"),
+                      keep=[bd, d1, d2, d3, c1, c2, c3])
+        fused.slane = c3.slane
+        self.fwd[self.fwd.index(c3)] = fused
+        self.fwd.remove(c1)
+        self.fwd.remove(c2)
+        flops = sum(fl for _, c, _, fl, _ in self.profile_meta if c in (c1, c2, c3))
+        self.profile_meta = [m for m in self.profile_meta if m[1] not in (c1, c2, c3)]
+        self.profile_meta.append(("fwd", fused, "bottleneck_infer_kernel", flops, (x.pixels * x.c + 2 * out.pixels * out.c) * self.es))
+        self._producers[id(out)] = [fused]
+        self._n_fused_bottlenecks = getattr(self, "_n_fused_bottlenecks", 0) + 1
         return True
 
     def _fuse_stem_pool(self, nd):
