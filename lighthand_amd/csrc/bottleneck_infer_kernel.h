@@ -9,14 +9,14 @@
 // residual, the 0.3 GB intermediates are written and read back); here only the block input is read and the block output
 // written -- the 64-channel intermediates never leave LDS.
 //
-//  * A persistent workgroup (8 waves, one per CU: 152 KB of LDS) walks over 16 x 16 output tiles.  Per tile:
+//  * A persistent workgroup (8 waves, one per CU: 148 KB of LDS) walks over 16 x 16 output tiles.  Per tile:
 //      P1  conv1 on the (16+2) x (16+2) haloed patch -> LDS patch [324 pixels][64 ch] (positions outside the image = 0: they are
 //          conv2's zero padding, not relu(shift));
-//      P2  conv2, the nine taps as nine offsets into that patch (conv3x3_direct_kernel.h's layout and swizzle) -> LDS [256][64],
-//          wave-private: a wave writes the two image rows it owns and is the only reader of them in P3;
+//      P2  conv2, the nine taps as nine offsets into that patch (conv3x3_direct_kernel.h's layout and swizzle); its output (bn2 +
+//          ReLU) goes through a wave-private 4 KB of LDS: a wave writes the two image rows it owns and is their only reader;
 //      P3  conv3 (+ bn3 + residual + ReLU) through the per-wave epilogue of igemm_wave_epilogue.h (full-line NHWC stores).
 //  * EVERYTHING that comes from memory -- the input patch in 32-channel chunks, and the three weight tensors -- arrives through
-//    ONE ring of three 25 KB stages filled by LDS-DMA, as a continuous stream of stages that runs ahead of the phases and
+//    ONE ring of four 25 KB stages filled by LDS-DMA, as a continuous stream of stages that runs ahead of the phases and
 //    across tile boundaries:   per tile  CIN/32 x { input chunk [324][32] + W1 chunk [64][32] },  3 x { W2 taps 3g..3g+2 },
 //    2 x { W3 rows 128h..128h+127 }.   One raw s_barrier per stage; counted vmcnt (every wave issues the same number of DMA
 //    instructions per stage kind: surplus ones copy the zero page into a dump kilobyte).
@@ -27,6 +27,62 @@
 #include "igemm_ring_kernel.h"
 #include "igemm_wave_epilogue.h"
 #include "conv3x3_direct_kernel.h"
+
+// Debug-only ablation builds (timing experiments; results are garbage): -DLH_BNK_ABL=<bits>  1 / 2 / 4 = no MFMAs in conv1 / conv2 /
+// conv3, 8 = no LDS-DMA, 16 = no output epilogue, 32 = no fragment reads in conv2.  Never set in the product build.
+#ifndef LH_BNK_ABL
+#define LH_BNK_ABL 0
+#endif
+
+// wave_epilogue (igemm_wave_epilogue.h) with the addend rows ALREADY IN REGISTERS: the residual of a tile is requested ahead of
+// conv3's MFMAs, instead of being loaded -- and waited for, four times per tile -- inside the epilogue.
+// Same arithmetic, same store pattern (every lane stores in every pass); ad[k] = the 16 bytes wave_epilogue would have loaded for
+// staging row k * 8 + (lane >> 3), columns cblk * 128 + sb * 64 + (lane & 7) * 8.
+template <typename T, typename PixFn>
+__device__ __forceinline__ void bneck_epilogue_half(const IgemmArgs& p, f32x4 (&acc)[8][2], unsigned char* stg, const float* cst, const int cblk,
+                                                    const int lane, PixFn&& pix, const uint4 (&adh)[2][4]) {
+    constexpr int ES = sizeof(T), EPC = 8, SUBW = 64, RS = SUBW * ES + 8, PT = 2, BM = 128;
+    const int q = lane >> 4, pl = lane & 15;
+    const int rrow = lane >> 3, rch = lane & 7;
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int i = sb * 4 + it;
+            const int col = i * 16 + q * 4;
+            const float4 sv = *reinterpret_cast<const float4*>(cst + col);
+            const float4 bv = *reinterpret_cast<const float4*>(cst + BM + col);
+#pragma unroll
+            for (int j = 0; j < PT; ++j) {
+                union { uint2 u; T e[4]; } pk;
+                pk.e[0] = from_f<T>(acc[i][j][0] * sv.x + bv.x);
+                pk.e[1] = from_f<T>(acc[i][j][1] * sv.y + bv.y);
+                pk.e[2] = from_f<T>(acc[i][j][2] * sv.z + bv.z);
+                pk.e[3] = from_f<T>(acc[i][j][3] * sv.w + bv.w);
+                *reinterpret_cast<uint2*>(stg + (j * 16 + pl) * RS + (it * 16 + q * 4) * ES) = pk.u;
+            }
+        }
+        const int col0 = cblk * BM + sb * SUBW + rch * EPC;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int row = k * 8 + rrow;
+            const long opix = pix(row);
+            const unsigned char* src = stg + row * RS + rch * 16;
+            const uint2 lo = *reinterpret_cast<const uint2*>(src);
+            const uint2 hi = *reinterpret_cast<const uint2*>(src + 8);
+            uint4 u = uint4{lo.x, lo.y, hi.x, hi.y};
+            float v[EPC], av[EPC];
+            unpack16<T>(u, v);
+            unpack16<T>(adh[sb][k], av);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) v[e] = fmaxf(v[e] + av[e], 0.f);
+            u = pack16<T>(v);
+            unsigned char* dst = opix >= 0 ? p.out + (opix * p.out_pix_stride + col0) * ES : p.dump + lane * 16;
+            *reinterpret_cast<uint4*>(dst) = u;
+        }
+    }
+}
 
 struct BottleneckArgs {
     IgemmArgs p3;                 // what the shared wave epilogue reads: out, out_pix_stride, cout, relu, addend (= residual), zero, dump
@@ -46,19 +102,18 @@ __device__ __forceinline__ void bottleneck_infer_body(const BottleneckArgs& a, u
     constexpr int MID = 64, COUT = 256, TH = 16, TW = 16, PH = 18, PW = 18, NPIX = PH * PW, NWAVE = 8;
     constexpr int NG1 = (NPIX + 15) / 16;                         // 21 pixel groups of conv1
     constexpr int PATCH = NPIX * MID * ES;                        // 41,472
-    constexpr int MID2 = TH * TW * MID * ES;                      // 32,768
     constexpr int IN_CH = NPIX * 64;                              // input chunk: 324 rows of 64 bytes (32 channels)
     constexpr int IN_INST = (IN_CH + 1023) / 1024;                // 21 LDS-DMA instructions (16 rows each; the last one 4 rows)
     constexpr int IN_PAD = IN_INST * 1024;                        // the last instruction's rows past the patch land in [IN_CH, IN_PAD): W1 sits behind them
     constexpr int SLOT = IN_PAD + 4096;                           // 25,600 >= 24,576 (three W2 taps) >= 16,384 (half of W3)
-    constexpr int OFF_PATCH = 0, OFF_MID2 = PATCH, OFF_RING = PATCH + MID2, OFF_DUMP = OFF_RING + 3 * SLOT, OFF_CST = OFF_DUMP + 1024;
+    constexpr int NSLOT = 4;                                      // ring depth: three stages (77 KB) in flight behind the one being consumed
+    constexpr int OFF_PATCH = 0, OFF_RING = PATCH, OFF_DUMP = OFF_RING + NSLOT * SLOT, OFF_CST = OFF_DUMP + 1024;
     constexpr int NI1 = 4, NI2 = 3, NI3 = 2;                      // DMA instructions per wave and stage kind (25 / 24 / 16 real ones)
     constexpr int RS = 64 * ES + 8, STG = 2 * 16 * RS;            // staging patch of the per-wave epilogue (32 rows x 64 channels)
-    static_assert(NWAVE * STG <= PATCH, "the epilogue's staging lives in the conv1 patch");
+    static_assert(NWAVE * STG <= PATCH && 32 * 128 <= STG, "the epilogue's staging and the wave's conv2 output rows live in the conv1 patch");
 
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x, lane0 = tid & 63, lane = lane0;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int q = lane >> 4, pl = lane & 15;
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
     const int NK1 = a.cin / 32;                                   // conv1 K chunks = S1 stages per tile
     const int SPT = NK1 + 5;                                      // stages per tile
@@ -96,9 +151,12 @@ __device__ __forceinline__ void bottleneck_infer_body(const BottleneckArgs& a, u
         tile_origin(i_tile < ntile ? i_tile : 0, iy0, ix0, n0);
         ibase = a.x + n0 * imgb;
     }
-    auto dump_dma = [&]() { d3_lds_dma16(a.p3.zero, lds_base + OFF_DUMP); };
+    auto dma = [&](const unsigned char* src, unsigned dst) { if (!(LH_BNK_ABL & 8)) d3_lds_dma16(src, dst); };
+    auto dump_dma = [&]() { dma(a.p3.zero, lds_base + OFF_DUMP); };
     auto issue = [&]() {
         const unsigned slot = lds_base + OFF_RING + i_slot * SLOT;
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));                            // (the same for the DMA source addresses: not hoisted, not spilled)
         if (i_k < NK1) {                                          // S1: input chunk (rows of 64 B, 16 rows per instruction) + W1 chunk
 #pragma unroll
             for (int j = 0; j < NI1; ++j) {
@@ -110,11 +168,11 @@ __device__ __forceinline__ void bottleneck_infer_body(const BottleneckArgs& a, u
                     const int iy = iy0 - 1 + py, ix = ix0 - 1 + px;
                     const bool ok = (pp < NPIX) & ((unsigned)iy < (unsigned)H) & ((unsigned)ix < (unsigned)W);
                     const unsigned char* src = ok ? ibase + iy * rowb + ix * pixb + i_k * 64 + c * 16 : a.p3.zero;
-                    d3_lds_dma16(src, slot + inst * 1024);
+                    dma(src, slot + inst * 1024);
                 } else if (inst < IN_INST + 4) {
                     const int r = (inst - IN_INST) * 16 + (lane >> 2);
                     const int c = (lane & 3) ^ ((r >> 2) & 3);
-                    d3_lds_dma16(a.w1 + ((long)r * a.kpad1 + i_k * 32 + c * 8) * ES, slot + IN_PAD + (inst - IN_INST) * 1024);
+                    dma(a.w1 + ((long)r * a.kpad1 + i_k * 32 + c * 8) * ES, slot + IN_PAD + (inst - IN_INST) * 1024);
                 } else dump_dma();
             }
         } else if (i_k < NK1 + 3) {                               // S2: three taps of W2, [tap][64 rows][128 B]
@@ -124,7 +182,7 @@ __device__ __forceinline__ void bottleneck_infer_body(const BottleneckArgs& a, u
                 const int inst = NWAVE * j + wave;                // 0 .. 23: tap tt = inst / 8, rows 8 (inst % 8) ..
                 const int tt = inst >> 3, r = (inst & 7) * 8 + (lane >> 3);
                 const int c = (lane & 7) ^ ((r >> 1) & 7);
-                d3_lds_dma16(a.w2 + (((long)r * 9 + 3 * g + tt) * 64 + c * 8) * ES, slot + inst * 1024);
+                dma(a.w2 + (((long)r * 9 + 3 * g + tt) * 64 + c * 8) * ES, slot + inst * 1024);
             }
         } else {                                                  // S3: half of W3, [128 rows][128 B]
             const int hh = i_k - NK1 - 3;
@@ -133,11 +191,11 @@ __device__ __forceinline__ void bottleneck_infer_body(const BottleneckArgs& a, u
                 const int inst = NWAVE * j + wave;                // 0 .. 15: rows 8 inst ..
                 const int r = inst * 8 + (lane >> 3);
                 const int c = (lane & 7) ^ ((r >> 1) & 7);
-                d3_lds_dma16(a.w3 + ((long)(128 * hh + r) * 64 + c * 8) * ES, slot + inst * 1024);
+                dma(a.w3 + ((long)(128 * hh + r) * 64 + c * 8) * ES, slot + inst * 1024);
             }
         }
         ++issued;
-        if (++i_slot == 3) i_slot = 0;
+        if (++i_slot == NSLOT) i_slot = 0;
         if (++i_k == SPT) {
             i_k = 0;
             i_tile += G;
@@ -150,8 +208,9 @@ __device__ __forceinline__ void bottleneck_infer_body(const BottleneckArgs& a, u
     auto ni_of = [&](int k_in_tile) { return k_in_tile < NK1 ? NI1 : k_in_tile < NK1 + 3 ? NI2 : NI3; };
 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (total > 0) issue();
-    if (total > 1) issue();
+#pragma unroll
+    for (int s0 = 0; s0 < NSLOT - 1; ++s0)
+        if (issued < total) issue();
 
     // ---- consume cursor
     long done = 0;                                                // stages consumed so far
@@ -161,24 +220,27 @@ __device__ __forceinline__ void bottleneck_infer_body(const BottleneckArgs& a, u
     // The output stores of the per-wave epilogue (8 per half tile and wave: wave_epilogue stores from every lane in every pass)
     // are YOUNGER than the stages that were in flight when they were issued: the waits that follow leave them in flight too
     // (`stores` = how many of them may still be behind the stage waited for).
-    auto stage_wait = [&](int k_in_tile, int stores) {
-        const long ahead = issued - 1 - done;                     // 1 in the steady state, 0 on the last stage of the stream
-        const int allow = (ahead >= 1 ? ni_of((k_in_tile + 1) % SPT) : 0) + stores;
-        switch (allow) {                                          // 0, 2, 3, 4 (+ 8 or 16): immediates
-            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-            case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-            case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
-            case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-            case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-            case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
-            case 19: asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); break;
-            case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+    auto stage_wait = [&](int k_in_tile, bool first_tile) {
+        // stores of the two half-tile epilogues still behind the stage waited for (see above): the second W3 stage has the first
+        // half's 8 behind it; the next tile's stages 0 / 1 / 2 have 16 / 16 / 8
+        // ... and so are the 8 residual loads each half requests behind the barrier of its W3 stage (consumed by the half's epilogue,
+        // but still counted among the operations younger than the stage waited for): 8 + 8 per half
+        const int stores = k_in_tile == NK1 + 4 ? 16 : first_tile ? 0 : k_in_tile < 2 ? 32 : k_in_tile == 2 ? 16 : 0;
+        const long ahead = issued - 1 - done;                     // NSLOT - 2 in the steady state, fewer at the end of the stream
+        int allow = stores;
+        if (ahead >= 1) allow += ni_of((k_in_tile + 1) % SPT);
+        if (ahead >= 2) allow += ni_of((k_in_tile + 2) % SPT);
+        if (allow > 32) allow = 32;                               // fewer than are really behind it: stricter, never wrong
+        // vmcnt(allow): allow <= 8 + 16; a binary ladder of immediates (the count is wave-uniform)
+#define LH_BN_WAIT(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+        switch (allow) {
+            LH_BN_WAIT(0) LH_BN_WAIT(1) LH_BN_WAIT(2) LH_BN_WAIT(3) LH_BN_WAIT(4) LH_BN_WAIT(5) LH_BN_WAIT(6) LH_BN_WAIT(7) LH_BN_WAIT(8)
+            LH_BN_WAIT(9) LH_BN_WAIT(10) LH_BN_WAIT(11) LH_BN_WAIT(12) LH_BN_WAIT(13) LH_BN_WAIT(14) LH_BN_WAIT(15) LH_BN_WAIT(16)
+            LH_BN_WAIT(17) LH_BN_WAIT(18) LH_BN_WAIT(19) LH_BN_WAIT(20) LH_BN_WAIT(21) LH_BN_WAIT(22) LH_BN_WAIT(23) LH_BN_WAIT(24)
+            LH_BN_WAIT(25) LH_BN_WAIT(26) LH_BN_WAIT(27) LH_BN_WAIT(28) LH_BN_WAIT(29) LH_BN_WAIT(30) LH_BN_WAIT(31) LH_BN_WAIT(32)
             default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
         }
+#undef LH_BN_WAIT
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -186,13 +248,18 @@ __device__ __forceinline__ void bottleneck_infer_body(const BottleneckArgs& a, u
     };
     auto stage_done = [&]() {
         ++done;
-        if (++c_slot == 3) c_slot = 0;
+        if (++c_slot == NSLOT) c_slot = 0;
     };
 
     const int ng1 = wave < NG1 - 2 * NWAVE ? 3 : 2;               // conv1 pixel groups of this wave: gq = wave, wave + 8 (, wave + 16)
+    const int q0 = lane >> 4, pl0 = lane & 15;
     for (int t = b; t < ntile; t += G) {
         int y0, x0, n;
         tile_origin(t, y0, x0, n);
+        // the lane's fragment coordinates, made opaque once per tile: every LDS address below is tile-invariant, and hoisted out of
+        // this loop (a hundred address registers) they would spill -- recomputing them per tile costs a few vector instructions
+        int q = q0, pl = pl0;
+        asm volatile("" : "+v"(q), "+v"(pl));
         // ================= P1: conv1 over the haloed patch, K in 32-channel stages
         f32x4 acc1[4][3];
 #pragma unroll
@@ -200,7 +267,7 @@ __device__ __forceinline__ void bottleneck_infer_body(const BottleneckArgs& a, u
 #pragma unroll
             for (int j = 0; j < 3; ++j) acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int k = 0; k < NK1; ++k) {
-            stage_wait(k, t != b ? (k == 0 ? 16 : k == 1 ? 8 : 0) : 0);
+            stage_wait(k, t == b);
             const unsigned char* st = smem + OFF_RING + c_slot * SLOT;
             uint4 A[4], B[3];
 #pragma unroll
@@ -218,7 +285,7 @@ __device__ __forceinline__ void bottleneck_infer_body(const BottleneckArgs& a, u
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 3; ++j)
-                    if (j < 2 || ng1 == 3) MmaR<T>::run(A[i], B[j], acc1[i][j]);
+                    if ((j < 2 || ng1 == 3) && !(LH_BNK_ABL & 1)) MmaR<T>::run(A[i], B[j], acc1[i][j]);
             stage_done();
         }
         // conv1 epilogue: bn1 + ReLU -> patch [pp][64 ch] (swizzled by pp); positions outside the image are conv2's zero padding
@@ -255,8 +322,13 @@ __device__ __forceinline__ void bottleneck_infer_body(const BottleneckArgs& a, u
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int oy0 = y0 + 2 * wave;
+        auto out_pix = [&](int row) {
+            const int y = oy0 + (row >> 4), x = x0 + (row & 15);
+            return (y < H && x < W) ? ((long)n * H + y) * W + x : -1L;
+        };
         for (int g = 0; g < 3; ++g) {
-            stage_wait(NK1 + g, 0);                               // (g == 0: also "every wave's part of the patch is written")
+            stage_wait(NK1 + g, t == b);                          // (g == 0: also "every wave's part of the patch is written")
             const unsigned char* st = smem + OFF_RING + c_slot * SLOT;
             const unsigned char* patch = smem + OFF_PATCH;
 #pragma unroll
@@ -278,46 +350,59 @@ __device__ __forceinline__ void bottleneck_infer_body(const BottleneckArgs& a, u
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) MmaR<T>::run(A[i], B[j], acc2[i][j]);
+                        for (int j = 0; j < 2; ++j)
+                            if (!(LH_BNK_ABL & 2)) MmaR<T>::run(A[i], B[j], acc2[i][j]);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             stage_done();
-        }
-        // conv2 epilogue: bn2 + ReLU -> mid2 rows of THIS wave's 32 pixels (wave-private: written and read by this wave only)
-        {
-            unsigned char* mid = smem + OFF_MID2 + wave * (32 * 128);
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int col = 16 * i + 4 * q, r = 16 * j + pl;
-                    const float4 sv = *reinterpret_cast<const float4*>(cst + 128 + col);
-                    const float4 bv = *reinterpret_cast<const float4*>(cst + 192 + col);
-                    union { uint2 u; T e[4]; } pk;
-                    pk.e[0] = from_f<T>(fmaxf(to_f<T>(from_f<T>(acc2[i][j][0] * sv.x + bv.x)), 0.f));
-                    pk.e[1] = from_f<T>(fmaxf(to_f<T>(from_f<T>(acc2[i][j][1] * sv.y + bv.y)), 0.f));
-                    pk.e[2] = from_f<T>(fmaxf(to_f<T>(from_f<T>(acc2[i][j][2] * sv.z + bv.z)), 0.f));
-                    pk.e[3] = from_f<T>(fmaxf(to_f<T>(from_f<T>(acc2[i][j][3] * sv.w + bv.w)), 0.f));
-                    *reinterpret_cast<uint2*>(mid + r * 128 + (((col >> 3) ^ ((r >> 1) & 7)) << 4) + (col & 7) * ES) = pk.u;
-                }
         }
         // ================= P3: conv3 in two halves of 128 output channels (one W3 stage each); B fragments = this wave's mid2 rows.
         // Each half goes straight through bn3 + residual + ReLU and out (64 accumulator registers instead of 128); the staging
         // patch of the epilogue = the conv1 patch, which every wave left before the barrier of the first W3 stage.
         uint4 Bm[2][2];
-        {
-            const unsigned char* mid = smem + OFF_MID2 + wave * (32 * 128);
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int r = 16 * j + pl;
-                    Bm[kk][j] = *reinterpret_cast<const uint4*>(mid + r * 128 + (((4 * kk + q) ^ ((r >> 1) & 7)) << 4));
-                }
-        }
         for (int hh = 0; hh < 2; ++hh) {
-            stage_wait(NK1 + 3 + hh, hh == 1 ? 8 : 0);
+            stage_wait(NK1 + 3 + hh, t == b);
             const unsigned char* st = smem + OFF_RING + c_slot * SLOT;
+            if (hh == 0) {
+                // conv2 epilogue, behind the barrier that ends conv2 for EVERY wave (the patch is dead now): bn2 + ReLU -> this
+                // wave's 32 pixels x 64 channels in its own slice of the patch (the slice its output epilogue stages in later),
+                // read straight back as conv3's B fragments -- wave-private, no further barrier
+                unsigned char* mid = smem + OFF_PATCH + wave * STG;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int col = 16 * i + 4 * q, r = 16 * j + pl;
+                        const float4 sv = *reinterpret_cast<const float4*>(cst + 128 + col);
+                        const float4 bv = *reinterpret_cast<const float4*>(cst + 192 + col);
+                        union { uint2 u; T e[4]; } pk;
+                        pk.e[0] = from_f<T>(fmaxf(to_f<T>(from_f<T>(acc2[i][j][0] * sv.x + bv.x)), 0.f));
+                        pk.e[1] = from_f<T>(fmaxf(to_f<T>(from_f<T>(acc2[i][j][1] * sv.y + bv.y)), 0.f));
+                        pk.e[2] = from_f<T>(fmaxf(to_f<T>(from_f<T>(acc2[i][j][2] * sv.z + bv.z)), 0.f));
+                        pk.e[3] = from_f<T>(fmaxf(to_f<T>(from_f<T>(acc2[i][j][3] * sv.w + bv.w)), 0.f));
+                        *reinterpret_cast<uint2*>(mid + r * 128 + (((col >> 3) ^ ((r >> 1) & 7)) << 4) + (col & 7) * ES) = pk.u;
+                    }
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int r = 16 * j + pl;
+                        Bm[kk][j] = *reinterpret_cast<const uint4*>(mid + r * 128 + (((4 * kk + q) ^ ((r >> 1) & 7)) << 4));
+                    }
+            }
+            // the residual rows of this half (this wave's 32 pixels x 128 channels): 8 loads requested here, ahead of conv3's MFMAs,
+            // instead of inside the epilogue (where each of its passes waited for its own) -- every lane loads (zero page outside)
+            uint4 resid[2][4];
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const long opix = out_pix(k * 8 + (lane >> 3));
+                    const long eoff = opix * a.p3.out_pix_stride + hh * 128 + sb * 64 + (lane & 7) * 8;
+                    resid[sb][k] = *reinterpret_cast<const uint4*>(opix >= 0 ? a.p3.addend + eoff * ES : a.p3.zero);
+                }
             f32x4 acc3[8][2];
 #pragma unroll
             for (int i = 0; i < 8; ++i)
@@ -325,22 +410,26 @@ __device__ __forceinline__ void bottleneck_infer_body(const BottleneckArgs& a, u
                 for (int j = 0; j < 2; ++j) acc3[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
+                // four weight fragments at a time (the compiler would otherwise hoist all sixteen reads of the stage: 64 registers)
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int r = 16 * i + pl;
-                    const uint4 A = *reinterpret_cast<const uint4*>(st + r * 128 + (((4 * kk + q) ^ ((r >> 1) & 7)) << 4));
+                for (int i0 = 0; i0 < 8; i0 += 4) {
+                    uint4 A[4];
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) MmaR<T>::run(A, Bm[kk][j], acc3[i][j]);
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = 16 * (i0 + i) + pl;
+                        A[i] = *reinterpret_cast<const uint4*>(st + r * 128 + (((4 * kk + q) ^ ((r >> 1) & 7)) << 4));
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            if (!(LH_BNK_ABL & 4)) MmaR<T>::run(A[i], Bm[kk][j], acc3[i0 + i][j]);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             stage_done();
             unsigned char* stg = smem + OFF_PATCH + wave * STG;
-            float s1d[1][8], s2d[1][8];
-            const int oy0 = y0 + 2 * wave;
-            wave_epilogue<T, 128, 2, false>(a.p3, acc3, stg, cst + 256 + hh * 256, hh, lane, [&](int row) {
-                const int y = oy0 + (row >> 4), x = x0 + (row & 15);
-                return (y < H && x < W) ? ((long)n * H + y) * W + x : -1L;
-            }, s1d, s2d);
+            bneck_epilogue_half<T>(a.p3, acc3, stg, cst + 256 + hh * 256, hh, lane, out_pix, resid);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -353,4 +442,4 @@ __global__ __launch_bounds__(512, 2) void bottleneck_infer_kernel(const Bottlene
     bottleneck_infer_body<T>(a, smem);
 }
 
-static inline int lh_bottleneck_lds_bytes() { return 18 * 18 * 64 * 2 + 16 * 16 * 64 * 2 + 3 * (21 * 1024 + 4096) + 1024 + (128 + 128 + 512) * 4; }
+static inline int lh_bottleneck_lds_bytes() { return 18 * 18 * 64 * 2 + 4 * (21 * 1024 + 4096) + 1024 + (128 + 128 + 512) * 4; }
