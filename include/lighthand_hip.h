@@ -305,7 +305,9 @@ typedef struct {
                                  * saved mean / invstd / running statistics: what lh_bn_finalize does) has NOT run yet and is part
                                  * of this call.  Small tensors fold the statistics slab inside the elementwise launch itself
                                  * (one launch instead of two on the dependency chain of every BatchNorm); otherwise the call
-                                 * launches the finalize first.  fin[t]->scale / ->shift must equal scale[t] / shift[t]. */
+                                 * launches the finalize first.  fin[t]->scale / ->shift must equal scale[t] / shift[t].
+                                 * ZERO-INITIALISE the descriptor (memset / = {0}): a caller compiled against the round-3 layout, or
+                                 * one that fills the fields one by one, would otherwise pass garbage pointers here. */
 } lh_fuse_desc;
 int lh_fuse_fwd(const lh_fuse_desc* d, void* out, int n, int h, int w, int c, int dtype, void* stream);
 /* Multi-problem forms (pose_hrnet.py:139-185, 247-265: the same layer position of the 2-4 parallel branches of a

@@ -1464,10 +1464,11 @@ extern "C" int lh_fuse_fwd(const lh_fuse_desc* d, void* out, int n, int h, int w
     int pre = 0;
     int rc = plan_fuse_fwd(d, out, n, h, w, c, dtype, &r.ff, &r.kind, &r.grid, &pre);
     if (rc) return rc;
-    std::vector<lh_bn_finalize_call> fins;
-    for (int t = 0; t < d->nterms; ++t)
-        if ((pre >> t) & 1) fins.push_back(*d->fin[t]);
-    rc = run_pending_finalizes(fins, stream);
+    lh_bn_finalize_call fins[4];                  // at most one pending finalize per term: no heap allocation on the launch path
+    int nf = 0;
+    for (int t = 0; t < d->nterms && t < 4; ++t)
+        if ((pre >> t) & 1) fins[nf++] = *d->fin[t];
+    if (nf) rc = lh_bn_finalize_multi(fins, nf, stream);
     if (rc) return rc;
     const BnLaunch* L[1] = {&r};
     return bn_run(L, 1, dtype, (hipStream_t)stream);

@@ -675,3 +675,46 @@ def test_fused_inference_bottleneck_is_bit_identical(tag, shape, precision):
     with torch.no_grad():
         want = fwd(sd, x.cpu(), False).numpy()
     assert rel(outs[0].cpu().numpy(), want) < (3e-2 if precision == "bf16" else 4e-3)
+
+
+_SLICE_SNIPPET = """
+import hashlib, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + "/tests")
+import numpy as np, torch
+from conftest import resnet_cfg
+from lighthand_amd.modeling.simplebaseline.pose_resnet import get_pose_net
+torch.manual_seed(31)
+m = get_pose_net(resnet_cfg(18), True).cuda().set_precision("bf16").train()
+x = torch.from_numpy(np.random.RandomState(3).randn(2, 3, 64, 64).astype(np.float32)).cuda()
+h = hashlib.sha256()
+for _ in range(2):                                    # two forwards: the running statistics move twice
+    out = m(x)
+    h.update(out.detach().float().cpu().numpy().tobytes())
+torch.cuda.synchronize()
+for k, v in sorted(m.state_dict().items()):
+    if "running" in k or "num_batches" in k:
+        h.update(v.detach().cpu().numpy().tobytes())
+plan = next(iter(m._lh_plans.values()))
+for kind, nd in plan.nodes:                            # every BatchNorm's folded scale / shift / saved mean / invstd
+    pass
+print("SHA", h.hexdigest())
+"""
+
+
+def test_bn_slice_kernel_is_bit_identical_to_finalize_then_apply():
+    """Round-4 advisor: the one-launch form of BatchNorm finalize + apply (fuse_fwd_slice_kernel, LH_BN_SLICE=1, off by default
+    because it measured slower) had no test.  Train-mode R18 forwards (batch statistics, running-statistic updates,
+    num_batches_tracked) in two processes, LH_BN_SLICE=0 and =1, static kernel choice: heat-maps and every running statistic must
+    agree bit for bit -- the slice kernel folds the statistics slab with the finalize kernel's own arithmetic and lets exactly
+    one workgroup per channel slice update the running statistics."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = _SLICE_SNIPPET.format(root=root)
+    shas = []
+    for sl in ("0", "1"):
+        env = dict(os.environ, LH_AUTOTUNE="0", LH_BN_SLICE=sl, LH_TUNE_CACHE="0")
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        shas.append([l for l in r.stdout.splitlines() if l.startswith("SHA ")][-1])
+    assert shas[0] == shas[1], shas
