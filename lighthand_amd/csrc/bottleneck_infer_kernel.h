@@ -6,8 +6,12 @@
 // with conv1 = 1x1 (CIN -> 64), conv2 = 3x3 / s1 / p1 (64 -> 64), conv3 = 1x1 (64 -> 256), every BatchNorm folded into a
 // per-channel scale / shift (running statistics).  Launched one by one these three convolutions move 4.8 GB per block at
 // BASELINE.json configs[4] (R50, 384 x 384, batch 256, fp16: the block's 1.2 GB input is read by conv1 and again as the
-// residual, the 0.3 GB intermediates are written and read back); here only the block input is read and the block output
-// written -- the 64-channel intermediates never leave LDS.
+// residual, the 0.3 GB intermediates are written and read back); here the 64-channel intermediates never leave LDS.
+// MEASURED (round 5, PMC): the launch still moves 4.4 GB through the fabric -- the input with its tile halo (1.27 x 1.2 GB), the
+// input AGAIN as the residual ten microseconds later (by then evicted from the 4 MB L2: 55 % hit rate) and the 1.2 GB output --
+// i.e. 8 % less than the three launches, not half; it runs 1 130 us per identity block against ~1 040 us for the three in the
+// step, and +2 % on the C5 step comes from the two launch boundaries and the projection block.  Halving the traffic needs the
+// tile's 128 KB of input held ON CHIP between conv1 and the residual add (64 registers per lane as conv1's B fragments).
 //
 //  * A persistent workgroup (8 waves, one per CU: 148 KB of LDS) walks over 16 x 16 output tiles.  Per tile:
 //      P1  conv1 on the (16+2) x (16+2) haloed patch -> LDS patch [324 pixels][64 ch] (positions outside the image = 0: they are
@@ -94,21 +98,27 @@ struct BottleneckArgs {
     int n, h, w, cin, kpad1, grid;
 };
 
-template <typename T>
+// TH x 16 output tiles, NWAVE waves, NSLOT ring slots:  <16, 8, 4> = one workgroup per CU (148 KB of LDS);  <8, 4, 3> = 75 KB, TWO
+// workgroups per CU, so that one's epilogue and DMA waits run under the other's MFMAs (at 1.5x the weight traffic per pixel).
+template <typename T, int TH, int NWAVE, int NSLOT>
 __device__ __forceinline__ void bottleneck_infer_body(const BottleneckArgs& a, unsigned char* smem) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int ES = sizeof(T);
     static_assert(ES == 2, "16-bit element types");
-    constexpr int MID = 64, COUT = 256, TH = 16, TW = 16, PH = 18, PW = 18, NPIX = PH * PW, NWAVE = 8;
-    constexpr int NG1 = (NPIX + 15) / 16;                         // 21 pixel groups of conv1
+    static_assert(TH == 2 * NWAVE && (NWAVE == 4 || NWAVE == 8) && (NSLOT == 3 || NSLOT == 4), "a wave owns two image rows of the tile");
+    constexpr int MID = 64, COUT = 256, TW = 16, PH = TH + 2, PW = 18, NPIX = PH * PW;
+    constexpr int NG1 = (NPIX + 15) / 16;                         // pixel groups of conv1: 21 (16 x 16 tile) / 12 (8 x 16)
+    constexpr int NGW = (NG1 + NWAVE - 1) / NWAVE;                // ... per wave: 3
     constexpr int PATCH = NPIX * MID * ES;                        // 41,472
     constexpr int IN_CH = NPIX * 64;                              // input chunk: 324 rows of 64 bytes (32 channels)
     constexpr int IN_INST = (IN_CH + 1023) / 1024;                // 21 LDS-DMA instructions (16 rows each; the last one 4 rows)
     constexpr int IN_PAD = IN_INST * 1024;                        // the last instruction's rows past the patch land in [IN_CH, IN_PAD): W1 sits behind them
-    constexpr int SLOT = IN_PAD + 4096;                           // 25,600 >= 24,576 (three W2 taps) >= 16,384 (half of W3)
-    constexpr int NSLOT = 4;                                      // ring depth: three stages (77 KB) in flight behind the one being consumed
+    constexpr int SLOT = IN_PAD + 4096;                           // 25,600 (16 x 16) / 16,384 (8 x 16): >= TPS taps of W2, >= half of W3
+    constexpr int TPS = SLOT / 8192;                              // W2 taps per stage: 3 / 2
+    constexpr int NS2 = (9 + TPS - 1) / TPS;                      // W2 stages per tile: 3 / 5 (the last one of the 8 x 16 form holds one tap)
     constexpr int OFF_PATCH = 0, OFF_RING = PATCH, OFF_DUMP = OFF_RING + NSLOT * SLOT, OFF_CST = OFF_DUMP + 1024;
-    constexpr int NI1 = 4, NI2 = 3, NI3 = 2;                      // DMA instructions per wave and stage kind (25 / 24 / 16 real ones)
+    // DMA instructions per wave and stage kind (every wave issues the same number: surplus ones copy the zero page to the dump KB)
+    constexpr int NI1 = (IN_INST + 4 + NWAVE - 1) / NWAVE, NI2 = (TPS * 8 + NWAVE - 1) / NWAVE, NI3 = 16 / NWAVE;
     constexpr int RS = 64 * ES + 8, STG = 2 * 16 * RS;            // staging patch of the per-wave epilogue (32 rows x 64 channels)
     static_assert(NWAVE * STG <= PATCH && 32 * 128 <= STG, "the epilogue's staging and the wave's conv2 output rows live in the conv1 patch");
 
@@ -116,7 +126,7 @@ __device__ __forceinline__ void bottleneck_infer_body(const BottleneckArgs& a, u
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
     const int NK1 = a.cin / 32;                                   // conv1 K chunks = S1 stages per tile
-    const int SPT = NK1 + 5;                                      // stages per tile
+    const int SPT = NK1 + NS2 + 2;                                // stages per tile
     const int H = a.h, W = a.w;
     const int tx_n = (W + TW - 1) / TW, ty_n = (H + TH - 1) / TH;
     const int ntile = a.n * ty_n * tx_n;
@@ -175,17 +185,18 @@ __device__ __forceinline__ void bottleneck_infer_body(const BottleneckArgs& a, u
                     dma(a.w1 + ((long)r * a.kpad1 + i_k * 32 + c * 8) * ES, slot + IN_PAD + (inst - IN_INST) * 1024);
                 } else dump_dma();
             }
-        } else if (i_k < NK1 + 3) {                               // S2: three taps of W2, [tap][64 rows][128 B]
+        } else if (i_k < NK1 + NS2) {                             // S2: TPS taps of W2, [tap][64 rows][128 B]
             const int g = i_k - NK1;
 #pragma unroll
             for (int j = 0; j < NI2; ++j) {
-                const int inst = NWAVE * j + wave;                // 0 .. 23: tap tt = inst / 8, rows 8 (inst % 8) ..
+                const int inst = NWAVE * j + wave;                // tap tt = inst / 8 of the stage, rows 8 (inst % 8) ..
                 const int tt = inst >> 3, r = (inst & 7) * 8 + (lane >> 3);
                 const int c = (lane & 7) ^ ((r >> 1) & 7);
-                dma(a.w2 + (((long)r * 9 + 3 * g + tt) * 64 + c * 8) * ES, slot + inst * 1024);
+                if (inst < TPS * 8 && TPS * g + tt < 9) dma(a.w2 + (((long)r * 9 + TPS * g + tt) * 64 + c * 8) * ES, slot + inst * 1024);
+                else dump_dma();
             }
         } else {                                                  // S3: half of W3, [128 rows][128 B]
-            const int hh = i_k - NK1 - 3;
+            const int hh = i_k - NK1 - NS2;
 #pragma unroll
             for (int j = 0; j < NI3; ++j) {
                 const int inst = NWAVE * j + wave;                // 0 .. 15: rows 8 inst ..
@@ -205,7 +216,7 @@ __device__ __forceinline__ void bottleneck_infer_body(const BottleneckArgs& a, u
         }
     };
     // DMA instructions per wave of the stage `k` positions behind the issue cursor (what may stay in flight)
-    auto ni_of = [&](int k_in_tile) { return k_in_tile < NK1 ? NI1 : k_in_tile < NK1 + 3 ? NI2 : NI3; };
+    auto ni_of = [&](int k_in_tile) { return k_in_tile < NK1 ? NI1 : k_in_tile < NK1 + NS2 ? NI2 : NI3; };
 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -225,7 +236,9 @@ __device__ __forceinline__ void bottleneck_infer_body(const BottleneckArgs& a, u
         // half's 8 behind it; the next tile's stages 0 / 1 / 2 have 16 / 16 / 8
         // ... and so are the 8 residual loads each half requests behind the barrier of its W3 stage (consumed by the half's epilogue,
         // but still counted among the operations younger than the stage waited for): 8 + 8 per half
-        const int stores = k_in_tile == NK1 + 4 ? 16 : first_tile ? 0 : k_in_tile < 2 ? 32 : k_in_tile == 2 ? 16 : 0;
+        // (what is still behind stage k of the NEXT tile depends on how far the ring runs ahead: NSLOT - 1 stages)
+        const int stores = k_in_tile == SPT - 1 ? 16 : first_tile ? 0
+                           : NSLOT == 4 ? (k_in_tile < 2 ? 32 : k_in_tile == 2 ? 16 : 0) : (k_in_tile == 0 ? 32 : k_in_tile == 1 ? 16 : 0);
         const long ahead = issued - 1 - done;                     // NSLOT - 2 in the steady state, fewer at the end of the stream
         int allow = stores;
         if (ahead >= 1) allow += ni_of((k_in_tile + 1) % SPT);
@@ -251,7 +264,8 @@ __device__ __forceinline__ void bottleneck_infer_body(const BottleneckArgs& a, u
         if (++c_slot == NSLOT) c_slot = 0;
     };
 
-    const int ng1 = wave < NG1 - 2 * NWAVE ? 3 : 2;               // conv1 pixel groups of this wave: gq = wave, wave + 8 (, wave + 16)
+    const int ng1 = NGW - (wave + NWAVE * (NGW - 1) >= NG1 ? 1 : 0);   // conv1 pixel groups of this wave: gq = wave, wave + NWAVE (, wave + 2 NWAVE)
+    static_assert(NGW == 3, "three conv1 pixel groups per wave at most");
     const int q0 = lane >> 4, pl0 = lane & 15;
     for (int t = b; t < ntile; t += G) {
         int y0, x0, n;
@@ -277,7 +291,7 @@ __device__ __forceinline__ void bottleneck_infer_body(const BottleneckArgs& a, u
             }
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                const int pp = 16 * (wave + 8 * j) + pl;
+                const int pp = 16 * (wave + NWAVE * j) + pl;
                 if (j < ng1) B[j] = *reinterpret_cast<const uint4*>(st + pp * 64 + ((q ^ ((pp >> 2) & 3)) << 4));
                 else B[j] = uint4{0u, 0u, 0u, 0u};
             }
@@ -294,7 +308,7 @@ __device__ __forceinline__ void bottleneck_infer_body(const BottleneckArgs& a, u
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 if (j >= ng1) continue;
-                const int pp = 16 * (wave + 8 * j) + pl;
+                const int pp = 16 * (wave + NWAVE * j) + pl;
                 const int py = pp / PW, px = pp - py * PW;
                 const int iy = y0 - 1 + py, ix = x0 - 1 + px;
                 const bool inside = ((unsigned)iy < (unsigned)H) & ((unsigned)ix < (unsigned)W);
@@ -327,31 +341,40 @@ __device__ __forceinline__ void bottleneck_infer_body(const BottleneckArgs& a, u
             const int y = oy0 + (row >> 4), x = x0 + (row & 15);
             return (y < H && x < W) ? ((long)n * H + y) * W + x : -1L;
         };
-        for (int g = 0; g < 3; ++g) {
+        for (int g = 0; g < NS2; ++g) {
             stage_wait(NK1 + g, t == b);                          // (g == 0: also "every wave's part of the patch is written")
             const unsigned char* st = smem + OFF_RING + c_slot * SLOT;
             const unsigned char* patch = smem + OFF_PATCH;
+            // 2 TPS steps (tap, K slice) per stage; the fragments of step n + 1 are requested before the MFMAs of step n issue
+            // (two fragment register sets: without it every step exposed its LDS round trip -- 38 % of the wave cycles parked)
+            const int nstep = 2 * (9 - TPS * g < TPS ? 9 - TPS * g : TPS);
+            uint4 A[2][4], B[2][2];
+            auto rd2 = [&](int step, uint4 (&av)[4], uint4 (&bv)[2]) {
+                const int tt = step >> 1, kk = step & 1;
+                const int tap = TPS * g + tt;                     // (dy, dx) of the 3 x 3 window, row-major
+                const int dy = tap / 3, dx = tap - 3 * dy;
 #pragma unroll
-            for (int tt = 0; tt < 3; ++tt) {
-                const int dy = g, dx = tt;                        // tap 3 g + tt = (dy, dx) of the 3 x 3 window, row-major
+                for (int i = 0; i < 4; ++i) {
+                    const int r = 16 * i + pl;
+                    av[i] = *reinterpret_cast<const uint4*>(st + tt * 8192 + r * 128 + (((4 * kk + q) ^ ((r >> 1) & 7)) << 4));
+                }
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    uint4 A[4], B[2];
+                for (int j = 0; j < 2; ++j) {
+                    const int pp = (2 * wave + j + dy) * PW + dx + pl;
+                    bv[j] = *reinterpret_cast<const uint4*>(patch + pp * 128 + (((4 * kk + q) ^ ((pp >> 1) & 7)) << 4));
+                }
+            };
+            rd2(0, A[0], B[0]);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int r = 16 * i + pl;
-                        A[i] = *reinterpret_cast<const uint4*>(st + tt * 8192 + r * 128 + (((4 * kk + q) ^ ((r >> 1) & 7)) << 4));
-                    }
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int pp = (2 * wave + j + dy) * PW + dx + pl;
-                        B[j] = *reinterpret_cast<const uint4*>(patch + pp * 128 + (((4 * kk + q) ^ ((pp >> 1) & 7)) << 4));
-                    }
+            for (int step = 0; step < 2 * TPS; ++step) {
+                if (step < nstep) {
+                    if (step + 1 < nstep) rd2(step + 1, A[(step + 1) & 1], B[(step + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
                         for (int j = 0; j < 2; ++j)
-                            if (!(LH_BNK_ABL & 2)) MmaR<T>::run(A[i], B[j], acc2[i][j]);
+                            if (!(LH_BNK_ABL & 2)) MmaR<T>::run(A[step & 1][i], B[step & 1][j], acc2[i][j]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -363,7 +386,7 @@ __device__ __forceinline__ void bottleneck_infer_body(const BottleneckArgs& a, u
         uint4 Bm[2][2];
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
-            stage_wait(NK1 + 3 + hh, t == b);
+            stage_wait(NK1 + NS2 + hh, t == b);
             const unsigned char* st = smem + OFF_RING + c_slot * SLOT;
             if (hh == 0) {
                 // conv2 epilogue, behind the barrier that ends conv2 for EVERY wave (the patch is dead now): bn2 + ReLU -> this
@@ -408,24 +431,27 @@ __device__ __forceinline__ void bottleneck_infer_body(const BottleneckArgs& a, u
             for (int i = 0; i < 8; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc3[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // four groups of four weight fragments (K slice kk, rows 64 (g4 & 1) ..): the next group is requested before this group's MFMAs
+            uint4 A3[2][4];
+            auto rd3 = [&](int g4, uint4 (&av)[4]) {
+                const int kk = g4 >> 1, i0 = (g4 & 1) * 4;
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                // four weight fragments at a time (the compiler would otherwise hoist all sixteen reads of the stage: 64 registers)
-#pragma unroll
-                for (int i0 = 0; i0 < 8; i0 += 4) {
-                    uint4 A[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int r = 16 * (i0 + i) + pl;
-                        A[i] = *reinterpret_cast<const uint4*>(st + r * 128 + (((4 * kk + q) ^ ((r >> 1) & 7)) << 4));
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j)
-                            if (!(LH_BNK_ABL & 4)) MmaR<T>::run(A[i], Bm[kk][j], acc3[i0 + i][j]);
-                    __builtin_amdgcn_sched_barrier(0);
+                for (int i = 0; i < 4; ++i) {
+                    const int r = 16 * (i0 + i) + pl;
+                    av[i] = *reinterpret_cast<const uint4*>(st + r * 128 + (((4 * kk + q) ^ ((r >> 1) & 7)) << 4));
                 }
+            };
+            rd3(0, A3[0]);
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                if (g4 + 1 < 4) rd3(g4 + 1, A3[(g4 + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        if (!(LH_BNK_ABL & 4)) MmaR<T>::run(A3[g4 & 1][i], Bm[g4 >> 1][j], acc3[(g4 & 1) * 4 + i][j]);
+                __builtin_amdgcn_sched_barrier(0);
             }
             stage_done();
             unsigned char* stg = smem + OFF_PATCH + wave * STG;
@@ -436,10 +462,13 @@ __device__ __forceinline__ void bottleneck_infer_body(const BottleneckArgs& a, u
 #endif
 }
 
-template <typename T>
-__global__ __launch_bounds__(512, 2) void bottleneck_infer_kernel(const BottleneckArgs a) {
+template <typename T, int TH, int NWAVE, int NSLOT>
+__global__ __launch_bounds__(64 * NWAVE, 2) void bottleneck_infer_kernel(const BottleneckArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    bottleneck_infer_body<T>(a, smem);
+    bottleneck_infer_body<T, TH, NWAVE, NSLOT>(a, smem);
 }
 
-static inline int lh_bottleneck_lds_bytes() { return 18 * 18 * 64 * 2 + 4 * (21 * 1024 + 4096) + 1024 + (128 + 128 + 512) * 4; }
+static inline int lh_bottleneck_lds_bytes(int th, int nslot) {
+    const int npix = (th + 2) * 18, in_inst = (npix * 64 + 1023) / 1024;
+    return npix * 128 + nslot * (in_inst * 1024 + 4096) + 1024 + (128 + 128 + 512) * 4;
+}

@@ -76,6 +76,21 @@ def main():
         direct = 2.0 * nbytes / world / (LINK_GBS * 1e9) * 1e3
         end_ring, end_dir = max(now, end_ring) + ring, max(now, end_dir) + direct
         print(f"  {i:7d} {ms:7.3f} {now:11.3f} {nbytes / 1e6:9.1f} | {ring:8.3f} {end_ring:8.3f} | {direct:9.3f} {end_dir:8.3f}")
+    if os.environ.get("LH_BUCKET_TABLE_SINGLE", "1") != "0":
+        # the same model as the plain single-GPU step (one graph), in this process, for the cost of the data-parallel FORM itself
+        del step
+        plain = TrainStep(model, batch, 256, 256, lr=1e-3)
+        plain.images.copy_(im); plain.joints.copy_(j)
+        for _ in range(5):
+            plain()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            plain()
+        e1.record()
+        torch.cuda.synchronize()
+        print(f"# the plain single-GPU step (one graph) in this process: {e0.elapsed_time(e1) / 20:.3f} ms")
     print(f"# backward + per-bucket Adam end at {now:.3f} ms; the last all-reduce ends at {end_ring:.3f} (ring) / {end_dir:.3f} (direct): "
           f"exposed tail {max(0.0, end_ring - now):.3f} / {max(0.0, end_dir - now):.3f} ms before the last bucket's Adam slice "
           f"(plus RCCL's launch latency per collective, ~10-20 us each, not modelled)")
