@@ -1182,7 +1182,10 @@ class Plan:
             for d in ds:
                 buf, n = self._igemm_candidates(d)
                 direct.append(next((tuple(buf[5 * i:5 * i + 4]) for i in range(n) if buf[5 * i + 2] == 100), None))
-            if os.environ.get("LH_MIXED", "0") == "1" and any(direct) and len(ds) >= 2:
+            mixed = os.environ.get("LH_MIXED", "0")        # "1": every member the direct kernel takes; "32": only the 32-channel ones (79 KB of LDS: two workgroups per CU)
+            if mixed == "32":
+                direct = [dc if dc is not None and dc[3] == 32 else None for dc in direct]
+            if mixed in ("1", "32") and any(direct) and len(ds) >= 2:
                 rest = None
                 for d, dc in zip(ds, direct):
                     if dc is None:
@@ -1314,7 +1317,7 @@ class Plan:
                 ring = {c for c in cfgs if c[2] != 100}
                 if len(ring) > 1 or any(not 2 <= c[2] < 10 or (c[0], c[1]) not in self._MULTI_TILES for c in ring):
                     return None
-                if len(ring) != len(cfgs) and (os.environ.get("LH_MIXED", "0") != "1" or any((c[0], c[1]) != (64, 128) for c in ring)):
+                if len(ring) != len(cfgs) and (os.environ.get("LH_MIXED", "0") not in ("1", "32") or any((c[0], c[1]) != (64, 128) for c in ring)):
                     # direct 3x3 members share a launch with the 64 x 128 tile only (igemm_mixed_kernel.h), and only when the
                     # mixed launch was asked for: members tuned one by one may pick the direct kernel in a default build, where
                     # the mixed kernel (measured slower) must not run -- they are launched one by one instead

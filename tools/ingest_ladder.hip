@@ -63,7 +63,9 @@ template <int L, int MAXS> __device__ __forceinline__ void wait_stages(int stage
 }
 
 // SRC 0..3 = rungs R0..R3's address form; ADD bit 0 = fragment reads, bit 1 = MFMAs; SYNC 0 = s_barrier per stage, 1 = none
-template <int NWAVE, int D, int SRC, int ADD, int SYNC>
+// DW > 0 (buffer form, plain loop only): the WEIGHT halves of the stages live in a ring of their own, DW stages deep, filled DW - D
+// stages further ahead than the pixel halves -- the weights are what every workgroup first-touches in lockstep (sitting 6)
+template <int NWAVE, int D, int SRC, int ADD, int SYNC, int DW = 0>
 __global__ __launch_bounds__(64 * NWAVE, 2) void ladder_kernel(const Args p) {
 #if defined(__HIP_DEVICE_COMPILE__)        // the buffer builtins do not exist in the host pass
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -128,6 +130,9 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void ladder_kernel(const Args p) {
 
     int itap = 0, ikc = 0, tj = 0, cdh = -1, cdw = -1, issued = 0, islot = 0;
     long woff = 0;
+    constexpr int WRING = DW * BM * KB;                           // bytes of the separate weight ring (0: weights share the stage slots)
+    int w_issued = 0, w_slot = 0, w_tap = 0, w_kc = 0;
+    long w_off = 0;
     // piece i of the stage being issued: i < NW a weight piece, else a pixel piece; `advance` closes the stage
     auto piece = [&](int i) {
         unsigned char* st = smem + islot * STAGE;
@@ -136,6 +141,7 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void ladder_kernel(const Args p) {
         if (SRC == 5) return;
         if (i < NW) {
             const int j = i, q = NWAVE * j + wave;
+            if (DW > 0) return;                                   // weights: issue_w()
             if (SRC == 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_p)(st + (q / HH) * GB + (q % HH) * 1024), 16, wvoff[j], (int)woff, 0, 0);
             else {
                 const unsigned char* src = SRC == 0 ? wsrc[j] + lin_off : wsrc[j] + woff;
@@ -143,7 +149,8 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void ladder_kernel(const Args p) {
             }
         } else {
             const int j = i - NW, q = NWAVE * j + wave;
-            lds_p dst = (lds_p)(st + BM * KB + (q / HH) * GB + (q % HH) * 1024);
+            lds_p dst = DW > 0 ? (lds_p)(smem + WRING + islot * (BP * KB) + (q / HH) * GB + (q % HH) * 1024)
+                               : (lds_p)(st + BM * KB + (q / HH) * GB + (q % HH) * 1024);
             if (SRC == 4) {
                 const int soff = ((cdh + 1) * p.wd + (cdw + 1)) * p.c * 2 + kbase * 2;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, dst, 16, cvoff[j], soff, 0, 0);
@@ -175,7 +182,19 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void ladder_kernel(const Args p) {
             }
         }
     };
+    auto issue_w = [&]() {                                        // the weight half of stage w_issued into the weight ring
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            const int q = NWAVE * j + wave;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_p)(smem + w_slot * (BM * KB) + (q / HH) * GB + (q % HH) * 1024), 16, wvoff[j], (int)w_off, 0, 0);
+        }
+        ++w_issued;
+        if (++w_slot == (DW > 0 ? DW : 1)) w_slot = 0;
+        w_off += KB;
+        if (++w_kc == kspt) { w_kc = 0; ++w_tap; w_off = (long)w_tap * kpad * 2; }
+    };
     auto issue = [&]() {
+        if (DW > 0 && w_issued < ntaps * kspt) issue_w();
 #pragma unroll
         for (int i = 0; i < L; ++i) piece(i);
         advance();
@@ -189,6 +208,11 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void ladder_kernel(const Args p) {
 
     const int S = ntaps * kspt;
     if (tid == 0) { t1 = wall_clock64(); c1 = clock64(); }
+    if (DW > 0) {
+#pragma unroll
+        for (int s = 0; s < DW - D; ++s)
+            if (w_issued < S) issue_w();                          // the weight ring's head start
+    }
 #pragma unroll
     for (int s = 0; s < D - 1; ++s)
         if (issued < S) issue();
@@ -199,7 +223,7 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void ladder_kernel(const Args p) {
         const int c = 4 * kk + (lane >> 4), r = lane & 15;
         const unsigned foff = r * KB + ((c ^ ((r / (16 / SL)) & (SL - 1))) << 4);
         offA[kk] = lds_base + wc * CT * GB + foff;
-        offB[kk] = lds_base + BM * KB + wp * PT * GB + foff;
+        offB[kk] = lds_base + (DW > 0 ? WRING : BM * KB) + wp * PT * GB + foff;
     }
     auto rd = [](auto Rc, uint4& dst, unsigned base_a, unsigned base_b) {
         constexpr int r = decltype(Rc)::value;
@@ -209,9 +233,11 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void ladder_kernel(const Args p) {
     };
     constexpr bool ILV = (ADD & 4) != 0;          // the stage's DMA pieces issued BETWEEN the MFMA groups instead of up front
     constexpr int SLOTS = 2 * CT, PER = (L + SLOTS - 1) / SLOTS, EVERY = SLOTS / (L < SLOTS ? L : SLOTS);
+    int cw_slot = 0;                                              // weight-ring slot of the stage being consumed (DW > 0)
     auto step = [&](auto KKc, unsigned so, bool dma) {
         constexpr int kk = decltype(KKc)::value;
-        const unsigned ca = offA[kk] + so, cb = offB[kk] + so;
+        const unsigned ca = offA[kk] + (DW > 0 ? (unsigned)(cw_slot * (BM * KB)) : so);
+        const unsigned cb = offB[kk] + (DW > 0 ? so / (unsigned)STAGE * (unsigned)(BP * KB) : so);
         uint4 F[NR];
         static_for<0, NR>([&](auto r) { rd(r, F[decltype(r)::value], ca, cb); });
         if constexpr ((ADD & 2) != 0) {
@@ -342,6 +368,7 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void ladder_kernel(const Args p) {
             if constexpr ((ADD & 1) != 0) step(ic<0>{}, so, false);
             if (late && issued < S) issue();
             if constexpr ((ADD & 1) != 0) step(ic<1>{}, so, false);
+            if (DW > 0 && ++cw_slot == DW) cw_slot = 0;
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -438,6 +465,9 @@ int main(int argc, char** argv) {
 #define RUN(NWAVE, D, SRC, ADD, SYNC, NAME) { \
         CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ladder_kernel<NWAVE, D, SRC, ADD, SYNC>), hipFuncAttributeMaxDynamicSharedMemorySize, D * STAGE)); \
         measure(NAME, [&]() { hipLaunchKernelGGL((ladder_kernel<NWAVE, D, SRC, ADD, SYNC>), dim3(NWG), dim3(64 * NWAVE), D * STAGE, 0, a); }); }
+#define RUNW(NWAVE, D, DW, ADD, NAME) { \
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ladder_kernel<NWAVE, D, 4, ADD, 0, DW>), hipFuncAttributeMaxDynamicSharedMemorySize, DW * BM * KB + D * BP * KB)); \
+        measure(NAME, [&]() { hipLaunchKernelGGL((ladder_kernel<NWAVE, D, 4, ADD, 0, DW>), dim3(NWG), dim3(64 * NWAVE), DW * BM * KB + D * BP * KB, 0, a); }); }
 
     const bool second = argc > 2 && atoi(argv[2]) >= 2;
     g_more_states = argc > 2 && atoi(argv[2]) == 3;
@@ -461,6 +491,20 @@ int main(int argc, char** argv) {
     RUN(4, 3, 0, 3, 0, "R0 + reads + MFMAs            D3 4w barrier")
     } else {
     // later sittings: what the complete loop is made of, the buffer form, pipelined stage loops
+    if (argc > 2 && atoi(argv[2]) == 4) {                       // sitting 7: a deeper ring for the weights only
+        RUN(8, 3, 4, 0, 0, "B3 buffer form, DMA only      D3 8w")
+        RUNW(8, 3, 5, 0, "B3 DMA only, weight ring 5 deep, pixels 3")
+        RUNW(8, 3, 7, 0, "B3 DMA only, weight ring 7 deep, pixels 3")
+        RUN(8, 3, 4, 3, 0, "B5 buffer form + reads + MFMA D3 8w")
+        RUNW(8, 3, 4, 3, "B5 weight ring 4 deep, pixels 3      8w")
+        RUNW(8, 3, 5, 3, "B5 weight ring 5 deep, pixels 3      8w")
+        RUNW(8, 3, 7, 3, "B5 weight ring 7 deep, pixels 3      8w")
+        RUNW(8, 2, 6, 3, "B5 weight ring 6 deep, pixels 2      8w")
+        RUN(4, 3, 4, 3, 0, "B5 buffer form + reads + MFMA D3 4w")
+        RUNW(4, 3, 5, 3, "B5 weight ring 5 deep, pixels 3      4w")
+        RUNW(4, 3, 7, 3, "B5 weight ring 7 deep, pixels 3      4w")
+        return 0;
+    }
     if (g_more_states) {
         RUN(8, 3, 4, 0, 0, "B3 buffer form, DMA only      D3 8w barrier")
         RUN(8, 3, 4, 3, 0, "B5 buffer form + reads + MFMA D3 8w barrier")
