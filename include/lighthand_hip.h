@@ -308,6 +308,11 @@ typedef struct {
                                  * launches the finalize first.  fin[t]->scale / ->shift must equal scale[t] / shift[t].
                                  * ZERO-INITIALISE the descriptor (memset / = {0}): a caller compiled against the round-3 layout, or
                                  * one that fills the fields one by one, would otherwise pass garbage pointers here. */
+    const void* l2_touch;       /* optional (round 5): l2_touch_bytes of device memory the NEXT launch on the stream reads first -- the
+                                 * weight pack of the convolution that consumes `out`.  The streaming kernels read one word of every
+                                 * 128-byte line of it in each XCD right before they end, so the convolution finds it in L2
+                                 * (speed only; ignored by the kernels that have no such tail).  NULL / 0 = off. */
+    size_t l2_touch_bytes;
 } lh_fuse_desc;
 int lh_fuse_fwd(const lh_fuse_desc* d, void* out, int n, int h, int w, int c, int dtype, void* stream);
 /* Multi-problem forms (pose_hrnet.py:139-185, 247-265: the same layer position of the 2-4 parallel branches of a
@@ -343,6 +348,8 @@ typedef struct {
     const float* pre_partial;   /* single BN term under a ReLU whose dout was written by lh_igemm_gated: dout is already the gated
                                  * gradient and these are its partial sums [pre_rows][2][c] -- no reduce pass, no mask */
     int pre_rows;
+    const void* l2_touch;       /* optional (round 5), as lh_fuse_desc.l2_touch: the last apply pass of the call warms these bytes in L2 */
+    size_t l2_touch_bytes;
 } lh_fuse_bwd_desc;
 size_t lh_fuse_bwd_workspace_bytes(int n, int h, int w, int c);
 int lh_fuse_bwd(const lh_fuse_bwd_desc* d, int n, int h, int w, int c, void* workspace,

@@ -33,7 +33,7 @@ class BnFinalizeCall(C.Structure):     # lh_bn_finalize_multi / lh_fuse_desc.fin
 class FuseDesc(C.Structure):
     _fields_ = [("x", C.c_void_p * 4), ("scale", C.c_void_p * 4), ("shift", C.c_void_p * 4),
                 ("log2up", C.c_int * 4), ("nterms", C.c_int), ("relu", C.c_int), ("relu_mask", C.c_void_p),
-                ("fin", C.POINTER(BnFinalizeCall) * 4)]
+                ("fin", C.POINTER(BnFinalizeCall) * 4), ("l2_touch", C.c_void_p), ("l2_touch_bytes", C.c_size_t)]
 
 
 class FuseBwdDesc(C.Structure):
@@ -41,7 +41,8 @@ class FuseBwdDesc(C.Structure):
                 ("shift", C.c_void_p * 4), ("save_mean", C.c_void_p * 4), ("save_invstd", C.c_void_p * 4), ("dx", C.c_void_p * 4),
                 ("dgamma", C.c_void_p * 4), ("dbeta", C.c_void_p * 4), ("log2up", C.c_int * 4),
                 ("accumulate", C.c_int * 4), ("nterms", C.c_int), ("relu", C.c_int),
-                ("relu_mask", C.c_void_p), ("strips_cap", C.c_int), ("pre_partial", C.c_void_p), ("pre_rows", C.c_int)]
+                ("relu_mask", C.c_void_p), ("strips_cap", C.c_int), ("pre_partial", C.c_void_p), ("pre_rows", C.c_int),
+                ("l2_touch", C.c_void_p), ("l2_touch_bytes", C.c_size_t)]
 
 
 class BnBwdGate(C.Structure):          # lh_igemm_gated

@@ -179,14 +179,14 @@ __device__ __forceinline__ void igemm_ring_body(const IgemmArgs& p, unsigned cha
         const int a = rem / p.wo, b = rem - a * p.wo;
         const int ih0 = a * p.sh, iw0 = b * p.sw;
         pvoff[j] = (unsigned)(((long)((n - n_first) * p.hi * p.wi + ih0 * p.wi + iw0) * p.in_pix_stride + c * EPC) * ES);
-        klim[j] = p.k_run - c * EPC;        // > 0 for every chunk of the first stage
+        klim[j] = p.k_run - c * EPC;        // <= 0: the chunk lies past the K run in every stage
         unsigned tm = 0;
         int t = 0;
         for (int ti = 0, dh = dh0; ti * tw < ntaps; ++ti, dh += dhs)
             for (int tjj = 0, dw = dw0; tjj < tw; ++tjj, dw += dws, ++t)
                 if (ok && (unsigned)(ih0 + dh) < (unsigned)p.hi && (unsigned)(iw0 + dw) < (unsigned)p.wi) tm |= 1u << t;
         tmask[j] = tm;
-        cvoff[j] = (tm & 1u) ? pvoff[j] : OOR;
+        cvoff[j] = ((tm & 1u) != 0 && klim[j] > 0) ? pvoff[j] : OOR;     // (a K run shorter than one stage: the chunks past it are masked from stage 0 on)
     }
     unsigned wvoff[NW];
 #pragma unroll

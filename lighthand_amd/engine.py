@@ -1047,6 +1047,7 @@ class Plan:
                 setter(ws_w[L].data_ptr())
             for setter, lane in self._ws_users_fuse:
                 setter(ws_f[lane if self.use_lanes else 0].data_ptr())
+        self._attach_l2_touch()
         if self._n_groups:
             self._merge_groups()
         # where the forward list first reads a pack written by the tiled pack launch (refresh_packs(overlap=True))
@@ -1069,6 +1070,53 @@ class Plan:
                 else:
                     self._late_packs = None
         self._pack_late, self._pack_event2 = None, None
+
+    def _attach_l2_touch(self):
+        """Training plans: an elementwise BatchNorm / ReLU pass (lh_fuse_fwd) that is followed on its stream by a tiled
+        convolution warms that convolution's weight pack in L2 at its tail (lh_fuse_desc.l2_touch; bn.hip lh_l2_touch).  Every
+        workgroup of such a convolution walks the same weight slab stage by stage, at once: each stage waits for lines no XCD has
+        seen yet (profiles/r05_ingest_ladder.txt, sitting 6: the complete K loop of the stage-3 3x3 takes 21.3 us, 19.1 us with the
+        pack in L2).  Only where the pack fits beside the pass's own stream in the 4 MB L2 of an XCD (LH_L2_TOUCH_MAX_MB, default 3;
+        LH_L2_TOUCH=0: off), and only for single launches on the main lane (HRNet's merged launches keep their own order)."""
+        if os.environ.get("LH_L2_TOUCH", "1") == "0" or not self.training:
+            return
+        lim = float(os.environ.get("LH_L2_TOUCH_MAX_MB", "3")) * (1 << 20)
+        lib, ig, n = self.lib, self._IG, 0
+        for i, c in enumerate(self.fwd):
+            if not isinstance(c, _Call) or c.fn is not lib.lh_fuse_fwd or c.mtag is not None:
+                continue
+            nxt = next((d for d in self.fwd[i + 1:i + 4] if isinstance(d, _Call) and d.fn is not lib.lh_bn_finalize), None)
+            if nxt is None or nxt.fn is not lib.lh_igemm or nxt.mtag is not None or nxt.slane != c.slane:
+                continue
+            d = nxt.keep
+            if d.cfg[2] in (1, 100) or not nxt.args[ig["pack"]]:            # pointwise / direct kernels fetch their panel once per workgroup
+                continue
+            kstep = 128 // self.es
+            nbytes = (d.cout + 127) // 128 * 128 * d.ntaps * ((d.k_run + kstep - 1) // kstep * kstep) * self.es
+            if not 0 < nbytes <= lim:
+                continue
+            fd = c.args[0]._obj
+            fd.l2_touch, fd.l2_touch_bytes = nxt.args[ig["pack"]], nbytes
+            n += 1
+        # the same in the backward list: the BatchNorm / ReLU backward of a node (lh_fuse_bwd: its last apply pass) in front of the
+        # data gradient that consumes the gradient it wrote
+        for i, c in enumerate(self.bwd):
+            if not isinstance(c, _Call) or c.fn is not lib.lh_fuse_bwd or c.mtag is not None or c.lane:
+                continue
+            nxt = next((d for d in self.bwd[i + 1:i + 3] if isinstance(d, _Call) and not d.lane), None)
+            if nxt is None or nxt.fn is not lib.lh_igemm or nxt.mtag is not None or nxt.slane != c.slane:
+                continue
+            d = nxt.keep
+            if d.cfg[2] in (1, 100) or not nxt.args[ig["pack"]]:
+                continue
+            kstep = 128 // self.es
+            nbytes = (d.cout + 127) // 128 * 128 * d.ntaps * ((d.k_run + kstep - 1) // kstep * kstep) * self.es
+            if not 0 < nbytes <= lim:
+                continue
+            bd = c.args[0]._obj
+            bd.l2_touch, bd.l2_touch_bytes = nxt.args[ig["pack"]], nbytes
+            n += 1
+        self._n_l2_touch = n
 
     def _call_packs(self, c):
         """Pack buffers a forward convolution call reads (addresses)."""

@@ -157,7 +157,8 @@ def test_ctypes_structs_mirror_the_header_layout(tmp_path):
     pairs = {"lh_igemm_desc": _lib.IgemmDesc, "lh_fuse_desc": _lib.FuseDesc, "lh_fuse_bwd_desc": _lib.FuseBwdDesc,
              "lh_igemm_call": _lib.IgemmCall, "lh_wgrad_call": _lib.WgradCall, "lh_fuse_fwd_call": _lib.FuseFwdCall,
              "lh_fuse_bwd_call": _lib.FuseBwdCall, "lh_bn_finalize_call": _lib.BnFinalizeCall, "lh_head": _lib.Head,
-             "lh_pack_item": _lib.PackItem, "lh_pack_out": _lib.PackOut, "lh_pack_conv": _lib.PackConv, "lh_bn_bwd_gate": _lib.BnBwdGate}
+             "lh_pack_item": _lib.PackItem, "lh_pack_out": _lib.PackOut, "lh_pack_conv": _lib.PackConv, "lh_bn_bwd_gate": _lib.BnBwdGate,
+             "lh_bottleneck_desc": _lib.BottleneckDesc}
     rename = {"in_": "in", "pad_": None}                       # ctypes-side spellings; None = padding without a C name
     lines = []
     for cname, cls in pairs.items():

@@ -1,3 +1,4 @@
+import os
 """Per-kernel parity on the GPU: every HIP op vs the same op in plain PyTorch fp32 on the CPU
 (golden set G4 of SURVEY.md section 8c is regenerated on the fly -- it needs no reference)."""
 import numpy as np
@@ -938,3 +939,172 @@ def test_direct3x3_kernel_bn_statistics(case, forced_plans):
         assert rel_err(a[2][k], b[2][k]) < 2e-2, k
     ref = copy.deepcopy(proto).train()
     assert rel_err(b[0], ref.torch_forward(x).detach()) < TOL["bf16"]
+
+
+D3_CASES = [
+    # cin, cout, n, h, w -- 3x3 / stride 1 / padding 1 with 32 or 64 input channels (pose_resnet.py:66-72 stage 1, pose_hrnet.py:139-185)
+    (64, 64, 2, 16, 16), (64, 64, 3, 12, 20), (64, 128, 1, 9, 9), (32, 32, 2, 16, 32), (32, 64, 1, 7, 5), (64, 32, 2, 8, 16), (64, 256, 1, 8, 8),
+]
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+@pytest.mark.parametrize("case", D3_CASES)
+def test_direct3x3_kernel_configurations(case, precision, forced_plans):
+    """The direct 3x3 kernel (conv3x3_direct_kernel.h: LDS-resident weights, one input patch per 8 x 16 tile, taps =
+    offsets into the patch) forced on forward and data gradient: bit-equal with the tiled LDS-DMA kernel (same tap-major
+    K order, same epilogue arithmetic) incl. ragged maps (partial tiles, zero padding at every border), several output
+    channel blocks, and within tolerance of PyTorch."""
+    ConvNet, _ = _mods()
+    cin, cout, n, h, w = case
+    torch.manual_seed(13)
+    x = quant(torch.randn(n, cin, h, w), precision)
+    ref_m = nn.Conv2d(cin, cout, 3, 1, 1, bias=False)
+    with torch.no_grad():
+        ref_m.weight.copy_(quant(ref_m.weight, precision))
+    xr = x.clone().requires_grad_(True)
+    ref = ref_m(xr)
+    dy = quant(torch.randn_like(ref), precision)
+    ref.backward(dy)
+
+    def run(pick):
+        forced_plans.force_cfg = pick
+        m = ConvNet(cin, cout, 3, 1, 1, bias=False)
+        m.conv.load_state_dict(ref_m.state_dict())
+        return _run_plan(m, x, lambda o: dy, precision)
+
+    base = run(lambda cands: next(c for c in cands if c[2] not in (1, 100)))
+    assert rel_err(base[0], ref.detach()) < TOL[precision] and rel_err(base[1], xr.grad) < TOL[precision]
+    used = []
+
+    def pick(cands):
+        d3 = [c for c in cands if c[2] == 100]
+        used.append(bool(d3))
+        return d3[0] if d3 else cands[0]
+    out, dx, _ = run(pick)
+    assert torch.equal(out, base[0]) and torch.equal(dx, base[1]), case
+    # forward: cin in {32, 64}; data gradient: its K is cout
+    assert used[0] and (len(used) < 2 or used[1] == (cout in (32, 64)))
+
+
+@pytest.mark.parametrize("case", [(64, 64, 2, 16, 16), (32, 32, 3, 12, 20), (64, 128, 1, 9, 9)])
+def test_direct3x3_kernel_bn_statistics(case, forced_plans):
+    """3x3 conv -> BN -> ReLU -> 1x1 with the direct kernel forced: one statistics row per workgroup.  Outputs equal the
+    tiled kernel's within the 16-bit tolerance, running statistics and BN gradients agree to fp32 summation order."""
+    import copy
+    from lighthand_amd.module import HipModule
+    cin, cout, n, h, w = case
+
+    class Net(HipModule):
+        def __init__(self):
+            super().__init__()
+            self.conv = nn.Conv2d(cin, cout, 3, 1, 1, bias=False)
+            self.bn = nn.BatchNorm2d(cout, momentum=0.1)
+            self.out = nn.Conv2d(cout, 8, 1, bias=False)
+
+        def describe(self, gb):
+            x = gb.input_act(cin)
+            gb.output(gb.conv(gb.fuse([(gb.conv(x, "conv", 3, 1, 1), "bn")]), "out", 1, 1, 0))
+
+        def torch_forward(self, x):
+            return self.out(F.relu(self.bn(self.conv(x))))
+
+    torch.manual_seed(23)
+    proto = Net()
+    with torch.no_grad():
+        for p_ in proto.parameters():
+            p_.copy_(p_.to(torch.bfloat16).float())
+    x = torch.randn(n, cin, h, w).to(torch.bfloat16).float()
+    res = {}
+    for which in ("tiled", "direct"):
+        if which == "tiled":
+            forced_plans.force_cfg = lambda cands: next(c for c in cands if c[2] not in (1, 100))
+        else:
+            forced_plans.force_cfg = lambda cands: next((c for c in cands if c[2] == 100), cands[0])
+        m = copy.deepcopy(proto)
+        torch.manual_seed(24)
+        out, dx, grads = _run_plan(m, x, lambda o: torch.randn_like(o), "bf16")
+        res[which] = (out, dx, grads, {k: v.cpu().clone() for k, v in m.state_dict().items() if "running" in k})
+        plan = next(iter(m._lh_plans.values()))
+        assert any(meta[2].startswith("conv3x3_direct_kernel") and meta[2].endswith("true>") for meta in plan.profile_meta) == (which == "direct")
+    a, b = res["tiled"], res["direct"]
+    if os.environ.get("LH_DBG"):
+        for nm, r in res.items():
+            print("DBG", case, nm, "out nan", int(torch.isnan(r[0]).sum()), "dx nan", int(torch.isnan(r[1]).sum()), "of", r[1].numel(),
+                  {k: int(torch.isnan(v).sum()) for k, v in r[2].items()})
+            nz = torch.isnan(r[1]).nonzero()
+            if len(nz):
+                print("DBG first nan idx", nz[:5].tolist(), "last", nz[-3:].tolist())
+    for k in a[3]:
+        assert rel_err(a[3][k], b[3][k]) < 1e-5, k
+    assert rel_err(a[0], b[0]) < 1e-2 and rel_err(a[1], b[1]) < 2e-2
+    for k in ("bn.weight", "bn.bias"):
+        assert rel_err(a[2][k], b[2][k]) < 2e-2, k
+    ref = copy.deepcopy(proto).train()
+    assert rel_err(b[0], ref.torch_forward(x).detach()) < TOL["bf16"]
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_short_k_run_does_not_read_past_the_operand(precision, forced_plans):
+    """A K run SHORTER than one ring stage (8 channels = 16 bytes per pixel against 64-byte stages: the data gradient of a
+    convolution with 8 output channels, or a convolution on an 8-channel input): the chunks past the K run must be masked from the
+    FIRST stage on.  Round 5's buffer form of the tiled kernel chose in-range / out-of-range per tap but forgot the K limit in the
+    initial choice: those lanes then read the following pixels -- times the zero K padding of the weight pack, harmless -- and, at the
+    end of the tensor, whatever lies behind it: NaN bits of a recycled block made the BatchNorm sums of a whole layer NaN.  Here the
+    operand sits at the end of a buffer whose tail is NaN: the launch must give the same bits as with a zero tail."""
+    from lighthand_amd.module import HipModule
+
+    class Net(HipModule):
+        def __init__(self):
+            super().__init__()
+            self.a = nn.Conv2d(8, 32, 3, 1, 1, bias=False)        # forward: K run = 8 per tap
+            self.b = nn.Conv2d(32, 8, 1, bias=False)              # data gradient: K run = 8
+
+        def describe(self, gb):
+            gb.output(gb.conv(gb.conv(gb.input_act(8), "a", 3, 1, 1), "b", 1, 1, 0))
+
+    forced_plans.force_cfg = lambda cands: next(c for c in cands if c[2] not in (1, 100))      # the tiled kernel
+    torch.manual_seed(5)
+    m = Net().cuda().set_precision(precision).train()
+    n, h, w = 3, 12, 20
+    plan = m.plan(n, h, w, training=True, backward=True)
+    lib, ig = plan.lib, plan._IG
+    s = torch.cuda.current_stream().cuda_stream
+    plan.in_act.buf.copy_(torch.randn(n, h, w, 8).to(plan.tdtype))
+    plan.refresh_packs(s)
+    plan.run_forward(s)
+    plan.dout_nchw.copy_(torch.randn_like(plan.out_nchw))
+    plan.run_backward(s)
+    torch.cuda.synchronize()
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+
+    def d2d(dst_ptr, src_ptr, nbytes):
+        assert hip.hipMemcpy(ctypes.c_void_p(dst_ptr), ctypes.c_void_p(src_ptr), ctypes.c_size_t(nbytes), 3) == 0      # hipMemcpyDeviceToDevice
+
+    checked = 0
+    es = 2
+    for lst in (plan.fwd, plan.bwd):
+        for c in lst:
+            if getattr(c, "fn", None) is not lib.lh_igemm or c.keep.k_run != 8:
+                continue
+            d = c.keep
+            numel = d.n * d.hi * d.wi * d.in_pix_stride
+            dst_elems = d.n * d.OH * d.OW * d.out_pix_stride
+            # the launch's own operand, copied to the HEAD of a buffer whose tail is zero / NaN: the tail lies right behind the operand
+            tmp = torch.empty(numel + 4096, dtype=plan.tdtype, device="cuda")
+            outs, old = [], c.args
+            for tail in (0.0, float("nan")):
+                tmp.fill_(tail)
+                torch.cuda.synchronize()
+                d2d(tmp.data_ptr(), old[ig["src"]], numel * es)
+                plan._patch(c, src=tmp.data_ptr())
+                c(s)
+                torch.cuda.synchronize()
+                c.args = old
+                got = torch.empty(dst_elems, dtype=plan.tdtype, device="cuda")
+                d2d(got.data_ptr(), old[ig["dst"]], dst_elems * es)
+                outs.append(got)
+            assert not torch.isnan(outs[1].float()).any(), c.what
+            assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16)), c.what
+            checked += 1
+    assert checked >= 2, checked
