@@ -29,3 +29,24 @@ def resnet_cfg(num_layers=50, style="pytorch", deconv_bias=False, final_kernel=1
     extra = ns(NUM_LAYERS=num_layers, DECONV_WITH_BIAS=deconv_bias, NUM_DECONV_LAYERS=3,
                NUM_DECONV_FILTERS=[256, 256, 256], NUM_DECONV_KERNELS=[4, 4, 4], FINAL_CONV_KERNEL=final_kernel)
     return ns(MODEL=ns(EXTRA=extra, STYLE=style))
+
+
+@pytest.fixture(autouse=True)
+def poisoned_allocator(request):
+    """GPU tests: before every test, the blocks the caching allocator hands out next are filled with NaN bit patterns (a few
+    hundred MB of NaN tensors of many sizes, allocated and released).  A kernel that reads memory it should not -- past the end of
+    an operand, a lane that should have been masked -- then fails HERE, in the test that exercises it, instead of only behind some
+    other test that happened to leave NaNs in a recycled block (round 5: the buffer form of the tiled kernel read past a short K run,
+    and only a particular test order showed it).  LH_TEST_POISON=0 turns it off."""
+    if request.node.get_closest_marker("gpu") is None or os.environ.get("LH_TEST_POISON", "1") == "0":
+        yield
+        return
+    import torch
+    if torch.cuda.is_available():
+        junk = []
+        for e in range(9, 27):
+            for mul in (1.0, 1.5):
+                junk.append(torch.full((int((1 << e) * mul) // 4,), float("nan"), device="cuda"))
+        torch.cuda.synchronize()
+        del junk
+    yield
