@@ -1081,6 +1081,7 @@ class Plan:
         if os.environ.get("LH_L2_TOUCH", "1") == "0" or not self.training:
             return
         lim = float(os.environ.get("LH_L2_TOUCH_MAX_MB", "3")) * (1 << 20)
+        touch_all = os.environ.get("LH_L2_TOUCH", "1") == "2"      # experiment: the persistent kernels' panels too
         lib, ig, n = self.lib, self._IG, 0
         for i, c in enumerate(self.fwd):
             if not isinstance(c, _Call) or c.fn is not lib.lh_fuse_fwd or c.mtag is not None:
@@ -1089,7 +1090,7 @@ class Plan:
             if nxt is None or nxt.fn is not lib.lh_igemm or nxt.mtag is not None or nxt.slane != c.slane:
                 continue
             d = nxt.keep
-            if d.cfg[2] in (1, 100) or not nxt.args[ig["pack"]]:            # pointwise / direct kernels fetch their panel once per workgroup
+            if (d.cfg[2] in (1, 100) and not touch_all) or not nxt.args[ig["pack"]]:    # pointwise / direct kernels fetch their panel once per workgroup
                 continue
             kstep = 128 // self.es
             nbytes = (d.cout + 127) // 128 * 128 * d.ntaps * ((d.k_run + kstep - 1) // kstep * kstep) * self.es
@@ -1107,7 +1108,7 @@ class Plan:
             if nxt is None or nxt.fn is not lib.lh_igemm or nxt.mtag is not None or nxt.slane != c.slane:
                 continue
             d = nxt.keep
-            if d.cfg[2] in (1, 100) or not nxt.args[ig["pack"]]:
+            if (d.cfg[2] in (1, 100) and not touch_all) or not nxt.args[ig["pack"]]:
                 continue
             kstep = 128 // self.es
             nbytes = (d.cout + 127) // 128 * 128 * d.ntaps * ((d.k_run + kstep - 1) // kstep * kstep) * self.es
