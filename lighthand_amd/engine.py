@@ -1077,46 +1077,46 @@ class Plan:
         workgroup of such a convolution walks the same weight slab stage by stage, at once: each stage waits for lines no XCD has
         seen yet (profiles/r05_ingest_ladder.txt, sitting 6: the complete K loop of the stage-3 3x3 takes 21.3 us, 19.1 us with the
         pack in L2).  Only where the pack fits beside the pass's own stream in the 4 MB L2 of an XCD (LH_L2_TOUCH_MAX_MB, default 3;
-        LH_L2_TOUCH=0: off), and only for single launches on the main lane (HRNet's merged launches keep their own order)."""
+        LH_L2_TOUCH=0: off).  Members of HRNet's batch groups only with LH_L2_TOUCH_GROUPS=1 (measured slightly slower)."""
         if os.environ.get("LH_L2_TOUCH", "1") == "0" or not self.training:
             return
         lim = float(os.environ.get("LH_L2_TOUCH_MAX_MB", "3")) * (1 << 20)
         touch_all = os.environ.get("LH_L2_TOUCH", "1") == "2"      # experiment: the persistent kernels' panels too
         lib, ig, n = self.lib, self._IG, 0
-        for i, c in enumerate(self.fwd):
-            if not isinstance(c, _Call) or c.fn is not lib.lh_fuse_fwd or c.mtag is not None:
-                continue
-            nxt = next((d for d in self.fwd[i + 1:i + 4] if isinstance(d, _Call) and d.fn is not lib.lh_bn_finalize), None)
-            if nxt is None or nxt.fn is not lib.lh_igemm or nxt.mtag is not None or nxt.slane != c.slane:
-                continue
-            d = nxt.keep
-            if (d.cfg[2] in (1, 100) and not touch_all) or not nxt.args[ig["pack"]]:    # pointwise / direct kernels fetch their panel once per workgroup
-                continue
-            kstep = 128 // self.es
-            nbytes = (d.cout + 127) // 128 * 128 * d.ntaps * ((d.k_run + kstep - 1) // kstep * kstep) * self.es
-            if not 0 < nbytes <= lim:
-                continue
-            fd = c.args[0]._obj
-            fd.l2_touch, fd.l2_touch_bytes = nxt.args[ig["pack"]], nbytes
-            n += 1
+        # members of HRNet's batch groups too (their descriptors travel into the merged calls)?  MEASURED (HRNet-W32 bs 32 fp16): 13.04-13.06
+        # ms with them, 13.01-13.02 without, 13.05-13.07 with no touch at all: off by default
+        grouped = os.environ.get("LH_L2_TOUCH_GROUPS", "0") == "1"
+
+        def attach(lst, fuse_fn, look):
+            nonlocal n
+            for i, c in enumerate(lst):
+                if not isinstance(c, _Call) or c.fn is not fuse_fn or c.lane or (c.mtag is not None and not grouped):
+                    continue
+                # the next convolution on this call's stream lane: right behind it (single launches), or the same member of the next
+                # position of a batch group (the other members' launches sit in between until _merge_groups merges them)
+                nxt = None
+                for d in lst[i + 1:i + 1 + (look if c.mtag is None else 4 * look)]:
+                    if not isinstance(d, _Call) or d.lane or d.fn is lib.lh_bn_finalize:
+                        continue
+                    if c.mtag is None or d.slane == c.slane:
+                        nxt = d
+                        break
+                if nxt is None or nxt.fn is not lib.lh_igemm or nxt.slane != c.slane or (nxt.mtag is None) != (c.mtag is None):
+                    continue
+                d = nxt.keep
+                if (d.cfg[2] in (1, 100) and not touch_all) or not nxt.args[ig["pack"]]:    # pointwise / direct kernels fetch their panel once per workgroup
+                    continue
+                kstep = 128 // self.es
+                nbytes = (d.cout + 127) // 128 * 128 * d.ntaps * ((d.k_run + kstep - 1) // kstep * kstep) * self.es
+                if not 0 < nbytes <= lim:
+                    continue
+                fd = c.args[0]._obj
+                fd.l2_touch, fd.l2_touch_bytes = nxt.args[ig["pack"]], nbytes
+                n += 1
+        attach(self.fwd, lib.lh_fuse_fwd, 3)
         # the same in the backward list: the BatchNorm / ReLU backward of a node (lh_fuse_bwd: its last apply pass) in front of the
         # data gradient that consumes the gradient it wrote
-        for i, c in enumerate(self.bwd):
-            if not isinstance(c, _Call) or c.fn is not lib.lh_fuse_bwd or c.mtag is not None or c.lane:
-                continue
-            nxt = next((d for d in self.bwd[i + 1:i + 3] if isinstance(d, _Call) and not d.lane), None)
-            if nxt is None or nxt.fn is not lib.lh_igemm or nxt.mtag is not None or nxt.slane != c.slane:
-                continue
-            d = nxt.keep
-            if (d.cfg[2] in (1, 100) and not touch_all) or not nxt.args[ig["pack"]]:
-                continue
-            kstep = 128 // self.es
-            nbytes = (d.cout + 127) // 128 * 128 * d.ntaps * ((d.k_run + kstep - 1) // kstep * kstep) * self.es
-            if not 0 < nbytes <= lim:
-                continue
-            bd = c.args[0]._obj
-            bd.l2_touch, bd.l2_touch_bytes = nxt.args[ig["pack"]], nbytes
-            n += 1
+        attach(self.bwd, lib.lh_fuse_bwd, 2)
         self._n_l2_touch = n
 
     def _call_packs(self, c):
