@@ -519,8 +519,13 @@ def main():
                     fr["note"] = ("frac = the family's own algorithmic bytes (5 passes per BatchNorm node) over the HBM peak; "
                                   "frac_of_section_8d_roof = the bytes SURVEY 8(d) charges to it (one re-read of y) over the HBM peak")
                 out["roofline_family"] = fr
+            # per kernel: [ms per step, launches, TFLOP/s of its algorithmic FLOPs, GB/s of its algorithmic bytes, governing roof of the
+            # sum of its launches] -- the stage-1 / stage-2 kernels that look slow in TFLOP/s are the HBM-bound ones
             out["kernel_breakdown_ms"] = {k: [round(v["ms"], 3), v["launches"],
-                                              round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] else None]
+                                              round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] else None,
+                                              round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 0) if v["bytes"] and v["ms"] > 0 else None,
+                                              ("hbm" if v["bytes"] / (PEAK_HBM_GBS * 1e9) >= v["flops"] / ((PEAK_F32_TFLOPS if es_ == 4 else PEAK_BF16_TFLOPS) * 1e12)
+                                               else "mfma") if (v["bytes"] or v["flops"]) else None]
                                           for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
         if not args.no_extra and (args.depth, args.size, args.batch, args.hrnet_width) == (50, 256, 64, 0):
             # the other single-GPU configurations of BASELINE.json, timed the same way (hipGraph replays, inputs resident)
