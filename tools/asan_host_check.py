@@ -139,8 +139,13 @@ def run():
     assert lib.lh_heatmap_argmax(None, 1, 4, 4, 4.0, None, None, None, None) != 0
     assert lib.lh_igemm_multi(None, 2, _lib.LH_BF16, None) != 0
     assert lib.lh_wgrad_fused_multi(None, 2, _lib.LH_BF16, None) != 0
+    bd = _lib.BottleneckDesc(2, 16, 16, 256, 64, 256)
+    assert lib.lh_bottleneck_infer(C.byref(bd), None, None, None, None, None, None, None, None, None, None, None, None, _lib.LH_F16, None) != 0
+    bd.mid = 128                                                                        # not the stage this kernel implements
+    one = C.c_void_p(16)
+    assert lib.lh_bottleneck_infer(C.byref(bd), one, one, one, one, one, one, one, one, one, one, one, C.c_void_p(32), _lib.LH_F16, None) != 0
     assert len(lib.lh_last_error()) > 0
-    calls += 10
+    calls += 12
 
 
 if __name__ == "__main__":
