@@ -205,3 +205,46 @@ def test_host_side_sanitizer_build_is_clean():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "asan_host_check.py")], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "clean" in r.stdout, (r.stdout[-1500:], r.stderr[-4000:])
     assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
+
+
+def test_pmc_traffic_tool_and_profile_guard(tmp_path):
+    """tools/pmc_traffic.py on synthetic rocprofv3 counter tables: per-kernel bytes per launch (KiB unit, gfx950 x2 read correction) and,
+    for a `bench.py --train-only` process (the once-per-step arg-max ran as often as Adam), the bytes all kernels moved per training
+    step -- bench.py's roofline.step_traffic; a process that also replayed the inference graph gets no such entry.  And
+    bench.profile_average_ns: the AverageNs bench.py compares with its live average before it attaches a committed PMC figure."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    conv = "_Z17igemm_ring_kernelIDF16bLi128ELi128ELi2ELi4ELi3ELi128EEv9IgemmArgs"
+
+    def table(path, counter, rows):
+        with open(path, "w") as f:
+            f.write('"Kernel_Name","Counter_Name","Counter_Value"\n')
+            for k, v in rows:
+                f.write(f'"{k}","{counter}",{v}\n')
+    steps = 3
+    kernels = [(conv, 1000.0)] * (2 * steps) + [("adam_kernel", 500.0)] * steps + [("heatmap_argmax_kernel(float const*)", 10.0)] * steps
+    table(tmp_path / "f.csv", "FETCH_SIZE", kernels)
+    table(tmp_path / "w.csv", "WRITE_SIZE", [(k, v / 2) for k, v in kernels])
+    out_txt, out_json = tmp_path / "o.txt", tmp_path / "o.json"
+    subprocess.run([sys.executable, os.path.join(root, "tools", "pmc_traffic.py"), str(tmp_path / "f.csv"), str(tmp_path / "w.csv"), str(out_txt), str(out_json)], check=True)
+    got = json.load(open(out_json))
+    k = "igemm_ring_kernel<__bf16, 128, 128, 2, 4, 3, 128>"
+    assert got[k] == {"read_bytes_per_launch": 2 * 1000 * 1024, "write_bytes_per_launch": 500 * 1024, "launches": 2 * steps}
+    per_step_read = 2 * 1024 * (2 * 1000 + 500 + 10)
+    per_step_write = 1024 * (2 * 500 + 250 + 5)
+    assert got["__train_step__"]["steps"] == steps
+    assert got["__train_step__"]["read_bytes"] == per_step_read and got["__train_step__"]["write_bytes"] == per_step_write
+    assert got["__train_step__"]["bytes"] == per_step_read + per_step_write
+    # an inference graph in the process: more arg-max launches than Adam launches -> no per-step figure
+    table(tmp_path / "f2.csv", "FETCH_SIZE", kernels + [("heatmap_argmax_kernel(float const*)", 10.0)] * 4)
+    subprocess.run([sys.executable, os.path.join(root, "tools", "pmc_traffic.py"), str(tmp_path / "f2.csv"), str(tmp_path / "w.csv"), str(out_txt), str(out_json)], check=True)
+    assert "__train_step__" not in json.load(open(out_json))
+    sys.path.insert(0, root)
+    import bench
+    stats = tmp_path / "stats.csv"
+    stats.write_text('"Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs","StdDev"\n'
+                     f'"{conv}",10,300000,30000.5,9.0,1,2,3\n"adam_kernel(float*)",1,1,150000.0,1,1,1,0\n')
+    assert bench.profile_average_ns(str(stats), k) == 30000.5
+    assert bench.profile_average_ns(str(stats), "no_such_kernel<float>") is None
+    assert bench.profile_average_ns(str(tmp_path / "missing.csv"), k) is None
