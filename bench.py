@@ -281,6 +281,9 @@ def main():
                     help="gradient transport for --gpus > 1: torch.distributed all-reduce between per-segment graphs (default) or "
                          "the C-ABI communicator lh_comm_* (RCCL inside ONE captured graph per step)")
     ap.add_argument("--grad-buckets", default="fp32", choices=["fp32", "bf16"], help="dtype the gradient buckets travel in")
+    ap.add_argument("--grad-algo", default="allreduce", choices=["allreduce", "direct"],
+                    help="how a gradient bucket is exchanged: RCCL's all-reduce (its own algorithm choice), or 'direct' = all-to-all + local "
+                         "sum + all-gather, i.e. reduce-scatter and all-gather with all seven xGMI peers at once (SURVEY 8e; --comm torch only)")
     ap.add_argument("--bucket-mib", type=int, default=64,
                     help="gradient bucket size for --gpus > 1.  64 MiB = 3 segments for R50: the data-parallel FORM of the step costs "
                          "+0.29 ms on one GPU (32 MiB / 5 segments: +0.63 ms; profiles/r05_dp_bucket_schedule_r50.txt), at the price of a "
@@ -338,7 +341,7 @@ def main():
     sync = None
     if world > 1:
         sync = parallel.GradSync(world, bucket_bytes=args.bucket_mib << 20, compress="bf16" if args.grad_buckets == "bf16" else None,
-                                 comm=parallel.LhComm() if args.comm == "lh" else None)
+                                 comm=parallel.LhComm() if args.comm == "lh" else None, algo=args.grad_algo)
     step = TrainStep(model, args.batch, args.size, args.size, lr=1e-3, use_graph=not args.no_graph, grad_sync=sync)
     images, joints = synthetic_batch(args.batch, args.size, dev, seed=9001 + rank)
     step.images.copy_(images)
@@ -401,7 +404,7 @@ def main():
         "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
         "config": {"workload": f"{name} {args.size}x{args.size} training step "
                                f"(fwd + JointsMSELoss + argmax decode + bwd + Adam), batch {args.batch}/GPU, 21 joints, "
-                               f"random init (seed 9001), hipGraph replay" + (f", dp{world} RCCL all-reduce ({args.comm}, {args.grad_buckets} buckets of {args.bucket_mib} MiB)" if world > 1 else ""),
+                               f"random init (seed 9001), hipGraph replay" + (f", dp{world} RCCL all-reduce ({args.comm}, {args.grad_algo}, {args.grad_buckets} buckets of {args.bucket_mib} MiB)" if world > 1 else ""),
                    "global_batch": world * args.batch, "parallelism": f"dp{world}"},
         "ms_per_step_median": round(median_ms, 3), "ranks_seen": ranks_seen,
         "dist_backend": torch.distributed.get_backend() if world > 1 else None,

@@ -513,6 +513,11 @@ int lh_copy_strided_f32(float* dst, const float* src, const int* shape4, const l
  * to_f32 = 1 widens `b16` back into `f32`.  n elements, any alignment. */
 int lh_cast_f32_bf16(float* f32, void* b16, long n, int to_f32, void* stream);
 
+/* The local reduction of the DIRECT gradient exchange (parallel.GradSync(algo="direct"): all-to-all + this + all-gather = reduce-scatter
+ * and all-gather with every xGMI peer at once): out[i] = sum over r < rows of in[r * len + i], accumulated in fp32 in row
+ * (= rank) order and rounded once; dtype LH_F32 or LH_BF16; `out` may be the first row of `in`. */
+int lh_sum_chunks(const void* in, void* out, int rows, long len, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -167,6 +167,7 @@ SIGNATURES = {
     "lh_comm_allreduce_sum": (_I, [_P, _P, _SZ, _I, _P]),
     "lh_comm_destroy": (_I, [_P]),
     "lh_cast_f32_bf16": (_I, [_P, _P, _L, _I, _P]),
+    "lh_sum_chunks": (_I, [_P, _P, _I, _L, _I, _P]),
     "lh_adam_step": (_I, [_P, _P, _P, _P, _L, _P, _P, _P, _F, _P]),
     "lh_adam_tick": (_I, [_P, _P, _P, _P]),
     "lh_adam_apply": (_I, [_P, _P, _P, _P, _L, _P, _F, _P]),

@@ -1049,3 +1049,28 @@ extern "C" int lh_cast_f32_bf16(float* src, void* dst, long n, int to_f32, void*
     LH_LAUNCH_CHECK("cast_f32_bf16 launch");
     return LH_OK;
 }
+
+
+// The local half of the DIRECT gradient exchange (parallel.GradSync(algo="direct"); SURVEY 8e: reduce-scatter + all-gather with all
+// seven xGMI peers at once instead of a ring): after the all-to-all a rank holds `rows` chunks of `len` elements -- chunk r = rank r's
+// contribution to the slice this rank owns -- and sums them IN RANK ORDER (fp32 accumulation; bf16 chunks are widened, the sum is
+// rounded once), so every rank's owned slice, and after the all-gather every rank's whole bucket, holds bit-identical values.
+template <typename T>
+__global__ void sum_chunks_kernel(const T* __restrict__ in, T* __restrict__ out, int rows, long len) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += stride) {
+        float acc = (float)in[i];
+        for (int r = 1; r < rows; ++r) acc += (float)in[(long)r * len + i];
+        out[i] = (T)acc;
+    }
+}
+
+extern "C" int lh_sum_chunks(const void* in, void* out, int rows, long len, int dtype, void* stream) {
+    LH_REQUIRE(in && out && rows >= 1 && len > 0, "lh_sum_chunks: bad arguments");
+    LH_REQUIRE(dtype == LH_F32 || dtype == LH_BF16, "lh_sum_chunks: fp32 or bf16 chunks (dtype %d)", dtype);
+    const int grid = (int)((len + 255) / 256 > 4096 ? 4096 : (len + 255) / 256);
+    if (dtype == LH_F32) hipLaunchKernelGGL(sum_chunks_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)in, (float*)out, rows, len);
+    else hipLaunchKernelGGL(sum_chunks_kernel<bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)in, (bf16*)out, rows, len);
+    LH_LAUNCH_CHECK("sum_chunks launch");
+    return LH_OK;
+}

@@ -166,12 +166,21 @@ class GradSync:
     """Launches one all-reduce per gradient bucket on a side stream; the optimizer waits for all of them (or updates each
     bucket's parameters right behind its all-reduce: launch(after=...))."""
 
-    def __init__(self, world_size=None, bucket_bytes=32 << 20, group=None, compress=None, comm=None):
+    def __init__(self, world_size=None, bucket_bytes=32 << 20, group=None, compress=None, comm=None, algo="allreduce"):
         """compress='bf16': every bucket travels as bfloat16 (half the bytes per xGMI link; the sum is formed in bf16 by
         the collective, the fp32 arena slice receives the result).  Default: fp32 buckets, exact sums.
         comm: an ``LhComm`` -- the buckets then go through the C-ABI communicator (lh_comm_allreduce_sum) instead of
         torch.distributed's all_reduce (same RCCL underneath)."""
         self.comm = comm
+        # algo="direct": a bucket is exchanged as all-to-all + local sum in rank order + all-gather -- reduce-scatter and all-gather
+        # with ALL peers at once (SURVEY 8e: 2 x bytes / N per xGMI link instead of a ring's 2 (N - 1) / N x bytes over one), and
+        # every rank ends with bit-identical sums.  "allreduce" leaves the algorithm to RCCL.  Not with the C-ABI communicator.
+        if algo not in ("allreduce", "direct"):
+            raise ValueError("algo must be 'allreduce' or 'direct'")
+        if algo == "direct" and comm is not None:
+            raise ValueError("the direct exchange runs on torch.distributed's collectives, not on the lh_comm_* communicator")
+        self.algo = algo
+        self._direct_bufs = {}
         self.world_size = world_size or (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.bucket_bytes = bucket_bytes
         self.group = group
@@ -186,6 +195,40 @@ class GradSync:
         # measurement only (bench.py allreduce_exposed_ms): with stub = True launch() keeps its stream hand-over, the bf16
         # staging and the `after` work but skips the collective itself -- the step then costs what it would with a free wire
         self.stub = False
+
+    def _direct_sum_(self, t):
+        """In-place sum of the 1-D tensor t over the ranks: all-to-all of its world_size chunks, local sum in rank order, all-gather.
+        A length that divides by world_size is exchanged in place (no staging copy); any other goes through a zero-padded send buffer."""
+        w, n = self.world_size, t.numel()
+        chunk = (n + w - 1) // w
+        key = (t.data_ptr(), n, t.dtype) if t.is_cuda else None   # (device buckets are arena slices: stable addresses)
+        bufs = self._direct_bufs.get(key) if key else None
+        if bufs is None:
+            bufs = (t if n == w * chunk else torch.zeros(w * chunk, dtype=t.dtype, device=t.device),
+                    torch.empty(w * chunk, dtype=t.dtype, device=t.device), torch.empty(chunk, dtype=t.dtype, device=t.device))
+            if key:
+                self._direct_bufs[key] = bufs
+        send, recv, mine = bufs
+        if send is not t:
+            send[:n].copy_(t)                                      # (the pad behind n stays zero)
+        dist.all_to_all_single(recv, send, group=self.group)       # recv chunk r = rank r's part of the slice this rank owns
+        if t.is_cuda:
+            from . import _lib
+            lib = _lib.load()
+            _lib.check(lib.lh_sum_chunks(recv.data_ptr(), mine.data_ptr(), w, chunk, _lib.dtype_code(t.dtype),
+                                         torch.cuda.current_stream().cuda_stream), "lh_sum_chunks")
+        else:
+            acc = recv[:chunk].float()
+            for r in range(1, w):
+                acc = acc + recv[r * chunk:(r + 1) * chunk].float()
+            mine.copy_(acc.to(t.dtype))
+        if dist.get_backend(self.group) == "gloo":
+            dist.all_gather(list(send.view(w, chunk).unbind(0)), mine, group=self.group)
+        else:
+            dist.all_gather_into_tensor(send, mine, group=self.group)
+        if send is not t:
+            t.copy_(send[:n])
+        return t
 
     def segments(self, plan):
         if self._segments is None:
@@ -210,7 +253,7 @@ class GradSync:
             self.stream.wait_event(ev)
             with torch.cuda.stream(self.stream):
                 reduce_ = (lambda t: None) if self.stub else self.comm.all_reduce_sum_ if self.comm is not None else \
-                    (lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group))
+                    self._direct_sum_ if self.algo == "direct" else (lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group))
                 if self.compress == "bf16":
                     half = self._staging.get(bucket)
                     if half is None:
@@ -230,8 +273,13 @@ class GradSync:
             self._pending.append(done)
         elif self.compress == "bf16":
             half = view.to(torch.bfloat16)
-            dist.all_reduce(half, op=dist.ReduceOp.SUM, group=self.group)
+            if self.algo == "direct":
+                self._direct_sum_(half)
+            else:
+                dist.all_reduce(half, op=dist.ReduceOp.SUM, group=self.group)
             view.copy_(half)
+        elif self.algo == "direct":
+            self._direct_sum_(view)
         else:
             self._pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 

@@ -1021,3 +1021,43 @@ def test_bench_gpus_2_starts_two_ranks():
                         "--batch", "4", "--size", "128", "--no-cpu-baseline", "--no-roofline", "--no-extra"],
                        env=env1, capture_output=True, text=True, timeout=600)
     assert r.returncode != 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_sum_chunks_matches_a_rank_ordered_fp32_sum(dtype):
+    """lh_sum_chunks (the local half of GradSync(algo="direct")): out[i] = sum_r in[r, i], fp32 accumulation in row order, one rounding;
+    ragged length, eight rows = the eight ranks of a node."""
+    from lighthand_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device="cpu").manual_seed(5)
+    rows, n = 8, 100003
+    x = torch.randn(rows, n, generator=g).to(dtype).cuda()
+    out = torch.empty(n, dtype=dtype, device="cuda")
+    _lib.check(lib.lh_sum_chunks(x.data_ptr(), out.data_ptr(), rows, n, _lib.dtype_code(dtype), torch.cuda.current_stream().cuda_stream), "lh_sum_chunks")
+    acc = x[0].float()
+    for r in range(1, rows):
+        acc = acc + x[r].float()
+    assert torch.equal(out, acc.to(dtype))
+    assert lib.lh_sum_chunks(x.data_ptr(), out.data_ptr(), rows, n, _lib.LH_F16, None) != 0        # fp32 / bf16 buckets only
+
+
+def test_bench_gpus_2_direct_gradient_exchange():
+    """The same two-rank rehearsal with --grad-algo direct (all-to-all + lh_sum_chunks + all-gather): the step runs, both ranks are seen
+    and the loss after the timed steps equals the all-reduce run's (two ranks: a + b in either order is the same fp32 sum)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LH_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    losses = {}
+    for algo in ("direct", "allreduce"):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--depth", "18",
+                            "--batch", "4", "--size", "128", "--no-cpu-baseline", "--no-roofline", "--no-extra", "--grad-algo", algo],
+                           env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+        out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and algo in out["config"]["workload"], out
+        losses[algo] = out["loss_after"]
+    assert losses["direct"] == losses["allreduce"], losses

@@ -17,7 +17,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q, compress=None):
+def _worker(rank, world, port, q, compress=None, algo="allreduce"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     from lighthand_amd import parallel
     r, w, _ = parallel.init_distributed(backend="gloo")
@@ -32,7 +32,7 @@ def _worker(rank, world, port, q, compress=None):
     class FakePlan:
         bwd_marks, arena_offsets, arena_numel = marks, offsets, off
 
-    sync = parallel.GradSync(world, bucket_bytes=4 * 20000, compress=compress)
+    sync = parallel.GradSync(world, bucket_bytes=4 * 20000, compress=compress, algo=algo)
     segs = sync.segments(FakePlan)
     torch.manual_seed(100 + rank)
     flat = torch.randn(off)
@@ -52,16 +52,23 @@ def _worker(rank, world, port, q, compress=None):
     ok = bool(torch.allclose(flat, want, rtol=0 if compress is None else 1e-2, atol=1e-6 if compress is None else 2e-2)) \
         and executed == marks[-1][0] and len(segs) >= 2
     avg_ok = bool(torch.allclose(flat * (1.0 / world), want / world, rtol=1e-2, atol=2e-2))
+    if algo == "direct":         # one rank sums each slice, in rank order, and hands the result out: every rank holds the same bits
+        theirs = [torch.zeros(off) for _ in range(world)]
+        dist.all_gather(theirs, flat)
+        ok = ok and all(torch.equal(t, theirs[0]) for t in theirs)
     q.put((rank, ok and avg_ok, [b for _, _, b in segs]))
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("algo", ["allreduce", "direct"])
 @pytest.mark.parametrize("compress", [None, "bf16"])
-def test_gradsync_gloo_world2(compress):
+def test_gradsync_gloo_world2(compress, algo):
+    """algo="direct": the bucket as all-to-all + local sum in rank order + all-gather (reduce-scatter and all-gather with every peer at
+    once) gives the same sums as the all-reduce."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, compress)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, compress, algo)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]
@@ -70,6 +77,29 @@ def test_gradsync_gloo_world2(compress):
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res), res
     assert res[0][2] == res[1][2]                    # both ranks cut identical buckets
+
+
+def test_gradsync_direct_gloo_world3_pads_ragged_buckets():
+    """Three ranks: no bucket of the fake model divides by 3, so the direct exchange goes through its zero-padded send buffer."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 3, port, q, None, "direct")) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
+
+
+def test_gradsync_rejects_unknown_algorithm_and_direct_on_the_c_abi_communicator():
+    from lighthand_amd import parallel
+    with pytest.raises(ValueError):
+        parallel.GradSync(1, algo="tree")
+    with pytest.raises(ValueError):
+        parallel.GradSync(1, algo="direct", comm=object())
 
 
 def test_init_distributed_single_process_is_noop(monkeypatch):
