@@ -417,6 +417,9 @@ def main():
     # whole-step roofline: per-GPU rate against the per-GPU peaks (2.760 TFLOP / 12.06 GB per R50 bs64 step)
     out["step_roofline"] = step_roofline(wkey, True, value / world, es)
     out["c_abi_calls_per_step"] = sum(1 for c in step.plan.packs + step.plan.fwd + step.plan.bwd if hasattr(c, "fn")) + 4
+    out["conv_bn_relu_launches"] = getattr(step.plan, "_n_fused_bn", 0)       # convolutions that carry their BatchNorm + ReLU (lh_igemm_bn_relu)
+    if step.plan.bn_sync_gave_up():
+        raise SystemExit("a fused convolution + BatchNorm launch gave up at its grid barrier: the step's results are wrong")
 
     if rank == 0 and world == 1 and not args.train_only:
         # eval-mode forward + decode throughput (the "infer" half of the metric)

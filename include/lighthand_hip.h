@@ -284,6 +284,31 @@ typedef struct {
     long long* num_batches_tracked; float momentum, eps; float* scale; float* shift; float* save_mean; float* save_invstd;
 } lh_bn_finalize_call;
 int lh_bn_finalize_multi(const lh_bn_finalize_call* calls, int n, void* stream);
+/* Convolution + training-mode BatchNorm + ReLU as ONE launch (pose_resnet.py:86-94: conv -> bn -> relu inside a block): the launch
+ * writes the raw output `out` and its statistics rows (fin->stats, as lh_igemm does), its workgroups meet at a grid barrier, each folds
+ * the rows of its channel tile, derives scale / shift EXACTLY as lh_bn_finalize does (same arithmetic, same order: bit-identical), and
+ * stores relu(out * scale + shift) -- lh_fuse_fwd's arithmetic -- to f->out from the values it still holds; everything lh_bn_finalize
+ * writes (scale, shift, saved mean / invstd, running statistics, num_batches_tracked) is written too.  Replaces three launches on the
+ * dependency chain (convolution, finalize, elementwise) and one read of `out`.
+ * Conditions (LH_ERR_UNSUPPORTED / LH_ERR_ARG otherwise): a tiled LDS-DMA configuration of a 16-bit type (d->cfg), dense output, no
+ * addend / bias / affine / ReLU in the descriptor, fewer than 256 statistics rows, and THE WHOLE GRID RESIDENT ON THE DEVICE AT ONCE
+ * (lh_igemm_bn_relu_resident; the launch checks it).  The barrier spins: the caller must not run two such launches concurrently
+ * (two streams, two processes on one GPU) -- each could hold the CUs the other waits for; a launch that waits for seconds gives up,
+ * sets sync[1] = 1 and finishes with whatever rows it sees.
+ * sync: two 32-bit device words, zero-initialised ONCE by the caller and owned by this call site (the arrival count only ever grows). */
+typedef struct {
+    const lh_bn_finalize_call* fin;     /* fin->stats = the launch's statistics slab [rows][2][cout] */
+    void* out;                          /* relu(BN(out)): the layout of `out` */
+    unsigned int* sync;
+} lh_bn_relu_fuse;
+int lh_igemm_bn_relu(const lh_igemm_desc* d, const void* in, const void* wpack, void* out, const lh_bn_relu_fuse* f, int dtype, void* stream);
+/* the sub-pixel phases of a transposed convolution (lh_igemm_phases) + BatchNorm + ReLU: pose_resnet.py:219-227 */
+int lh_igemm_phases_bn_relu(const lh_igemm_desc* const* descs, int nphase, const void* in, const void* const* wpacks, void* out,
+                            const lh_bn_relu_fuse* f, int dtype, void* stream);
+/* 1 when the launch the descriptors name (nphase = 1: lh_igemm_bn_relu) holds its whole grid on the current device at once, 0 when not,
+ * negative when the form does not run on a tiled 16-bit configuration.  out3 (optional) = { workgroups, workgroups per CU, CUs }. */
+int lh_igemm_bn_relu_resident(const lh_igemm_desc* const* descs, int nphase, int dtype, int* out3);
+
 /* Eval mode: scale/shift from running statistics. */
 int lh_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
                       const float* running_var, float eps, int c, float* scale, float* shift,

@@ -6,6 +6,7 @@
 #define LH_BN_EXP_DEFAULT 4      // measured (round 4): non-temporal loads of the BN inputs in the forward pass, -0.11 ms per R50 step
 #endif
 #include "multi.h"
+#include "bn_fold.h"
 #include <type_traits>
 #include <vector>
 #include <algorithm>
@@ -41,28 +42,7 @@ __device__ __forceinline__ void slab_totals_then(const TI* slab, int rows, int c
     __shared__ double red[2][16][17];
     const int ch = bid * 16 + (threadIdx.x & 15), rl = threadIdx.x >> 4;
     double a = 0.0, b = 0.0;
-    if (ch < c) {
-        int r = rl;
-        for (; r + 112 < rows; r += 128) {        // eight independent row groups in flight (the fold is a latency chain)
-            TI av[8], bv[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { av[u] = slab[((long)(r + 16 * u) * 2) * c + ch]; bv[u] = slab[((long)(r + 16 * u) * 2 + 1) * c + ch]; }
-            a += (((double)av[0] + (double)av[1]) + ((double)av[2] + (double)av[3])) + (((double)av[4] + (double)av[5]) + ((double)av[6] + (double)av[7]));
-            b += (((double)bv[0] + (double)bv[1]) + ((double)bv[2] + (double)bv[3])) + (((double)bv[4] + (double)bv[5]) + ((double)bv[6] + (double)bv[7]));
-        }
-        for (; r + 48 < rows; r += 64) {          // four independent row groups in flight
-            const TI a0 = slab[((long)r * 2) * c + ch], b0 = slab[((long)r * 2 + 1) * c + ch];
-            const TI a1 = slab[((long)(r + 16) * 2) * c + ch], b1 = slab[((long)(r + 16) * 2 + 1) * c + ch];
-            const TI a2 = slab[((long)(r + 32) * 2) * c + ch], b2 = slab[((long)(r + 32) * 2 + 1) * c + ch];
-            const TI a3 = slab[((long)(r + 48) * 2) * c + ch], b3 = slab[((long)(r + 48) * 2 + 1) * c + ch];
-            a += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
-            b += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
-        }
-        for (; r < rows; r += 16) {
-            a += (double)slab[((long)r * 2) * c + ch];
-            b += (double)slab[((long)r * 2 + 1) * c + ch];
-        }
-    }
+    if (ch < c) slab_lane16(slab, rows, c, ch, rl, [](const TI* q) { return *q; }, a, b);
     red[0][rl][threadIdx.x & 15] = a;
     red[1][rl][threadIdx.x & 15] = b;
     __syncthreads();
@@ -201,42 +181,10 @@ extern "C" size_t lh_bn_stats_slab_bytes(int rows, int c) {
     return ((size_t)rows * 2 * c + 2) * 4 + (size_t)(ceil_div(rows, 256) + 1) * 2 * c * 8;
 }
 
-struct FinalizeArgs {
-    const void* slab;            // [rows][2][c] floats (or doubles: the second level of a two-launch fold)
-    int rows, count, c;
-    const float* gamma;
-    const float* beta;
-    float* rmean;
-    float* rvar;
-    long long* nbt;
-    float momentum, eps;
-    float* scale;
-    float* shift;
-    float* smean;
-    float* sinv;
-};
-
 template <typename TI>
 __device__ __forceinline__ void bn_finalize_fused_body(const FinalizeArgs& p, const int bid, const int nblk) {
     if (bid == 0 && threadIdx.x == 0 && p.nbt) *p.nbt += 1;
-    const int count = p.count;
-    auto fin = [&](int ch, double s0, double s1) {
-        const double mean = s0 / count;
-        double var = s1 / count - mean * mean;
-        if (var < 0.0) var = 0.0;
-        const float invstd = (float)(1.0 / sqrt(var + (double)p.eps));
-        const float g = p.gamma ? p.gamma[ch] : 1.f, b = p.beta ? p.beta[ch] : 0.f;
-        const float sc = g * invstd;
-        p.scale[ch] = sc;
-        p.shift[ch] = b - (float)mean * sc;
-        if (p.smean) p.smean[ch] = (float)mean;
-        if (p.sinv) p.sinv[ch] = invstd;
-        if (p.rmean) p.rmean[ch] = (1.f - p.momentum) * p.rmean[ch] + p.momentum * (float)mean;
-        if (p.rvar) {
-            const double unb = count > 1 ? var * ((double)count / (count - 1)) : var;
-            p.rvar[ch] = (1.f - p.momentum) * p.rvar[ch] + p.momentum * (float)unb;
-        }
-    };
+    auto fin = [&](int ch, double s0, double s1) { float sc, sh; bn_finalize_channel(p, ch, s0, s1, true, sc, sh); };
     if (p.rows >= LH_FOLD_WIDE_ROWS) slab_totals_then64((const TI*)p.slab, p.rows, p.c, bid, fin);
     else slab_totals_then((const TI*)p.slab, p.rows, p.c, bid, fin);
 }

@@ -1,6 +1,7 @@
 // Kernel-argument block shared by the two implicit-GEMM kernels (igemm.hip, igemm_ring.hip).
 #pragma once
 #include "common.h"
+#include "bn_fold.h"
 
 struct IgemmArgs {
     const unsigned char* in;
@@ -28,6 +29,15 @@ struct IgemmArgs {
     const float* head_bias;
     float* head_out;
     int head_j, head_wstride;       // valid head channels (<= 32), bytes between head_w rows
+    // Training-mode BatchNorm + ReLU carried by the launch itself (lh_igemm_bn_relu; tiled configurations, the whole grid resident at
+    // once): the epilogue stores the raw output and its statistics rows as ever, then the grid meets at a barrier (bn_sync: one device
+    // word that only ever grows), every workgroup folds the rows of ITS channel tile (bn.slab = the launch's statistics slab), derives
+    // scale / shift exactly as lh_bn_finalize does, and stores relu(raw * scale + shift) from the values it still holds to bn_out.  The
+    // first workgroup of each channel tile also writes what the finalize writes (scale, shift, saved mean / invstd, running statistics).
+    unsigned char* bn_out;           // NULL: off
+    unsigned* bn_sync;               // [0] arrivals (never reset), [1] set to 1 when a launch gave up waiting (grid not resident)
+    FinalizeArgs bn;
+    int bn_query;                    // host side only: launch nothing, report the grid and what the device holds at once (lh_ring_resident)
     int n, hi, wi, in_pix_stride, k_run, kspt, kpad;   // kpad: elements per (row, tap) of the weight pack
     int ho, wo, M, sh, sw, cout;
     int OH, OW, osh, osw, ooh, oow, out_pix_stride;
@@ -69,6 +79,8 @@ static inline void lh_pw_grid(int bm, int kc, int pt, long M, int cout, int occ,
 
 
 // igemm_ring.hip
+void lh_ring_resident_set(int grid, int per_cu, int ncu);     // what the last bn_out / bn_query launch of this thread found
+void lh_ring_resident_get(int* out3);
 bool lh_ring_supported(const lh_igemm_desc* d, int dtype);
 bool lh_tap_grid(const lh_igemm_desc* d, int* tw, int* dh0, int* dhs, int* dw0, int* dws);
 int lh_ring_resolve(const lh_igemm_desc* d, int dtype, RingCfg* out);

@@ -350,8 +350,16 @@ static int lh_ring_offsets_fit(const IgemmArgs& a, int bm, int bp, int es) {
 const unsigned char* lh_ring_zero_page() { return zero_page(); }      // bottleneck_infer.hip
 unsigned char* lh_ring_dump_page() { return dump_page(); }
 
+static thread_local int g_resident[3] = {0, 0, 0};
+void lh_ring_resident_set(int grid, int per_cu, int ncu) { g_resident[0] = grid; g_resident[1] = per_cu; g_resident[2] = ncu; }
+void lh_ring_resident_get(int* out3) { out3[0] = g_resident[0]; out3[1] = g_resident[1]; out3[2] = g_resident[2]; }
+
 int lh_igemm_ring_launch(const IgemmArgs& a0, const RingCfg& c, int dtype, hipStream_t s) {
     IgemmArgs a = a0;
+    if ((a.bn_out || a.bn_query) && (c.depth == 1 || c.depth == 100)) {
+        lh_set_error("lh_igemm_bn_relu: the persistent kernels hold no grid barrier (ring depth %d)", c.depth);
+        return LH_ERR_UNSUPPORTED;
+    }
     a.zero = zero_page();
     a.dump = dump_page();
     if (!a.zero || !a.dump) {

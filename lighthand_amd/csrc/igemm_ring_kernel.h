@@ -381,7 +381,7 @@ __device__ __forceinline__ void igemm_ring_body(const IgemmArgs& p, unsigned cha
             return;
         }
     }
-    igemm_epilogue<T, BM, BP, WC, WP>(p, smem, acc, pblk, cblk, tid, lane, wc, wp, hw, ooh, oow, stats);
+    igemm_epilogue<T, BM, BP, WC, WP>(p, smem, acc, pblk, cblk, tid, lane, wc, wp, hw, ooh, oow, stats, pblk == 0 && stats == p.stats);
 #endif
 }
 
@@ -409,7 +409,8 @@ static int launch_ring(const IgemmArgs& a, hipStream_t s) {
     constexpr int ES = sizeof(T);
     constexpr int ring = D * (BM + BP) * KB;
     constexpr int epi = lh_epi_lds_bytes<T, BM, BP, (BM == 256 && BP == 256 && ES == 2)>();   // tile + the fused head's weights + per-channel constants
-    constexpr int lds = ring > epi ? ring : epi;
+    constexpr int lds0 = ring > epi ? ring : epi;
+    constexpr int lds = lds0 > lh_bnfold_lds_bytes<BM>() ? lds0 : lh_bnfold_lds_bytes<BM>();
     static_assert(lds <= 160 * 1024, "LDS budget");
     if (lds > 64 * 1024) {
         // per-device function attribute; cheap enough to set on every launch (no process-wide "done" flag:
@@ -422,6 +423,21 @@ static int launch_ring(const IgemmArgs& a, hipStream_t s) {
         }
     }
     dim3 grid(ceil_div(a.M, BP) * ceil_div(a.cout, BM) * (a.nphase > 1 ? a.nphase : 1));
+    if (a.bn_out || a.bn_query) {
+        // the launch holds a grid barrier: every workgroup must be resident at once
+        int per_cu = 0, dev = 0, ncu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&igemm_ring_kernel<T, BM, BP, WC, WP, D, KB>), 64 * WC * WP, lds) != hipSuccess ||
+            hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+            lh_set_error("igemm_ring: occupancy query failed");
+            return LH_ERR_HIP;
+        }
+        lh_ring_resident_set((int)grid.x, per_cu, ncu);
+        if (a.bn_query) return LH_OK;
+        if (ES != 2 || (long)grid.x > (long)per_cu * ncu) {
+            lh_set_error("lh_igemm_bn_relu: %u workgroups, the device holds %d x %d at once (16-bit types only)", grid.x, per_cu, ncu);
+            return LH_ERR_UNSUPPORTED;
+        }
+    }
     hipLaunchKernelGGL((igemm_ring_kernel<T, BM, BP, WC, WP, D, KB>), grid, dim3(64 * WC * WP), lds, s, a);
     LH_LAUNCH_CHECK("igemm_ring launch");
     return LH_OK;

@@ -339,6 +339,10 @@ class Plan:
     force_wgrad = None
     fuse_head = True             # test hook: False keeps the inference head as separate launches (A/B against _fuse_head)
     fuse_stem = True             # test hook: False keeps the inference stem as convolution + max-pool launches (A/B against _fuse_stem_pool)
+    # Training plans: conv -> BatchNorm (batch statistics) -> ReLU as ONE launch where the convolution's whole grid is resident at once
+    # (lh_igemm_bn_relu: stages 3-4 and the first deconvolutions of the ResNets at batch 64).  "0" keeps the three launches; "2" also
+    # takes grids of up to two workgroups per CU.
+    fuse_bn_train = os.environ.get("LH_FUSE_BN_TRAIN", "0")
     fuse_bottleneck = os.environ.get("LH_FUSE_BOTTLENECK", "1") != "0"    # False keeps the stage-1 bottlenecks of inference plans as three launches (A/B against _fuse_bottleneck)
     _tune_file_loaded = False
 
@@ -1847,11 +1851,15 @@ class Plan:
             fd.relu_mask = relu_bits.data_ptr()
         if self.training and self.with_bwd and relu and len(terms) == 1 and terms[0][1] is not None and terms[0][2] == 0:
             self._gate_info[id(out)] = dict(raw=terms[0][0], st=bn_state[0])
-        self.fwd.append(_Call(self.lib.lh_fuse_fwd, (C.byref(fd), obuf.data_ptr(), out.n, out.h, out.w, c, self.dt), "fuse fwd"))
-        if self.training and relu and len(terms) == 1 and terms[0][1] is not None and terms[0][2] == 0 and relu_bits is None:
-            # what a max-pool that follows needs to take this node's elementwise pass over (_c_maxpool)
-            self._bnrelu_info[id(out)] = dict(raw=terms[0][0], st=bn_state[0], call=self.fwd[-1], fin=fd.fin[0])
-        self.profile_meta.append(("fwd", self.fwd[-1], "fuse_fwd(all kernels)", 0.0, (sum(a.pixels for a, _, _ in terms) + out.pixels) * c * self.es))
+        if self.training and relu and len(terms) == 1 and terms[0][1] is not None and terms[0][2] == 0 and relu_bits is None and \
+                self._fuse_bn_into_conv(terms[0][0], fd.fin[0], obuf):
+            pass                                         # the producing convolution carries finalize + BN + ReLU (lh_igemm_bn_relu)
+        else:
+            self.fwd.append(_Call(self.lib.lh_fuse_fwd, (C.byref(fd), obuf.data_ptr(), out.n, out.h, out.w, c, self.dt), "fuse fwd"))
+            if self.training and relu and len(terms) == 1 and terms[0][1] is not None and terms[0][2] == 0 and relu_bits is None:
+                # what a max-pool that follows needs to take this node's elementwise pass over (_c_maxpool)
+                self._bnrelu_info[id(out)] = dict(raw=terms[0][0], st=bn_state[0], call=self.fwd[-1], fin=fd.fin[0])
+            self.profile_meta.append(("fwd", self.fwd[-1], "fuse_fwd(all kernels)", 0.0, (sum(a.pixels for a, _, _ in terms) + out.pixels) * c * self.es))
         if not self.with_bwd:
             return
         self._ws_fuse = max(self._ws_fuse, self.lib.lh_fuse_bwd_workspace_bytes(out.n, out.h, out.w, c))
@@ -1902,6 +1910,58 @@ class Plan:
             # what SURVEY 8(d)'s traffic model itself charges to the BatchNorm backward: ONE re-read of y per BatchNorm term
             self.bn_bwd_8d_bytes = getattr(self, "bn_bwd_8d_bytes", 0.0) + float(n_bn) * out.pixels * c * self.es
         blk.append(emit)
+
+    def _fuse_bn_into_conv(self, raw, fin_ptr, obuf):
+        """Training plans: the convolution that produces `raw` takes the node relu(BN(raw)) over (lh_igemm_bn_relu / lh_igemm_phases_bn_relu:
+        statistics rows, grid barrier, in-launch finalize, second store) when it is ONE tiled launch on the plan's only stream whose whole
+        grid is resident at once -- the barrier spins, so nothing that could wait for it may hold its CUs.  Returns True when the launch
+        was rewritten (the caller then emits no elementwise call)."""
+        mode = Plan.fuse_bn_train
+        if mode == "0" or not self.training or self.es != 2 or self.n_lanes != 1 or self._forced is not None or not fin_ptr:
+            return False
+        prods = self._producers.get(id(raw)) or []
+        if len(prods) != 1 or raw.c != raw.c_valid or raw.stats is None or not (0 < raw.stats_rows < 256):
+            return False
+        call = prods[0]
+        lib = self.lib
+        if call.fn is lib.lh_igemm:
+            d, src, pack, dst, addend, amask, bias, scale, shift, stats, dt = call.args
+            descs, n = (C.POINTER(IgemmDesc) * 1)(C.pointer(call.keep)), 1
+        elif call.fn is lib.lh_igemm_phases:
+            arr, n, src, packs, dst, addend, amask, bias, scale, shift, stats, dt = call.args
+            descs = arr
+        else:
+            return False
+        if addend or amask or bias or scale or shift or not stats or call not in self.fwd:
+            return False
+        if any(dd.relu or dd.out_pix_stride != dd.cout for dd in (call.keep if isinstance(call.keep, list) else [call.keep])):
+            return False
+        res = (C.c_int * 3)()
+        if lib.lh_igemm_bn_relu_resident(descs, n, self.dt, res) != 1 or res[0] > res[2] * (2 if mode == "2" else 1):
+            return False
+        if not hasattr(self, "_bn_sync"):
+            self._bn_sync, self._bn_sync_used = self._alloc(64 * 32, dtype=torch.int32), 0      # one 128-byte line per call site
+            self._bn_sync.zero_()
+        assert self._bn_sync_used < 64, "more fused BatchNorm launches than sync words"
+        sync = self._bn_sync.data_ptr() + 128 * self._bn_sync_used
+        self._bn_sync_used += 1
+        f = _lib.BnReluFuse(fin_ptr, obuf.data_ptr(), sync)
+        self.keep += [f, descs]
+        if n == 1:
+            call.fn, call.args = lib.lh_igemm_bn_relu, (d, src, pack, dst, C.byref(f), dt)
+            call.ig = dict(src=1, dst=3)
+        else:
+            call.fn, call.args = lib.lh_igemm_phases_bn_relu, (arr, n, src, packs, dst, C.byref(f), dt)
+            call.ig = dict(src=2, dst=4)
+        call.what += " + BN + ReLU"
+        self._n_fused_bn = getattr(self, "_n_fused_bn", 0) + 1
+        return True
+
+    def bn_sync_gave_up(self):
+        """True when a fused convolution + BatchNorm launch of this plan ever gave up at its grid barrier (its results are then wrong)."""
+        if not hasattr(self, "_bn_sync"):
+            return False
+        return bool(self._bn_sync.view(-1, 32)[:, 1].any().item())
 
     def _next_writer_is_conv(self, a, nd):
         """True when, walking backward from fuse node `nd`, the next writer of a.grad is a stride-1-output convolution /

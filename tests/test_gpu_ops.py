@@ -1108,3 +1108,89 @@ def test_short_k_run_does_not_read_past_the_operand(precision, forced_plans):
             assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16)), c.what
             checked += 1
     assert checked >= 2, checked
+
+
+FUSED_BN_CASES = [(256, 2, 16, 16), (96, 3, 12, 20), (64, 1, 9, 9), (512, 2, 8, 8)]
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+@pytest.mark.parametrize("tile", ["big", "small", "tuned"])
+@pytest.mark.parametrize("case", FUSED_BN_CASES)
+def test_conv_bn_relu_as_one_launch_is_bit_identical(case, tile, precision, forced_plans):
+    """lh_igemm_bn_relu (conv + batch-statistics BatchNorm + ReLU in ONE launch: statistics rows, grid barrier, in-launch fold with
+    lh_bn_finalize's arithmetic, second store) against the three launches it replaces (lh_igemm, finalize, lh_fuse_fwd): forward output,
+    running statistics, every gradient bit for bit -- ragged pixel counts, channel counts below the tile, largest / smallest / measured tile."""
+    import copy
+    _, BnNet = _mods()
+    c, n, h, w = case
+    torch.manual_seed(11)
+    proto = BnNet(c, "plain")
+    x = torch.randn(n, c, h, w).to(torch.bfloat16).float()
+    tiled = lambda cands: [q for q in cands if q[2] not in (1, 100)] or cands          # not the persistent pointwise / direct 3x3 kernels
+    if tile != "tuned":
+        forced_plans.force_cfg = (lambda cands: max(tiled(cands), key=lambda q: (q[0] * q[1], q[3]))) if tile == "big" else \
+            (lambda cands: min(tiled(cands), key=lambda q: (q[0] * q[1], q[3])))
+    res = {}
+    try:
+        for mode in ("1", "0"):
+            forced_plans.fuse_bn_train = mode
+            m = copy.deepcopy(proto)
+            torch.manual_seed(12)
+            out, dx, grads = _run_plan(m, x, lambda o: torch.randn_like(o), precision)
+            plan = next(iter(m._lh_plans.values()))
+            nf = getattr(plan, "_n_fused_bn", 0)
+            assert nf == 0 if mode == "0" else (nf == 1 or tile == "tuned"), (mode, [cc.what for cc in plan.fwd if hasattr(cc, "fn")])
+            assert not plan.bn_sync_gave_up()
+            res[mode] = (out, dx, grads, {k: v.cpu().clone() for k, v in m.state_dict().items() if "running" in k or "tracked" in k})
+    finally:
+        forced_plans.fuse_bn_train = "0"
+    a, b = res["1"], res["0"]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for k in b[2]:
+        assert torch.equal(a[2][k], b[2][k]), k
+    for k in b[3]:
+        assert torch.equal(a[3][k], b[3][k]), k
+    assert int(a[3]["bn.num_batches_tracked"]) == 1
+
+
+@pytest.mark.parametrize("case", [(128, 64, 2, 8, 8), (64, 96, 3, 6, 10)])
+def test_deconv_bn_relu_as_one_launch_is_bit_identical(case, forced_plans):
+    """The four sub-pixel phases of a 4x4 / stride-2 transposed convolution + BatchNorm + ReLU as one launch (lh_igemm_phases_bn_relu)
+    against the three launches: bit for bit (pose_resnet.py:219-227)."""
+    import copy
+    from lighthand_amd.module import HipModule
+    cin, cout, n, h, w = case
+
+    class DeconvBn(HipModule):
+        def __init__(self):
+            super().__init__()
+            self.up = nn.ConvTranspose2d(cin, cout, 4, 2, 1, 0, bias=False)
+            self.bn = nn.BatchNorm2d(cout, momentum=0.1)
+            self.out = nn.Conv2d(cout, 8, 1, bias=False)
+
+        def describe(self, gb):
+            x = gb.input_act(cin)
+            gb.output(gb.conv(gb.fuse([(gb.deconv(x, "up", 4), "bn")]), "out", 1, 1, 0))
+
+    torch.manual_seed(21)
+    proto = DeconvBn()
+    x = torch.randn(n, cin, h, w).to(torch.bfloat16).float()
+    res = {}
+    try:
+        for mode in ("1", "0"):
+            forced_plans.fuse_bn_train = mode
+            m = copy.deepcopy(proto)
+            torch.manual_seed(22)
+            out, dx, grads = _run_plan(m, x, lambda o: torch.randn_like(o), "bf16")
+            plan = next(iter(m._lh_plans.values()))
+            assert getattr(plan, "_n_fused_bn", 0) == (1 if mode == "1" else 0), [cc.what for cc in plan.fwd if hasattr(cc, "fn")]
+            assert not plan.bn_sync_gave_up()
+            res[mode] = (out, dx, grads, {k: v.cpu().clone() for k, v in m.state_dict().items() if "running" in k})
+    finally:
+        forced_plans.fuse_bn_train = "0"
+    a, b = res["1"], res["0"]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for k in b[2]:
+        assert torch.equal(a[2][k], b[2][k]), k
+    for k in b[3]:
+        assert torch.equal(a[3][k], b[3][k]), k
