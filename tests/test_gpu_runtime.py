@@ -1061,3 +1061,32 @@ def test_bench_gpus_2_direct_gradient_exchange():
         assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and algo in out["config"]["workload"], out
         losses[algo] = out["loss_after"]
     assert losses["direct"] == losses["allreduce"], losses
+
+
+@pytest.mark.parametrize("depth,precision", [(50, "bf16"), (18, "fp16")])
+def test_train_step_with_conv_bn_relu_launches_is_bit_identical(depth, precision):
+    """LH_FUSE_BN_TRAIN=1 (Plan.fuse_bn_train): the convolutions whose whole grid is resident carry their BatchNorm + ReLU
+    (lh_igemm_bn_relu).  Three captured training steps of a whole network with and without them: the same losses, weights and
+    running statistics BIT FOR BIT (same statistics rows, lh_bn_finalize's fold arithmetic, lh_fuse_fwd's elementwise arithmetic)."""
+    from lighthand_amd.engine import Plan
+    from lighthand_amd.runtime import TrainStep
+    x, j = _batch(8, 128, 3)
+    res = []
+    try:
+        for mode in ("1", "0"):
+            Plan.fuse_bn_train = mode
+            m = _model(depth, precision)
+            step = TrainStep(m, 8, 128, 128, lr=1e-3, use_graph=True)
+            losses = [float(step(x, j)) for _ in range(3)]
+            nf = getattr(step.plan, "_n_fused_bn", 0)
+            assert (nf >= 6) if mode == "1" else nf == 0, nf
+            assert not step.plan.bn_sync_gave_up()
+            res.append((losses, m.arena().flat.clone(), {k: v.clone() for k, v in m.named_buffers()}))
+            step.close()
+    finally:
+        Plan.fuse_bn_train = "0"
+    (la, wa, ba), (lb, wb, bb) = res
+    assert la == lb, (la, lb)
+    assert torch.equal(wa, wb)
+    for k in bb:
+        assert torch.equal(ba[k], bb[k]), k
