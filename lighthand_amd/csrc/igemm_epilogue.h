@@ -41,7 +41,13 @@ __device__ __forceinline__ void igemm_epilogue_consts(const IgemmArgs& p, float*
     }
 }
 
-template <typename T, int BM, int BP, int WC, int WP>
+// rows of the tile a thread stores (NR of igemm_epilogue): the in-launch BatchNorm (BNF) keeps them in registers across its grid
+// barrier, so it exists for the forms with at most four (the 8-wave forms of the <= 128 x 128 tiles and the small 4-wave tiles)
+template <typename T, int BM, int BP, int WC, int WP> constexpr bool lh_bn_variant() {
+    return sizeof(T) == 2 && BP / ((64 * WC * WP) / (BM * (int)sizeof(T) / 16)) <= 4;
+}
+
+template <typename T, int BM, int BP, int WC, int WP, bool BNF = false>
 __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, unsigned char* smem, f32x4 (&acc)[BM / WC / 16][BP / WP / 16],
                                                int pblk, int cblk, int tid, int lane, int wc, int wp, int hw,
                                                int ooh, int oow, float* stats, bool bn_writer = false) {
@@ -128,7 +134,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, unsigned char
     int opx[NR];                                      // output pixel of row k, -1: nothing to store
     uint4 ad[NR];
     uint4 xd[NR];                                     // BatchNorm-backward gate (lh_igemm_gated): the BN input at the output position
-    uint4 yv[NR];                                     // fused BatchNorm (lh_igemm_bn_relu): the stored values, kept for the second store
+    uint4 yv[BNF ? NR : 1];                           // fused BatchNorm (lh_igemm_bn_relu, BNF kernels): the stored values, kept for the second store
     unsigned mbits[NR];
     // gate constants of this thread's EPC channels (every thread loads, index clamped)
     float gmean[EPC], ginv[EPC], gsc[EPC], gsh[EPC];
@@ -212,7 +218,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, unsigned char
             for (int e = 0; e < EPC; ++e) { s1[e] += sv[e]; s2[e] += sv[e] * sv[e]; }
         }
         if (!(LH_ABL & 16) || u.x == 0x12345678u) *reinterpret_cast<uint4*>(p.out + eoff * ES) = u;
-        yv[k] = u;
+        if constexpr (BNF) yv[k] = u;
     }
 
     if (stats) {
@@ -232,12 +238,12 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, unsigned char
             const int gc = cblk * BM + col;
             if (gc < p.cout) {
                 float* dst = stats + ((long)pblk * 2 + which) * p.cout + gc;
-                if (p.bn_out) __hip_atomic_store(dst, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // sc1: read by other CUs of THIS launch
+                if constexpr (BNF) __hip_atomic_store(dst, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // sc1: read by other CUs of THIS launch
                 else *dst = a;
             }
         }
     }
-    if constexpr (ES == 2) {
+    if constexpr (BNF) {
         if (p.bn_out) {
             // ---- BatchNorm (batch statistics) + ReLU inside the launch.  Hand-off of the statistics rows between the workgroups
             //      (MI355X guide, cross-workgroup hand-offs): every byte stored sc1 by whole-line wave stores, each storing wave

@@ -31,7 +31,8 @@
 #define LH_DENSE_DEPTH 20
 #define LH_RING_CFGS_DENSE(X) \
     X(128,128,2,4,2,128) X(128,128,2,4,3,128) X(128,64,4,2,3,128) X(64,128,2,4,3,128) \
-    X(64,64,2,4,2,128) X(64,64,2,4,4,128)
+    X(64,64,2,4,2,128) X(64,64,2,4,4,128) \
+    X(128,256,2,4,2,128) X(128,256,2,4,3,128) X(256,128,4,2,2,128) X(256,128,4,2,3,128)
 #define LH_RING_CFGS_F32(X) \
     X(128,64,4,1,2,64) X(128,64,4,1,4,64) X(64,128,1,4,2,64) X(64,128,1,4,4,64) \
     X(64,64,2,2,2,64) X(64,64,2,2,4,64)

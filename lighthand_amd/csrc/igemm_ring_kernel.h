@@ -102,7 +102,7 @@ template <int L, int MAXS> __device__ __forceinline__ void wait_stages(int stage
 
 // The kernel proper, for workgroup `bid` of `nblk` of ONE problem: the plain kernel passes its block index, the
 // multi-problem kernel (multi.h) the index inside the problem the workgroup belongs to.
-template <typename T, int BM, int BP, int WC, int WP, int D, int KB>
+template <typename T, int BM, int BP, int WC, int WP, int D, int KB, bool BNF = false>
 __device__ __forceinline__ void igemm_ring_body(const IgemmArgs& p, unsigned char* smem, const int bid, const int nblk) {
 #if defined(__HIP_DEVICE_COMPILE__)      // the buffer builtins exist in the device pass only
     constexpr int ES = sizeof(T);
@@ -381,7 +381,7 @@ __device__ __forceinline__ void igemm_ring_body(const IgemmArgs& p, unsigned cha
             return;
         }
     }
-    igemm_epilogue<T, BM, BP, WC, WP>(p, smem, acc, pblk, cblk, tid, lane, wc, wp, hw, ooh, oow, stats, pblk == 0 && stats == p.stats);
+    igemm_epilogue<T, BM, BP, WC, WP, BNF>(p, smem, acc, pblk, cblk, tid, lane, wc, wp, hw, ooh, oow, stats, pblk == 0 && stats == p.stats);
 #endif
 }
 
@@ -393,6 +393,13 @@ template <typename T, int BM, int BP, int WC, int WP, int D, int KB>
 __global__ __launch_bounds__(64 * WC * WP, (ring_waves_per_simd<BM, BP, WC, WP>())) void igemm_ring_kernel(const IgemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     igemm_ring_body<T, BM, BP, WC, WP, D, KB>(p, smem, blockIdx.x, gridDim.x);
+}
+// the same kernel with the in-launch BatchNorm + ReLU in its epilogue (lh_igemm_bn_relu): an instantiation of its own, so that the
+// plain kernel's epilogue keeps its registers (the 256 x 256 tile would hold 16 more rows of 16 bytes per thread and spill)
+template <typename T, int BM, int BP, int WC, int WP, int D, int KB>
+__global__ __launch_bounds__(64 * WC * WP, (ring_waves_per_simd<BM, BP, WC, WP>())) void igemm_ring_bn_kernel(const IgemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    igemm_ring_body<T, BM, BP, WC, WP, D, KB, true>(p, smem, blockIdx.x, gridDim.x);
 }
 
 // Up to LH_MULTI_MAX independent convolutions that share the kernel configuration as ONE grid (lh_igemm_multi).
@@ -409,8 +416,7 @@ static int launch_ring(const IgemmArgs& a, hipStream_t s) {
     constexpr int ES = sizeof(T);
     constexpr int ring = D * (BM + BP) * KB;
     constexpr int epi = lh_epi_lds_bytes<T, BM, BP, (BM == 256 && BP == 256 && ES == 2)>();   // tile + the fused head's weights + per-channel constants
-    constexpr int lds0 = ring > epi ? ring : epi;
-    constexpr int lds = lds0 > lh_bnfold_lds_bytes<BM>() ? lds0 : lh_bnfold_lds_bytes<BM>();
+    constexpr int lds = ring > epi ? ring : epi;
     static_assert(lds <= 160 * 1024, "LDS budget");
     if (lds > 64 * 1024) {
         // per-device function attribute; cheap enough to set on every launch (no process-wide "done" flag:
@@ -425,16 +431,31 @@ static int launch_ring(const IgemmArgs& a, hipStream_t s) {
     dim3 grid(ceil_div(a.M, BP) * ceil_div(a.cout, BM) * (a.nphase > 1 ? a.nphase : 1));
     if (a.bn_out || a.bn_query) {
         // the launch holds a grid barrier: every workgroup must be resident at once
-        int per_cu = 0, dev = 0, ncu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&igemm_ring_kernel<T, BM, BP, WC, WP, D, KB>), 64 * WC * WP, lds) != hipSuccess ||
-            hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
-            lh_set_error("igemm_ring: occupancy query failed");
-            return LH_ERR_HIP;
-        }
-        lh_ring_resident_set((int)grid.x, per_cu, ncu);
-        if (a.bn_query) return LH_OK;
-        if (ES != 2 || (long)grid.x > (long)per_cu * ncu) {
-            lh_set_error("lh_igemm_bn_relu: %u workgroups, the device holds %d x %d at once (16-bit types only)", grid.x, per_cu, ncu);
+        if constexpr (lh_bn_variant<T, BM, BP, WC, WP>()) {
+            constexpr int ldsb = lds > lh_bnfold_lds_bytes<BM>() ? lds : lh_bnfold_lds_bytes<BM>();
+            static_assert(ldsb <= 160 * 1024, "LDS budget");
+            const void* fn = reinterpret_cast<const void*>(&igemm_ring_bn_kernel<T, BM, BP, WC, WP, D, KB>);
+            if (ldsb > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb) != hipSuccess) {
+                lh_set_error("igemm_ring: cannot raise dynamic LDS to %d bytes", ldsb);
+                return LH_ERR_HIP;
+            }
+            int per_cu = 0, dev = 0, ncu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * WC * WP, ldsb) != hipSuccess ||
+                hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+                lh_set_error("igemm_ring: occupancy query failed");
+                return LH_ERR_HIP;
+            }
+            lh_ring_resident_set((int)grid.x, per_cu, ncu);
+            if (a.bn_query) return LH_OK;
+            if ((long)grid.x > (long)per_cu * ncu) {
+                lh_set_error("lh_igemm_bn_relu: %u workgroups, the device holds %d x %d at once", grid.x, per_cu, ncu);
+                return LH_ERR_UNSUPPORTED;
+            }
+            hipLaunchKernelGGL((igemm_ring_bn_kernel<T, BM, BP, WC, WP, D, KB>), grid, dim3(64 * WC * WP), ldsb, s, a);
+            LH_LAUNCH_CHECK("igemm_ring (BatchNorm + ReLU) launch");
+            return LH_OK;
+        } else {
+            lh_set_error("lh_igemm_bn_relu: tile %d x %d with %d waves has no BatchNorm form (more than four tile rows per thread)", BM, BP, WC * WP);
             return LH_ERR_UNSUPPORTED;
         }
     }

@@ -748,9 +748,9 @@ class Plan:
                 return f"igemm_pw_kernel<{t}, {bm}, {kb}, {bp // 16}, {'true' if stats else 'false'}>"
             if depth == 100:
                 return f"conv3x3_direct_kernel<{t}, {kb}, {'true' if stats else 'false'}>"
-            wc, wp = {(256, 256): (2, 4), (128, 256): (2, 2), (128, 128): (2, 2), (128, 64): (4, 1), (64, 128): (1, 4), (64, 64): (2, 2)}[(bm, bp)]
+            wc, wp = {(256, 256): (2, 4), (128, 256): (2, 2), (256, 128): (4, 2), (128, 128): (2, 2), (128, 64): (4, 1), (64, 128): (1, 4), (64, 64): (2, 2)}[(bm, bp)]
             if 20 <= depth < 30:                # the dense-wave forms (eight waves on the 4-wave tiles, igemm_ring_cfgs.h)
-                wc, wp = {(128, 128): (2, 4), (128, 64): (4, 2), (64, 128): (2, 4), (64, 64): (2, 4)}[(bm, bp)]
+                wc, wp = {(128, 128): (2, 4), (128, 64): (4, 2), (64, 128): (2, 4), (64, 64): (2, 4), (128, 256): (2, 4), (256, 128): (4, 2)}[(bm, bp)]
                 depth -= 20
             elif 10 <= depth < 20:              # the wide-wave form of the 256 x 256 tile (four waves)
                 wc, wp, depth = 2, 2, depth - 10
