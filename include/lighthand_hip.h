@@ -284,6 +284,20 @@ typedef struct {
     long long* num_batches_tracked; float momentum, eps; float* scale; float* shift; float* save_mean; float* save_invstd;
 } lh_bn_finalize_call;
 int lh_bn_finalize_multi(const lh_bn_finalize_call* calls, int n, void* stream);
+/* A 1x1 convolution whose input is relu(BN(in)) of the layer before it (pose_resnet.py:89-94: bn2 -> relu -> conv3), with the BatchNorm +
+ * ReLU applied to the operand ON ITS WAY INTO THE MFMA instead of by an elementwise launch: `in` is the RAW output of the previous
+ * convolution, scale / shift [k_run] that BatchNorm's coefficients (lh_bn_finalize must have run), and the activated rows -- what
+ * lh_fuse_fwd would have stored, bit for bit -- are written to act_out (the layout of `in`) on the way, because this convolution's weight
+ * gradient reads them.  One launch and one read of the raw tensor less per BatchNorm.  Persistent pointwise kernel only (d->cfg must name
+ * a pointwise configuration: ring depth 1, K <= 256), stride 1, with statistics (training-mode forward); LH_ERR_UNSUPPORTED otherwise. */
+typedef struct {
+    const float* scale;
+    const float* shift;
+    void* act_out;
+} lh_bn_in;
+int lh_igemm_bn_in(const lh_igemm_desc* d, const void* in, const void* wpack, void* out, const lh_bn_in* bin, const float* bias,
+                   float* stats, int dtype, void* stream);
+
 /* Convolution + training-mode BatchNorm + ReLU as ONE launch (pose_resnet.py:86-94: conv -> bn -> relu inside a block): the launch
  * writes the raw output `out` and its statistics rows (fin->stats, as lh_igemm does), its workgroups meet at a grid barrier, each folds
  * the rows of its channel tile, derives scale / shift EXACTLY as lh_bn_finalize does (same arithmetic, same order: bit-identical), and

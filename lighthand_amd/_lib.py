@@ -45,6 +45,10 @@ class FuseBwdDesc(C.Structure):
                 ("l2_touch", C.c_void_p), ("l2_touch_bytes", C.c_size_t)]
 
 
+class BnIn(C.Structure):               # lh_igemm_bn_in
+    _fields_ = [("scale", C.c_void_p), ("shift", C.c_void_p), ("act_out", C.c_void_p)]
+
+
 class BnReluFuse(C.Structure):         # lh_igemm_bn_relu
     _fields_ = [("fin", C.POINTER(BnFinalizeCall)), ("out", C.c_void_p), ("sync", C.c_void_p)]
 
@@ -126,6 +130,7 @@ SIGNATURES = {
     "lh_wgrad_candidates": (_I, [C.POINTER(IgemmDesc), _I, _I, _I, C.POINTER(_I), _I]),
     "lh_igemm_stats_rows": (_I, [C.POINTER(IgemmDesc), _I]),
     "lh_igemm_gated": (_I, [C.POINTER(IgemmDesc), _P, _P, _P, _P, _P, C.POINTER(BnBwdGate), _I, _P]),
+    "lh_igemm_bn_in": (_I, [C.POINTER(IgemmDesc), _P, _P, _P, C.POINTER(BnIn), _P, _P, _I, _P]),
     "lh_igemm_bn_relu": (_I, [C.POINTER(IgemmDesc), _P, _P, _P, C.POINTER(BnReluFuse), _I, _P]),
     "lh_igemm_phases_bn_relu": (_I, [C.POINTER(C.POINTER(IgemmDesc)), _I, _P, C.POINTER(C.c_void_p), _P, C.POINTER(BnReluFuse), _I, _P]),
     "lh_igemm_bn_relu_resident": (_I, [C.POINTER(C.POINTER(IgemmDesc)), _I, _I, C.POINTER(C.c_int)]),

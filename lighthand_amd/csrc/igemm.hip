@@ -347,7 +347,7 @@ static int igemm_impl(const lh_igemm_desc* d, const void* in, const void* wpack,
                       const void* addend, const void* addend_mask, const float* bias, const float* scale, const float* shift, float* stats,
                       int dtype, void* stream, const PhaseSet* phases = nullptr, const lh_head* head = nullptr,
                       IgemmArgs* prep_args = nullptr, RingCfg* prep_cfg = nullptr, const lh_bn_bwd_gate* gate = nullptr,
-                      const lh_bn_relu_fuse* bnf = nullptr, bool bn_query = false) {
+                      const lh_bn_relu_fuse* bnf = nullptr, bool bn_query = false, const lh_bn_in* bin = nullptr) {
     LH_REQUIRE(d && in && wpack && (out || head), "lh_igemm: null pointer");
     const int es = lh_dtype_size(dtype);
     LH_REQUIRE(es > 0, "lh_igemm: bad dtype %d", dtype);
@@ -369,6 +369,12 @@ static int igemm_impl(const lh_igemm_desc* d, const void* in, const void* wpack,
     LH_REQUIRE((scale == nullptr) == (shift == nullptr), "lh_igemm: scale and shift must come together");
     a.head_w = nullptr; a.head_bias = nullptr; a.head_out = nullptr; a.head_j = 0; a.head_wstride = 0;
     a.gx = nullptr; a.gmean = a.ginv = a.gscale = a.gshift = nullptr;
+    a.in_scale = a.in_shift = nullptr; a.in_out = nullptr;
+    if (bin) {
+        LH_REQUIRE(bin->scale && bin->shift && bin->act_out && bin->act_out != in && stats && !addend && !phases && !head && !gate && !bnf,
+                   "lh_igemm_bn_in: scale, shift, a destination for the activated input and a statistics slab are required (plain forward launch)");
+        a.in_scale = bin->scale; a.in_shift = bin->shift; a.in_out = (unsigned char*)bin->act_out;
+    }
     a.bn_out = nullptr; a.bn_sync = nullptr; a.bn_query = bn_query ? 1 : 0;
     memset((void*)&a.bn, 0, sizeof a.bn);
     if (bnf) {
@@ -447,6 +453,10 @@ static int igemm_impl(const lh_igemm_desc* d, const void* in, const void* wpack,
         *prep_args = a;
         *prep_cfg = rc_;
         return LH_OK;
+    }
+    if (bin && !(ring && rc_.depth == 1)) {
+        lh_set_error("lh_igemm_bn_in: the launch does not run on the persistent pointwise kernel (ring depth %d; set d->cfg to a pointwise configuration)", ring ? rc_.depth : 0);
+        return LH_ERR_UNSUPPORTED;
     }
     if ((bnf || bn_query) && !(ring && rc_.depth >= 2 && rc_.depth != 100 && es == 2)) {
         lh_set_error("lh_igemm_bn_relu: the launch does not run on a tiled LDS-DMA configuration of a 16-bit type (ring depth %d)", ring ? rc_.depth : 0);
@@ -615,6 +625,13 @@ extern "C" int lh_igemm_phases_head(const lh_igemm_desc* const* descs, int nphas
     LH_REQUIRE(descs[lead]->ntaps > 0 && wpacks[lead], "lh_igemm_phases_head: no phase has taps");
     PhaseSet ps = {descs, wpacks, nphase};
     return igemm_impl(descs[lead], in, wpacks[lead], nullptr, nullptr, nullptr, nullptr, scale, shift, nullptr, dtype, stream, &ps, head);
+}
+
+// 1x1 convolution whose input is relu(BN(in)) of the previous layer, applied on the operand's way into the MFMA (include/lighthand_hip.h).
+extern "C" int lh_igemm_bn_in(const lh_igemm_desc* d, const void* in, const void* wpack, void* out, const lh_bn_in* bin, const float* bias,
+                              float* stats, int dtype, void* stream) {
+    LH_REQUIRE(bin, "lh_igemm_bn_in: null descriptor");
+    return igemm_impl(d, in, wpack, out, nullptr, nullptr, bias, nullptr, nullptr, stats, dtype, stream, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, false, bin);
 }
 
 // Convolution + training-mode BatchNorm + ReLU as ONE launch (include/lighthand_hip.h; igemm_epilogue.h holds the in-launch finalize).

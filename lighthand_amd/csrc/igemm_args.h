@@ -34,6 +34,12 @@ struct IgemmArgs {
     // word that only ever grows), every workgroup folds the rows of ITS channel tile (bn.slab = the launch's statistics slab), derives
     // scale / shift exactly as lh_bn_finalize does, and stores relu(raw * scale + shift) from the values it still holds to bn_out.  The
     // first workgroup of each channel tile also writes what the finalize writes (scale, shift, saved mean / invstd, running statistics).
+    // BatchNorm + ReLU applied to the INPUT operand on its way into the MFMA (lh_igemm_bn_in; persistent pointwise kernel only: its operand
+    // rows pass through registers): in = the raw output of the previous convolution, in_scale / in_shift [k_run] = that BatchNorm's
+    // scale / shift, in_out = where relu(in * scale + shift) is stored as well (layout of `in`): the weight gradient reads it
+    const float* in_scale;           // NULL: off
+    const float* in_shift;
+    unsigned char* in_out;
     unsigned char* bn_out;           // NULL: off
     unsigned* bn_sync;               // [0] arrivals (never reset), [1] set to 1 when a launch gave up waiting (grid not resident)
     FinalizeArgs bn;
@@ -64,7 +70,9 @@ struct RingCfg {
 
 // workgroups per channel block of a pointwise launch: every CU holds `occ` workgroups for the whole launch (occ = what the
 // occupancy query reports for the instantiation, 1..4: lh_pw_occupancy)
-static inline int lh_pw_lds_bytes(int bm, int kc, int pt) { return bm * kc * 2 + 4 * pt * 16 * (64 * 2 + 8) + 2 * bm * 4; }
+static inline int lh_pw_lds_bytes(int bm, int kc, int pt, bool bnin = false) {      // panel, staging, output constants (+ BNIN: the input BatchNorm's table)
+    return bm * kc * 2 + 4 * pt * 16 * (64 * 2 + 8) + 2 * bm * 4 + (bnin ? 2 * kc * 4 : 0);
+}
 
 static inline void lh_pw_grid(int bm, int kc, int pt, long M, int cout, int occ, int* G, int* CB) {
     const int cb = (cout + bm - 1) / bm;

@@ -343,6 +343,9 @@ class Plan:
     # (lh_igemm_bn_relu: stages 3-4 and the first deconvolutions of the ResNets at batch 64).  "0" keeps the three launches; "2" also
     # takes grids of up to two workgroups per CU.
     fuse_bn_train = os.environ.get("LH_FUSE_BN_TRAIN", "0")
+    # Training plans: the 1x1 convolution behind a BatchNorm + ReLU applies them to its operand rows itself (lh_igemm_bn_in) where it runs
+    # on the persistent pointwise kernel -- conv3 of the bottlenecks of stages 1-3.  "0": the elementwise launch stays.
+    bn_in = os.environ.get("LH_BN_IN", "0")
     fuse_bottleneck = os.environ.get("LH_FUSE_BOTTLENECK", "1") != "0"    # False keeps the stage-1 bottlenecks of inference plans as three launches (A/B against _fuse_bottleneck)
     _tune_file_loaded = False
 
@@ -1574,7 +1577,8 @@ class Plan:
             self._stats_for(y, [d])
             stats_ptr = y.stats
         flops = 2.0 * y.pixels * cout * cin * k * k
-        self._igemm(self.fwd, d, xbuf, pack, ybuf, None, bias, stats_ptr, nd["w"] + " fwd", produces=y)
+        if not self._conv_takes_input_bn(nd, d, x, xbuf, pack, ybuf, bias, stats_ptr):
+            self._igemm(self.fwd, d, xbuf, pack, ybuf, None, bias, stats_ptr, nd["w"] + " fwd", produces=y)
         self.profile_meta.append(("fwd", self.fwd[-1], self._kname(d, stats=stats_ptr is not None), flops, (x.pixels * x.c + y.pixels * y.c) * self.es))
         if not self.with_bwd:
             return
@@ -1910,6 +1914,34 @@ class Plan:
             # what SURVEY 8(d)'s traffic model itself charges to the BatchNorm backward: ONE re-read of y per BatchNorm term
             self.bn_bwd_8d_bytes = getattr(self, "bn_bwd_8d_bytes", 0.0) + float(n_bn) * out.pixels * c * self.es
         blk.append(emit)
+
+    def _conv_takes_input_bn(self, nd, d, x, xbuf, pack, ybuf, bias, stats_ptr):
+        """Training plans: x = relu(BN(raw)) feeds ONLY this 1x1 convolution (bn2 -> relu -> conv3 of a bottleneck, pose_resnet.py:89-94)
+        and the convolution runs on the persistent pointwise kernel, whose operand rows pass through registers: the kernel applies the
+        BatchNorm + ReLU there (lh_igemm_bn_in) and stores the activated rows on the way (this convolution's weight gradient reads them);
+        the node's elementwise launch becomes its finalize alone.  Bit-identical: lh_fuse_fwd's arithmetic, rounded before the MFMA."""
+        info = self._bnrelu_info.get(id(x))
+        if (Plan.bn_in == "0" or info is None or not self.training or self.es != 2 or self._forced is not None or stats_ptr is None
+                or (nd["k"], nd["s"], nd["p"]) != (1, 1, 0) or len(self._uses.get(id(x), [])) != 1 or x.c != x.c_valid or info["call"] not in self.fwd):
+            return False
+        cfg = (C.c_int * 5)()
+        if self.lib.lh_igemm_config(C.byref(d), self.dt, cfg) != 0 or cfg[2] != 1 or cfg[3] > 256:
+            return False
+        raw, st, fin = info["raw"], info["st"], info["fin"]
+        i = self.fwd.index(info["call"])
+        self.fwd[i] = _Call(self.lib.lh_bn_finalize_multi, (fin, 1), "bn finalize (its BN + ReLU rides in the next convolution)")
+        self.profile_meta = [m for m in self.profile_meta if m[1] is not info["call"]]
+        del self._bnrelu_info[id(x)]
+        bi = _lib.BnIn(st["scale"].data_ptr(), st["shift"].data_ptr(), xbuf.data_ptr())
+        self.keep += [d, bi, fin]
+        c = _Call(self.lib.lh_igemm_bn_in, (C.byref(d), raw.buf.data_ptr(), _ptr(pack), _ptr(ybuf), C.byref(bi), _ptr(bias), _ptr(stats_ptr), self.dt),
+                  nd["w"] + " fwd (BN + ReLU on the operand)")
+        c.keep, c.ig = d, dict(src=1, dst=3)
+        self.fwd.append(c)
+        self._producers.setdefault(id(nd["y"]), []).append(c)
+        self._ready[id(x)] = len(self.fwd)               # the activated input is complete only behind this launch
+        self._n_bn_in = getattr(self, "_n_bn_in", 0) + 1
+        return True
 
     def _fuse_bn_into_conv(self, raw, fin_ptr, obuf):
         """Training plans: the convolution that produces `raw` takes the node relu(BN(raw)) over (lh_igemm_bn_relu / lh_igemm_phases_bn_relu:

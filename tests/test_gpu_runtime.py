@@ -1090,3 +1090,31 @@ def test_train_step_with_conv_bn_relu_launches_is_bit_identical(depth, precision
     assert torch.equal(wa, wb)
     for k in bb:
         assert torch.equal(ba[k], bb[k]), k
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_train_step_with_bn_on_the_operand_is_bit_identical(precision):
+    """LH_BN_IN=1 (Plan.bn_in): conv3 of a bottleneck applies bn2 + ReLU to its operand rows itself (lh_igemm_bn_in, persistent pointwise
+    kernel) and stores the activated rows on the way; the node's elementwise launch shrinks to its finalize.  Three captured training
+    steps of R50 with and without: the same losses, weights and running statistics BIT FOR BIT."""
+    from lighthand_amd.engine import Plan
+    from lighthand_amd.runtime import TrainStep
+    x, j = _batch(8, 128, 5)
+    res = []
+    try:
+        for mode in ("1", "0"):
+            Plan.bn_in = mode
+            m = _model(50, precision)
+            step = TrainStep(m, 8, 128, 128, lr=1e-3, use_graph=True)
+            losses = [float(step(x, j)) for _ in range(3)]
+            nb = getattr(step.plan, "_n_bn_in", 0)
+            assert (nb >= 4) if mode == "1" else nb == 0, (nb, [c.what for c in step.plan.fwd if hasattr(c, "fn")])
+            res.append((losses, m.arena().flat.clone(), {k: v.clone() for k, v in m.named_buffers()}))
+            step.close()
+    finally:
+        Plan.bn_in = "0"
+    (la, wa, ba), (lb, wb, bb) = res
+    assert la == lb, (la, lb)
+    assert torch.equal(wa, wb)
+    for k in bb:
+        assert torch.equal(ba[k], bb[k]), k
