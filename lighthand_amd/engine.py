@@ -1972,12 +1972,9 @@ class Plan:
         if lib.lh_igemm_bn_relu_resident(descs, n, self.dt, res) != 1 or res[0] > res[2] * (2 if mode == "2" else 1):
             return False
         if not hasattr(self, "_bn_sync"):
-            self._bn_sync, self._bn_sync_used = self._alloc(64 * 32, dtype=torch.int32), 0      # one 128-byte line per call site
-            self._bn_sync.zero_()
-        assert self._bn_sync_used < 64, "more fused BatchNorm launches than sync words"
-        sync = self._bn_sync.data_ptr() + 128 * self._bn_sync_used
-        self._bn_sync_used += 1
-        f = _lib.BnReluFuse(fin_ptr, obuf.data_ptr(), sync)
+            self._bn_sync = []
+        self._bn_sync.append(self._alloc(32, dtype=torch.int32, zero=True))       # a 128-byte line per call site: [0] arrivals, [1] gave up
+        f = _lib.BnReluFuse(fin_ptr, obuf.data_ptr(), self._bn_sync[-1].data_ptr())
         self.keep += [f, descs]
         if n == 1:
             call.fn, call.args = lib.lh_igemm_bn_relu, (d, src, pack, dst, C.byref(f), dt)
@@ -1991,9 +1988,7 @@ class Plan:
 
     def bn_sync_gave_up(self):
         """True when a fused convolution + BatchNorm launch of this plan ever gave up at its grid barrier (its results are then wrong)."""
-        if not hasattr(self, "_bn_sync"):
-            return False
-        return bool(self._bn_sync.view(-1, 32)[:, 1].any().item())
+        return any(bool(t[1].item()) for t in getattr(self, "_bn_sync", []))
 
     def _next_writer_is_conv(self, a, nd):
         """True when, walking backward from fuse node `nd`, the next writer of a.grad is a stride-1-output convolution /
