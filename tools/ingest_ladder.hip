@@ -65,7 +65,10 @@ template <int L, int MAXS> __device__ __forceinline__ void wait_stages(int stage
 // SRC 0..3 = rungs R0..R3's address form; ADD bit 0 = fragment reads, bit 1 = MFMAs; SYNC 0 = s_barrier per stage, 1 = none
 // DW > 0 (buffer form, plain loop only): the WEIGHT halves of the stages live in a ring of their own, DW stages deep, filled DW - D
 // stages further ahead than the pixel halves -- the weights are what every workgroup first-touches in lockstep (sitting 6)
-template <int NWAVE, int D, int SRC, int ADD, int SYNC, int DW = 0>
+// KS = 2 (sitting 8): SPLIT-K emulation -- twice the workgroups, each walks HALF the stages of a tile (workgroup 2 t + h: tile t,
+// stages 18 h .. 18 h + 17), two of them per CU (D = 2: 64 KB of LDS each): does a CU with two independent half-loops finish a tile's
+// 36 stages sooner than one workgroup walking them in a row?  (No reduction of the two partial tiles is done: timing only.)
+template <int NWAVE, int D, int SRC, int ADD, int SYNC, int DW = 0, int KS = 1>
 __global__ __launch_bounds__(64 * NWAVE, 2) void ladder_kernel(const Args p) {
 #if defined(__HIP_DEVICE_COMPILE__)        // the buffer builtins do not exist in the host pass
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -77,7 +80,9 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void ladder_kernel(const Args p) {
     const int bid = blockIdx.x, nblk = gridDim.x;
     unsigned long long t0 = 0, t1 = 0, t2 = 0, c1 = 0, c2 = 0;
     if (tid == 0) t0 = wall_clock64();
-    const int w = xcd_remap(bid, nblk);
+    const int w0 = xcd_remap(bid, nblk);
+    const int khalf = KS > 1 ? w0 % KS : 0;
+    const int w = KS > 1 ? w0 / KS : w0;
     const int pblk = w / 2, cblk = w % 2;
     const int hw = p.h * p.wd, ntaps = 9, kspt = p.c * 2 / KB;
     const long kpad = p.c;
@@ -206,7 +211,11 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void ladder_kernel(const Args p) {
 #pragma unroll
         for (int j = 0; j < PT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int S = ntaps * kspt;
+    const int S = ntaps * kspt / KS;
+    if (KS > 1 && khalf > 0) {                                    // fast-forward the stage walk to this half's first stage
+        for (int s = 0; s < S * khalf; ++s) advance();
+        issued = 0; islot = 0;
+    }
     if (tid == 0) { t1 = wall_clock64(); c1 = clock64(); }
     if (DW > 0) {
 #pragma unroll
@@ -415,7 +424,7 @@ int main(int argc, char** argv) {
     float* sink; unsigned long long* stamps;
     CK(hipMalloc(&in_raw, in_bytes + 2 * guard)); CK(hipMalloc(&twin, in_bytes)); CK(hipMalloc(&wgt, w_bytes));
     CK(hipMalloc(&zero, 256)); CK(hipMalloc(&lin, (size_t)NWG * 65536)); CK(hipMalloc(&flush, 512u << 20));
-    CK(hipMalloc(&sink, NWG * 512 * 4)); CK(hipMalloc(&stamps, NWG * 5 * 8));
+    CK(hipMalloc(&sink, 2 * NWG * 512 * 4)); CK(hipMalloc(&stamps, 2 * NWG * 5 * 8));
     {   // random bit patterns of ordinary bf16 magnitude (zero operands clock higher)
         std::vector<unsigned short> hbuf((in_bytes + 2 * guard) / 2);
         unsigned s = 12345u;
@@ -427,7 +436,8 @@ int main(int argc, char** argv) {
         CK(hipMemset(zero, 0, 256));
     }
     Args a{in_raw + guard, wgt, zero, lin, sink, stamps, N, H, W, C, COUT};
-    std::vector<unsigned long long> hs(NWG * 5);
+    std::vector<unsigned long long> hs(2 * NWG * 5);
+    int nrun = NWG;                                               // workgroups of the launch being measured (split-K sitting: 2 NWG)
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
 
     printf("# rung / ring / waves / sync                    state     span us   loop us  prologue us  GB/s per CU (loop)   wall us (events)\n");
@@ -444,16 +454,16 @@ int main(int argc, char** argv) {
                 CK(hipEventRecord(e1, 0));
                 CK(hipEventSynchronize(e1));
                 float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
-                CK(hipMemcpy(hs.data(), stamps, NWG * 5 * 8, hipMemcpyDeviceToHost));
+                CK(hipMemcpy(hs.data(), stamps, (size_t)nrun * 5 * 8, hipMemcpyDeviceToHost));
                 if (r < 2) continue;
                 unsigned long long mn = ~0ull, mx = 0; double lp = 0, pr = 0, cy = 0;
-                for (int i = 0; i < NWG; ++i) {
+                for (int i = 0; i < nrun; ++i) {
                     mn = std::min(mn, hs[i * 5]); mx = std::max(mx, hs[i * 5 + 2]);
                     lp += (double)(hs[i * 5 + 2] - hs[i * 5 + 1]); pr += (double)(hs[i * 5 + 1] - hs[i * 5]);
                     cy += (double)(hs[i * 5 + 4] - hs[i * 5 + 3]);
                 }
                 ghz.push_back(cy / (lp * 10.0));            // shader cycles per ns over the loop (s_memtime / s_memrealtime at 100 MHz)
-                span.push_back((mx - mn) * 0.01); loop.push_back(lp / NWG * 0.01); pro.push_back(pr / NWG * 0.01); wall.push_back(ms * 1e3);
+                span.push_back((mx - mn) * 0.01); loop.push_back(lp / nrun * 0.01); pro.push_back(pr / nrun * 0.01); wall.push_back(ms * 1e3);
             }
             auto med = [](std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
             const double l = med(loop);
@@ -465,6 +475,11 @@ int main(int argc, char** argv) {
 #define RUN(NWAVE, D, SRC, ADD, SYNC, NAME) { \
         CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ladder_kernel<NWAVE, D, SRC, ADD, SYNC>), hipFuncAttributeMaxDynamicSharedMemorySize, D * STAGE)); \
         measure(NAME, [&]() { hipLaunchKernelGGL((ladder_kernel<NWAVE, D, SRC, ADD, SYNC>), dim3(NWG), dim3(64 * NWAVE), D * STAGE, 0, a); }); }
+#define RUNK(NWAVE, D, ADD, NAME) { \
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ladder_kernel<NWAVE, D, 4, ADD, 0, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, D * STAGE)); \
+        nrun = 2 * NWG; \
+        measure(NAME, [&]() { hipLaunchKernelGGL((ladder_kernel<NWAVE, D, 4, ADD, 0, 0, 2>), dim3(2 * NWG), dim3(64 * NWAVE), D * STAGE, 0, a); }); \
+        nrun = NWG; }
 #define RUNW(NWAVE, D, DW, ADD, NAME) { \
         CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ladder_kernel<NWAVE, D, 4, ADD, 0, DW>), hipFuncAttributeMaxDynamicSharedMemorySize, DW * BM * KB + D * BP * KB)); \
         measure(NAME, [&]() { hipLaunchKernelGGL((ladder_kernel<NWAVE, D, 4, ADD, 0, DW>), dim3(NWG), dim3(64 * NWAVE), DW * BM * KB + D * BP * KB, 0, a); }); }
@@ -491,6 +506,16 @@ int main(int argc, char** argv) {
     RUN(4, 3, 0, 3, 0, "R0 + reads + MFMAs            D3 4w barrier")
     } else {
     // later sittings: what the complete loop is made of, the buffer form, pipelined stage loops
+    if (argc > 2 && atoi(argv[2]) == 5) {                       // sitting 8: split-K emulation (span = the whole launch; 'loop' = ONE half)
+        RUN(8, 3, 4, 3, 0, "B5 buffer form + reads + MFMA D3 8w (256 WGs x 36 stages)")
+        RUN(8, 2, 4, 3, 0, "B5 buffer form + reads + MFMA D2 8w (256 WGs x 36 stages)")
+        RUNK(8, 2, 3, "K2 split-K 2: 512 WGs x 18 stages, D2 8w, two per CU")
+        RUNK(4, 2, 3, "K2 split-K 2: 512 WGs x 18 stages, D2 4w, two per CU")
+        RUNK(4, 3, 3, "K2 split-K 2: 512 WGs x 18 stages, D3 4w (one per CU: 96 KB)")
+        RUN(8, 3, 4, 0, 0, "B3 DMA only D3 8w (256 WGs x 36 stages)")
+        RUNK(8, 2, 0, "K2 DMA only: 512 WGs x 18 stages, D2 8w")
+        return 0;
+    }
     if (argc > 2 && atoi(argv[2]) == 4) {                       // sitting 7: a deeper ring for the weights only
         RUN(8, 3, 4, 0, 0, "B3 buffer form, DMA only      D3 8w")
         RUNW(8, 3, 5, 0, "B3 DMA only, weight ring 5 deep, pixels 3")
