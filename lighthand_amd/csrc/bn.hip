@@ -1698,6 +1698,100 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* x, T* out, un
     }
 }
 
+// The BN = true pass as a COLUMN STRIP kernel (round 5): a thread owns one 16-byte channel chunk of R vertically adjacent pooled
+// pixels, so the 2 R + 1 input rows its windows touch are loaded and run through relu(x * scale + shift) once per strip instead of once
+// per window (9 -> (6 R + 3) / R chunk transforms per pooled chunk), and the maxima are taken on INTEGER keys: after the ReLU every tap
+// is >= 0, so the 16-bit patterns of the rounded values order like the values; key = magnitude << 16 | (3 - row) << 3 | (3 - col) << 1 |
+// sign bit picks the largest value and, among equals (-0 = +0 as for floats), the first position in scan order -- the old kernel's
+// `strictly greater replaces` rule -- and carries the winner's sign bit back out.  Same pooled values, same window positions, bit for bit.
+template <typename T, int R>
+__global__ __launch_bounds__(256) void bn_relu_pool_strip_kernel(const T* x, T* out, unsigned char* idx, int n, int h, int w, int c, int ho, int wo,
+                                                                const float* scale, const float* shift) {
+    static_assert(sizeof(T) == 2, "16-bit element types");
+    constexpr int EPC = 8, NRW = 2 * R + 1;
+    const int nchunk = c / EPC, strips = (ho + R - 1) / R;
+    const unsigned total = (unsigned)n * strips * wo * nchunk;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const unsigned pix = i / (unsigned)nchunk;
+        const int ch = (int)(i - pix * (unsigned)nchunk);
+        const unsigned t2 = pix / (unsigned)wo;
+        const int ow = (int)(pix - t2 * (unsigned)wo);
+        const int b = (int)(t2 / (unsigned)strips), oh0 = (int)(t2 - (unsigned)b * (unsigned)strips) * R;
+        // every tap is requested before the first is used (taps outside the image re-read a tap that is inside; their keys are 0)
+        uint4 raw[NRW][3];
+        bool rok[NRW], cok[3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) cok[s] = (unsigned)(ow * 2 - 1 + s) < (unsigned)w;
+#pragma unroll
+        for (int r = 0; r < NRW; ++r) {
+            const int ih = oh0 * 2 - 1 + r;
+            rok[r] = (unsigned)ih < (unsigned)h;
+            const int jh = rok[r] ? ih : oh0 * 2;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int jw = cok[s] ? ow * 2 - 1 + s : ow * 2;
+                raw[r][s] = *reinterpret_cast<const uint4*>(x + (((long)b * h + jh) * w + jw) * c + ch * EPC);
+            }
+        }
+        float sc[EPC], sh[EPC];
+        load_vec<EPC>(scale + ch * EPC, sc);
+        load_vec<EPC>(shift + ch * EPC, sh);
+        unsigned hkey[NRW][EPC];                       // per input row: the best of its three columns (0: no tap of the row is inside)
+#pragma unroll
+        for (int r = 0; r < NRW; ++r) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) hkey[r][e] = 0u;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                float v[EPC];
+                unpack16<T>(raw[r][s], v);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) v[e] = fmaxf(v[e] * sc[e] + sh[e], 0.f);
+                const uint4 u = pack16<T>(v);         // the rounding of the stored activation
+                const unsigned wd[4] = {u.x, u.y, u.z, u.w};
+                const bool ok = rok[r] && cok[s];
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const unsigned bits = (e & 1) ? wd[e >> 1] >> 16 : wd[e >> 1] & 0xffffu;
+                    const unsigned key = ((bits & 0x7fffu) << 16) | ((unsigned)(3 - s) << 1) | (bits >> 15);
+                    const unsigned k2 = ok ? key : 0u;
+                    hkey[r][e] = k2 > hkey[r][e] ? k2 : hkey[r][e];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const int oh = oh0 + j;
+            if (oh >= ho) break;
+            unsigned best[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) best[e] = 0u;
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const unsigned hk = hkey[2 * j + r][e];
+                    const unsigned k = hk ? (hk | ((unsigned)(3 - r) << 3)) : 0u;
+                    best[e] = k > best[e] ? k : best[e];
+                }
+            unsigned ov[4], pk[2];
+#pragma unroll
+            for (int e = 0; e < EPC; e += 2) {
+                const unsigned lo = (best[e] >> 16) | ((best[e] & 1u) << 15), hi = (best[e + 1] >> 16) | ((best[e + 1] & 1u) << 15);
+                ov[e >> 1] = lo | (hi << 16);
+            }
+            unsigned tpos[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) tpos[e] = (3u - ((best[e] >> 3) & 3u)) * 3u + (3u - ((best[e] >> 1) & 3u));
+            pk[0] = tpos[0] | (tpos[1] << 8) | (tpos[2] << 16) | (tpos[3] << 24);
+            pk[1] = tpos[4] | (tpos[5] << 8) | (tpos[6] << 16) | (tpos[7] << 24);
+            const long o = ((((long)b * ho + oh) * wo + ow) * nchunk + ch) * EPC;
+            *reinterpret_cast<uint4*>(out + o) = uint4{ov[0], ov[1], ov[2], ov[3]};
+            if (idx) *reinterpret_cast<uint2*>(idx + o) = uint2{pk[0], pk[1]};
+        }
+    }
+}
+
 // GATE = true (lh_maxpool3x3s2_bwd_gated): dx is the gradient of a = relu(BN(gx)); the pass stores the ReLU-gated gradient
 // and writes the BatchNorm-backward partial sums { sum g, sum g * xhat } of its elements, one row per workgroup (what
 // lh_igemm_gated does for a data gradient): lh_fuse_bwd then runs without its reduce pass.  Needs a power-of-two number of
@@ -1788,6 +1882,98 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* dout, const u
     }
 }
 
+// The gated pass as a 2 x 2 BLOCK kernel (round 5): a thread owns one channel chunk of the input pixels (2a, 2b), (2a, 2b+1), (2a+1, 2b),
+// (2a+1, 2b+1).  Only the four windows (a, b), (a, b+1), (a+1, b), (a+1, b+1) reach them, at fixed positions: centre of (a, b) for the
+// even-even pixel, two windows for the mixed ones, all four for the odd-odd one -- four (gradient, position) loads and nine compare-adds
+// per element and block instead of sixteen of each behind per-lane `continue`s, added in the old kernel's window order (same dx bits).
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_block_kernel(const T* dout, const unsigned char* idx, T* dx, int n, int h, int w, int c, int ho, int wo,
+                                                               const PoolGate gt) {
+    static_assert(sizeof(T) == 2, "16-bit element types");
+    constexpr int EPC = 8;
+    const int nchunk = c / EPC, hb = (h + 1) >> 1, wb = (w + 1) >> 1;
+    const unsigned total = (unsigned)n * hb * wb * nchunk;
+    float gmean[EPC], ginv[EPC], gsc[EPC], gsh[EPC], s1[EPC], s2[EPC];
+    {
+        const int chunk = threadIdx.x & (nchunk - 1);
+        load_vec<EPC>(gt.mean + chunk * EPC, gmean); load_vec<EPC>(gt.invstd + chunk * EPC, ginv);
+        load_vec<EPC>(gt.scale + chunk * EPC, gsc); load_vec<EPC>(gt.shift + chunk * EPC, gsh);
+        fill_vec<EPC>(s1, 0.f); fill_vec<EPC>(s2, 0.f);
+    }
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const unsigned blk = i / (unsigned)nchunk;
+        const int ch = (int)(i - blk * (unsigned)nchunk);
+        const unsigned t2 = blk / (unsigned)wb;
+        const int bb = (int)(blk - t2 * (unsigned)wb);
+        const int b = (int)(t2 / (unsigned)hb), a = (int)(t2 - (unsigned)b * (unsigned)hb);
+        // windows W[k] = (a + (k >> 1), bb + (k & 1)); the ones outside the pooled image re-read window 0 and are never used
+        const bool wok[4] = {true, bb + 1 < wo, a + 1 < ho, a + 1 < ho && bb + 1 < wo};      // (a < ho and bb < wo always: h, w >= 1)
+        uint4 dv[4];
+        uint2 pk[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int oh = wok[k] ? a + (k >> 1) : a, ow = wok[k] ? bb + (k & 1) : bb;
+            const long o = (((long)b * ho + oh) * wo + ow) * c + ch * EPC;
+            dv[k] = *reinterpret_cast<const uint4*>(dout + o);
+            pk[k] = *reinterpret_cast<const uint2*>(idx + o);
+        }
+        const int ih0 = 2 * a, iw0 = 2 * bb;
+        const bool pok[4] = {true, iw0 + 1 < w, ih0 + 1 < h, ih0 + 1 < h && iw0 + 1 < w};     // pixel p = (ih0 + (p >> 1), iw0 + (p & 1))
+        uint4 xr[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const long o = pok[p] ? (((long)b * h + ih0 + (p >> 1)) * w + iw0 + (p & 1)) * c + ch * EPC : (((long)b * h + ih0) * w + iw0) * c + ch * EPC;
+            xr[p] = *reinterpret_cast<const uint4*>(gt.x + o * 2);
+        }
+        float d[4][EPC];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) unpack16<T>(dv[k], d[k]);
+        // pixel p takes window k's gradient where that window's stored position is code(p, k): position (r, s) = (ih + 1 - 2 oh, iw + 1 - 2 ow)
+        //   p0 (even, even): k0 at (1,1)=4              p1 (even, odd): k0 at (1,2)=5, k1 at (1,0)=3
+        //   p2 (odd, even):  k0 at (2,1)=7, k2 at (0,1)=1   p3 (odd, odd): k0 (2,2)=8, k1 (2,0)=6, k2 (0,2)=2, k3 (0,0)=0
+        constexpr int code[4][4] = {{4, -1, -1, -1}, {5, 3, -1, -1}, {7, -1, 1, -1}, {8, 6, 2, 0}};
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            if (!pok[p]) continue;
+            float g[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) g[e] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (code[p][k] < 0) continue;
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const unsigned pos = (((e < 4 ? pk[k].x : pk[k].y) >> (8 * (e & 3))) & 0xffu);
+                    if (wok[k] && pos == (unsigned)code[p][k]) g[e] += d[k][e];
+                }
+            }
+            float xv[EPC];
+            unpack16<T>(xr[p], xv);
+            unpack16<T>(pack16<T>(g), g);            // the gradient as the ungated pass stores it
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                g[e] = (xv[e] * gsc[e] + gsh[e]) > 0.f ? g[e] : 0.f;
+                s1[e] += g[e];
+                s2[e] += g[e] * (xv[e] - gmean[e]) * ginv[e];
+            }
+            const long o = (((long)b * h + ih0 + (p >> 1)) * w + iw0 + (p & 1)) * c + ch * EPC;
+            *reinterpret_cast<uint4*>(dx + o) = pack16<T>(g);
+        }
+    }
+    __shared__ float red[256 * EPC * 2];
+    const int lanes = 256 / nchunk, chunk = threadIdx.x & (nchunk - 1), rl = threadIdx.x / nchunk;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { red[((rl * nchunk + chunk) * EPC + e) * 2] = s1[e]; red[((rl * nchunk + chunk) * EPC + e) * 2 + 1] = s2[e]; }
+    __syncthreads();
+    float* row = gt.partial + (long)blockIdx.x * 2 * c;
+    for (int t = threadIdx.x; t < c; t += 256) {
+        float a2 = 0.f, b2 = 0.f;
+        for (int k = 0; k < lanes; ++k) { a2 += red[((k * nchunk) * EPC + t) * 2]; b2 += red[((k * nchunk) * EPC + t) * 2 + 1]; }
+        row[t] = a2;
+        row[c + t] = b2;
+    }
+}
+
 extern "C" int lh_maxpool3x3s2_fwd(const void* x, void* out, unsigned char* idx, int n, int h, int w, int c,
                                    int dtype, void* stream) {
     LH_REQUIRE(x && out && n > 0 && h > 0 && w > 0, "lh_maxpool3x3s2_fwd: bad arguments");
@@ -1811,6 +1997,21 @@ extern "C" int lh_bn_relu_maxpool3x3s2_fwd(const void* x, const float* scale, co
     const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
     const long total = (long)n * ho * wo * (c / (16 / es));
     LH_REQUIRE((long)n * h * w * (c / (16 / es)) < (1L << 31), "lh_bn_relu_maxpool3x3s2_fwd: tensor too large for 32-bit chunk indices");
+    static const int strip = [] { const char* e = getenv("LH_POOL_STRIP"); return e ? atoi(e) : 4; }();      // 0: the window-per-thread kernel
+    if (es == 2 && strip > 0) {
+        const int R = strip >= 4 ? 4 : 2;
+        const long items = (long)n * ((ho + R - 1) / R) * wo * (c / 8);
+        const int g = (int)((items + 255) / 256 > 8192 ? 8192 : (items + 255) / 256);
+        if (dtype == LH_BF16) {
+            if (R == 4) hipLaunchKernelGGL((bn_relu_pool_strip_kernel<bf16, 4>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)out, idx, n, h, w, c, ho, wo, scale, shift);
+            else hipLaunchKernelGGL((bn_relu_pool_strip_kernel<bf16, 2>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)out, idx, n, h, w, c, ho, wo, scale, shift);
+        } else {
+            if (R == 4) hipLaunchKernelGGL((bn_relu_pool_strip_kernel<f16, 4>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const f16*)x, (f16*)out, idx, n, h, w, c, ho, wo, scale, shift);
+            else hipLaunchKernelGGL((bn_relu_pool_strip_kernel<f16, 2>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const f16*)x, (f16*)out, idx, n, h, w, c, ho, wo, scale, shift);
+        }
+        LH_LAUNCH_CHECK("bn_relu_maxpool_fwd (strip) launch");
+        return LH_OK;
+    }
     const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
     LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((maxpool_fwd_kernel<T, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
                                                    (const T*)x, (T*)out, idx, n, h, w, c, ho, wo, scale, shift));
@@ -1838,7 +2039,7 @@ extern "C" int lh_maxpool3x3s2_bwd_gated_rows(int n, int h, int w, int c, int dt
     const int es = lh_dtype_size(dtype);
     if (es <= 0 || c % (16 / es)) return 0;
     const long total = (long)n * h * w * (c / (16 / es));
-    return (int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
+    return (int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);       // (512 .. 8192 rows re-measured in round 5: 103 .. 130 us, 1024: 104)
 }
 
 extern "C" int lh_maxpool3x3s2_bwd_gated(const void* dout, const unsigned char* idx, void* dx, const lh_bn_bwd_gate* gate, int n, int h,
@@ -1855,6 +2056,13 @@ extern "C" int lh_maxpool3x3s2_bwd_gated(const void* dout, const unsigned char* 
     const int grid = lh_maxpool3x3s2_bwd_gated_rows(n, h, w, c, dtype);
     PoolGate g;
     g.x = (const unsigned char*)gate->x; g.mean = gate->mean; g.invstd = gate->invstd; g.scale = gate->scale; g.shift = gate->shift; g.partial = gate->partial;
+    static const bool block = [] { const char* e = getenv("LH_POOL_BLOCK"); return !e || atoi(e) != 0; }();      // 0: the pixel-per-thread kernel
+    if (block) {
+        if (dtype == LH_BF16) hipLaunchKernelGGL((maxpool_bwd_block_kernel<bf16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)dout, idx, (bf16*)dx, n, h, w, c, ho, wo, g);
+        else hipLaunchKernelGGL((maxpool_bwd_block_kernel<f16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const f16*)dout, idx, (f16*)dx, n, h, w, c, ho, wo, g);
+        LH_LAUNCH_CHECK("maxpool_bwd_gated (block) launch");
+        return LH_OK;
+    }
     if (dtype == LH_BF16) hipLaunchKernelGGL((maxpool_bwd_kernel<bf16, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)dout, idx, (bf16*)dx, n, h, w, c, ho, wo, g);
     else hipLaunchKernelGGL((maxpool_bwd_kernel<f16, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const f16*)dout, idx, (f16*)dx, n, h, w, c, ho, wo, g);
     LH_LAUNCH_CHECK("maxpool_bwd_gated launch");

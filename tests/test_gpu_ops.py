@@ -1,3 +1,4 @@
+import ctypes as C
 import os
 """Per-kernel parity on the GPU: every HIP op vs the same op in plain PyTorch fp32 on the CPU
 (golden set G4 of SURVEY.md section 8c is regenerated on the fly -- it needs no reference)."""
@@ -1197,3 +1198,41 @@ def test_deconv_bn_relu_as_one_launch_is_bit_identical(case, forced_plans):
         assert torch.equal(a[2][k], b[2][k]), k
     for k in b[3]:
         assert torch.equal(a[3][k], b[3][k]), k
+
+
+@pytest.mark.parametrize("shape", [(3, 64, 34, 30), (2, 128, 17, 23), (1, 64, 8, 8), (2, 64, 9, 16)])
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_gated_pool_backward_equals_plain_backward_then_gate(shape, dtype):
+    """lh_maxpool3x3s2_bwd_gated (the training stem: the pool follows bn1 + relu, pose_resnet.py:153-156; a 2 x 2 block of input pixels per
+    thread since round 5): its dx must equal lh_maxpool3x3s2_bwd's, gated by the activation's sign, BIT FOR BIT (same additions in the same
+    window order) -- even and odd sizes, ties (post-ReLU zeros) -- and its partial-sum rows must add up to sum g and sum g * xhat."""
+    from lighthand_amd import _lib
+    lib = _lib.load()
+    n, c, h, w = shape
+    td = {"bf16": torch.bfloat16, "fp16": torch.float16}[dtype]
+    dt = {"bf16": _lib.LH_BF16, "fp16": _lib.LH_F16}[dtype]
+    torch.manual_seed(9)
+    raw = torch.randn(n, h, w, c).to(td).cuda()
+    scale, shift = (0.5 + torch.rand(c)).cuda(), (0.3 * torch.randn(c)).cuda()
+    mean, invstd = (0.1 * torch.randn(c)).cuda(), (0.5 + torch.rand(c)).cuda()
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    s = torch.cuda.current_stream().cuda_stream
+    out, idx = torch.empty(n, ho, wo, c, dtype=td, device="cuda"), torch.empty(n, ho, wo, c, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.lh_bn_relu_maxpool3x3s2_fwd(raw.data_ptr(), scale.data_ptr(), shift.data_ptr(), out.data_ptr(), idx.data_ptr(), n, h, w, c, dt, s))
+    dy = torch.randn(n, ho, wo, c).to(td).cuda()
+    plain = torch.empty(n, h, w, c, dtype=td, device="cuda")
+    _lib.check(lib.lh_maxpool3x3s2_bwd(dy.data_ptr(), idx.data_ptr(), plain.data_ptr(), n, h, w, c, dt, s))
+    rows = lib.lh_maxpool3x3s2_bwd_gated_rows(n, h, w, c, dt)
+    partial = torch.zeros(rows, 2, c, device="cuda")
+    gated = torch.full((n, h, w, c), float("nan"), dtype=td, device="cuda")
+    gate = _lib.BnBwdGate(raw.data_ptr(), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), partial.data_ptr())
+    _lib.check(lib.lh_maxpool3x3s2_bwd_gated(dy.data_ptr(), idx.data_ptr(), gated.data_ptr(), C.byref(gate), n, h, w, c, dt, s))
+    torch.cuda.synchronize()
+    on = (raw.float() * scale + shift) > 0
+    want = torch.where(on, plain, torch.zeros_like(plain))
+    assert torch.equal(gated, want)
+    g64 = want.double()
+    xhat = (raw.double() - mean.double()) * invstd.double()
+    got = partial.double().sum(0)
+    assert torch.allclose(got[0], g64.sum((0, 1, 2)), rtol=2e-3, atol=2e-2)
+    assert torch.allclose(got[1], (g64 * xhat).sum((0, 1, 2)), rtol=2e-3, atol=2e-2)
