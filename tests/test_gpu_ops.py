@@ -1,7 +1,7 @@
-import ctypes as C
-import os
 """Per-kernel parity on the GPU: every HIP op vs the same op in plain PyTorch fp32 on the CPU
 (golden set G4 of SURVEY.md section 8c is regenerated on the fly -- it needs no reference)."""
+import ctypes as C
+import os
 import numpy as np
 import pytest
 import torch
