@@ -28,11 +28,13 @@ extern "C" int lh_dtype_size(int dtype) {
 // ------------------------------------------------------------------------------------------------ transforms
 template <typename T>
 __global__ void image_to_nhwc4_kernel(const float* src, T* dst, int n, int h, int w, int pad, int hp, int wp) {
-    const long total = (long)n * hp * wp;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int x = (int)(i % wp);
-        const long t = i / wp;
-        const int y = (int)(t % hp), b = (int)(t / hp);
+    // 32-bit index arithmetic (the launcher checks n * hp * wp < 2^31: the 64-bit divisions were most of this kernel's instructions)
+    // and one store per pixel
+    const unsigned total = (unsigned)n * hp * wp;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const unsigned t = i / (unsigned)wp;
+        const int x = (int)(i - t * (unsigned)wp);
+        const int b = (int)(t / (unsigned)hp), y = (int)(t - (unsigned)b * (unsigned)hp);
         const int sy = y - pad, sx = x - pad;
         float v[3] = {0.f, 0.f, 0.f};
         if ((unsigned)sy < (unsigned)h && (unsigned)sx < (unsigned)w) {
@@ -40,8 +42,14 @@ __global__ void image_to_nhwc4_kernel(const float* src, T* dst, int n, int h, in
 #pragma unroll
             for (int c = 0; c < 3; ++c) v[c] = src[base + (long)c * h * w];
         }
-        T* o = dst + i * 4;
-        o[0] = from_f<T>(v[0]); o[1] = from_f<T>(v[1]); o[2] = from_f<T>(v[2]); o[3] = from_f<T>(0.f);
+        if constexpr (sizeof(T) == 2) {
+            union { uint2 u; T e[4]; } pk;
+            pk.e[0] = from_f<T>(v[0]); pk.e[1] = from_f<T>(v[1]); pk.e[2] = from_f<T>(v[2]); pk.e[3] = from_f<T>(0.f);
+            *reinterpret_cast<uint2*>(dst + (long)i * 4) = pk.u;
+        } else {
+            T* o = dst + (long)i * 4;
+            o[0] = from_f<T>(v[0]); o[1] = from_f<T>(v[1]); o[2] = from_f<T>(v[2]); o[3] = from_f<T>(0.f);
+        }
     }
 }
 
@@ -50,6 +58,7 @@ extern "C" int lh_image_to_nhwc4(const float* nchw, void* out, int n, int h, int
     LH_REQUIRE(nchw && out && n > 0 && h > 0 && w > 0 && pad >= 0 && wp >= w + 2 * pad, "lh_image_to_nhwc4: bad arguments");
     const int hp = h + 2 * pad;
     const long total = (long)n * hp * wp;
+    LH_REQUIRE(total < (1L << 31), "lh_image_to_nhwc4: image batch too large for 32-bit pixel indices");
     const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
     LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((image_to_nhwc4_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
                                                    nchw, (T*)out, n, h, w, pad, hp, wp));
@@ -264,7 +273,18 @@ __global__ void nhwc_to_nchw_kernel(const T* src, float* dst, int n, int hw, int
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int b = (int)(i / hw), p = (int)(i % hw);
         const T* s = src + i * cs;
-        for (int ch = 0; ch < c; ++ch) dst[((long)b * c + ch) * hw + p] = to_f<T>(s[ch]);
+        constexpr int EPC = 16 / sizeof(T);
+        if (cs % EPC == 0) {                     // whole 16-byte chunks per pixel: one vector load per EPC channels (was one 2-byte load per channel)
+            for (int c0 = 0; c0 < c; c0 += EPC) {
+                float v[EPC];
+                unpack16<T>(*reinterpret_cast<const uint4*>(s + c0), v);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e)
+                    if (c0 + e < c) dst[((long)b * c + c0 + e) * hw + p] = v[e];
+            }
+        } else {
+            for (int ch = 0; ch < c; ++ch) dst[((long)b * c + ch) * hw + p] = to_f<T>(s[ch]);
+        }
     }
 }
 template <typename T>
