@@ -261,6 +261,28 @@ int lh_wgrad_fused_multi(const lh_wgrad_call* calls, int n, int dtype, void* str
 int lh_wgrad_fused(const lh_igemm_desc* d, int rows, const void* x, const void* dy, int dy_pix_stride, int n_out, int n_in,
                    void* workspace, float* grad, long so, long si, long sr, long ss, const int* taps_rs, int accumulate,
                    int dtype, void* stream);
+/* Table launches -- the deferred weight gradients of a whole stage (loss.backward(), src/utils/method.py:182, through the blocks of
+ * one layerN of pose_resnet.py:61-99,177-192 or the branches of one HighResolutionModule, pose_hrnet.py:247-265) as ONE grid of the
+ * LDS-DMA weight-gradient kernel plus at most ONE fold grid, whatever their number and shapes.  lh_wgrad_table_build (host only, once
+ * per plan: every pointer of a plan is static) turns n lh_wgrad_call entries (16-bit types, rows <= 1; their `workspace` fields are
+ * ignored) into a table blob the caller uploads to device memory: argument blocks + work-item lists.  cfg4 = { tile output channels,
+ * tile input channels, pixel rows per ring stage, ring depth } (one of the compiled-in configurations, see lh_wgrad_candidates);
+ * EVERY PROBLEM GETS ITS OWN PIXEL-SPLIT COUNT: work items of about `target_stages` ring stages each (0 = automatic: split-free when
+ * the tiles alone fill the machine twice, else about four rounds of its workgroup slots), ordered longest first.  A problem with one
+ * split, one tap and a gradient that is dense in [o][i] is written by the kernel itself (no slab, no fold entry).  The sums are a
+ * deterministic function of (calls, cfg4, target_stages).  Call with host_blob = NULL to size the blob and the shared fp32 slab
+ * workspace (info->table_bytes, info->workspace_bytes; runs without a device), then with both buffers.  lh_wgrad_table_run replays it:
+ * `table` = the device copy of the blob. */
+typedef struct {
+    int bo, bi, kps, depth;              /* kernel configuration */
+    int n_problems, n_fold;              /* problems in the table, problems that need the fold launch */
+    int n_items, n_fold_items;           /* workgroups of the weight-gradient launch / of the fold launch (0: no fold launch) */
+    int fold_lds, target_stages, nsplit_max, reserved;
+    size_t off_items, off_fold_args, off_fold_items, table_bytes, workspace_bytes;
+} lh_wgrad_table_info;
+int lh_wgrad_table_build(const lh_wgrad_call* calls, int n, int dtype, const int* cfg4, int target_stages, void* workspace,
+                         void* host_blob, size_t host_bytes, lh_wgrad_table_info* info);
+int lh_wgrad_table_run(const void* table, const lh_wgrad_table_info* info, int dtype, void* stream);
 
 /* ------------------------------------------------------------------ BatchNorm / fused elementwise
  * nn.BatchNorm2d(C, momentum=0.1): pose_resnet.py:19,35,... ; nn.ReLU / residual add:

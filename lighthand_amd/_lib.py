@@ -69,6 +69,13 @@ class WgradCall(C.Structure):          # lh_wgrad_fused_multi
                 ("sr", C.c_long), ("ss", C.c_long), ("taps_rs", C.POINTER(C.c_int)), ("accumulate", C.c_int)]
 
 
+class WgradTableInfo(C.Structure):     # lh_wgrad_table_build / lh_wgrad_table_run
+    _fields_ = [("bo", C.c_int), ("bi", C.c_int), ("kps", C.c_int), ("depth", C.c_int), ("n_problems", C.c_int), ("n_fold", C.c_int),
+                ("n_items", C.c_int), ("n_fold_items", C.c_int), ("fold_lds", C.c_int), ("target_stages", C.c_int), ("nsplit_max", C.c_int),
+                ("reserved", C.c_int), ("off_items", C.c_size_t), ("off_fold_args", C.c_size_t), ("off_fold_items", C.c_size_t),
+                ("table_bytes", C.c_size_t), ("workspace_bytes", C.c_size_t)]
+
+
 class FuseFwdCall(C.Structure):        # lh_fuse_fwd_multi
     _fields_ = [("d", C.POINTER(FuseDesc)), ("out", C.c_void_p), ("n", C.c_int), ("h", C.c_int), ("w", C.c_int), ("c", C.c_int)]
 
@@ -140,6 +147,8 @@ SIGNATURES = {
     "lh_wgrad_workspace_bytes": (_SZ, [C.POINTER(IgemmDesc), _I, _I, _I]),
     "lh_wgrad_fused": (_I, [C.POINTER(IgemmDesc), _I, _P, _P, _I, _I, _I, _P, _P, _L, _L, _L, _L, C.POINTER(_I), _I, _I, _P]),
     "lh_wgrad_fused_multi": (_I, [C.POINTER(WgradCall), _I, _I, _P]),
+    "lh_wgrad_table_build": (_I, [C.POINTER(WgradCall), _I, _I, C.POINTER(_I), _I, _P, _P, _SZ, C.POINTER(WgradTableInfo)]),
+    "lh_wgrad_table_run": (_I, [_P, C.POINTER(WgradTableInfo), _I, _P]),
     "lh_wgrad_reduce": (_I, [C.POINTER(IgemmDesc), _P, _P, _I, _I, _L, _L, _L, _L, C.POINTER(_I), _I, _I, _P]),
     "lh_bn_stats": (_I, [_P, _I, _I, _P, C.POINTER(_I), _I, _P]),
     "lh_bn_stats_rows": (_I, [_I, _I]),

@@ -17,6 +17,8 @@
 #endif
 #include <algorithm>
 #include <stdlib.h>
+#include <string.h>
+#include <vector>
 
 #include "wgrad_ring_kernel.h"
 #include "wgrad_cfgs.h"
@@ -175,6 +177,7 @@ struct WreduceArgs {
     const float* slab;
     float* grad;
     int n_out, n_in, ntaps, nsplit, accumulate;
+    int contig;                  // table launches: this problem folds on the transposing path (wgrad_reduce_contig_body)
     long so, si, sr, ss;
     signed char r[64];
     signed char s[64];
@@ -182,10 +185,9 @@ struct WreduceArgs {
 
 // Fast path for the plain layout grad[(o*n_in + i)*ntaps + t]: a workgroup folds 256 consecutive (o, i)
 // pairs (coalesced slab reads per tap), transposes through LDS and writes 256*ntaps contiguous floats.
-__global__ __launch_bounds__(256) void wgrad_reduce_contig_kernel(const WreduceArgs p) {
-    extern __shared__ float tile[];                       // [256][ntaps + 1]
+__device__ __forceinline__ void wgrad_reduce_contig_body(const WreduceArgs& p, float* tile, const int bid) {
     const long per = (long)p.n_out * p.n_in;
-    const long base = (long)blockIdx.x * 256;
+    const long base = (long)bid * 256;
     const long idx = base + threadIdx.x;
     const int ld = p.ntaps + 1;
     if (idx < per) {
@@ -204,6 +206,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_contig_kernel(const WreduceA
         const float v = tile[pair * ld + t];
         g[e] = p.accumulate ? g[e] + v : v;
     }
+}
+__global__ __launch_bounds__(256) void wgrad_reduce_contig_kernel(const WreduceArgs p) {
+    extern __shared__ float tile[];                       // [256][ntaps + 1]
+    wgrad_reduce_contig_body(p, tile, blockIdx.x);
 }
 
 // Generic layout / small tensors: one thread per (tap, o, FOUR consecutive i) -- 16-byte coalesced slab reads, eight splits
@@ -270,6 +276,16 @@ __global__ void wgrad_reduce_multi_kernel(const LhMulti<WreduceArgs> m) {
     int bid, nblk;
     const int i = lh_multi_pick(m, bid, nblk);
     wgrad_reduce_body(m.a[i], bid, nblk);
+}
+// Table launch: the folds of any number of weight gradients as one grid (items[b] = problem, block index inside it); a problem
+// folds on the transposing path or the generic one (WreduceArgs.contig).  With ONE pixel split the fold is the transposition
+// [tap][o][i] -> the reference layout.
+__global__ __launch_bounds__(256) void wgrad_reduce_table_kernel(const WreduceArgs* __restrict__ tab, const int2* __restrict__ items) {
+    extern __shared__ float tile[];
+    const int2 it = items[blockIdx.x];
+    const WreduceArgs& p = tab[__builtin_amdgcn_readfirstlane(it.x)];
+    if (p.contig) wgrad_reduce_contig_body(p, tile, it.y);
+    else wgrad_reduce_body(p, it.y, 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -451,7 +467,7 @@ static int launch_wgrad(const WgradArgs& a, hipStream_t s) {
 
 static int wgrad_impl(const lh_igemm_desc* d, const void* x, const void* dy, int dy_pix_stride,
                       int n_out, int n_in, float* slab, int dtype, void* stream, int fold_rows,
-                      WgradArgs* prep_args = nullptr, WgradPlan* prep_plan = nullptr) {
+                      WgradArgs* prep_args = nullptr, WgradPlan* prep_plan = nullptr, const WgradPlan* forced = nullptr) {
     LH_REQUIRE(d && x && dy && slab, "lh_wgrad: null pointer");
     const int es = lh_dtype_size(dtype);
     LH_REQUIRE(es > 0, "lh_wgrad: bad dtype %d", dtype);
@@ -460,8 +476,13 @@ static int wgrad_impl(const lh_igemm_desc* d, const void* x, const void* dy, int
     LH_REQUIRE(n_in == d->k_run && n_in % epc == 0, "lh_wgrad: n_in %d must equal k_run %d and be a multiple of %d", n_in, d->k_run, epc);
     LH_REQUIRE(n_out % epc == 0 && dy_pix_stride % epc == 0 && dy_pix_stride >= n_out, "lh_wgrad: n_out %d / stride %d", n_out, dy_pix_stride);
     WgradPlan c;
-    const int rc = wgrad_plan(d, n_out, n_in, dtype, &c);
-    if (rc) return rc;
+    if (forced) {                 // table launches: the table's tile / stage / depth and this problem's own split count
+        LH_REQUIRE(wgrad_ring_ok(d, es), "lh_wgrad_table: problem does not run on the LDS-DMA weight-gradient kernel");
+        c = *forced;
+    } else {
+        const int rc = wgrad_plan(d, n_out, n_in, dtype, &c);
+        if (rc) return rc;
+    }
     WgradArgs a;
     a.x = (const unsigned char*)x; a.dy = (const unsigned char*)dy; a.slab = slab; a.zero = nullptr;
     a.n = d->n; a.hi = d->hi; a.wi = d->wi; a.in_pix_stride = d->in_pix_stride; a.k_run = d->k_run;
@@ -550,6 +571,7 @@ static int reduce_prepare(const lh_igemm_desc* d, const float* slab, float* grad
     const int rc = wgrad_plan(d, n_out, n_in, dtype, &c);
     if (rc) return rc;
     a.nsplit = c.nsplit;
+    a.contig = 0;
     a.slab = slab; a.grad = grad; a.n_out = n_out; a.n_in = n_in; a.ntaps = d->ntaps;
     a.accumulate = accumulate; a.so = so; a.si = si; a.sr = sr; a.ss = ss;
     for (int t = 0; t < 64; ++t) {
@@ -656,4 +678,151 @@ extern "C" int lh_wgrad_fused_multi(const lh_wgrad_call* calls, int n, int dtype
         }
     }
     return flush();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Table launches: the deferred weight gradients of a whole stage as ONE grid + (at most) ONE fold grid.
+int lh_wgrad_ring_table_launch_bf16(const WgradArgs* tab, const int2* items, int n_items, int bo, int bi, int kps, int depth, hipStream_t s);
+int lh_wgrad_ring_table_launch_f16(const WgradArgs* tab, const int2* items, int n_items, int bo, int bi, int kps, int depth, hipStream_t s);
+
+static inline size_t up256(size_t v) { return (v + 255) / 256 * 256; }
+
+extern "C" int lh_wgrad_table_build(const lh_wgrad_call* calls, int n, int dtype, const int* cfg4, int target_stages, void* workspace,
+                                    void* host_blob, size_t host_bytes, lh_wgrad_table_info* info) {
+    LH_REQUIRE(calls && n >= 1 && cfg4 && info, "lh_wgrad_table_build: bad arguments");
+    LH_REQUIRE(lh_dtype_size(dtype) == 2, "lh_wgrad_table_build: 16-bit types only");
+    WgradPlan base = {cfg4[0], cfg4[1], cfg4[2], cfg4[3], 1, 0};
+    bool found = false;
+    for (int i = 0; i < kNWCfg && !found; ++i)
+        found = kWCfg[i].bo == base.bo && kWCfg[i].bi == base.bi && kWCfg[i].depth == base.depth && kWCfg[i].kps == base.kps;
+    if (!found) {
+        lh_set_error("lh_wgrad_table_build: tile %dx%d stage %d depth %d is not compiled in", base.bo, base.bi, base.kps, base.depth);
+        return LH_ERR_UNSUPPORTED;
+    }
+    // every problem's stage count; the automatic item length aims at ~4 rounds of the machine's workgroup slots
+    const int lds = base.depth * base.kps * (base.bo + base.bi) * 2;
+    const int per_cu = base.bo * base.bi >= 256 * 256 ? 1 : std::min(2, (160 * 1024) / lds);
+    const long slots = 256L * per_cu;
+    std::vector<long> stages(n), tiles(n);
+    long work = 0, smax = 0;
+    for (int i = 0; i < n; ++i) {
+        const lh_wgrad_call& q = calls[i];
+        LH_REQUIRE(q.d && q.x && q.dy && q.grad && q.taps_rs && q.rows <= 1, "lh_wgrad_table_build: bad problem %d", i);
+        LH_REQUIRE(q.d->ntaps > 0 && q.d->ntaps <= 64, "lh_wgrad_table_build: ntaps %d out of range (problem %d)", q.d->ntaps, i);
+        const long M = (long)q.d->n * q.d->ho * q.d->wo;
+        stages[i] = (M + base.kps - 1) / base.kps;
+        tiles[i] = (long)ceil_div(q.n_out, base.bo) * ceil_div(q.n_in, base.bi) * q.d->ntaps;
+        work += stages[i] * tiles[i];
+        smax = std::max(smax, stages[i]);
+    }
+    const long min_stages = std::max(1, 256 / base.kps);          // >= 256 pixels per work item
+    long L = target_stages;
+    if (L <= 0) {
+        // split-free when the tiles alone make two rounds of the slots; else the item length that makes about four rounds
+        long tsum = 0;
+        for (int i = 0; i < n; ++i) tsum += tiles[i];
+        L = tsum >= 2 * slots ? smax : std::max(min_stages, work / (4 * slots));
+    }
+    L = std::max(L, min_stages);
+    // blob layout: [WgradArgs x n][int2 items][WreduceArgs x nfold][int2 fold items]
+    std::vector<WgradArgs> args(n);
+    std::vector<WreduceArgs> folds;
+    std::vector<int> order(n);
+    size_t ws = 0;
+    int fold_lds = 0;
+    for (int i = 0; i < n; ++i) {
+        const lh_wgrad_call& q = calls[i];
+        long ns = (stages[i] + L / 2) / L;                            // nearest split count for items of ~L stages
+        const long max_split = std::min(128L, std::max(1L, stages[i] / min_stages));
+        ns = std::max(1L, std::min(ns, max_split));
+        WgradPlan c = base;
+        c.sps = (int)((stages[i] + ns - 1) / ns);
+        c.nsplit = (int)((stages[i] + c.sps - 1) / c.sps);
+        const size_t per = (size_t)q.n_out * q.n_in;
+        // one split, one tap, the gradient dense in [o][i]: the kernel's 16-byte stores ARE the gradient -- no slab, no fold
+        const bool direct = c.nsplit == 1 && q.d->ntaps == 1 && !q.accumulate && q.so == q.n_in && q.si == 1 &&
+                            ((uintptr_t)q.grad & 15) == 0;
+        float* slab = direct ? q.grad : (workspace ? (float*)((char*)workspace + ws) : (float*)(uintptr_t)256);
+        if (host_blob) {
+            const int rc = wgrad_impl(q.d, q.x, q.dy, q.dy_pix_stride, q.n_out, q.n_in, slab, dtype, nullptr, 0, &args[i], &c, &c);
+            if (rc) return rc;
+        } else {                                                      // size query (no device needed): the launch shape only
+            LH_REQUIRE(wgrad_ring_ok(q.d, 2), "lh_wgrad_table: problem %d does not run on the LDS-DMA weight-gradient kernel", i);
+            args[i].i_tiles = ceil_div(q.n_in, c.bi);
+            args[i].tiles = ceil_div(q.n_out, c.bo) * args[i].i_tiles;
+            args[i].ntaps = q.d->ntaps; args[i].nsplit = c.nsplit; args[i].steps_per_split = c.sps;
+        }
+        if (!direct) {
+            WreduceArgs ra;
+            bool contig = false;
+            const int rr = reduce_prepare(q.d, slab, q.grad, q.n_out, q.n_in, q.so, q.si, q.sr, q.ss, q.taps_rs, q.accumulate, dtype, &ra, &contig);
+            if (rr) return rr;
+            ra.nsplit = c.nsplit;
+            ra.contig = contig ? 1 : 0;
+            if (contig) fold_lds = std::max(fold_lds, (int)(256 * (q.d->ntaps + 1) * sizeof(float)));
+            folds.push_back(ra);
+            ws += up256((size_t)c.nsplit * q.d->ntaps * per * sizeof(float));
+        }
+        order[i] = i;
+    }
+    // longest items first: workgroups are dispatched in grid order and the launch ends with its last one
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return args[x].steps_per_split > args[y].steps_per_split; });
+    long n_items = 0, n_fold_items = 0;
+    for (int i = 0; i < n; ++i) n_items += (long)args[i].tiles * args[i].ntaps * args[i].nsplit;
+    for (const WreduceArgs& r : folds)
+        n_fold_items += r.contig ? ceil_div((long)r.n_out * r.n_in, 256) : ceil_div(wgrad_reduce_threads(r.n_out, r.n_in, r.ntaps), 256);
+    LH_REQUIRE(n_items < (1L << 30) && n_fold_items < (1L << 30), "lh_wgrad_table_build: too many work items");
+    lh_wgrad_table_info t;
+    memset(&t, 0, sizeof(t));
+    t.bo = base.bo; t.bi = base.bi; t.kps = base.kps; t.depth = base.depth;
+    t.n_problems = n; t.n_fold = (int)folds.size();
+    t.n_items = (int)n_items; t.n_fold_items = (int)n_fold_items; t.fold_lds = fold_lds;
+    t.target_stages = (int)L;
+    t.off_items = up256(sizeof(WgradArgs) * n);
+    t.off_fold_args = t.off_items + up256(sizeof(int2) * n_items);
+    t.off_fold_items = t.off_fold_args + up256(sizeof(WreduceArgs) * folds.size());
+    t.table_bytes = t.off_fold_items + up256(sizeof(int2) * n_fold_items);
+    t.workspace_bytes = std::max(ws, (size_t)256);
+    for (int i = 0; i < n; ++i) t.nsplit_max = std::max(t.nsplit_max, args[i].nsplit);
+    *info = t;
+    if (!host_blob) return LH_OK;                                   // size query
+    LH_REQUIRE(workspace && host_bytes >= t.table_bytes, "lh_wgrad_table_build: blob of %zu bytes needs %zu (and a workspace)", host_bytes, t.table_bytes);
+    char* blob = (char*)host_blob;
+    memset(blob, 0, t.table_bytes);
+    memcpy(blob, args.data(), sizeof(WgradArgs) * n);
+    int2* it = (int2*)(blob + t.off_items);
+    for (int k = 0; k < n; ++k) {
+        const int i = order[k], cnt = args[i].tiles * args[i].ntaps * args[i].nsplit;
+        for (int b = 0; b < cnt; ++b) *it++ = int2{i, b};
+    }
+    if (!folds.empty()) memcpy(blob + t.off_fold_args, folds.data(), sizeof(WreduceArgs) * folds.size());
+    int2* fi = (int2*)(blob + t.off_fold_items);
+    for (int k = 0; k < (int)folds.size(); ++k) {
+        const WreduceArgs& r = folds[k];
+        const int cnt = r.contig ? ceil_div((long)r.n_out * r.n_in, 256) : ceil_div(wgrad_reduce_threads(r.n_out, r.n_in, r.ntaps), 256);
+        for (int b = 0; b < cnt; ++b) *fi++ = int2{k, b};
+    }
+    return LH_OK;
+}
+
+extern "C" int lh_wgrad_table_run(const void* table, const lh_wgrad_table_info* info, int dtype, void* stream) {
+    LH_REQUIRE(table && info && info->n_items > 0, "lh_wgrad_table_run: bad arguments");
+    LH_REQUIRE(dtype == LH_BF16 || dtype == LH_F16, "lh_wgrad_table_run: 16-bit types only");
+    hipStream_t s = (hipStream_t)stream;
+    const char* blob = (const char*)table;
+    const WgradArgs* tab = (const WgradArgs*)blob;
+    const int2* items = (const int2*)(blob + info->off_items);
+    const int rc = dtype == LH_BF16 ? lh_wgrad_ring_table_launch_bf16(tab, items, info->n_items, info->bo, info->bi, info->kps, info->depth, s)
+                                    : lh_wgrad_ring_table_launch_f16(tab, items, info->n_items, info->bo, info->bi, info->kps, info->depth, s);
+    if (rc == 1) {
+        lh_set_error("lh_wgrad_table_run: no kernel for tile %dx%d stage %d depth %d", info->bo, info->bi, info->kps, info->depth);
+        return LH_ERR_UNSUPPORTED;
+    }
+    if (rc) return rc;
+    if (info->n_fold_items > 0) {
+        hipLaunchKernelGGL(wgrad_reduce_table_kernel, dim3(info->n_fold_items), dim3(256), info->fold_lds, s,
+                           (const WreduceArgs*)(blob + info->off_fold_args), (const int2*)(blob + info->off_fold_items));
+        LH_LAUNCH_CHECK("wgrad_reduce_table launch");
+    }
+    return LH_OK;
 }

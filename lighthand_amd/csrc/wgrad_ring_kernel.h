@@ -89,8 +89,11 @@ template <> struct WMma<f16> {
 
 // The kernel proper for workgroup `bid` of `nblk` of ONE problem (plain launch: the block index; multi-problem launch,
 // multi.h: the index inside the problem the workgroup belongs to).
+// tap_dh / tap_dw: the tap offset tables (the argument block's own arrays, or -- table launches, whose block is a register copy of
+// a table entry -- the entry's arrays in device memory: a dynamically indexed array inside a local copy would live in scratch).
 template <typename T, int BO, int BI, int WO, int WI, int D, int KPS>
-__device__ __forceinline__ void wgrad_ring_body(const WgradArgs& p, unsigned char* smem, const int bid, const int nblk) {
+__device__ __forceinline__ void wgrad_ring_body(const WgradArgs& p, const signed char* tap_dh, const signed char* tap_dw, unsigned char* smem,
+                                                const int bid, const int nblk) {
     static_assert(sizeof(T) == 2, "16-bit types only");
     constexpr int KP = 32;                                    // pixels per logical step (one MFMA K slice)
     constexpr int KSUB = KPS / KP;
@@ -116,7 +119,7 @@ __device__ __forceinline__ void wgrad_ring_body(const WgradArgs& p, unsigned cha
     // the tap offsets come out of the argument block through a VECTOR load (dynamic index): consume them here -- left to the
     // compiler their first use lands behind the first LDS-DMA instructions, and the s_waitcnt vmcnt(0) in front of it waits
     // for those too (one memory latency per workgroup, in launches of 10-30 us per workgroup)
-    const int dh = __builtin_amdgcn_readfirstlane((int)p.dh[tap]), dw = __builtin_amdgcn_readfirstlane((int)p.dw[tap]);
+    const int dh = __builtin_amdgcn_readfirstlane((int)tap_dh[tap]), dw = __builtin_amdgcn_readfirstlane((int)tap_dw[tap]);
     const int hw = p.ho * p.wo;
     const long m_begin = (long)split * p.steps_per_split * KPS;
     long m_end = m_begin + (long)p.steps_per_split * KPS;
@@ -306,7 +309,7 @@ __device__ __forceinline__ void wgrad_ring_body(const WgradArgs& p, unsigned cha
 template <typename T, int BO, int BI, int WO, int WI, int D, int KPS>
 __global__ __launch_bounds__(64 * WO * WI, 2) void wgrad_ring_kernel(const WgradArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    wgrad_ring_body<T, BO, BI, WO, WI, D, KPS>(p, smem, blockIdx.x, gridDim.x);
+    wgrad_ring_body<T, BO, BI, WO, WI, D, KPS>(p, p.dh, p.dw, smem, blockIdx.x, gridDim.x);
 }
 
 // Up to LH_MULTI_MAX independent weight gradients that share the tile / stage / ring depth as ONE grid (lh_wgrad_fused_multi).
@@ -315,5 +318,28 @@ __global__ __launch_bounds__(64 * WO * WI, 2) void wgrad_ring_multi_kernel(const
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int bid, nblk;
     const int i = lh_multi_pick(m, bid, nblk);
-    wgrad_ring_body<T, BO, BI, WO, WI, D, KPS>(m.a[i], smem, bid, nblk);
+    wgrad_ring_body<T, BO, BI, WO, WI, D, KPS>(m.a[i], m.a[i].dh, m.a[i].dw, smem, bid, nblk);
+}
+
+// Table launch (lh_wgrad_table_run): ANY number of independent weight gradients of one tile / stage / ring depth as ONE grid -- the
+// deferred weight gradients of a whole stage (pose_resnet.py:61-99 x the blocks of a layer, 207-232).  The argument blocks live in
+// DEVICE memory (built once per plan: every pointer of a plan is static); workgroup b runs work item items[b] = (problem, block index
+// inside the problem).  Every problem carries its OWN pixel-split count, so the deep-K layers of the late stages run split-free (their
+// tiles alone fill the machine once they share a grid) while the few-tile layers of the early stages keep their splits; items are
+// ordered longest first.  The scalar fields of the entry are copied into registers (the stage loop's counted waits are asm statements
+// with memory clobbers: fields read through a pointer would be re-fetched behind every one of them).
+template <typename T, int BO, int BI, int WO, int WI, int D, int KPS>
+__global__ __launch_bounds__(64 * WO * WI, 2) void wgrad_ring_table_kernel(const WgradArgs* __restrict__ tab, const int2* __restrict__ items) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int2 it = items[blockIdx.x];
+    const int prob = __builtin_amdgcn_readfirstlane(it.x), bid = __builtin_amdgcn_readfirstlane(it.y);
+    const WgradArgs* g = tab + prob;
+    WgradArgs p;
+    p.x = g->x; p.dy = g->dy; p.zero = g->zero; p.slab = g->slab;
+    p.n = g->n; p.hi = g->hi; p.wi = g->wi; p.in_pix_stride = g->in_pix_stride; p.k_run = g->k_run;
+    p.ho = g->ho; p.wo = g->wo; p.M = g->M; p.sh = g->sh; p.sw = g->sw;
+    p.dy_pix_stride = g->dy_pix_stride; p.n_out = g->n_out; p.n_in = g->n_in;
+    p.ntaps = g->ntaps; p.nsplit = g->nsplit; p.steps_per_split = g->steps_per_split; p.i_tiles = g->i_tiles;
+    p.tiles = g->tiles; p.xcd = g->xcd; p.fold_k = g->fold_k; p.adv_n = g->adv_n; p.adv_a = g->adv_a; p.adv_b = g->adv_b;
+    wgrad_ring_body<T, BO, BI, WO, WI, D, KPS>(p, g->dh, g->dw, smem, bid, p.tiles * p.ntaps * p.nsplit);
 }

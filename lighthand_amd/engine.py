@@ -152,7 +152,7 @@ def _taps_array(rs):
 class _Call:
     """A pre-bound C-ABI call; the stream is appended at run time.  ``lane`` 1 marks work that may run on
     the side stream of the backward pass (weight gradients: they only feed the optimizer)."""
-    __slots__ = ("fn", "args", "what", "keep", "lane", "ig", "slane", "mtag", "keep_desc", "ws_ent")
+    __slots__ = ("fn", "args", "what", "keep", "lane", "ig", "slane", "mtag", "keep_desc", "ws_ent", "wargs", "wbufs")
 
     def __init__(self, fn, args, what, keep=None, lane=0):
         self.fn, self.args, self.what, self.keep, self.lane = fn, args, what, keep, lane
@@ -161,6 +161,8 @@ class _Call:
         self.keep_desc = None        # weight-gradient calls: their descriptor (Plan._batch_wgrads)
         self.mtag = None             # (group, section, member, position): calls of one batch group that may merge (Plan._merge_groups)
         self.ws_ent = None           # weight-gradient calls: their entry in Plan._ws_users (the slab follows the call's stream)
+        self.wargs = None            # weight-gradient calls: the argument list of lh_wgrad_fused (Plan._table_wgrads reads it before the slab is bound)
+        self.wbufs = None            # ... and the tensors behind its x / dy pointers
 
     def __call__(self, stream):
         rc = self.fn(*self.args, stream)
@@ -218,6 +220,10 @@ class Plan:
         self.batch = os.environ.get("LH_BATCH", "1") != "0" and self.es == 2 and self.n_lanes > 1
         self.batch_split = os.environ.get("LH_BATCH", "1") == "2"
         self.wgrad_batch = os.environ.get("LH_WGRAD_BATCH", "1") != "0" and self.es == 2
+        # Table launches (round 6): ALL weight gradients of a deferred group that share a tile class run as ONE grid with a split count
+        # per layer + at most one fold grid (lh_wgrad_table_run; _table_wgrads).  LH_WGRAD_TABLE=0: one launch (+ fold) per layer.
+        self.wgrad_table = os.environ.get("LH_WGRAD_TABLE", "1") != "0" and self.es == 2
+        self.wgrad_tables = []             # (call, info, member names) of every table launch of the plan
         self._forced = None                # kernel choices of the group being compiled (see _tune_group)
         self._n_groups = 0
         self._lane_streams = {L: torch.cuda.Stream(device=self.device) for L in range(1, self.n_lanes)} if self.use_lanes else {}
@@ -788,15 +794,17 @@ class Plan:
         p = self._pend.get(src)
         if not p or not p["calls"]:
             return
+        if self.wgrad_table:
+            p["calls"] = self._table_wgrads(p["calls"])
         if self.wgrad_batch:
             p["calls"] = self._batch_wgrads(p["calls"])
         lanes = [-1 - ((self._w_flushes + i) % self._w_lanes) for i in range(self._w_lanes if spread else 1)]
         self._w_flushes += 1
         # units that must stay together on one stream, in order: a weight-gradient call with the small calls that follow
         # it (crop / unstage / bias), and the calls tagged to merge into one multi-problem launch
-        fused, clusters = self.lib.lh_wgrad_fused, []
+        fused, table_run, clusters = self.lib.lh_wgrad_fused, self.lib.lh_wgrad_table_run, []
         for c in p["calls"]:
-            head = isinstance(c, _Call) and c.fn is fused
+            head = isinstance(c, _Call) and (c.fn is fused or c.fn is table_run)
             same = head and clusters and c.mtag is not None and getattr(clusters[-1][0], "mtag", None) is not None \
                 and clusters[-1][0].mtag[:2] == c.mtag[:2]
             if clusters and (same or not head):
@@ -826,6 +834,157 @@ class Plan:
         if p["names"]:
             self.bwd_marks.append((len(self.bwd), p["names"]))
         self._pend[src] = dict(calls=[], names=[], layers=0, ws=[], bytes=0)
+
+    # kernel configurations (tile o, tile i, pixel rows per stage, ring depth) offered to a table of a tile class, best guess first
+    _TABLE_CFGS = {
+        (256, 256): ((256, 256, 32, 3), (256, 256, 64, 2), (128, 128, 64, 3), (128, 128, 64, 2)),
+        (128, 128): ((128, 128, 64, 3), (128, 128, 64, 2), (128, 128, 32, 4)),
+        (128, 64): ((128, 64, 64, 3), (128, 64, 64, 2), (128, 64, 32, 4), (64, 64, 64, 3)),
+        (64, 128): ((64, 128, 64, 3), (64, 128, 64, 2), (64, 128, 32, 4), (64, 64, 64, 3)),
+        (64, 64): ((64, 64, 64, 3), (64, 64, 64, 2), (64, 64, 32, 4)),
+    }
+
+    def _table_wgrads(self, calls):
+        """The weight gradients of a deferred group are independent of each other and of everything else on their side stream: all of
+        them that share a tile class become ONE lh_wgrad_table_run call -- one grid of the LDS-DMA weight-gradient kernel over a device
+        table of argument blocks, every layer with its own pixel-split count, plus at most one fold grid.  The deep-K layers of stages
+        3-4 and the head then run split-free or nearly so (their tiles fill the machine together), and a stage costs two launches instead
+        of two per layer.  Kernel configuration and work-item length are measured on the real operands (_tune_table).  Calls that do not
+        fit (the stem's row fold, fp32) stay as they are; the small calls that follow a tabled gradient (crop, bias) follow its table."""
+        fused = self.lib.lh_wgrad_fused
+        units = []
+        for c in calls:
+            if isinstance(c, _Call) and c.fn is fused:
+                units.append([c])
+            elif units:
+                units[-1].append(c)
+            else:
+                units.append([c])
+        big = os.environ.get("LH_WGRAD_TABLE_BIG", "1") != "0"
+
+        def cls(u):
+            c = u[0]
+            if not (isinstance(c, _Call) and c.fn is fused and c.wargs is not None and c.wargs[1] <= 1):
+                return None
+            n_out, n_in = c.wargs[5], c.wargs[6]
+            if n_out % 8 or n_in % 8:
+                return None
+            if big and n_out >= 256 and n_in >= 256:
+                return (256, 256)
+            return (128 if n_out >= 128 else 64, 128 if n_in >= 128 else 64)
+        groups = {}
+        for u in units:
+            groups.setdefault(cls(u), []).append(u)
+        out, rest = [], []
+        for k, us in groups.items():
+            if k is None or len(us) < 2:
+                rest += us
+                continue
+            out.append(self._make_table(k, us))
+            for u in us:
+                out += u[1:]
+        for u in units:                      # the others keep their order
+            if any(u is r for r in rest):
+                out += u
+        return out
+
+    def _make_table(self, tile_class, units):
+        lib = self.lib
+        members = [u[0] for u in units]
+        n = len(members)
+        arr = (_lib.WgradCall * n)()
+        for i, c in enumerate(members):
+            a = c.wargs
+            arr[i].d, arr[i].rows, arr[i].x, arr[i].dy, arr[i].dy_pix_stride, arr[i].n_out, arr[i].n_in = C.pointer(a[0]._obj), *a[1:7]
+            arr[i].workspace = None
+            arr[i].grad, arr[i].so, arr[i].si, arr[i].sr, arr[i].ss = a[8:13]
+            arr[i].taps_rs, arr[i].accumulate = C.cast(a[13], C.POINTER(C.c_int)), a[14]
+        cands = [cf for cf in Plan._TABLE_CFGS[tile_class]]
+        cfg, target = self._tune_table(arr, members, cands)
+        info, blob, ws = self._build_table(arr, n, cfg, target)
+        names = [c.what.replace(" wgrad", "") for c in members]
+        call = _Call(lib.lh_wgrad_table_run, (blob.data_ptr(), C.byref(info), self.dt), f"{n} x wgrad (table)", keep=(arr, info, blob, ws, members), lane=1)
+        # bookkeeping: the members leave the shared-slab users and the profile attribution; the table takes their sums
+        gone = {id(c.ws_ent) for c in members if c.ws_ent is not None}
+        self._ws_users = [e for e in self._ws_users if id(e) not in gone]
+        for pend in self._pend.values():
+            pend["ws"] = [e for e in pend["ws"] if id(e) not in gone]
+        ids = {id(c) for c in members}
+        ms = [m for m in self.profile_meta if id(m[1]) in ids]
+        self.profile_meta = [m for m in self.profile_meta if id(m[1]) not in ids]
+        t = {"fp32": "float", "bf16": "__bf16", "fp16": "_Float16"}[self.precision]
+        wo, wi = {(256, 256): (2, 4), (128, 128): (2, 2), (128, 64): (4, 1), (64, 128): (1, 4), (64, 64): (2, 2)}[(info.bo, info.bi)]
+        self.profile_meta.append(("bwd", call, f"wgrad_ring_table_kernel<{t}, {info.bo}, {info.bi}, {wo}, {wi}, {info.depth}, {info.kps}>",
+                                  sum(m[3] for m in ms), sum(m[4] for m in ms)))
+        self.wgrad_tables.append((call, info, names))
+        return call
+
+    def _build_table(self, arr, n, cfg, target):
+        """(info, device blob, slab workspace) of one table: size query, allocation, build on the host, upload."""
+        lib = self.lib
+        info = _lib.WgradTableInfo()
+        cfg4 = (C.c_int * 4)(*cfg)
+        check(lib.lh_wgrad_table_build(arr, n, self.dt, cfg4, target, None, None, 0, C.byref(info)), "lh_wgrad_table_build (sizes)")
+        ws = torch.empty(info.workspace_bytes, dtype=torch.uint8, device=self.device)
+        host = (C.c_ubyte * info.table_bytes)()
+        check(lib.lh_wgrad_table_build(arr, n, self.dt, cfg4, target, ws.data_ptr(), host, info.table_bytes, C.byref(info)), "lh_wgrad_table_build")
+        blob = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(self.device)
+        return info, blob, ws
+
+    def _tune_table(self, arr, members, cands):
+        """Measured (kernel configuration, work-item length in ring stages) of one table: every offered configuration x a ladder of item
+        lengths (split-free, 1/2, 1/3 ... of the longest member's stage count, and the library's automatic choice), timed on the
+        members' REAL operand buffers filled with random bits for the measurement (cold caches: a deferred group runs long after its
+        operands were written).  The choice fixes every member's split count, i.e. the fp32 summation order: cached per table signature."""
+        n = len(members)
+        if os.environ.get("LH_AUTOTUNE", "1") == "0":
+            return cands[0], 0
+        forced = os.environ.get("LH_WGRAD_TABLE_FORCE")       # experiments: "bo,bi,kps,depth,target"
+        if forced:
+            v = [int(t) for t in forced.split(",")]
+            return tuple(v[:4]), v[4]
+        key = ("wt", self.dt, tuple((self._desc_key(c.wargs[0]._obj), c.wargs[4], c.wargs[5], c.wargs[6]) for c in members))
+        hit = Plan._TUNE_CACHE.get(key)
+        if hit is not None and tuple(hit[:4]) in cands:
+            return tuple(hit[:4]), hit[4]
+        stream = torch.cuda.current_stream()
+        sp = stream.cuda_stream
+        bufs, saved = {}, []
+        for c in members:
+            for t in c.wbufs:
+                bufs[t.data_ptr()] = t
+        for t in bufs.values():
+            saved.append((t, t.clone()))
+            t.view(torch.int16).random_(-16000, 16000)
+        best = None
+        try:
+            for cfg in cands:
+                kps = cfg[2]
+                smax = max((c.wargs[0]._obj.n * c.wargs[0]._obj.ho * c.wargs[0]._obj.wo + kps - 1) // kps for c in members)
+                ladder = [0] + sorted({max(256 // kps, -(-smax // q)) for q in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32)}, reverse=True)
+                seen = set()
+                for target in ladder:
+                    info, blob, ws = self._build_table(arr, n, cfg, target)
+                    sig = (info.n_items, info.n_fold_items, info.workspace_bytes)
+                    if sig in seen:
+                        continue
+                    seen.add(sig)
+                    run = lambda: check(self.lib.lh_wgrad_table_run(blob.data_ptr(), C.byref(info), self.dt, sp), "autotune lh_wgrad_table_run")
+                    run()
+                    t = self._timed_cold(run, [], Plan.tune_iters())
+                    if os.environ.get("LH_WGRAD_TABLE_LOG"):
+                        print(f"[table {n} x wgrad] cfg {cfg} target {target:5d} items {info.n_items:5d} fold {info.n_fold_items:5d} "
+                              f"slab {info.workspace_bytes >> 20:4d} MiB nsplit<= {info.nsplit_max:3d}: {t / Plan.tune_iters() * 1e3:8.1f} us", flush=True)
+                    if best is None or t < best[0]:
+                        best = (t, cfg, info.target_stages if target else 0)
+                    del blob, ws
+        finally:
+            for t, keep in saved:
+                t.copy_(keep)
+        hit = tuple(best[1]) + (best[2],)
+        Plan._TUNE_CACHE[key] = hit
+        Plan._tune_measured.add(key)
+        return tuple(hit[:4]), hit[4]
 
     def _batch_wgrads(self, calls):
         """The weight gradients of a deferred group are independent of each other and of everything else on their side
@@ -1612,6 +1771,7 @@ class Plan:
             tail = 1
             cw = _Call(self.lib.lh_wgrad_fused, None, nd["w"] + " wgrad", keep=rs_arr, lane=1)
             cw.keep_desc = d
+            cw.wargs, cw.wbufs = a, (xbuf, dy)
 
             def set_ws(ptr, cw=cw, a=a):
                 a[7] = ptr
@@ -1794,6 +1954,7 @@ class Plan:
             dy = self._act_grad(y)
             a = [C.byref(dg), 0, dy.data_ptr(), xbuf.data_ptr(), x.c, cin, cout, 0, gw.data_ptr(), cout * k * k, k * k, k, 1, rs_arr, 0, self.dt]
             cw = _Call(self.lib.lh_wgrad_fused, None, nd["w"] + " wgrad", keep=rs_arr, lane=1)
+            cw.wargs, cw.wbufs = a, (dy, xbuf)
 
             def set_ws(ptr):
                 a[7] = ptr

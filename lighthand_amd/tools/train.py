@@ -9,7 +9,12 @@ CosineAnnealingLR(T_max=epoch) stepped per epoch, best-validation-loss checkpoin
 ``<root_path>/<root>/<name>/checkpoint-good/state_dict.bin`` with the reference's dict keys, early stop on
 ``--count``.  New flags (they do not change existing semantics): ``--depth`` (ResNet depth, the reference
 hard-codes 50), ``--hrnet_width``, ``--precision {fp32,bf16,fp16}``, ``--size``, ``--synthetic N`` (seeded
-synthetic samples; the reference's datasets are not redistributable), ``--no_graph``.
+synthetic samples; the reference's datasets are not redistributable), ``--no_graph``, ``--transfer_from PATH`` (where
+``--transfer`` reads its checkpoint; default: the reference's ``output/<model>/frei/ori/checkpoint-good/state_dict.bin``),
+``--drop_last`` (skip the short last batch: the reference trains and validates on it, src/tools/train.py:27-38 builds both
+loaders with the default ``drop_last=False``), ``--lr_resume_fix`` (on resume, continue the cosine schedule where the saved run
+left it; the reference builds a FRESH ``CosineAnnealingLR`` behind ``optimizer.load_state_dict``, src/tools/train.py:50-58, and
+that is the default here too).
 
 Datasets (src/tools/train.py:24-38 builds them from files this repository cannot ship): ``main(args, train_set=,
 val_set=)`` takes any ``torch.utils.data.Dataset`` whose samples are tuples starting with ``(image, joint_2d)`` --
@@ -61,6 +66,9 @@ def parse_args(argv=None, phase="train"):
     p.add_argument("--synthetic", default=0, type=int, help="train on N seeded synthetic samples")
     p.add_argument("--val_synthetic", default=0, type=int)
     p.add_argument("--no_graph", action="store_true")
+    p.add_argument("--transfer_from", default=None, type=str, help="checkpoint --transfer loads (default: the reference's path)")
+    p.add_argument("--drop_last", action="store_true", help="skip the short last batch of the training epoch (reference: trained on)")
+    p.add_argument("--lr_resume_fix", action="store_true", help="resume the cosine schedule at the saved epoch (reference: fresh schedule)")
     args = p.parse_args(argv)
     args.phase = phase
     args.model = args.root.split("/")[0]                  # src/tools/dataset.py:59 overwrites it from the name
@@ -146,9 +154,78 @@ def resume_checkpoint(model, path):
     return sd["best_loss"], sd["epoch"] + 1, sd["count"], sd.get("optimizer_state_dict")
 
 
+def transfer_path(args):
+    """Where --transfer reads its weights: src/utils/argparser.py:167-175 hard-codes output/<model>/frei/ori (relative to the
+    working directory, NOT --root_path)."""
+    return args.transfer_from or os.path.join(f"output/{args.model}/frei/ori", "checkpoint-good/state_dict.bin")
+
+
+def load_model_state(model, args):
+    """The checkpoint logic of load_model (src/utils/argparser.py:100-189) on an already built model: resume from
+    <output_dir>/checkpoint-good/state_dict.bin unless --reset, THEN (--transfer) overwrite the weights with those of the transfer
+    checkpoint, keeping the resumed epoch / best loss / count / optimizer state (the reference discards the transfer checkpoint's:
+    `_, _, _model, _, _ = resume_checkpoint(...)`, :169).  A missing transfer checkpoint is an error, as in the reference (torch.load).
+    Returns (best_loss, first epoch, count, optimizer_state | None)."""
+    best_loss, epo, count, opt_state = np.inf, 0, 0, None
+    ckpt = os.path.join(args.output_dir, "checkpoint-good", "state_dict.bin")
+    if os.path.isfile(ckpt) and not args.reset:
+        best_loss, epo, count, opt_state = resume_checkpoint(model, ckpt)
+    if args.transfer:
+        resume_checkpoint(model, transfer_path(args))
+        if int(os.environ.get("RANK", "0")) == 0:
+            print("Transfer_Loading ===> %s" % transfer_path(args))
+    return best_loss, epo, count, opt_state
+
+
+def make_scheduler(optimizer, args, epo, opt_state):
+    """Optimizer state + learning-rate schedule at (re)start, src/tools/train.py:45-58: the saved optimizer state is loaded unless
+    --optim, THEN a fresh CosineAnnealingLR(T_max=args.epoch) is built on the optimizer -- on a resume its param_groups carry the
+    saved run's `lr` and `initial_lr`, so the schedule restarts its cosine from the saved learning rate (what the installed PyTorch
+    does with such a group is the reference's behaviour, not restated here).  --lr_resume_fix instead fast-forwards a schedule that
+    starts at args.lr by the epochs already run.  Call it AFTER the TrainStep exists (the fused Adam binds the arena there)."""
+    if opt_state and not args.optim:
+        optimizer.load_state_dict(opt_state)
+    if getattr(args, "lr_resume_fix", False):
+        for g in optimizer.param_groups:
+            g["lr"] = args.lr
+            g.pop("initial_lr", None)
+        scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, T_max=args.epoch)
+        for _ in range(epo):
+            scheduler.step()
+        return scheduler
+    return torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, T_max=args.epoch)
+
+
+def run_epochs(args, epo, train_loader, train_batch, validate_fn, save_fn, optimizer, scheduler, stopper, log=print, rank=0, world=1):
+    """The epoch loop of src/tools/train.py:60-117 with the device work behind three callables: train_batch(it, batch) runs one
+    iteration (any batch size: the short last batch included) and returns a callable that reads the running loss (called once per
+    logging interval: the only device->host read of the loop), validate_fn() -> (val_loss, pck, epe), save_fn(epoch, best, count).
+    Same order as the reference: train, validate, best / count bookkeeping, checkpoint on improvement, break on count == --count,
+    THEN scheduler.step()."""
+    for epoch in range(epo, args.epoch):
+        t0, seen = time.time(), 0
+        for it, batch in enumerate(train_loader):
+            read_loss = train_batch(it, batch)
+            seen += len(batch[0])
+            if it % args.logging_steps == 0 and rank == 0:
+                log(f"epoch {epoch} iter {it}/{len(train_loader)} loss {float(read_loss()):.6f} "
+                    f"{world * seen / (time.time() - t0 + 1e-9):.0f} img/s lr {optimizer.param_groups[0]['lr']:.2e}")
+        val_loss, pck, epe = validate_fn()
+        if rank == 0:
+            log(f"epoch {epoch} valid loss {val_loss:.6f} pck {pck:.2f}% epe {epe * 0.26:.2f} mm")     # method.py:131
+        improved, stop = stopper.update(val_loss)     # val_loss is rank-invariant (reduce_validation): collective decision
+        if improved:
+            save_fn(epoch, stopper.best_loss, stopper.count)
+        if stop:
+            break
+        scheduler.step()
+    return stopper.best_loss
+
+
 def validate(model, loader, args, u8_step=None):
     """Runner.run validation branch (src/utils/method.py:218-287): loss, PCK@0.2 (bbox-normalised), EPE.
-    ``u8_step``: an InferStep(input_u8=...) of the model for loaders that yield raw uint8 frames."""
+    ``u8_step``: an InferStep(input_u8=...) of the model for loaders that yield raw uint8 frames, or a callable
+    batch size -> InferStep (the short last batch of the loader needs a step of its own shape)."""
     from lighthand_amd.heatmap import JointsMSELoss, max_preds_device, render_targets
     from lighthand_amd.metrics import device_pck_epe
     model.eval()
@@ -158,9 +235,10 @@ def validate(model, loader, args, u8_step=None):
         for batch in loader:
             images, joints = batch[0].cuda(non_blocking=True), batch[1][..., :2].float().cuda(non_blocking=True)
             if images.dtype == torch.uint8:
-                u8_step.refresh_weights()
-                u8_step(images)
-                pred = u8_step.heatmaps
+                st = u8_step(images.shape[0]) if callable(u8_step) and not hasattr(u8_step, "heatmaps") else u8_step
+                st.refresh_weights()
+                st(images)
+                pred = st.heatmaps
             else:
                 pred = model(images)
             hs = pred.shape[-1]
@@ -224,49 +302,60 @@ def main(args, train_set=None, val_set=None):
     workers = args.num_workers if not isinstance(train_set.base, SyntheticHands) else 0
     # persistent workers: a worker is forked from THIS process, which by the first epoch holds a HIP context and hundreds of
     # GB of mappings (~20 s per fork measured on the GPU box) -- fork them once per loader, not once per epoch
-    kw = dict(batch_size=args.batch_size, drop_last=True, pin_memory=True, num_workers=workers, persistent_workers=workers > 0)
-    train_loader = torch.utils.data.DataLoader(train_set, shuffle=True, **kw)
-    val_loader = torch.utils.data.DataLoader(val_set, shuffle=False, **kw)
+    # the reference builds both loaders with drop_last=False (src/tools/train.py:27-38): the short last batch is trained on and
+    # validated on.  Data-parallel training keeps whole batches only (every rank must take part in every bucket's exchange, and the
+    # reference has no multi-GPU loop to be faithful to); --drop_last asks for that on one GPU too.
+    kw = dict(batch_size=args.batch_size, pin_memory=True, num_workers=workers, persistent_workers=workers > 0)
+    train_loader = torch.utils.data.DataLoader(train_set, shuffle=True, drop_last=bool(args.drop_last or world > 1), **kw)
+    val_loader = torch.utils.data.DataLoader(val_set, shuffle=False, drop_last=False, **kw)
 
     model = build_model(args).cuda().set_precision(args.precision)
-    best_loss, epo, count, opt_state = np.inf, 0, 0, None
-    ckpt = os.path.join(args.output_dir, "checkpoint-good", "state_dict.bin")
-    if os.path.isfile(ckpt) and not args.reset:
-        best_loss, epo, count, opt_state = resume_checkpoint(model, ckpt)
+    best_loss, epo, count, opt_state = load_model_state(model, args)
     optimizer = Adam(model.parameters(), lr=args.lr)
-    scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, T_max=args.epoch)
-    for _ in range(epo):
-        scheduler.step()
     sync = parallel.GradSync(world) if world > 1 else None
     # raw uint8 frames: ToTensor / Resize / ColorJitter(0.5, 0.5, 0.5, 0.5) / Normalize fused on the device (dataset.py:128-159)
     jitter = (0.5, 0.5, 0.5, 0.5) if kind == "u8" and args.ratio_of_aug > 0 else None
     step = TrainStep(model, args.batch_size, args.size, args.size, optimizer=optimizer, use_graph=not args.no_graph, grad_sync=sync,
                      input_u8=raw_hw, color_jitter=jitter)
-    if opt_state and not args.optim:                      # src/tools/train.py:50
-        optimizer.load_state_dict(opt_state)
-    val_step = InferStep(model, args.batch_size, args.size, args.size, input_u8=val_hw) if val_kind == "u8" else None
+    scheduler = make_scheduler(optimizer, args, epo, opt_state)       # src/tools/train.py:50-58, in the reference's order
+    steps = {args.batch_size: step}
+
+    def step_for(b):
+        """The short last batch of an epoch runs on a step of its own shape (plans are per static shape): eager launches, the
+        library's static kernel choice (one batch per epoch is not worth a measurement), the same optimizer -- moments and step
+        count live in the optimizer, so full and short batches update one Adam state, as in the reference loop."""
+        st = steps.get(b)
+        if st is None:
+            prev = os.environ.get("LH_AUTOTUNE")
+            os.environ["LH_AUTOTUNE"] = "0"
+            try:
+                st = steps[b] = TrainStep(model, b, args.size, args.size, optimizer=optimizer, use_graph=False, grad_sync=sync,
+                                          input_u8=raw_hw, color_jitter=jitter)
+            finally:
+                if prev is None:
+                    os.environ.pop("LH_AUTOTUNE", None)
+                else:
+                    os.environ["LH_AUTOTUNE"] = prev
+        return st
+
+    val_steps = {}
+
+    def val_step_for(b):
+        if b not in val_steps:
+            val_steps[b] = InferStep(model, b, args.size, args.size, input_u8=val_hw)
+        return val_steps[b]
+
+    def train_batch(it, batch):
+        images, joints, aug = batch
+        st = step_for(images.shape[0])
+        st(images.cuda(non_blocking=True), joints.cuda(non_blocking=True), aug=aug if jitter else None)
+        return lambda: st.loss
 
     stopper = EarlyStop(best_loss, count, args.count)
-    for epoch in range(epo, args.epoch):
-        t0, seen, running = time.time(), 0, None
-        for it, (images, joints, aug) in enumerate(train_loader):
-            step(images.cuda(non_blocking=True), joints.cuda(non_blocking=True), aug=aug if jitter else None)
-            seen += images.shape[0]
-            if it % args.logging_steps == 0:            # the ONLY device->host read of the loop
-                running = float(step.loss)
-                if rank == 0:
-                    print(f"epoch {epoch} iter {it}/{len(train_loader)} loss {running:.6f} "
-                          f"{world * seen / (time.time() - t0 + 1e-9):.0f} img/s lr {optimizer.param_groups[0]['lr']:.2e}")
-        val_loss, pck, epe = validate(model, val_loader, args, val_step)
-        if rank == 0:
-            print(f"epoch {epoch} valid loss {val_loss:.6f} pck {pck:.2f}% epe {epe * 0.26:.2f} mm")     # method.py:131
-        improved, stop = stopper.update(val_loss)     # val_loss is rank-invariant (reduce_validation): collective decision
-        if improved:
-            save_checkpoint(model, args, epoch, optimizer, stopper.best_loss, stopper.count, "good")
-        if stop:
-            break
-        scheduler.step()
-    return stopper.best_loss
+    return run_epochs(args, epo, train_loader, train_batch,
+                      lambda: validate(model, val_loader, args, val_step_for if val_kind == "u8" else None),
+                      lambda epoch, best, cnt: save_checkpoint(model, args, epoch, optimizer, best, cnt, "good"),
+                      optimizer, scheduler, stopper, rank=rank, world=world)
 
 
 if __name__ == "__main__":

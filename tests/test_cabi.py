@@ -144,6 +144,42 @@ def test_explicit_wgrad_configuration_must_fit():
     assert b"does not fit" in lib.lh_last_error()
 
 
+def test_wgrad_table_planner_runs_without_a_device():
+    """lh_wgrad_table_build's size query is host arithmetic: the weight gradients of R50's stage 4 at batch 64 (three bottlenecks +
+    the projection, pose_resnet.py:61-99, 177-192: M = 64 x 8 x 8 pixels) in one table.  Automatic item length: the tiles alone fill the
+    machine twice -> split-free, the 1x1 members written by the kernel itself (only the 3x3 ones need the fold launch); a short item
+    length splits every member; an unknown tile is refused."""
+    from lighthand_amd import _lib
+    lib = _lib.load()
+    shapes = [(512, 2048, 1), (512, 512, 3), (2048, 512, 1)] * 2 + [(512, 1024, 1), (512, 512, 3), (2048, 512, 1), (2048, 1024, 1)]
+    descs, rs, calls = [], [], (_lib.WgradCall * len(shapes))()
+    for i, (cout, cin, k) in enumerate(shapes):
+        d = _conv_desc(cin, cout, hw=8, k=k)
+        d.n = 64
+        taps = (C.c_int * (2 * k * k))(*[v for r in range(k) for q in range(k) for v in (r, q)])
+        descs.append(d); rs.append(taps)
+        calls[i].d, calls[i].rows, calls[i].x, calls[i].dy, calls[i].dy_pix_stride = C.pointer(d), 0, 4096, 8192, cout
+        calls[i].n_out, calls[i].n_in, calls[i].grad = cout, cin, 1 << 20
+        calls[i].so, calls[i].si, calls[i].sr, calls[i].ss = cin * k * k, k * k, k, 1
+        calls[i].taps_rs, calls[i].accumulate = C.cast(taps, C.POINTER(C.c_int)), 0
+    info = _lib.WgradTableInfo()
+    cfg = (C.c_int * 4)(128, 128, 64, 3)
+    assert lib.lh_wgrad_table_build(calls, len(shapes), _lib.LH_BF16, cfg, 0, None, None, 0, C.byref(info)) == 0, lib.lh_last_error()
+    tiles = sum((co // 128) * (ci // 128) * k * k for co, ci, k in shapes)
+    assert (info.n_problems, info.n_items, info.nsplit_max, info.n_fold) == (len(shapes), tiles, 1, 3)
+    assert info.target_stages == 64 * 8 * 8 // 64 and info.n_fold_items > 0
+    assert info.workspace_bytes == 3 * 512 * 512 * 9 * 4 and info.table_bytes > info.off_fold_items > info.off_fold_args > info.off_items > 0
+    assert lib.lh_wgrad_table_build(calls, len(shapes), _lib.LH_BF16, cfg, 8, None, None, 0, C.byref(info)) == 0
+    assert info.nsplit_max == 8 and info.n_items == 8 * tiles and info.n_fold == len(shapes)
+    big = (C.c_int * 4)(256, 256, 32, 3)
+    assert lib.lh_wgrad_table_build(calls, len(shapes), _lib.LH_BF16, big, 0, None, None, 0, C.byref(info)) == 0
+    assert 3 * 256 < info.n_items < 6 * 256 and info.nsplit_max >= 2   # 236 tiles do not fill 256 CUs twice: about four rounds of items
+    bad = (C.c_int * 4)(96, 96, 64, 3)
+    assert lib.lh_wgrad_table_build(calls, len(shapes), _lib.LH_BF16, bad, 0, None, None, 0, C.byref(info)) == -3
+    assert b"not compiled in" in lib.lh_last_error()
+    assert lib.lh_wgrad_table_build(calls, len(shapes), _lib.LH_F32, cfg, 0, None, None, 0, C.byref(info)) == -1
+
+
 def test_ctypes_structs_mirror_the_header_layout(tmp_path):
     """The ctypes mirrors in lighthand_amd/_lib.py must have the size and the field offsets of the structs that
     include/lighthand_hip.h declares: a probe compiled with gcc against the header prints sizeof / offsetof of every field
@@ -158,7 +194,7 @@ def test_ctypes_structs_mirror_the_header_layout(tmp_path):
              "lh_igemm_call": _lib.IgemmCall, "lh_wgrad_call": _lib.WgradCall, "lh_fuse_fwd_call": _lib.FuseFwdCall,
              "lh_fuse_bwd_call": _lib.FuseBwdCall, "lh_bn_finalize_call": _lib.BnFinalizeCall, "lh_head": _lib.Head,
              "lh_pack_item": _lib.PackItem, "lh_pack_out": _lib.PackOut, "lh_pack_conv": _lib.PackConv, "lh_bn_bwd_gate": _lib.BnBwdGate,
-             "lh_bottleneck_desc": _lib.BottleneckDesc}
+             "lh_bottleneck_desc": _lib.BottleneckDesc, "lh_wgrad_table_info": _lib.WgradTableInfo}
     rename = {"in_": "in", "pad_": None}                       # ctypes-side spellings; None = padding without a C name
     lines = []
     for cname, cls in pairs.items():

@@ -942,108 +942,6 @@ def test_direct3x3_kernel_bn_statistics(case, forced_plans):
     assert rel_err(b[0], ref.torch_forward(x).detach()) < TOL["bf16"]
 
 
-D3_CASES = [
-    # cin, cout, n, h, w -- 3x3 / stride 1 / padding 1 with 32 or 64 input channels (pose_resnet.py:66-72 stage 1, pose_hrnet.py:139-185)
-    (64, 64, 2, 16, 16), (64, 64, 3, 12, 20), (64, 128, 1, 9, 9), (32, 32, 2, 16, 32), (32, 64, 1, 7, 5), (64, 32, 2, 8, 16), (64, 256, 1, 8, 8),
-]
-
-
-@pytest.mark.parametrize("precision", ["bf16", "fp16"])
-@pytest.mark.parametrize("case", D3_CASES)
-def test_direct3x3_kernel_configurations(case, precision, forced_plans):
-    """The direct 3x3 kernel (conv3x3_direct_kernel.h: LDS-resident weights, one input patch per 8 x 16 tile, taps =
-    offsets into the patch) forced on forward and data gradient: bit-equal with the tiled LDS-DMA kernel (same tap-major
-    K order, same epilogue arithmetic) incl. ragged maps (partial tiles, zero padding at every border), several output
-    channel blocks, and within tolerance of PyTorch."""
-    ConvNet, _ = _mods()
-    cin, cout, n, h, w = case
-    torch.manual_seed(13)
-    x = quant(torch.randn(n, cin, h, w), precision)
-    ref_m = nn.Conv2d(cin, cout, 3, 1, 1, bias=False)
-    with torch.no_grad():
-        ref_m.weight.copy_(quant(ref_m.weight, precision))
-    xr = x.clone().requires_grad_(True)
-    ref = ref_m(xr)
-    dy = quant(torch.randn_like(ref), precision)
-    ref.backward(dy)
-
-    def run(pick):
-        forced_plans.force_cfg = pick
-        m = ConvNet(cin, cout, 3, 1, 1, bias=False)
-        m.conv.load_state_dict(ref_m.state_dict())
-        return _run_plan(m, x, lambda o: dy, precision)
-
-    base = run(lambda cands: next(c for c in cands if c[2] not in (1, 100)))
-    assert rel_err(base[0], ref.detach()) < TOL[precision] and rel_err(base[1], xr.grad) < TOL[precision]
-    used = []
-
-    def pick(cands):
-        d3 = [c for c in cands if c[2] == 100]
-        used.append(bool(d3))
-        return d3[0] if d3 else cands[0]
-    out, dx, _ = run(pick)
-    assert torch.equal(out, base[0]) and torch.equal(dx, base[1]), case
-    # forward: cin in {32, 64}; data gradient: its K is cout
-    assert used[0] and (len(used) < 2 or used[1] == (cout in (32, 64)))
-
-
-@pytest.mark.parametrize("case", [(64, 64, 2, 16, 16), (32, 32, 3, 12, 20), (64, 128, 1, 9, 9)])
-def test_direct3x3_kernel_bn_statistics(case, forced_plans):
-    """3x3 conv -> BN -> ReLU -> 1x1 with the direct kernel forced: one statistics row per workgroup.  Outputs equal the
-    tiled kernel's within the 16-bit tolerance, running statistics and BN gradients agree to fp32 summation order."""
-    import copy
-    from lighthand_amd.module import HipModule
-    cin, cout, n, h, w = case
-
-    class Net(HipModule):
-        def __init__(self):
-            super().__init__()
-            self.conv = nn.Conv2d(cin, cout, 3, 1, 1, bias=False)
-            self.bn = nn.BatchNorm2d(cout, momentum=0.1)
-            self.out = nn.Conv2d(cout, 8, 1, bias=False)
-
-        def describe(self, gb):
-            x = gb.input_act(cin)
-            gb.output(gb.conv(gb.fuse([(gb.conv(x, "conv", 3, 1, 1), "bn")]), "out", 1, 1, 0))
-
-        def torch_forward(self, x):
-            return self.out(F.relu(self.bn(self.conv(x))))
-
-    torch.manual_seed(23)
-    proto = Net()
-    with torch.no_grad():
-        for p_ in proto.parameters():
-            p_.copy_(p_.to(torch.bfloat16).float())
-    x = torch.randn(n, cin, h, w).to(torch.bfloat16).float()
-    res = {}
-    for which in ("tiled", "direct"):
-        if which == "tiled":
-            forced_plans.force_cfg = lambda cands: next(c for c in cands if c[2] not in (1, 100))
-        else:
-            forced_plans.force_cfg = lambda cands: next((c for c in cands if c[2] == 100), cands[0])
-        m = copy.deepcopy(proto)
-        torch.manual_seed(24)
-        out, dx, grads = _run_plan(m, x, lambda o: torch.randn_like(o), "bf16")
-        res[which] = (out, dx, grads, {k: v.cpu().clone() for k, v in m.state_dict().items() if "running" in k})
-        plan = next(iter(m._lh_plans.values()))
-        assert any(meta[2].startswith("conv3x3_direct_kernel") and meta[2].endswith("true>") for meta in plan.profile_meta) == (which == "direct")
-    a, b = res["tiled"], res["direct"]
-    if os.environ.get("LH_DBG"):
-        for nm, r in res.items():
-            print("DBG", case, nm, "out nan", int(torch.isnan(r[0]).sum()), "dx nan", int(torch.isnan(r[1]).sum()), "of", r[1].numel(),
-                  {k: int(torch.isnan(v).sum()) for k, v in r[2].items()})
-            nz = torch.isnan(r[1]).nonzero()
-            if len(nz):
-                print("DBG first nan idx", nz[:5].tolist(), "last", nz[-3:].tolist())
-    for k in a[3]:
-        assert rel_err(a[3][k], b[3][k]) < 1e-5, k
-    assert rel_err(a[0], b[0]) < 1e-2 and rel_err(a[1], b[1]) < 2e-2
-    for k in ("bn.weight", "bn.bias"):
-        assert rel_err(a[2][k], b[2][k]) < 2e-2, k
-    ref = copy.deepcopy(proto).train()
-    assert rel_err(b[0], ref.torch_forward(x).detach()) < TOL["bf16"]
-
-
 @pytest.mark.parametrize("precision", ["bf16", "fp16"])
 def test_short_k_run_does_not_read_past_the_operand(precision, forced_plans):
     """A K run SHORTER than one ring stage (8 channels = 16 bytes per pixel against 64-byte stages: the data gradient of a

@@ -248,3 +248,140 @@ def test_pmc_traffic_tool_and_profile_guard(tmp_path):
     assert bench.profile_average_ns(str(stats), k) == 30000.5
     assert bench.profile_average_ns(str(stats), "no_such_kernel<float>") is None
     assert bench.profile_average_ns(str(tmp_path / "missing.csv"), k) is None
+
+
+def _loop_pieces(tmp_path, tag):
+    """A tiny CPU model + index datasets for the host-loop tests: 2.5 training batches, 1.5 validation batches."""
+    import torch
+
+    class Idx(torch.utils.data.Dataset):
+        def __init__(self, n):
+            self.n = n
+
+        def __len__(self):
+            return self.n
+
+        def __getitem__(self, i):
+            return torch.full((3,), float(i)), torch.zeros(21, 2)
+
+    torch.manual_seed(0)
+    model = torch.nn.Linear(3, 2)
+    return model, Idx(20), Idx(12), str(tmp_path / tag)
+
+
+def test_epoch_loop_matches_the_reference_loop(tmp_path):
+    """tools/train.py's host loop (run_epochs + load_model_state + make_scheduler) against the oracle's restatement of
+    src/tools/train.py:13-120 / src/utils/argparser.py:100-189 on the CPU, device work replaced by a real Adam step on a tiny model:
+    a 2.5-batch epoch (the short last batch IS trained and validated on, train.py:27-38), best-loss / count / early-stop decisions,
+    and a RESUME: the saved optimizer state is loaded and a fresh CosineAnnealingLR is built behind it (train.py:50-58) -- the
+    learning rate of every epoch must equal the oracle's, as must the weights at the end.  --lr_resume_fix is the opt-in
+    continuation of the first run's schedule; --transfer overwrites the weights and keeps the resumed counters."""
+    import copy
+    import types
+    import torch
+    from lighthand_amd.tools import train as T
+    from oracle import loop as O
+
+    val_seq = [1.0, 0.8, 0.9, 0.7, 0.75, 0.76, 0.77, 0.5, 0.6, 0.61, 0.62, 0.63]
+
+    def train_batch_ref(model, optimizer, batch):
+        optimizer.zero_grad()
+        model(batch[0]).pow(2).mean().backward()
+        optimizer.step()
+
+    def run_product(model, train_set, val_set, out_dir, epochs, extra=()):
+        args = T.parse_args(["--root_path", out_dir, "--batch_size", "8", "--epoch", str(epochs), "--count", "3", "--lr", "0.01", *extra])
+        args.logging_steps = 2
+        torch.manual_seed(9001)
+        tl = torch.utils.data.DataLoader(train_set, batch_size=8, shuffle=True, drop_last=args.drop_last)
+        vl = torch.utils.data.DataLoader(val_set, batch_size=8, shuffle=False, drop_last=False)
+        best, epo, count, opt_state = T.load_model_state(model, args)
+        optimizer = torch.optim.Adam(model.parameters(), lr=args.lr)
+        scheduler = T.make_scheduler(optimizer, args, epo, opt_state)
+        trace, cur = [], {}
+
+        def train_batch(it, batch):
+            if it == 0:
+                cur.update(lr=optimizer.param_groups[0]["lr"], batch_sizes=[])
+            cur["batch_sizes"].append(len(batch[0]))
+            train_batch_ref(model, optimizer, batch)
+            return lambda: 0.0
+
+        def validate_fn():
+            cur["val_batch_sizes"] = [len(b[0]) for b in vl]
+            cur["epoch"] = epo + len(trace)
+            return val_seq[cur["epoch"]], 0.0, 0.0
+
+        def save_fn(epoch, b, c):
+            cur["saved"] = True
+            T.save_checkpoint(model, args, epoch, optimizer, b, c)
+
+        stopper = T.EarlyStop(best, count, args.count)
+        orig_update = stopper.update
+
+        def update(v):
+            r = orig_update(v)
+            trace.append(dict(cur, val_loss=v, saved=r[0], count=stopper.count))
+            cur.clear()
+            return r
+        stopper.update = update
+        T.run_epochs(args, epo, tl, train_batch, validate_fn, save_fn, optimizer, scheduler, stopper, log=lambda *_: None)
+        return trace, args
+
+    m0, train_set, val_set, out_p = _loop_pieces(tmp_path, "product")
+    _, _, _, out_o = _loop_pieces(tmp_path, "oracle")
+    mp, mo = copy.deepcopy(m0), copy.deepcopy(m0)
+    # first run: best at epoch 3 (0.7), then 0.75, 0.76, 0.77 -> count reaches --count = 3 at epoch 6: stopped after 7 of 12 epochs
+    tp, args = run_product(mp, train_set, val_set, out_p, 12)
+    to = O.main(mo, train_set, val_set, os.path.join(out_o, "simplebaseline/ours/84k"), 8, 12, 0.01, 3, train_batch_ref, lambda e: val_seq[e])
+    assert [e["batch_sizes"] for e in tp] == [e["batch_sizes"] for e in to] == [[8, 8, 4]] * len(to)
+    assert [e["val_batch_sizes"] for e in tp] == [[8, 4]] * len(to)
+    assert len(tp) == len(to) == 7 and to[-1]["count"] == 3                       # stopped early by --count
+    for a, b in zip(tp, to):
+        assert (a["epoch"], a["saved"], a["count"], a["val_loss"]) == (b["epoch"], b["saved"], b["count"], b["val_loss"])
+        assert a["lr"] == b["lr"], (a["epoch"], a["lr"], b["lr"])
+    for a, b in zip(mp.parameters(), mo.parameters()):
+        assert torch.equal(a, b)
+    ck_p = torch.load(os.path.join(args.output_dir, "checkpoint-good", "state_dict.bin"))
+    ck_o = torch.load(os.path.join(out_o, "simplebaseline/ours/84k", "checkpoint-good", "state_dict.bin"))
+    assert sorted(ck_p) == sorted(ck_o) and (ck_p["epoch"], ck_p["count"], ck_p["best_loss"]) == (ck_o["epoch"], ck_o["count"], ck_o["best_loss"]) == (3, 0, 0.7)
+    # resume (a new process in the reference: fresh model object, state from the checkpoint)
+    mp2, mo2 = copy.deepcopy(m0), copy.deepcopy(m0)
+    tp2, _ = run_product(mp2, train_set, val_set, out_p, 12)
+    to2 = O.main(mo2, train_set, val_set, os.path.join(out_o, "simplebaseline/ours/84k"), 8, 12, 0.01, 3, train_batch_ref, lambda e: val_seq[e])
+    assert [e["epoch"] for e in tp2] == [e["epoch"] for e in to2] and tp2[0]["epoch"] == 4
+    assert [e["lr"] for e in tp2] == [e["lr"] for e in to2]
+    assert [(e["saved"], e["count"]) for e in tp2] == [(e["saved"], e["count"]) for e in to2]
+    for a, b in zip(mp2.parameters(), mo2.parameters()):
+        assert torch.equal(a, b)
+    # the reference's resumed schedule is NOT the continuation of the first run's: the opt-in flag gives that
+    import math
+    mp3 = copy.deepcopy(m0)
+    saved_ck = torch.load(os.path.join(args.output_dir, "checkpoint-good", "state_dict.bin"))
+    tp3, _ = run_product(mp3, train_set, val_set, out_p, 12, extra=("--lr_resume_fix",))
+    e0 = saved_ck["epoch"] + 1
+    assert tp3[0]["epoch"] == e0 and abs(tp3[0]["lr"] - 0.01 * (1 + math.cos(math.pi * e0 / 12)) / 2) < 1e-12
+    # --optim: the saved optimizer state is ignored (train.py:50): a fresh Adam at args.lr
+    tp4, _ = run_product(copy.deepcopy(m0), train_set, val_set, out_p, 12, extra=("--optim",))
+    to4 = O.main(copy.deepcopy(m0), train_set, val_set, os.path.join(out_o, "simplebaseline/ours/84k"), 8, 12, 0.01, 3, train_batch_ref,
+                 lambda e: val_seq[e], optim=True)
+    assert [e["lr"] for e in tp4] == [e["lr"] for e in to4] and tp4[0]["lr"] == 0.01
+    # --transfer: weights from the transfer checkpoint, counters from the resume point; a missing file is an error as in the reference
+    donor = copy.deepcopy(m0)
+    with torch.no_grad():
+        for p in donor.parameters():
+            p.fill_(0.25)
+    tdir = tmp_path / "donor" / "checkpoint-good"
+    tdir.mkdir(parents=True)
+    torch.save({"epoch": 99, "optimizer_state_dict": {}, "best_loss": 0.0, "count": 7, "model_state_dict": donor.state_dict()}, tdir / "state_dict.bin")
+    a5 = T.parse_args(["--root_path", out_p, "--transfer", "--transfer_from", str(tdir / "state_dict.bin")])
+    m5 = copy.deepcopy(m0)
+    best, epo, count, opt_state = T.load_model_state(m5, a5)
+    m6 = copy.deepcopy(m0)
+    assert (best, epo, count) == O.load_model(m6, os.path.join(out_o, "simplebaseline/ours/84k"), False, True, str(tdir / "state_dict.bin"))[:3]
+    assert all(bool((p == 0.25).all()) for p in m5.parameters()) and all(torch.equal(a, b) for a, b in zip(m5.parameters(), m6.parameters()))
+    assert opt_state and epo > 0                                  # counters and optimizer state are the RESUME point's, not the donor's (99 / 7)
+    a7 = T.parse_args(["--root_path", out_p, "--transfer"])
+    assert T.transfer_path(a7) == "output/simplebaseline/frei/ori/checkpoint-good/state_dict.bin"      # argparser.py:171-173
+    with pytest.raises(FileNotFoundError):
+        T.load_model_state(copy.deepcopy(m0), a7)
