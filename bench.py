@@ -118,7 +118,8 @@ def profile_kernels(step, iters=3, plan=None, fwd_only=False):
                 if m is None:
                     call(s)
                     continue
-                parts = _split_wgrad(plan.lib, call) if getattr(call, "fn", None) is plan.lib.lh_wgrad_fused else None
+                parts = _split_wgrad(plan.lib, call) if getattr(call, "fn", None) is plan.lib.lh_wgrad_fused else \
+                    _split_table(plan.lib, call) if getattr(call, "fn", None) is plan.lib.lh_wgrad_table_run else None
                 if parts:                                        # weight gradient and its split-K fold are two kernels: time them apart
                     for fn_, mm in zip(parts, (m, ("wgrad_reduce(kernels)", 0.0, 0.0))):
                         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -165,6 +166,55 @@ def _split_wgrad(lib, call):
     else:
         first = lambda st: check(lib.lh_wgrad(d, x, dy, dys, n_out, n_in, ws, dt, st), "lh_wgrad")
     return first, (lambda st: check(lib.lh_wgrad_reduce(d, ws, grad, n_out, n_in, so, si, sr, ss, taps, acc, dt, st), "lh_wgrad_reduce"))
+
+
+def _split_table(lib, call):
+    """lh_wgrad_table_run = the table grid of the weight-gradient kernel, then the fold grid: the same call with
+    lh_wgrad_table_info.run_parts = 1 / 2 runs each by itself (None when the table needs no fold launch)."""
+    import copy
+    import ctypes as C
+    from lighthand_amd._lib import check
+    blob, info_ref, dt = call.args
+    info = info_ref._obj
+    if info.n_fold_items <= 0:
+        return None
+    a, b = copy.copy(info), copy.copy(info)
+    a.run_parts, b.run_parts = 1, 2
+    call.keep = (call.keep, a, b)
+    return (lambda st: check(lib.lh_wgrad_table_run(blob, C.byref(a), dt, st), "lh_wgrad_table_run (gradient grid)"),
+            lambda st: check(lib.lh_wgrad_table_run(blob, C.byref(b), dt, st), "lh_wgrad_table_run (fold grid)"))
+
+
+def epe_auc_parity():
+    """The "EPE/AUC parity" half of BASELINE.json's metric: pred_eval's per-category AUC and EPE (src/utils/argparser.py:326-388)
+    computed by the DEVICE path (lh_pck_curve -> metrics.auc_from_counts) on the synthetic evaluation set of golden G7, against the
+    values the REFERENCE's own pred_eval produced for that set (tests/golden/g7_metrics.json, generated by importing the reference:
+    tests/golden/make_golden.py) -- thresholds pckb [0.1, 0.3], mm [0, 30], mm [0, 50], four occlusion categories.
+    The model-side parity (heat-maps, arg-max indices) lives in the tests; this is the metric arithmetic on identical predictions."""
+    from lighthand_amd.metrics import auc_from_counts, device_pck_curve
+    path = os.path.join(ROOT, "tests", "golden", "g7_metrics.json")
+    try:
+        g = json.load(open(path))
+    except (OSError, ValueError):
+        return {"status": "tests/golden/g7_metrics.json missing"}
+    cats = g["evaluation"][0]
+    d_auc = d_epe = 0.0
+    n = 0
+    curves_equal = True
+    for key, T, method in (("pckb", [0.1, 0.3], "pckb"), ("mm30", [0, 30], "mm"), ("mm50", [0, 50], "mm")):
+        for cat, v in cats.items():
+            pred = torch.tensor(v["pred"], dtype=torch.float32).cuda()
+            gt = torch.tensor(v["gt"], dtype=torch.float32).cuda()
+            bb = torch.tensor(v["bb"], dtype=torch.float32).cuda()
+            counts, nvis, dsum, nall = (t.cpu().numpy() for t in device_pck_curve(pred, gt, bb, T, method))
+            auc, epe, curve = auc_from_counts(counts, nvis[0], dsum[0], nall[0], T, method)
+            want = g["pred_eval"][key][cat]
+            d_auc, d_epe = max(d_auc, abs(auc - want[0])), max(d_epe, abs(epe - want[1]))
+            curves_equal = curves_equal and bool(np.allclose(curve, want[2], rtol=0, atol=1e-9))
+            n += 1
+    return {"max_abs_auc_diff": d_auc, "max_abs_epe_mm_diff": d_epe, "pck_curves_equal": curves_equal, "cases": n,
+            "against": "the reference's pred_eval on the same predictions (golden G7: 4 occlusion categories x pckb[0.1,0.3] / mm[0,30] / mm[0,50])",
+            "within_0p05_mm": bool(d_epe < 0.05)}
 
 
 def kernel_roofline(flops, nbytes, ms, es=2):
@@ -283,7 +333,8 @@ def main():
     ap.add_argument("--grad-buckets", default="fp32", choices=["fp32", "bf16"], help="dtype the gradient buckets travel in")
     ap.add_argument("--grad-algo", default="allreduce", choices=["allreduce", "direct"],
                     help="how a gradient bucket is exchanged: RCCL's all-reduce (its own algorithm choice), or 'direct' = all-to-all + local "
-                         "sum + all-gather, i.e. reduce-scatter and all-gather with all seven xGMI peers at once (SURVEY 8e; --comm torch only)")
+                         "sum + all-gather, i.e. reduce-scatter and all-gather with all seven xGMI peers at once (SURVEY 8e).  With --comm lh the three "
+                         "steps are C-ABI launches inside the ONE captured graph of the step")
     ap.add_argument("--bucket-mib", type=int, default=64,
                     help="gradient bucket size for --gpus > 1.  64 MiB = 3 segments for R50: the data-parallel FORM of the step costs "
                          "+0.29 ms on one GPU (32 MiB / 5 segments: +0.63 ms; profiles/r05_dp_bucket_schedule_r50.txt), at the price of a "
@@ -390,11 +441,26 @@ def main():
             return float(dt_) / k * 1e3
         k2 = max(2, min(args.steps, 30))
         with_ms = timed(k2)
+        # with the collectives stubbed every rank applies its OWN gradients: weights and Adam state diverge across the ranks.
+        # Snapshot them first and put them back afterwards, so the ranks are bit-identical again for whatever follows.
+        arena_ = model.arena()
+        flat_ = step.optimizer.state.get("flat", {})
+        snap = [arena_.flat.clone()] + [flat_[k].clone() for k in ("exp_avg", "exp_avg_sq") if k in flat_]
+        step_count = step.optimizer._dev[0]["step"].clone() if 0 in step.optimizer._dev else None
+        bufs_ = {k: v.clone() for k, v in model.named_buffers()}
         sync.stub = True
         for _ in range(2):
             step()
         stub_ms = timed(k2)
         sync.stub = False
+        torch.cuda.synchronize()
+        arena_.flat.copy_(snap[0])
+        for k, t_ in zip([k for k in ("exp_avg", "exp_avg_sq") if k in flat_], snap[1:]):
+            flat_[k].copy_(t_)
+        if step_count is not None:
+            step.optimizer._dev[0]["step"].copy_(step_count)
+        for k, v in model.named_buffers():
+            v.copy_(bufs_[k])
         exposed = {"allreduce_exposed_ms": round(with_ms - stub_ms, 3), "ms_per_step_with_collectives": round(with_ms, 3),
                    "ms_per_step_collectives_stubbed": round(stub_ms, 3), "steps": k2}
 
@@ -417,10 +483,9 @@ def main():
     # whole-step roofline: per-GPU rate against the per-GPU peaks (2.760 TFLOP / 12.06 GB per R50 bs64 step)
     out["step_roofline"] = step_roofline(wkey, True, value / world, es)
     out["c_abi_calls_per_step"] = sum(1 for c in step.plan.packs + step.plan.fwd + step.plan.bwd if hasattr(c, "fn")) + 4
-    out["conv_bn_relu_launches"] = getattr(step.plan, "_n_fused_bn", 0)       # convolutions that carry their BatchNorm + ReLU (lh_igemm_bn_relu)
-    if step.plan.bn_sync_gave_up():
-        raise SystemExit("a fused convolution + BatchNorm launch gave up at its grid barrier: the step's results are wrong")
 
+    if rank == 0 and not args.train_only:
+        out["epe_auc_parity"] = epe_auc_parity()
     if rank == 0 and world == 1 and not args.train_only:
         # eval-mode forward + decode throughput (the "infer" half of the metric)
         torch.cuda.synchronize()

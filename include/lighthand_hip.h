@@ -277,7 +277,8 @@ typedef struct {
     int bo, bi, kps, depth;              /* kernel configuration */
     int n_problems, n_fold;              /* problems in the table, problems that need the fold launch */
     int n_items, n_fold_items;           /* workgroups of the weight-gradient launch / of the fold launch (0: no fold launch) */
-    int fold_lds, target_stages, nsplit_max, reserved;
+    int fold_lds, target_stages, nsplit_max;
+    int run_parts;                       /* lh_wgrad_table_run: 0 = both launches, 1 = the weight-gradient grid only, 2 = the fold grid only (timing) */
     size_t off_items, off_fold_args, off_fold_items, table_bytes, workspace_bytes;
 } lh_wgrad_table_info;
 int lh_wgrad_table_build(const lh_wgrad_call* calls, int n, int dtype, const int* cfg4, int target_stages, void* workspace,
@@ -306,45 +307,6 @@ typedef struct {
     long long* num_batches_tracked; float momentum, eps; float* scale; float* shift; float* save_mean; float* save_invstd;
 } lh_bn_finalize_call;
 int lh_bn_finalize_multi(const lh_bn_finalize_call* calls, int n, void* stream);
-/* A 1x1 convolution whose input is relu(BN(in)) of the layer before it (pose_resnet.py:89-94: bn2 -> relu -> conv3), with the BatchNorm +
- * ReLU applied to the operand ON ITS WAY INTO THE MFMA instead of by an elementwise launch: `in` is the RAW output of the previous
- * convolution, scale / shift [k_run] that BatchNorm's coefficients (lh_bn_finalize must have run), and the activated rows -- what
- * lh_fuse_fwd would have stored, bit for bit -- are written to act_out (the layout of `in`) on the way, because this convolution's weight
- * gradient reads them.  One launch and one read of the raw tensor less per BatchNorm.  Persistent pointwise kernel only (d->cfg must name
- * a pointwise configuration: ring depth 1, K <= 256), stride 1, with statistics (training-mode forward); LH_ERR_UNSUPPORTED otherwise. */
-typedef struct {
-    const float* scale;
-    const float* shift;
-    void* act_out;
-} lh_bn_in;
-int lh_igemm_bn_in(const lh_igemm_desc* d, const void* in, const void* wpack, void* out, const lh_bn_in* bin, const float* bias,
-                   float* stats, int dtype, void* stream);
-
-/* Convolution + training-mode BatchNorm + ReLU as ONE launch (pose_resnet.py:86-94: conv -> bn -> relu inside a block): the launch
- * writes the raw output `out` and its statistics rows (fin->stats, as lh_igemm does), its workgroups meet at a grid barrier, each folds
- * the rows of its channel tile, derives scale / shift EXACTLY as lh_bn_finalize does (same arithmetic, same order: bit-identical), and
- * stores relu(out * scale + shift) -- lh_fuse_fwd's arithmetic -- to f->out from the values it still holds; everything lh_bn_finalize
- * writes (scale, shift, saved mean / invstd, running statistics, num_batches_tracked) is written too.  Replaces three launches on the
- * dependency chain (convolution, finalize, elementwise) and one read of `out`.
- * Conditions (LH_ERR_UNSUPPORTED / LH_ERR_ARG otherwise): a tiled LDS-DMA configuration of a 16-bit type (d->cfg), dense output, no
- * addend / bias / affine / ReLU in the descriptor, fewer than 256 statistics rows, and THE WHOLE GRID RESIDENT ON THE DEVICE AT ONCE
- * (lh_igemm_bn_relu_resident; the launch checks it).  The barrier spins: the caller must not run two such launches concurrently
- * (two streams, two processes on one GPU) -- each could hold the CUs the other waits for; a launch that waits for seconds gives up,
- * sets sync[1] = 1 and finishes with whatever rows it sees.
- * sync: two 32-bit device words, zero-initialised ONCE by the caller and owned by this call site (the arrival count only ever grows). */
-typedef struct {
-    const lh_bn_finalize_call* fin;     /* fin->stats = the launch's statistics slab [rows][2][cout] */
-    void* out;                          /* relu(BN(out)): the layout of `out` */
-    unsigned int* sync;
-} lh_bn_relu_fuse;
-int lh_igemm_bn_relu(const lh_igemm_desc* d, const void* in, const void* wpack, void* out, const lh_bn_relu_fuse* f, int dtype, void* stream);
-/* the sub-pixel phases of a transposed convolution (lh_igemm_phases) + BatchNorm + ReLU: pose_resnet.py:219-227 */
-int lh_igemm_phases_bn_relu(const lh_igemm_desc* const* descs, int nphase, const void* in, const void* const* wpacks, void* out,
-                            const lh_bn_relu_fuse* f, int dtype, void* stream);
-/* 1 when the launch the descriptors name (nphase = 1: lh_igemm_bn_relu) holds its whole grid on the current device at once, 0 when not,
- * negative when the form does not run on a tiled 16-bit configuration.  out3 (optional) = { workgroups, workgroups per CU, CUs }. */
-int lh_igemm_bn_relu_resident(const lh_igemm_desc* const* descs, int nphase, int dtype, int* out3);
-
 /* Eval mode: scale/shift from running statistics. */
 int lh_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
                       const float* running_var, float eps, int c, float* scale, float* shift,
@@ -560,6 +522,18 @@ typedef struct lh_comm lh_comm;
 int lh_comm_unique_id(void* id128);
 int lh_comm_init(lh_comm** comm, int rank, int nranks, const void* id128);
 int lh_comm_allreduce_sum(lh_comm* comm, void* buf, size_t count, int dtype, void* stream);
+/* The pieces of a DIRECT gradient exchange (reduce-scatter + all-gather with all seven xGMI peers at once, 2 x bytes / N
+ * per link instead of a ring's 2 (N - 1) / N x bytes over one), all stream-ordered and capturable like the all-reduce, so that the whole
+ * data-parallel step stays ONE hipGraph (parallel.LhComm.direct_sum_):
+ *   lh_comm_alltoall            recv chunk r <- rank r's send chunk `rank` (grouped point-to-point exchange, `count` elements per chunk);
+ *                               then lh_sum_chunks adds the N received chunks in RANK order -- every rank ends with the same bits;
+ *   lh_comm_allgather           recv chunk r <- rank r's `count` elements (recv + rank * count == send: in place);
+ *   lh_comm_reduce_scatter_sum  RCCL's own reduce-scatter (recv <- the sum of every rank's send chunk `rank`), for comparison.
+ * lh_comm_size: the rank / rank count the communicator was created with. */
+int lh_comm_reduce_scatter_sum(lh_comm* comm, const void* send, void* recv, size_t count, int dtype, void* stream);
+int lh_comm_allgather(lh_comm* comm, const void* send, void* recv, size_t count, int dtype, void* stream);
+int lh_comm_alltoall(lh_comm* comm, const void* send, void* recv, size_t count, int dtype, void* stream);
+int lh_comm_size(const lh_comm* comm, int* rank, int* nranks);
 int lh_comm_destroy(lh_comm* comm);
 
 /* dst[i0][i1][i2][i3] = src[i0][i1][i2][i3], fp32, element strides on both sides (shape4 / strides are HOST arrays read at

@@ -45,14 +45,6 @@ class FuseBwdDesc(C.Structure):
                 ("l2_touch", C.c_void_p), ("l2_touch_bytes", C.c_size_t)]
 
 
-class BnIn(C.Structure):               # lh_igemm_bn_in
-    _fields_ = [("scale", C.c_void_p), ("shift", C.c_void_p), ("act_out", C.c_void_p)]
-
-
-class BnReluFuse(C.Structure):         # lh_igemm_bn_relu
-    _fields_ = [("fin", C.POINTER(BnFinalizeCall)), ("out", C.c_void_p), ("sync", C.c_void_p)]
-
-
 class BnBwdGate(C.Structure):          # lh_igemm_gated
     _fields_ = [("x", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p),
                 ("partial", C.c_void_p)]
@@ -72,7 +64,7 @@ class WgradCall(C.Structure):          # lh_wgrad_fused_multi
 class WgradTableInfo(C.Structure):     # lh_wgrad_table_build / lh_wgrad_table_run
     _fields_ = [("bo", C.c_int), ("bi", C.c_int), ("kps", C.c_int), ("depth", C.c_int), ("n_problems", C.c_int), ("n_fold", C.c_int),
                 ("n_items", C.c_int), ("n_fold_items", C.c_int), ("fold_lds", C.c_int), ("target_stages", C.c_int), ("nsplit_max", C.c_int),
-                ("reserved", C.c_int), ("off_items", C.c_size_t), ("off_fold_args", C.c_size_t), ("off_fold_items", C.c_size_t),
+                ("run_parts", C.c_int), ("off_items", C.c_size_t), ("off_fold_args", C.c_size_t), ("off_fold_items", C.c_size_t),
                 ("table_bytes", C.c_size_t), ("workspace_bytes", C.c_size_t)]
 
 
@@ -137,10 +129,6 @@ SIGNATURES = {
     "lh_wgrad_candidates": (_I, [C.POINTER(IgemmDesc), _I, _I, _I, C.POINTER(_I), _I]),
     "lh_igemm_stats_rows": (_I, [C.POINTER(IgemmDesc), _I]),
     "lh_igemm_gated": (_I, [C.POINTER(IgemmDesc), _P, _P, _P, _P, _P, C.POINTER(BnBwdGate), _I, _P]),
-    "lh_igemm_bn_in": (_I, [C.POINTER(IgemmDesc), _P, _P, _P, C.POINTER(BnIn), _P, _P, _I, _P]),
-    "lh_igemm_bn_relu": (_I, [C.POINTER(IgemmDesc), _P, _P, _P, C.POINTER(BnReluFuse), _I, _P]),
-    "lh_igemm_phases_bn_relu": (_I, [C.POINTER(C.POINTER(IgemmDesc)), _I, _P, C.POINTER(C.c_void_p), _P, C.POINTER(BnReluFuse), _I, _P]),
-    "lh_igemm_bn_relu_resident": (_I, [C.POINTER(C.POINTER(IgemmDesc)), _I, _I, C.POINTER(C.c_int)]),
     "lh_wgrad_slab_bytes": (_SZ, [C.POINTER(IgemmDesc), _I, _I, _I]),
     "lh_wgrad": (_I, [C.POINTER(IgemmDesc), _P, _P, _I, _I, _I, _P, _I, _P]),
     "lh_wgrad_rowfold": (_I, [C.POINTER(IgemmDesc), _I, _P, _P, _I, _I, _P, _I, _P]),
@@ -186,6 +174,10 @@ SIGNATURES = {
     "lh_comm_unique_id": (_I, [_P]),
     "lh_comm_init": (_I, [C.POINTER(_P), _I, _I, _P]),
     "lh_comm_allreduce_sum": (_I, [_P, _P, _SZ, _I, _P]),
+    "lh_comm_reduce_scatter_sum": (_I, [_P, _P, _P, _SZ, _I, _P]),
+    "lh_comm_allgather": (_I, [_P, _P, _P, _SZ, _I, _P]),
+    "lh_comm_alltoall": (_I, [_P, _P, _P, _SZ, _I, _P]),
+    "lh_comm_size": (_I, [_P, C.POINTER(_I), C.POINTER(_I)]),
     "lh_comm_destroy": (_I, [_P]),
     "lh_cast_f32_bf16": (_I, [_P, _P, _L, _I, _P]),
     "lh_sum_chunks": (_I, [_P, _P, _I, _L, _I, _P]),

@@ -1,5 +1,4 @@
-// The BatchNorm statistics fold and finalize arithmetic, shared by the finalize kernels (bn.hip) and the convolution launch that
-// carries its own finalize (lh_igemm_bn_relu, igemm_epilogue.h): ONE definition, so both produce the same bits.
+// The BatchNorm statistics fold and finalize arithmetic of the finalize kernels (bn.hip).
 #pragma once
 #include "common.h"
 
@@ -44,62 +43,6 @@ __device__ __forceinline__ void slab_lane16(const TI* slab, int rows, int c, int
         a += (double)ld(slab + ((long)r * 2) * c + ch);
         b += (double)ld(slab + ((long)r * 2 + 1) * c + ch);
     }
-}
-
-// The same partial totals for FOUR consecutive channels ch0 .. ch0 + 3 (ch0 % 4 == 0, c % 4 == 0) of a slab other workgroups of THIS launch
-// wrote with sc1 stores: 16-byte sc1 loads (L1 bypassed), all loads of a row group in flight before the first is used.  Per channel the
-// additions are slab_lane16's, in its order: the totals are bit-identical.
-__device__ __forceinline__ void slab_lane16_x4_sc1(const float* slab, int rows, int c, int ch0, int rl, double (&a)[4], double (&b)[4]) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    typedef float f4 __attribute__((ext_vector_type(4)));
-    auto ld = [](const float* q) { f4 v; asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(q) : "memory"); return v; };
-    auto landed = []() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); };
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { a[e] = 0.0; b[e] = 0.0; }
-    int r = rl;
-    for (; r + 112 < rows; r += 128) {
-        f4 av[8], bv[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { av[u] = ld(slab + ((long)(r + 16 * u) * 2) * c + ch0); bv[u] = ld(slab + ((long)(r + 16 * u) * 2 + 1) * c + ch0); }
-        landed();
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { asm volatile("" : "+v"(av[u])); asm volatile("" : "+v"(bv[u])); }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            a[e] += (((double)av[0][e] + (double)av[1][e]) + ((double)av[2][e] + (double)av[3][e])) + (((double)av[4][e] + (double)av[5][e]) + ((double)av[6][e] + (double)av[7][e]));
-            b[e] += (((double)bv[0][e] + (double)bv[1][e]) + ((double)bv[2][e] + (double)bv[3][e])) + (((double)bv[4][e] + (double)bv[5][e]) + ((double)bv[6][e] + (double)bv[7][e]));
-        }
-    }
-    for (; r + 48 < rows; r += 64) {
-        f4 av[4], bv[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { av[u] = ld(slab + ((long)(r + 16 * u) * 2) * c + ch0); bv[u] = ld(slab + ((long)(r + 16 * u) * 2 + 1) * c + ch0); }
-        landed();
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { asm volatile("" : "+v"(av[u])); asm volatile("" : "+v"(bv[u])); }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            a[e] += ((double)av[0][e] + (double)av[1][e]) + ((double)av[2][e] + (double)av[3][e]);
-            b[e] += ((double)bv[0][e] + (double)bv[1][e]) + ((double)bv[2][e] + (double)bv[3][e]);
-        }
-    }
-    {   // the last (at most three) rows of this lane: requested together, added one by one
-        f4 av[3], bv[3];
-        int nrest = 0;
-#pragma unroll
-        for (int u = 0; u < 3; ++u)
-            if (r + 16 * u < rows) { av[u] = ld(slab + ((long)(r + 16 * u) * 2) * c + ch0); bv[u] = ld(slab + ((long)(r + 16 * u) * 2 + 1) * c + ch0); nrest = u + 1; }
-        landed();
-#pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            if (u < nrest) {
-                asm volatile("" : "+v"(av[u])); asm volatile("" : "+v"(bv[u]));
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { a[e] += (double)av[u][e]; b[e] += (double)bv[u][e]; }
-            }
-        }
-    }
-#endif
 }
 
 // Batch totals of channel ch -> scale = gamma * rsqrt(var + eps), shift = beta - mean * scale (returned), and -- when `write` --

@@ -17,6 +17,12 @@ struct RcclApi {
     decltype(&ncclGetUniqueId) get_unique_id = nullptr;
     decltype(&ncclCommInitRank) comm_init_rank = nullptr;
     decltype(&ncclAllReduce) all_reduce = nullptr;
+    decltype(&ncclReduceScatter) reduce_scatter = nullptr;
+    decltype(&ncclAllGather) all_gather = nullptr;
+    decltype(&ncclSend) send = nullptr;
+    decltype(&ncclRecv) recv = nullptr;
+    decltype(&ncclGroupStart) group_start = nullptr;
+    decltype(&ncclGroupEnd) group_end = nullptr;
     decltype(&ncclCommDestroy) comm_destroy = nullptr;
     decltype(&ncclGetErrorString) error_string = nullptr;
     bool ok = false;
@@ -37,8 +43,15 @@ const RcclApi& rccl() {
         api.comm_init_rank = (decltype(api.comm_init_rank))dlsym(h, "ncclCommInitRank");
         api.all_reduce = (decltype(api.all_reduce))dlsym(h, "ncclAllReduce");
         api.comm_destroy = (decltype(api.comm_destroy))dlsym(h, "ncclCommDestroy");
+        api.reduce_scatter = (decltype(api.reduce_scatter))dlsym(h, "ncclReduceScatter");
+        api.all_gather = (decltype(api.all_gather))dlsym(h, "ncclAllGather");
+        api.send = (decltype(api.send))dlsym(h, "ncclSend");
+        api.recv = (decltype(api.recv))dlsym(h, "ncclRecv");
+        api.group_start = (decltype(api.group_start))dlsym(h, "ncclGroupStart");
+        api.group_end = (decltype(api.group_end))dlsym(h, "ncclGroupEnd");
         api.error_string = (decltype(api.error_string))dlsym(h, "ncclGetErrorString");
-        api.ok = api.get_unique_id && api.comm_init_rank && api.all_reduce && api.comm_destroy && api.error_string;
+        api.ok = api.get_unique_id && api.comm_init_rank && api.all_reduce && api.comm_destroy && api.error_string &&
+                 api.reduce_scatter && api.all_gather && api.send && api.recv && api.group_start && api.group_end;
     });
     return api;
 }
@@ -88,6 +101,62 @@ extern "C" int lh_comm_allreduce_sum(lh_comm* comm, void* buf, size_t count, int
     }
     const ncclResult_t r = rccl().all_reduce(buf, buf, count, t, ncclSum, comm->comm, (hipStream_t)stream);
     if (r != ncclSuccess) return fail("ncclAllReduce", r);
+    return LH_OK;
+}
+
+static int comm_dtype(const char* who, int dtype, ncclDataType_t* t, size_t* es) {
+    switch (dtype) {
+        case LH_F32: *t = ncclFloat32; *es = 4; return LH_OK;
+        case LH_BF16: *t = ncclBfloat16; *es = 2; return LH_OK;
+        case LH_F16: *t = ncclFloat16; *es = 2; return LH_OK;
+    }
+    lh_set_error("%s: bad dtype %d", who, dtype);
+    return LH_ERR_ARG;
+}
+
+// recv[0 .. count) = sum over the ranks r of THEIR send[rank * count .. (rank + 1) * count): RCCL's reduce-scatter (its own algorithm).
+extern "C" int lh_comm_reduce_scatter_sum(lh_comm* comm, const void* send, void* recv, size_t count, int dtype, void* stream) {
+    LH_REQUIRE(comm && send && recv, "lh_comm_reduce_scatter_sum: null pointer");
+    ncclDataType_t t; size_t es;
+    if (comm_dtype("lh_comm_reduce_scatter_sum", dtype, &t, &es)) return LH_ERR_ARG;
+    const ncclResult_t r = rccl().reduce_scatter(send, recv, count, t, ncclSum, comm->comm, (hipStream_t)stream);
+    if (r != ncclSuccess) return fail("ncclReduceScatter", r);
+    return LH_OK;
+}
+
+// recv[r * count .. (r + 1) * count) = rank r's send[0 .. count); recv + rank * count == send is the in-place form.
+extern "C" int lh_comm_allgather(lh_comm* comm, const void* send, void* recv, size_t count, int dtype, void* stream) {
+    LH_REQUIRE(comm && send && recv, "lh_comm_allgather: null pointer");
+    ncclDataType_t t; size_t es;
+    if (comm_dtype("lh_comm_allgather", dtype, &t, &es)) return LH_ERR_ARG;
+    const ncclResult_t r = rccl().all_gather(send, recv, count, t, comm->comm, (hipStream_t)stream);
+    if (r != ncclSuccess) return fail("ncclAllGather", r);
+    return LH_OK;
+}
+
+// recv[r * count .. (r + 1) * count) = rank r's send[rank * count .. (rank + 1) * count): every rank exchanges one chunk with every
+// other rank AT ONCE (grouped point-to-point sends / receives: over a fully connected xGMI mesh all seven links of a GPU carry a
+// chunk each, 1/N of the buffer per link) -- the first half of the direct gradient exchange; send != recv.
+extern "C" int lh_comm_alltoall(lh_comm* comm, const void* send, void* recv, size_t count, int dtype, void* stream) {
+    LH_REQUIRE(comm && send && recv && send != recv, "lh_comm_alltoall: null pointer / in-place call");
+    ncclDataType_t t; size_t es;
+    if (comm_dtype("lh_comm_alltoall", dtype, &t, &es)) return LH_ERR_ARG;
+    const RcclApi& a = rccl();
+    ncclResult_t r = a.group_start();
+    if (r != ncclSuccess) return fail("ncclGroupStart", r);
+    for (int p = 0; p < comm->nranks && r == ncclSuccess; ++p) {
+        r = a.send((const char*)send + (size_t)p * count * es, count, t, p, comm->comm, (hipStream_t)stream);
+        if (r == ncclSuccess) r = a.recv((char*)recv + (size_t)p * count * es, count, t, p, comm->comm, (hipStream_t)stream);
+    }
+    const ncclResult_t e = a.group_end();
+    if (r != ncclSuccess) return fail("ncclSend / ncclRecv", r);
+    if (e != ncclSuccess) return fail("ncclGroupEnd", e);
+    return LH_OK;
+}
+
+extern "C" int lh_comm_size(const lh_comm* comm, int* rank, int* nranks) {
+    LH_REQUIRE(comm && rank && nranks, "lh_comm_size: null pointer");
+    *rank = comm->rank; *nranks = comm->nranks;
     return LH_OK;
 }
 

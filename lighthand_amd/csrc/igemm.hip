@@ -346,8 +346,7 @@ struct PhaseSet {                 // lh_igemm_phases: the other descriptors / pa
 static int igemm_impl(const lh_igemm_desc* d, const void* in, const void* wpack, void* out,
                       const void* addend, const void* addend_mask, const float* bias, const float* scale, const float* shift, float* stats,
                       int dtype, void* stream, const PhaseSet* phases = nullptr, const lh_head* head = nullptr,
-                      IgemmArgs* prep_args = nullptr, RingCfg* prep_cfg = nullptr, const lh_bn_bwd_gate* gate = nullptr,
-                      const lh_bn_relu_fuse* bnf = nullptr, bool bn_query = false, const lh_bn_in* bin = nullptr) {
+                      IgemmArgs* prep_args = nullptr, RingCfg* prep_cfg = nullptr, const lh_bn_bwd_gate* gate = nullptr) {
     LH_REQUIRE(d && in && wpack && (out || head), "lh_igemm: null pointer");
     const int es = lh_dtype_size(dtype);
     LH_REQUIRE(es > 0, "lh_igemm: bad dtype %d", dtype);
@@ -369,26 +368,6 @@ static int igemm_impl(const lh_igemm_desc* d, const void* in, const void* wpack,
     LH_REQUIRE((scale == nullptr) == (shift == nullptr), "lh_igemm: scale and shift must come together");
     a.head_w = nullptr; a.head_bias = nullptr; a.head_out = nullptr; a.head_j = 0; a.head_wstride = 0;
     a.gx = nullptr; a.gmean = a.ginv = a.gscale = a.gshift = nullptr;
-    a.in_scale = a.in_shift = nullptr; a.in_out = nullptr;
-    if (bin) {
-        LH_REQUIRE(bin->scale && bin->shift && bin->act_out && bin->act_out != in && stats && !addend && !phases && !head && !gate && !bnf,
-                   "lh_igemm_bn_in: scale, shift, a destination for the activated input and a statistics slab are required (plain forward launch)");
-        a.in_scale = bin->scale; a.in_shift = bin->shift; a.in_out = (unsigned char*)bin->act_out;
-    }
-    a.bn_out = nullptr; a.bn_sync = nullptr; a.bn_query = bn_query ? 1 : 0;
-    memset((void*)&a.bn, 0, sizeof a.bn);
-    if (bnf) {
-        const lh_bn_finalize_call* f = bnf->fin;
-        LH_REQUIRE(f && bnf->out && bnf->sync && f->stats && f->scale && f->shift && f->rows > 0 && f->count > 0, "lh_igemm_bn_relu: null pointer / empty finalize");
-        LH_REQUIRE(stats == f->stats && f->c == d->cout, "lh_igemm_bn_relu: the finalize must fold THIS launch's statistics slab (c = cout)");
-        LH_REQUIRE(!addend && !bias && !scale && !d->relu && !head && !gate && d->out_pix_stride == d->cout && bnf->out != out,
-                   "lh_igemm_bn_relu: a plain training-mode forward convolution with a dense output is required");
-        LH_REQUIRE(f->rows < 256, "lh_igemm_bn_relu: %d statistics rows (the in-launch fold is the 16-lane fold: < 256 rows)", f->rows);
-        a.bn_out = (unsigned char*)bnf->out; a.bn_sync = bnf->sync;
-        a.bn.slab = f->stats; a.bn.rows = f->rows; a.bn.count = f->count; a.bn.c = f->c; a.bn.gamma = f->gamma; a.bn.beta = f->beta;
-        a.bn.rmean = f->running_mean; a.bn.rvar = f->running_var; a.bn.nbt = f->num_batches_tracked; a.bn.momentum = f->momentum; a.bn.eps = f->eps;
-        a.bn.scale = f->scale; a.bn.shift = f->shift; a.bn.smean = f->save_mean; a.bn.sinv = f->save_invstd;
-    }
     if (gate) {
         LH_REQUIRE(gate->x && gate->mean && gate->invstd && gate->scale && gate->shift && gate->partial, "lh_igemm_gated: null pointer in the gate");
         LH_REQUIRE(!bias && !scale && !d->relu && !phases && !head, "lh_igemm_gated: a data gradient carries no bias / affine / ReLU / phases");
@@ -454,19 +433,7 @@ static int igemm_impl(const lh_igemm_desc* d, const void* in, const void* wpack,
         *prep_cfg = rc_;
         return LH_OK;
     }
-    if (bin && !(ring && rc_.depth == 1)) {
-        lh_set_error("lh_igemm_bn_in: the launch does not run on the persistent pointwise kernel (ring depth %d; set d->cfg to a pointwise configuration)", ring ? rc_.depth : 0);
-        return LH_ERR_UNSUPPORTED;
-    }
-    if ((bnf || bn_query) && !(ring && rc_.depth >= 2 && rc_.depth != 100 && es == 2)) {
-        lh_set_error("lh_igemm_bn_relu: the launch does not run on a tiled LDS-DMA configuration of a 16-bit type (ring depth %d)", ring ? rc_.depth : 0);
-        return LH_ERR_UNSUPPORTED;
-    }
-    if (bnf) {
-        const int rows_launch = ceil_div(a.M, bp) * (phases ? phases->n : 1);
-        LH_REQUIRE(rows_launch == a.bn.rows, "lh_igemm_bn_relu: the launch writes %d statistics rows, the finalize folds %d", rows_launch, a.bn.rows);
-    }
-    if (gate && !(ring && ((rc_.depth >= 2 && rc_.depth < 10) || (rc_.depth >= LH_DENSE_DEPTH && rc_.depth < LH_DENSE_DEPTH + 10)) && es == 2)) {
+    if (gate && !(ring && ((rc_.depth >= 2 && rc_.depth < 10) || (rc_.depth >= LH_DENSE_DEPTH && rc_.depth < LH_KSPLIT_DEPTH + 10)) && es == 2)) {
         lh_set_error("lh_igemm_gated: the launch does not run on a tiled LDS-DMA configuration (ring depth %d)", ring ? rc_.depth : 0);
         return LH_ERR_UNSUPPORTED;
     }
@@ -625,50 +592,5 @@ extern "C" int lh_igemm_phases_head(const lh_igemm_desc* const* descs, int nphas
     LH_REQUIRE(descs[lead]->ntaps > 0 && wpacks[lead], "lh_igemm_phases_head: no phase has taps");
     PhaseSet ps = {descs, wpacks, nphase};
     return igemm_impl(descs[lead], in, wpacks[lead], nullptr, nullptr, nullptr, nullptr, scale, shift, nullptr, dtype, stream, &ps, head);
-}
-
-// 1x1 convolution whose input is relu(BN(in)) of the previous layer, applied on the operand's way into the MFMA (include/lighthand_hip.h).
-extern "C" int lh_igemm_bn_in(const lh_igemm_desc* d, const void* in, const void* wpack, void* out, const lh_bn_in* bin, const float* bias,
-                              float* stats, int dtype, void* stream) {
-    LH_REQUIRE(bin, "lh_igemm_bn_in: null descriptor");
-    return igemm_impl(d, in, wpack, out, nullptr, nullptr, bias, nullptr, nullptr, stats, dtype, stream, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, false, bin);
-}
-
-// Convolution + training-mode BatchNorm + ReLU as ONE launch (include/lighthand_hip.h; igemm_epilogue.h holds the in-launch finalize).
-extern "C" int lh_igemm_bn_relu(const lh_igemm_desc* d, const void* in, const void* wpack, void* out, const lh_bn_relu_fuse* f, int dtype, void* stream) {
-    LH_REQUIRE(f && f->fin, "lh_igemm_bn_relu: null descriptor");
-    return igemm_impl(d, in, wpack, out, nullptr, nullptr, nullptr, nullptr, nullptr, (float*)f->fin->stats, dtype, stream, nullptr, nullptr, nullptr, nullptr, nullptr, f);
-}
-
-extern "C" int lh_igemm_phases_bn_relu(const lh_igemm_desc* const* descs, int nphase, const void* in, const void* const* wpacks, void* out,
-                                       const lh_bn_relu_fuse* f, int dtype, void* stream) {
-    LH_REQUIRE(f && f->fin, "lh_igemm_phases_bn_relu: null descriptor");
-    LH_REQUIRE(phases_ok(descs, nphase) && wpacks, "lh_igemm_phases_bn_relu: 2..4 descriptors that differ only in taps / placement are required");
-    const int lead = phase_lead(descs, nphase);
-    LH_REQUIRE(descs[lead]->ntaps > 0 && wpacks[lead], "lh_igemm_phases_bn_relu: no phase has taps");
-    PhaseSet ps = {descs, wpacks, nphase};
-    return igemm_impl(descs[lead], in, wpacks[lead], out, nullptr, nullptr, nullptr, nullptr, nullptr, (float*)f->fin->stats, dtype, stream, &ps, nullptr, nullptr, nullptr, nullptr, f);
-}
-
-// Would the launch (descriptor(s) with their cfg) hold its whole grid on the device at once?  out[0..2] = workgroups, workgroups one CU
-// holds, CUs.  Returns 1 / 0, or a negative status when the form does not run on a tiled 16-bit configuration at all.
-extern "C" int lh_igemm_bn_relu_resident(const lh_igemm_desc* const* descs, int nphase, int dtype, int* out3) {
-    LH_REQUIRE(descs && nphase >= 1 && nphase <= 4 && descs[0], "lh_igemm_bn_relu_resident: bad arguments");
-    static const unsigned char dummy[16] = {0};
-    int rc;
-    if (nphase == 1) {
-        rc = igemm_impl(descs[0], dummy, dummy, (void*)dummy, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, dtype, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, true);
-    } else {
-        LH_REQUIRE(phases_ok(descs, nphase), "lh_igemm_bn_relu_resident: 2..4 descriptors that differ only in taps / placement are required");
-        const int lead = phase_lead(descs, nphase);
-        const void* packs[4] = {dummy, dummy, dummy, dummy};
-        PhaseSet ps = {descs, packs, nphase};
-        rc = igemm_impl(descs[lead], dummy, dummy, (void*)dummy, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, dtype, nullptr, &ps, nullptr, nullptr, nullptr, nullptr, nullptr, true);
-    }
-    if (rc) return rc;
-    int r[3];
-    lh_ring_resident_get(r);
-    if (out3) { out3[0] = r[0]; out3[1] = r[1]; out3[2] = r[2]; }
-    return (long)r[0] <= (long)r[1] * r[2] ? 1 : 0;
 }
 

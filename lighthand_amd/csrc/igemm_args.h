@@ -1,7 +1,6 @@
 // Kernel-argument block shared by the two implicit-GEMM kernels (igemm.hip, igemm_ring.hip).
 #pragma once
 #include "common.h"
-#include "bn_fold.h"
 
 struct IgemmArgs {
     const unsigned char* in;
@@ -29,21 +28,6 @@ struct IgemmArgs {
     const float* head_bias;
     float* head_out;
     int head_j, head_wstride;       // valid head channels (<= 32), bytes between head_w rows
-    // Training-mode BatchNorm + ReLU carried by the launch itself (lh_igemm_bn_relu; tiled configurations, the whole grid resident at
-    // once): the epilogue stores the raw output and its statistics rows as ever, then the grid meets at a barrier (bn_sync: one device
-    // word that only ever grows), every workgroup folds the rows of ITS channel tile (bn.slab = the launch's statistics slab), derives
-    // scale / shift exactly as lh_bn_finalize does, and stores relu(raw * scale + shift) from the values it still holds to bn_out.  The
-    // first workgroup of each channel tile also writes what the finalize writes (scale, shift, saved mean / invstd, running statistics).
-    // BatchNorm + ReLU applied to the INPUT operand on its way into the MFMA (lh_igemm_bn_in; persistent pointwise kernel only: its operand
-    // rows pass through registers): in = the raw output of the previous convolution, in_scale / in_shift [k_run] = that BatchNorm's
-    // scale / shift, in_out = where relu(in * scale + shift) is stored as well (layout of `in`): the weight gradient reads it
-    const float* in_scale;           // NULL: off
-    const float* in_shift;
-    unsigned char* in_out;
-    unsigned char* bn_out;           // NULL: off
-    unsigned* bn_sync;               // [0] arrivals (never reset), [1] set to 1 when a launch gave up waiting (grid not resident)
-    FinalizeArgs bn;
-    int bn_query;                    // host side only: launch nothing, report the grid and what the device holds at once (lh_ring_resident)
     int n, hi, wi, in_pix_stride, k_run, kspt, kpad;   // kpad: elements per (row, tap) of the weight pack
     int ho, wo, M, sh, sw, cout;
     int OH, OW, osh, osw, ooh, oow, out_pix_stride;
@@ -70,8 +54,8 @@ struct RingCfg {
 
 // workgroups per channel block of a pointwise launch: every CU holds `occ` workgroups for the whole launch (occ = what the
 // occupancy query reports for the instantiation, 1..4: lh_pw_occupancy)
-static inline int lh_pw_lds_bytes(int bm, int kc, int pt, bool bnin = false) {      // panel, staging, output constants (+ BNIN: the input BatchNorm's table)
-    return bm * kc * 2 + 4 * pt * 16 * (64 * 2 + 8) + 2 * bm * 4 + (bnin ? 2 * kc * 4 : 0);
+static inline int lh_pw_lds_bytes(int bm, int kc, int pt) {      // panel, staging, output constants
+    return bm * kc * 2 + 4 * pt * 16 * (64 * 2 + 8) + 2 * bm * 4;
 }
 
 static inline void lh_pw_grid(int bm, int kc, int pt, long M, int cout, int occ, int* G, int* CB) {
@@ -87,8 +71,6 @@ static inline void lh_pw_grid(int bm, int kc, int pt, long M, int cout, int occ,
 
 
 // igemm_ring.hip
-void lh_ring_resident_set(int grid, int per_cu, int ncu);     // what the last bn_out / bn_query launch of this thread found
-void lh_ring_resident_get(int* out3);
 bool lh_ring_supported(const lh_igemm_desc* d, int dtype);
 bool lh_tap_grid(const lh_igemm_desc* d, int* tw, int* dh0, int* dhs, int* dw0, int* dws);
 int lh_ring_resolve(const lh_igemm_desc* d, int dtype, RingCfg* out);

@@ -8,17 +8,12 @@
 #ifndef LH_ABL
 #define LH_ABL 0
 #endif
-#ifndef LH_BNF_ABL
-#define LH_BNF_ABL 0      // debug builds only (timing of lh_igemm_bn_relu's parts; results are garbage): 1 no grid barrier, 2 no fold loads, 4 no second store, 8 no wait for the tile stores
-#endif
 
 // LDS bytes of the epilogue: the [BP][BM] tile (row pitch BM * ES + 8), the fused head's 32 weight rows where it exists,
 // and the per-channel bias / scale / shift of the tile's BM channels (3 * BM floats).
 template <typename T, int BM, int BP, bool HEAD> constexpr int lh_epi_lds_bytes() {
     return BP * (BM * (int)sizeof(T) + 8) + (HEAD ? 32 * (BM * (int)sizeof(T) + 16) : 0) + 3 * BM * 4;
 }
-// LDS bytes of the in-launch BatchNorm fold (lh_igemm_bn_relu): 16 row lanes x BM channels x {sum, sum of squares} in fp64 + scale / shift
-template <int BM> constexpr int lh_bnfold_lds_bytes() { return 2 * 16 * (BM + 1) * 8 + 2 * BM * 4; }
 
 // The tile's per-channel constants, fetched by the workgroup in ONE round trip into LDS at `cst` ([3][BM] floats: value to
 // add, factor, -- both already combined as the epilogue applies them): every thread loads (index clamped, dropped by a
@@ -41,16 +36,16 @@ __device__ __forceinline__ void igemm_epilogue_consts(const IgemmArgs& p, float*
     }
 }
 
-// rows of the tile a thread stores (NR of igemm_epilogue): the in-launch BatchNorm (BNF) keeps them in registers across its grid
-// barrier, so it exists for the forms with at most four (the 8-wave forms of the <= 128 x 128 tiles and the small 4-wave tiles)
-template <typename T, int BM, int BP, int WC, int WP> constexpr bool lh_bn_variant() {
-    return sizeof(T) == 2 && BP / ((64 * WC * WP) / (BM * (int)sizeof(T) / 16)) <= 4;
-}
+// LDS bytes the K-split wave pairs (KZ = 2, igemm_ring_kernel.h) need BEHIND the tile and its constants: one fp32 partial tile per pair
+template <int BM, int BP, int WC, int WP> constexpr int lh_epi_ksplit_bytes() { return (BM / WC) * (BP / WP) * 4 * WC * WP; }
 
-template <typename T, int BM, int BP, int WC, int WP, bool BNF = false>
+// KZ = 2: the workgroup holds WC x WP PAIRS of waves; both waves of a pair accumulated the same (BM / WC) x (BP / WP) sub-tile over
+// alternate K slices.  Wave kz = 1 of a pair hands its partial sums to wave kz = 0 through LDS (fp32, one addition per element: the
+// sum order differs from the KZ = 1 kernels' by exactly that), wave 0 writes the tile, all 64 * WC * WP * KZ threads store its rows.
+template <typename T, int BM, int BP, int WC, int WP, int KZ = 1>
 __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, unsigned char* smem, f32x4 (&acc)[BM / WC / 16][BP / WP / 16],
                                                int pblk, int cblk, int tid, int lane, int wc, int wp, int hw,
-                                               int ooh, int oow, float* stats, bool bn_writer = false) {
+                                               int ooh, int oow, float* stats, int kz = 0) {
     constexpr int ES = sizeof(T);
     constexpr int EPC = 16 / ES;
     constexpr int TC = BM / WC, TP = BP / WP;
@@ -69,11 +64,27 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, unsigned char
     __syncthreads();
     float* cst = reinterpret_cast<float*>(smem + BP * RS);
     const bool affine = p.bias || p.scale;              // wave-uniform: training-mode forward / gradient launches carry neither
-    if (affine) {
+    if constexpr (KZ == 2) {
+        f32x4* part = reinterpret_cast<f32x4*>(smem + BP * RS + 3 * BM * 4) + (wc * WP + wp) * (CT * PT * 64) + lane;
+        if (kz == 1) {
+#pragma unroll
+            for (int i = 0; i < CT; ++i)
+#pragma unroll
+                for (int j = 0; j < PT; ++j) part[(i * PT + j) * 64] = acc[i][j];
+        }
+        if (affine) igemm_epilogue_consts<BM, 64 * WC * WP * KZ>(p, cst, cblk * BM, tid);
+        __syncthreads();
+        if (kz == 0) {
+#pragma unroll
+            for (int i = 0; i < CT; ++i)
+#pragma unroll
+                for (int j = 0; j < PT; ++j) acc[i][j] += part[(i * PT + j) * 64];
+        }
+    } else if (affine) {
         igemm_epilogue_consts<BM, 64 * WC * WP>(p, cst, cblk * BM, tid);
         __syncthreads();
     }
-    {
+    if (KZ == 1 || kz == 0) {
         const int q = lane >> 4, pl = lane & 15;
 #pragma unroll
         for (int i = 0; i < CT; ++i) {
@@ -103,7 +114,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, unsigned char
     __syncthreads();
 
     constexpr int CH = BM * ES / 16;
-    constexpr int NT = 64 * WC * WP;                  // threads of the workgroup
+    constexpr int NT = 64 * WC * WP * KZ;             // threads of the workgroup
     constexpr int RPP = NT / CH;
     const int chunk = tid % CH, r0 = tid / CH;
     const int col0 = cblk * BM + chunk * EPC;
@@ -134,7 +145,6 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, unsigned char
     int opx[NR];                                      // output pixel of row k, -1: nothing to store
     uint4 ad[NR];
     uint4 xd[NR];                                     // BatchNorm-backward gate (lh_igemm_gated): the BN input at the output position
-    uint4 yv[BNF ? NR : 1];                           // fused BatchNorm (lh_igemm_bn_relu, BNF kernels): the stored values, kept for the second store
     unsigned mbits[NR];
     // gate constants of this thread's EPC channels (every thread loads, index clamped)
     float gmean[EPC], ginv[EPC], gsc[EPC], gsh[EPC];
@@ -218,7 +228,6 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, unsigned char
             for (int e = 0; e < EPC; ++e) { s1[e] += sv[e]; s2[e] += sv[e] * sv[e]; }
         }
         if (!(LH_ABL & 16) || u.x == 0x12345678u) *reinterpret_cast<uint4*>(p.out + eoff * ES) = u;
-        if constexpr (BNF) yv[k] = u;
     }
 
     if (stats) {
@@ -238,73 +247,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, unsigned char
             const int gc = cblk * BM + col;
             if (gc < p.cout) {
                 float* dst = stats + ((long)pblk * 2 + which) * p.cout + gc;
-                if constexpr (BNF) __hip_atomic_store(dst, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // sc1: read by other CUs of THIS launch
-                else *dst = a;
-            }
-        }
-    }
-    if constexpr (BNF) {
-        if (p.bn_out) {
-            // ---- BatchNorm (batch statistics) + ReLU inside the launch.  Hand-off of the statistics rows between the workgroups
-            //      (MI355X guide, cross-workgroup hand-offs): every byte stored sc1 by whole-line wave stores, each storing wave
-            //      waits vmcnt(0), workgroup barrier, ONE lane adds to the arrival counter (agent scope) and polls it with sc1
-            //      loads, workgroup barrier, every load of the rows sc1.
-            if (!(LH_BNF_ABL & 8)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0 && !(LH_BNF_ABL & 1)) {
-                const unsigned nwg = gridDim.x;
-                const unsigned old = __hip_atomic_fetch_add(p.bn_sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned target = old - old % nwg + nwg;
-                int polls = 0;
-                while ((int)(__hip_atomic_load(p.bn_sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-                    __builtin_amdgcn_s_sleep(2);
-                    if (++polls > (1 << 22)) {            // seconds: the grid is not resident at once (the host checks that it can be)
-                        __hip_atomic_store(p.bn_sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        break;
-                    }
-                }
-            }
-            __syncthreads();
-            double* fred = reinterpret_cast<double*>(smem);                       // [2][16][BM + 1]
-            float* fcs = reinterpret_cast<float*>(smem + 2 * 16 * (BM + 1) * 8);    // [2][BM]: scale, shift
-            const float* slab = reinterpret_cast<const float*>(p.bn.slab);
-            for (int item = tid; item < 16 * (BM / 4); item += NT) {             // (row lane, four channels): 16-byte sc1 loads
-                const int rl = item / (BM / 4), col = (item - rl * (BM / 4)) * 4, ch = cblk * BM + col;
-                double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
-                if (ch < p.cout && !(LH_BNF_ABL & 2)) slab_lane16_x4_sc1(slab, p.bn.rows, p.cout, ch, rl, a, b);     // (cout % 8 == 0: four channels in or out together)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    fred[(0 * 16 + rl) * (BM + 1) + col + e] = a[e];
-                    fred[(1 * 16 + rl) * (BM + 1) + col + e] = b[e];
-                }
-            }
-            __syncthreads();
-            if (bn_writer && cblk == 0 && tid == 0 && p.bn.nbt) *p.bn.nbt += 1;
-            for (int col = tid; col < BM; col += NT) {
-                const int ch = cblk * BM + col;
-                float sc = 0.f, sh = 0.f;
-                if (ch < p.cout) {
-                    double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) { s0 += fred[(0 * 16 + i) * (BM + 1) + col]; s1 += fred[(1 * 16 + i) * (BM + 1) + col]; }
-                    bn_finalize_channel(p.bn, ch, s0, s1, bn_writer, sc, sh);
-                }
-                fcs[col] = sc;
-                fcs[BM + col] = sh;
-            }
-            __syncthreads();
-            float sc8[EPC], sh8[EPC];
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) { sc8[e] = fcs[chunk * EPC + e]; sh8[e] = fcs[BM + chunk * EPC + e]; }
-#pragma unroll
-            for (int k = 0; k < NR; ++k) {
-                if (opx[k] < 0) continue;
-                const long eoff = (long)((unsigned long)(unsigned)opx[k] * (unsigned)p.out_pix_stride) + col0;
-                float v[EPC];
-                unpack16<T>(yv[k], v);
-#pragma unroll
-                for (int e = 0; e < EPC; ++e) v[e] = fmaxf(v[e] * sc8[e] + sh8[e], 0.f);      // lh_fuse_fwd's arithmetic (bn.hip fuse_fwd_flat_body)
-                if (!(LH_BNF_ABL & 4) || v[0] == 123.456f) *reinterpret_cast<uint4*>(p.bn_out + eoff * ES) = pack16<T>(v);
+                *dst = a;
             }
         }
     }

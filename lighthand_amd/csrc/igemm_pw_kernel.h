@@ -26,11 +26,7 @@
 #define LH_PW_NT 0          // debug builds only (-DLH_PW_NT=1): A/B of the cache policy of the operand-row loads
 #endif
 
-// BNIN (lh_igemm_bn_in): the operand rows are the RAW output of the previous convolution; relu(x * scale + shift) of that layer's
-// BatchNorm is applied to every fragment in registers before it meets the MFMA (lh_fuse_fwd's arithmetic, rounded to the element
-// type: the MFMA sees the bits the elementwise pass would have stored), and the activated rows are stored to p.in_out on the way
-// (the weight gradient of this convolution reads them): the elementwise launch and its read of the raw tensor disappear.
-template <typename T, int BM, int KC, int PT, bool STATS, bool BNIN = false>
+template <typename T, int BM, int KC, int PT, bool STATS>
 __global__ __launch_bounds__(256, 2) void igemm_pw_kernel(const IgemmArgs p) {
     // two operand register sets (the rows of tile n + 1 are requested before tile n is multiplied) where the register
     // file holds them beside the accumulators and the statistics
@@ -49,7 +45,6 @@ __global__ __launch_bounds__(256, 2) void igemm_pw_kernel(const IgemmArgs p) {
     constexpr int RS = SUBW * ES + 8;                 // staging row pitch: 34 dwords -> the ds_write_b64 of 16 pixels hit 32 banks once
     constexpr int STG = PT * 16 * RS;                 // staging bytes per wave
     constexpr int CST = PANEL + 4 * STG;              // per-channel constants: float sv[BM], bv[BM]
-    constexpr int INT = CST + 2 * BM * 4;             // BNIN: the input BatchNorm's scale[KC], shift[KC] (lh_pw_lds_bytes(.., true) reserves them)
     constexpr int NI = PANEL / 1024;                  // LDS-DMA instructions that fill the panel
     static_assert(NI % 4 == 0 && NI / 4 <= 60, "panel fill: instructions per wave");
 
@@ -86,14 +81,6 @@ __global__ __launch_bounds__(256, 2) void igemm_pw_kernel(const IgemmArgs p) {
             }
             cst[c] = sv;
             cst[BM + c] = bv;
-        }
-        if constexpr (BNIN) {
-            float* tab = reinterpret_cast<float*>(smem + INT);
-            for (int c = tid; c < KC; c += 256) {
-                const int cc = c < p.k_run ? c : p.k_run - 1;
-                tab[c] = p.in_scale[cc];
-                tab[KC + c] = p.in_shift[cc];
-            }
         }
     }
 
@@ -132,34 +119,6 @@ __global__ __launch_bounds__(256, 2) void igemm_pw_kernel(const IgemmArgs p) {
             }
         }
     };
-    // BNIN: fragment (j, kk) of this lane = channels 32 kk + 8 q .. + 7 of pixel 16 j + pl.  Every lane stores its activated chunk, every
-    // time (chunks outside the problem and the workgroups of channel blocks > 0 -- they read the same rows -- store to the dump page):
-    // straight-line code, like the loads
-    const float* intab = reinterpret_cast<const float*>(smem + INT);
-    auto xformB = [&](int tile, uint4 (&B)[PT][KS]) {
-#pragma unroll
-        for (int j = 0; j < PT; ++j) {
-            const int m = (tile * PT + j) * 16 + pl;
-#pragma unroll
-            for (int kk = 0; kk < KS; ++kk) {
-                const bool ok = m < M && kk * 32 + q * EPC < p.k_run;
-                float v[EPC];
-                unpack16<T>(B[j][kk], v);
-                const float4 s0 = *reinterpret_cast<const float4*>(intab + kk * 32 + q * EPC), s1v = *reinterpret_cast<const float4*>(intab + kk * 32 + q * EPC + 4);
-                const float4 h0 = *reinterpret_cast<const float4*>(intab + KC + kk * 32 + q * EPC), h1 = *reinterpret_cast<const float4*>(intab + KC + kk * 32 + q * EPC + 4);
-                const float sc[EPC] = {s0.x, s0.y, s0.z, s0.w, s1v.x, s1v.y, s1v.z, s1v.w}, sh[EPC] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
-#pragma unroll
-                for (int e = 0; e < EPC; ++e) v[e] = fmaxf(v[e] * sc[e] + sh[e], 0.f);
-                uint4 u = pack16<T>(v);
-                if (!ok) u = uint4{0u, 0u, 0u, 0u};
-                B[j][kk] = u;
-                if (cblk == 0) {                              // (uniform: the workgroups of the other channel blocks read the same rows)
-                    unsigned char* dst = ok ? p.in_out + ((long)m * p.in_pix_stride + kk * 32 + q * EPC) * ES : p.dump + lane * 16;
-                    *reinterpret_cast<uint4*>(dst) = u;
-                }
-            }
-        }
-    };
     int t = g * 4 + wave;
     uint4 B0[PT][KS], B1[DB ? PT : 1][DB ? KS : 1];
     loadB(t, B0);
@@ -179,7 +138,6 @@ __global__ __launch_bounds__(256, 2) void igemm_pw_kernel(const IgemmArgs p) {
         for (int e = 0; e < EPC; ++e) s1[i][e] = s2[i][e] = 0.f;
 
     auto tilework = [&](const int t, uint4 (&Bf)[PT][KS], auto&& prefetch) {
-        if constexpr (BNIN) xformB(t, Bf);
         f32x4 acc[CT][PT];
 #pragma unroll
         for (int i = 0; i < CT; ++i)
@@ -272,27 +230,6 @@ static int launch_pw(const IgemmArgs& a0, hipStream_t s) {
     lh_pw_grid(BM, KC, PT, a.M, a.cout, occ, &a.pw_g, &a.pw_cb);
     const int lds = lh_pw_lds_bytes(BM, KC, PT);
     dim3 grid(a.pw_g * a.pw_cb);
-    if (a.in_scale) {
-        // BatchNorm + ReLU on the operand rows (lh_igemm_bn_in): the training-mode forward forms with K <= 256 have the instantiation
-        if constexpr (KC <= 256) {
-            if (!a.stats || !(a.sh == 1 && a.sw == 1 && a.hi == a.ho && a.wi == a.wo)) {
-                lh_set_error("lh_igemm_bn_in: a stride-1 training-mode forward launch (with statistics) is required");
-                return LH_ERR_UNSUPPORTED;
-            }
-            const void* fn = reinterpret_cast<const void*>(&igemm_pw_kernel<T, BM, KC, PT, true, true>);
-            const int ldsb = lh_pw_lds_bytes(BM, KC, PT, true);
-            if (ldsb > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb) != hipSuccess) {
-                lh_set_error("igemm_pw: cannot raise dynamic LDS to %d bytes", ldsb);
-                return LH_ERR_HIP;
-            }
-            hipLaunchKernelGGL((igemm_pw_kernel<T, BM, KC, PT, true, true>), grid, dim3(256), ldsb, s, a);
-            LH_LAUNCH_CHECK("igemm_pw (BatchNorm on the operand) launch");
-            return LH_OK;
-        } else {
-            lh_set_error("lh_igemm_bn_in: no instantiation for K %d", KC);
-            return LH_ERR_UNSUPPORTED;
-        }
-    }
     if (a.stats) hipLaunchKernelGGL((igemm_pw_kernel<T, BM, KC, PT, true>), grid, dim3(256), lds, s, a);
     else hipLaunchKernelGGL((igemm_pw_kernel<T, BM, KC, PT, false>), grid, dim3(256), lds, s, a);
     LH_LAUNCH_CHECK("igemm_pw launch");

@@ -34,6 +34,13 @@
 #define LH_RING_CFGS_DENSE(X) \
     X(128,128,2,4,2,128) X(128,128,2,4,3,128) X(128,64,4,2,3,128) X(64,128,2,4,3,128) \
     X(64,64,2,4,2,128) X(64,64,2,4,4,128)
+// The "K-split" forms (round 6): EIGHT waves as WC x WP pairs; the two waves of a pair multiply alternate 64-byte K slices of every 128-byte
+// stage into the same (BM / WC) x (BP / WP) sub-tile and add their partial sums in the epilogue: two thirds of the LDS fragment reads per
+// MFMA of the dense-wave forms at the same occupancy.  The accumulation order differs from every other form (results agree to fp32
+// rounding, not bit for bit).  X(BM, BP, WC, WP, D, KB) with WC x WP = the PAIR grid; RingCfg depth = depth + LH_KSPLIT_DEPTH.
+#define LH_KSPLIT_DEPTH 30
+#define LH_RING_CFGS_KSPLIT(X) \
+    X(128,128,2,2,2,128) X(128,128,2,2,3,128) X(128,128,2,2,4,128)
 #define LH_RING_CFGS_F32(X) \
     X(128,64,4,1,2,64) X(128,64,4,1,4,64) X(64,128,1,4,2,64) X(64,128,1,4,4,64) \
     X(64,64,2,2,2,64) X(64,64,2,2,4,64)

@@ -8,9 +8,13 @@
 #define LH_DCODE 0          // offset of the ring depth in RingCfg.depth (LH_WIDE_DEPTH for the wide-wave configurations)
 #endif
 
+#ifndef LH_LAUNCH
+#define LH_LAUNCH launch_ring   // launch_ring_ksplit for the K-split wave-pair forms
+#endif
+
 int LH_FN(const IgemmArgs& a, const RingCfg& c, hipStream_t s) {
 #define X(BM, BP, WC, WP, D, KB) \
-    if (c.bm == BM && c.bp == BP && c.depth == D + LH_DCODE && c.kb == KB) return launch_ring<LH_T, BM, BP, WC, WP, D, KB>(a, s);
+    if (c.bm == BM && c.bp == BP && c.depth == D + LH_DCODE && c.kb == KB) return LH_LAUNCH<LH_T, BM, BP, WC, WP, D, KB>(a, s);
     LH_LIST(X)
 #undef X
     return 1;

@@ -102,7 +102,13 @@ template <int L, int MAXS> __device__ __forceinline__ void wait_stages(int stage
 
 // The kernel proper, for workgroup `bid` of `nblk` of ONE problem: the plain kernel passes its block index, the
 // multi-problem kernel (multi.h) the index inside the problem the workgroup belongs to.
-template <typename T, int BM, int BP, int WC, int WP, int D, int KB, bool BNF = false>
+// KZ = 2, the K-SPLIT WAVE PAIR (round 6): WC x WP pairs of waves, each pair owning a (BM / WC) x (BP / WP) sub-tile -- 64 x 64 on the
+// 128 x 128 tile where the 8-wave form gives a wave 64 x 32 -- and the two waves of a pair taking ALTERNATE K slices of every 128-byte
+// stage.  Per stage a wave issues PT + CT = 8 fragment reads for 16 MFMAs instead of 2 x 6 reads for 2 x 8: two thirds of the LDS
+// fragment bytes per MFMA at the same occupancy (two waves per SIMD, one workgroup per CU for a 256-tile launch).  The partial sums of
+// a pair meet in the epilogue (one fp32 addition per element through LDS), so the accumulation ORDER differs from the KZ = 1 kernels:
+// results agree with them to fp32 rounding, not bit for bit.  RingCfg depth = depth + LH_KSPLIT_DEPTH.
+template <typename T, int BM, int BP, int WC, int WP, int D, int KB, int KZ = 1>
 __device__ __forceinline__ void igemm_ring_body(const IgemmArgs& p, unsigned char* smem, const int bid, const int nblk) {
 #if defined(__HIP_DEVICE_COMPILE__)      // the buffer builtins exist in the device pass only
     constexpr int ES = sizeof(T);
@@ -115,7 +121,8 @@ __device__ __forceinline__ void igemm_ring_body(const IgemmArgs& p, unsigned cha
     constexpr int SL = KB / 16;                       // 16-byte slots per row
     constexpr int RPI = 64 / SL;                      // rows one LDS-DMA instruction covers
     constexpr int GB = 16 * KB;                       // bytes of one 16-row group
-    constexpr int NWAVE = WC * WP;                    // 4 waves, or 8 for the 256 x 256 tile
+    constexpr int NWAVE = WC * WP * KZ;               // 4 waves, or 8 (the 256 x 256 tile, the dense-wave forms, the K-split pairs)
+    static_assert(KZ == 1 || (KZ == 2 && KB == 128 && sizeof(T) == 2), "K-split pairs: two K slices per stage, 16-bit types");
     constexpr int NW = BM / 16 * H / NWAVE, NX = BP / 16 * H / NWAVE;   // instructions per wave and stage
     constexpr int L = NW + NX;
     constexpr int KSUB = KB / 64;                     // logical steps (MFMA K slices) per stage
@@ -124,7 +131,9 @@ __device__ __forceinline__ void igemm_ring_body(const IgemmArgs& p, unsigned cha
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wc = wave / WP, wp = wave % WP;
+    const int kz = KZ == 2 ? wave / (WC * WP) : 0;   // K-split pairs: which K slice of every stage this wave multiplies
+    const int wq = KZ == 2 ? wave % (WC * WP) : wave;
+    const int wc = wq / WP, wp = wq % WP;
     // 1-D grid; work item w = (pixel tile, channel tile) with the channel tile fastest: the channel tiles of one pixel
     // tile and neighbouring pixel tiles (3x3 halos) run on one XCD at about the same time and share its L2.
     const int CB = (p.cout + BM - 1) / BM;
@@ -266,10 +275,8 @@ __device__ __forceinline__ void igemm_ring_body(const IgemmArgs& p, unsigned cha
         if constexpr (r < PT) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(base_b), "n"(r * GB));
         else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(base_a), "n"((r - PT) * GB));
     };
-    // one logical step: K slice kk of the stage at byte offset `so`
-    auto step = [&](auto KKc, unsigned so) {
-        constexpr int kk = decltype(KKc)::value;
-        const unsigned ca = offA[kk] + so, cb = offB[kk] + so;
+    // one logical step: the K slice whose fragment base addresses are ca / cb
+    auto step_at = [&](const unsigned ca, const unsigned cb) {
         uint4 F[NR];
         static_for<0, NR>([&](auto r) { rd(r, F[decltype(r)::value], ca, cb); });
         if (LH_PRIO) __builtin_amdgcn_s_setprio(LH_PRIO);      // experiment: the wave in its MFMA phase issues ahead of its SIMD partner
@@ -286,6 +293,8 @@ __device__ __forceinline__ void igemm_ring_body(const IgemmArgs& p, unsigned cha
         });
         if (LH_PRIO) __builtin_amdgcn_s_setprio(0);
     };
+    // K slice kk of the stage at byte offset `so`
+    auto step = [&](auto KKc, unsigned so) { step_at(offA[decltype(KKc)::value] + so, offB[decltype(KKc)::value] + so); };
 
     // The wide-wave form (one wave per SIMD, 128 x 128 per wave): no partner wave covers this wave's stalls, so the stage is
     // software-pipelined instead -- the fragment reads of the first K slice are issued BEFORE the ring refill (they land
@@ -348,6 +357,11 @@ __device__ __forceinline__ void igemm_ring_body(const IgemmArgs& p, unsigned cha
         }
         // the refill goes into the slot of stage s - 1, whose reads every wave retired before the barrier
         if (!late && issued < S) issue();
+        if constexpr (KZ == 2) {                     // this wave's K slice of the stage only (its pair partner takes the other)
+            step_at(offA[KSUB - 1 < kz ? KSUB - 1 : kz] + so, offB[KSUB - 1 < kz ? KSUB - 1 : kz] + so);
+            if (late && issued < S) issue();
+            continue;
+        }
         if constexpr (LH_PREREAD && KSUB == 2 && NR <= 8) {
             // experiment: the fragment reads of BOTH K slices of the stage up front (a second fragment register set), the
             // second slice's read latency under the first slice's MFMAs
@@ -381,7 +395,7 @@ __device__ __forceinline__ void igemm_ring_body(const IgemmArgs& p, unsigned cha
             return;
         }
     }
-    igemm_epilogue<T, BM, BP, WC, WP, BNF>(p, smem, acc, pblk, cblk, tid, lane, wc, wp, hw, ooh, oow, stats, pblk == 0 && stats == p.stats);
+    igemm_epilogue<T, BM, BP, WC, WP, KZ>(p, smem, acc, pblk, cblk, tid, lane, wc, wp, hw, ooh, oow, stats, kz);
 #endif
 }
 
@@ -394,12 +408,11 @@ __global__ __launch_bounds__(64 * WC * WP, (ring_waves_per_simd<BM, BP, WC, WP>(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     igemm_ring_body<T, BM, BP, WC, WP, D, KB>(p, smem, blockIdx.x, gridDim.x);
 }
-// the same kernel with the in-launch BatchNorm + ReLU in its epilogue (lh_igemm_bn_relu): an instantiation of its own, so that the
-// plain kernel's epilogue keeps its registers (the 256 x 256 tile would hold 16 more rows of 16 bytes per thread and spill)
+// the K-split wave-pair form (KZ = 2 above): 2 x WC x WP waves
 template <typename T, int BM, int BP, int WC, int WP, int D, int KB>
-__global__ __launch_bounds__(64 * WC * WP, (ring_waves_per_simd<BM, BP, WC, WP>())) void igemm_ring_bn_kernel(const IgemmArgs p) {
+__global__ __launch_bounds__(128 * WC * WP, 1) void igemm_ring_ksplit_kernel(const IgemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    igemm_ring_body<T, BM, BP, WC, WP, D, KB, true>(p, smem, blockIdx.x, gridDim.x);
+    igemm_ring_body<T, BM, BP, WC, WP, D, KB, 2>(p, smem, blockIdx.x, gridDim.x);
 }
 
 // Up to LH_MULTI_MAX independent convolutions that share the kernel configuration as ONE grid (lh_igemm_multi).
@@ -429,41 +442,35 @@ static int launch_ring(const IgemmArgs& a, hipStream_t s) {
         }
     }
     dim3 grid(ceil_div(a.M, BP) * ceil_div(a.cout, BM) * (a.nphase > 1 ? a.nphase : 1));
-    if (a.bn_out || a.bn_query) {
-        // the launch holds a grid barrier: every workgroup must be resident at once
-        if constexpr (lh_bn_variant<T, BM, BP, WC, WP>()) {
-            constexpr int ldsb = lds > lh_bnfold_lds_bytes<BM>() ? lds : lh_bnfold_lds_bytes<BM>();
-            static_assert(ldsb <= 160 * 1024, "LDS budget");
-            const void* fn = reinterpret_cast<const void*>(&igemm_ring_bn_kernel<T, BM, BP, WC, WP, D, KB>);
-            if (ldsb > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb) != hipSuccess) {
-                lh_set_error("igemm_ring: cannot raise dynamic LDS to %d bytes", ldsb);
-                return LH_ERR_HIP;
-            }
-            int per_cu = 0, dev = 0, ncu = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * WC * WP, ldsb) != hipSuccess ||
-                hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
-                lh_set_error("igemm_ring: occupancy query failed");
-                return LH_ERR_HIP;
-            }
-            lh_ring_resident_set((int)grid.x, per_cu, ncu);
-            if (a.bn_query) return LH_OK;
-            if ((long)grid.x > (long)per_cu * ncu) {
-                lh_set_error("lh_igemm_bn_relu: %u workgroups, the device holds %d x %d at once", grid.x, per_cu, ncu);
-                return LH_ERR_UNSUPPORTED;
-            }
-            hipLaunchKernelGGL((igemm_ring_bn_kernel<T, BM, BP, WC, WP, D, KB>), grid, dim3(64 * WC * WP), ldsb, s, a);
-            LH_LAUNCH_CHECK("igemm_ring (BatchNorm + ReLU) launch");
-            return LH_OK;
-        } else {
-            lh_set_error("lh_igemm_bn_relu: tile %d x %d with %d waves has no BatchNorm form (more than four tile rows per thread)", BM, BP, WC * WP);
-            return LH_ERR_UNSUPPORTED;
-        }
-    }
     hipLaunchKernelGGL((igemm_ring_kernel<T, BM, BP, WC, WP, D, KB>), grid, dim3(64 * WC * WP), lds, s, a);
     LH_LAUNCH_CHECK("igemm_ring launch");
     return LH_OK;
 }
 
+
+template <typename T, int BM, int BP, int WC, int WP, int D, int KB>
+static int launch_ring_ksplit(const IgemmArgs& a, hipStream_t s) {
+    constexpr int ring = D * (BM + BP) * KB;
+    constexpr int epi = lh_epi_lds_bytes<T, BM, BP, false>() + lh_epi_ksplit_bytes<BM, BP, WC, WP>();
+    constexpr int lds = ring > epi ? ring : epi;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    if (a.head_w) {
+        lh_set_error("igemm_ring: the K-split form carries no fused head");
+        return LH_ERR_UNSUPPORTED;
+    }
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_ring_ksplit_kernel<T, BM, BP, WC, WP, D, KB>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) {
+            lh_set_error("igemm_ring (K-split): cannot raise dynamic LDS to %d bytes: %s", lds, hipGetErrorString(e));
+            return LH_ERR_HIP;
+        }
+    }
+    dim3 grid(ceil_div(a.M, BP) * ceil_div(a.cout, BM) * (a.nphase > 1 ? a.nphase : 1));
+    hipLaunchKernelGGL((igemm_ring_ksplit_kernel<T, BM, BP, WC, WP, D, KB>), grid, dim3(128 * WC * WP), lds, s, a);
+    LH_LAUNCH_CHECK("igemm_ring (K-split) launch");
+    return LH_OK;
+}
 
 template <typename T, int BM, int BP, int WC, int WP, int D, int KB>
 static int launch_ring_multi(const LhMulti<IgemmArgs>& m, hipStream_t s) {

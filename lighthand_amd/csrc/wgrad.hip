@@ -812,14 +812,16 @@ extern "C" int lh_wgrad_table_run(const void* table, const lh_wgrad_table_info* 
     const char* blob = (const char*)table;
     const WgradArgs* tab = (const WgradArgs*)blob;
     const int2* items = (const int2*)(blob + info->off_items);
-    const int rc = dtype == LH_BF16 ? lh_wgrad_ring_table_launch_bf16(tab, items, info->n_items, info->bo, info->bi, info->kps, info->depth, s)
-                                    : lh_wgrad_ring_table_launch_f16(tab, items, info->n_items, info->bo, info->bi, info->kps, info->depth, s);
+    int rc = LH_OK;
+    if (info->run_parts != 2)
+        rc = dtype == LH_BF16 ? lh_wgrad_ring_table_launch_bf16(tab, items, info->n_items, info->bo, info->bi, info->kps, info->depth, s)
+                              : lh_wgrad_ring_table_launch_f16(tab, items, info->n_items, info->bo, info->bi, info->kps, info->depth, s);
     if (rc == 1) {
         lh_set_error("lh_wgrad_table_run: no kernel for tile %dx%d stage %d depth %d", info->bo, info->bi, info->kps, info->depth);
         return LH_ERR_UNSUPPORTED;
     }
     if (rc) return rc;
-    if (info->n_fold_items > 0) {
+    if (info->n_fold_items > 0 && info->run_parts != 1) {
         hipLaunchKernelGGL(wgrad_reduce_table_kernel, dim3(info->n_fold_items), dim3(256), info->fold_lds, s,
                            (const WreduceArgs*)(blob + info->off_fold_args), (const int2*)(blob + info->off_fold_items));
         LH_LAUNCH_CHECK("wgrad_reduce_table launch");

@@ -345,13 +345,6 @@ class Plan:
     force_wgrad = None
     fuse_head = True             # test hook: False keeps the inference head as separate launches (A/B against _fuse_head)
     fuse_stem = True             # test hook: False keeps the inference stem as convolution + max-pool launches (A/B against _fuse_stem_pool)
-    # Training plans: conv -> BatchNorm (batch statistics) -> ReLU as ONE launch where the convolution's whole grid is resident at once
-    # (lh_igemm_bn_relu: stages 3-4 and the first deconvolutions of the ResNets at batch 64).  "0" keeps the three launches; "2" also
-    # takes grids of up to two workgroups per CU.
-    fuse_bn_train = os.environ.get("LH_FUSE_BN_TRAIN", "0")
-    # Training plans: the 1x1 convolution behind a BatchNorm + ReLU applies them to its operand rows itself (lh_igemm_bn_in) where it runs
-    # on the persistent pointwise kernel -- conv3 of the bottlenecks of stages 1-3.  "0": the elementwise launch stays.
-    bn_in = os.environ.get("LH_BN_IN", "0")
     fuse_bottleneck = os.environ.get("LH_FUSE_BOTTLENECK", "1") != "0"    # False keeps the stage-1 bottlenecks of inference plans as three launches (A/B against _fuse_bottleneck)
     _tune_file_loaded = False
 
@@ -582,6 +575,9 @@ class Plan:
                         b.record(stream)
                         b.synchronize()
                         t = a.elapsed_time(b)
+                    if os.environ.get("LH_TUNE_LOG"):
+                        print(f"[tune {role or ''} {lead.k_run}x{lead.ntaps}->{lead.cout} M={lead.n * lead.ho * lead.wo} addend={addend}] cfg {cfg}: "
+                              f"{t / Plan.tune_iters() * 1e3:7.1f} us", flush=True)
                     if best is None or t < best[0]:
                         best = (t, cfg)
                 hit = best[1]
@@ -679,7 +675,7 @@ class Plan:
             gi = self._gate_info.get(id(x)) if (self.bn_gate and first and len(descs) == 1 and self.n_lanes == 1 and self.es == 2) else None
             cfg = (C.c_int * 5)()
             if gi is not None and len(self._uses.get(id(x), [])) == 1 and x.c == x.c_valid and x.pixels * x.c * self.es <= self.bn_gate_bytes and \
-                    self.lib.lh_igemm_config(C.byref(dd), self.dt, cfg) == 0 and (2 <= cfg[2] < 10 or 20 <= cfg[2] < 30):
+                    self.lib.lh_igemm_config(C.byref(dd), self.dt, cfg) == 0 and (2 <= cfg[2] < 10 or 20 <= cfg[2] < 40):
                 # x = relu(BN(raw)) with this convolution as its only consumer: the launch stores the ReLU-gated gradient
                 # and the BatchNorm-backward partial sums of its tile (the node's backward skips its reduce pass)
                 rows = self.lib.lh_igemm_stats_rows(C.byref(dd), self.dt)
@@ -758,6 +754,8 @@ class Plan:
             if depth == 100:
                 return f"conv3x3_direct_kernel<{t}, {kb}, {'true' if stats else 'false'}>"
             wc, wp = {(256, 256): (2, 4), (128, 256): (2, 2), (256, 128): (4, 2), (128, 128): (2, 2), (128, 64): (4, 1), (64, 128): (1, 4), (64, 64): (2, 2)}[(bm, bp)]
+            if 30 <= depth < 40:                # the K-split wave-pair forms (igemm_ring_cfgs.h)
+                return f"igemm_ring_ksplit_kernel<{t}, {bm}, {bp}, {wc}, {wp}, {depth - 30}, {kb}>"
             if 20 <= depth < 30:                # the dense-wave forms (eight waves on the 4-wave tiles, igemm_ring_cfgs.h)
                 wc, wp = {(128, 128): (2, 4), (128, 64): (4, 2), (64, 128): (2, 4), (64, 64): (2, 4), (128, 256): (2, 4), (256, 128): (4, 2)}[(bm, bp)]
                 depth -= 20
@@ -836,11 +834,12 @@ class Plan:
         self._pend[src] = dict(calls=[], names=[], layers=0, ws=[], bytes=0)
 
     # kernel configurations (tile o, tile i, pixel rows per stage, ring depth) offered to a table of a tile class, best guess first
+    # (measured, R50 bs 64: the 8-wave 256 x 256 tile with 64-row stages wins the >= 256-channel table by 20 % over 128 x 128; the
+    #  layers with a side below 128 channels stream their operands -- 64 x 64 tiles are as fast for them as 128 x 64 / 64 x 128, and
+    #  ONE class for all of them is one launch instead of three)
     _TABLE_CFGS = {
-        (256, 256): ((256, 256, 32, 3), (256, 256, 64, 2), (128, 128, 64, 3), (128, 128, 64, 2)),
+        (256, 256): ((256, 256, 64, 2), (256, 256, 32, 3), (128, 128, 64, 2)),
         (128, 128): ((128, 128, 64, 3), (128, 128, 64, 2), (128, 128, 32, 4)),
-        (128, 64): ((128, 64, 64, 3), (128, 64, 64, 2), (128, 64, 32, 4), (64, 64, 64, 3)),
-        (64, 128): ((64, 128, 64, 3), (64, 128, 64, 2), (64, 128, 32, 4), (64, 64, 64, 3)),
         (64, 64): ((64, 64, 64, 3), (64, 64, 64, 2), (64, 64, 32, 4)),
     }
 
@@ -871,7 +870,7 @@ class Plan:
                 return None
             if big and n_out >= 256 and n_in >= 256:
                 return (256, 256)
-            return (128 if n_out >= 128 else 64, 128 if n_in >= 128 else 64)
+            return (128, 128) if n_out >= 128 and n_in >= 128 else (64, 64)
         groups = {}
         for u in units:
             groups.setdefault(cls(u), []).append(u)
@@ -961,7 +960,7 @@ class Plan:
             for cfg in cands:
                 kps = cfg[2]
                 smax = max((c.wargs[0]._obj.n * c.wargs[0]._obj.ho * c.wargs[0]._obj.wo + kps - 1) // kps for c in members)
-                ladder = [0] + sorted({max(256 // kps, -(-smax // q)) for q in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32)}, reverse=True)
+                ladder = [0] + sorted({max(256 // kps, -(-smax // q)) for q in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64)}, reverse=True)
                 seen = set()
                 for target in ladder:
                     info, blob, ws = self._build_table(arr, n, cfg, target)
@@ -1440,6 +1439,9 @@ class Plan:
                         d.cfg[0], d.cfg[1], d.cfg[2], d.cfg[3] = mc
                     run()
                     t = self._timed_cold(run, warm, Plan.tune_iters())
+                    if os.environ.get("LH_TUNE_LOG"):
+                        print(f"[tune {role or ''} {lead.k_run}x{lead.ntaps}->{lead.cout} M={lead.n * lead.ho * lead.wo} addend={addend}] cfg {cfg}: "
+                              f"{t / Plan.tune_iters() * 1e3:7.1f} us", flush=True)
                     if best is None or t < best[0]:
                         best = (t, cfg)
                 hit = best[1]
@@ -1736,8 +1738,7 @@ class Plan:
             self._stats_for(y, [d])
             stats_ptr = y.stats
         flops = 2.0 * y.pixels * cout * cin * k * k
-        if not self._conv_takes_input_bn(nd, d, x, xbuf, pack, ybuf, bias, stats_ptr):
-            self._igemm(self.fwd, d, xbuf, pack, ybuf, None, bias, stats_ptr, nd["w"] + " fwd", produces=y)
+        self._igemm(self.fwd, d, xbuf, pack, ybuf, None, bias, stats_ptr, nd["w"] + " fwd", produces=y)
         self.profile_meta.append(("fwd", self.fwd[-1], self._kname(d, stats=stats_ptr is not None), flops, (x.pixels * x.c + y.pixels * y.c) * self.es))
         if not self.with_bwd:
             return
@@ -2016,15 +2017,11 @@ class Plan:
             fd.relu_mask = relu_bits.data_ptr()
         if self.training and self.with_bwd and relu and len(terms) == 1 and terms[0][1] is not None and terms[0][2] == 0:
             self._gate_info[id(out)] = dict(raw=terms[0][0], st=bn_state[0])
-        if self.training and relu and len(terms) == 1 and terms[0][1] is not None and terms[0][2] == 0 and relu_bits is None and \
-                self._fuse_bn_into_conv(terms[0][0], fd.fin[0], obuf):
-            pass                                         # the producing convolution carries finalize + BN + ReLU (lh_igemm_bn_relu)
-        else:
-            self.fwd.append(_Call(self.lib.lh_fuse_fwd, (C.byref(fd), obuf.data_ptr(), out.n, out.h, out.w, c, self.dt), "fuse fwd"))
-            if self.training and relu and len(terms) == 1 and terms[0][1] is not None and terms[0][2] == 0 and relu_bits is None:
-                # what a max-pool that follows needs to take this node's elementwise pass over (_c_maxpool)
-                self._bnrelu_info[id(out)] = dict(raw=terms[0][0], st=bn_state[0], call=self.fwd[-1], fin=fd.fin[0])
-            self.profile_meta.append(("fwd", self.fwd[-1], "fuse_fwd(all kernels)", 0.0, (sum(a.pixels for a, _, _ in terms) + out.pixels) * c * self.es))
+        self.fwd.append(_Call(self.lib.lh_fuse_fwd, (C.byref(fd), obuf.data_ptr(), out.n, out.h, out.w, c, self.dt), "fuse fwd"))
+        if self.training and relu and len(terms) == 1 and terms[0][1] is not None and terms[0][2] == 0 and relu_bits is None:
+            # what a max-pool that follows needs to take this node's elementwise pass over (_c_maxpool)
+            self._bnrelu_info[id(out)] = dict(raw=terms[0][0], st=bn_state[0], call=self.fwd[-1], fin=fd.fin[0])
+        self.profile_meta.append(("fwd", self.fwd[-1], "fuse_fwd(all kernels)", 0.0, (sum(a.pixels for a, _, _ in terms) + out.pixels) * c * self.es))
         if not self.with_bwd:
             return
         self._ws_fuse = max(self._ws_fuse, self.lib.lh_fuse_bwd_workspace_bytes(out.n, out.h, out.w, c))
@@ -2075,81 +2072,6 @@ class Plan:
             # what SURVEY 8(d)'s traffic model itself charges to the BatchNorm backward: ONE re-read of y per BatchNorm term
             self.bn_bwd_8d_bytes = getattr(self, "bn_bwd_8d_bytes", 0.0) + float(n_bn) * out.pixels * c * self.es
         blk.append(emit)
-
-    def _conv_takes_input_bn(self, nd, d, x, xbuf, pack, ybuf, bias, stats_ptr):
-        """Training plans: x = relu(BN(raw)) feeds ONLY this 1x1 convolution (bn2 -> relu -> conv3 of a bottleneck, pose_resnet.py:89-94)
-        and the convolution runs on the persistent pointwise kernel, whose operand rows pass through registers: the kernel applies the
-        BatchNorm + ReLU there (lh_igemm_bn_in) and stores the activated rows on the way (this convolution's weight gradient reads them);
-        the node's elementwise launch becomes its finalize alone.  Bit-identical: lh_fuse_fwd's arithmetic, rounded before the MFMA."""
-        info = self._bnrelu_info.get(id(x))
-        if (Plan.bn_in == "0" or info is None or not self.training or self.es != 2 or self._forced is not None or stats_ptr is None
-                or (nd["k"], nd["s"], nd["p"]) != (1, 1, 0) or len(self._uses.get(id(x), [])) != 1 or x.c != x.c_valid or info["call"] not in self.fwd):
-            return False
-        cfg = (C.c_int * 5)()
-        if self.lib.lh_igemm_config(C.byref(d), self.dt, cfg) != 0 or cfg[2] != 1 or cfg[3] > 256:
-            return False
-        raw, st, fin = info["raw"], info["st"], info["fin"]
-        i = self.fwd.index(info["call"])
-        self.fwd[i] = _Call(self.lib.lh_bn_finalize_multi, (fin, 1), "bn finalize (its BN + ReLU rides in the next convolution)")
-        self.profile_meta = [m for m in self.profile_meta if m[1] is not info["call"]]
-        del self._bnrelu_info[id(x)]
-        bi = _lib.BnIn(st["scale"].data_ptr(), st["shift"].data_ptr(), xbuf.data_ptr())
-        self.keep += [d, bi, fin]
-        c = _Call(self.lib.lh_igemm_bn_in, (C.byref(d), raw.buf.data_ptr(), _ptr(pack), _ptr(ybuf), C.byref(bi), _ptr(bias), _ptr(stats_ptr), self.dt),
-                  nd["w"] + " fwd (BN + ReLU on the operand)")
-        c.keep, c.ig = d, dict(src=1, dst=3)
-        self.fwd.append(c)
-        self._producers.setdefault(id(nd["y"]), []).append(c)
-        self._ready[id(x)] = len(self.fwd)               # the activated input is complete only behind this launch
-        self._n_bn_in = getattr(self, "_n_bn_in", 0) + 1
-        return True
-
-    def _fuse_bn_into_conv(self, raw, fin_ptr, obuf):
-        """Training plans: the convolution that produces `raw` takes the node relu(BN(raw)) over (lh_igemm_bn_relu / lh_igemm_phases_bn_relu:
-        statistics rows, grid barrier, in-launch finalize, second store) when it is ONE tiled launch on the plan's only stream whose whole
-        grid is resident at once -- the barrier spins, so nothing that could wait for it may hold its CUs.  Returns True when the launch
-        was rewritten (the caller then emits no elementwise call)."""
-        mode = Plan.fuse_bn_train
-        if mode == "0" or not self.training or self.es != 2 or self.n_lanes != 1 or self._forced is not None or not fin_ptr:
-            return False
-        prods = self._producers.get(id(raw)) or []
-        if len(prods) != 1 or raw.c != raw.c_valid or raw.stats is None or not (0 < raw.stats_rows < 256):
-            return False
-        call = prods[0]
-        lib = self.lib
-        if call.fn is lib.lh_igemm:
-            d, src, pack, dst, addend, amask, bias, scale, shift, stats, dt = call.args
-            descs, n = (C.POINTER(IgemmDesc) * 1)(C.pointer(call.keep)), 1
-        elif call.fn is lib.lh_igemm_phases:
-            arr, n, src, packs, dst, addend, amask, bias, scale, shift, stats, dt = call.args
-            descs = arr
-        else:
-            return False
-        if addend or amask or bias or scale or shift or not stats or call not in self.fwd:
-            return False
-        if any(dd.relu or dd.out_pix_stride != dd.cout for dd in (call.keep if isinstance(call.keep, list) else [call.keep])):
-            return False
-        res = (C.c_int * 3)()
-        if lib.lh_igemm_bn_relu_resident(descs, n, self.dt, res) != 1 or res[0] > res[2] * (2 if mode == "2" else 1):
-            return False
-        if not hasattr(self, "_bn_sync"):
-            self._bn_sync = []
-        self._bn_sync.append(self._alloc(32, dtype=torch.int32, zero=True))       # a 128-byte line per call site: [0] arrivals, [1] gave up
-        f = _lib.BnReluFuse(fin_ptr, obuf.data_ptr(), self._bn_sync[-1].data_ptr())
-        self.keep += [f, descs]
-        if n == 1:
-            call.fn, call.args = lib.lh_igemm_bn_relu, (d, src, pack, dst, C.byref(f), dt)
-            call.ig = dict(src=1, dst=3)
-        else:
-            call.fn, call.args = lib.lh_igemm_phases_bn_relu, (arr, n, src, packs, dst, C.byref(f), dt)
-            call.ig = dict(src=2, dst=4)
-        call.what += " + BN + ReLU"
-        self._n_fused_bn = getattr(self, "_n_fused_bn", 0) + 1
-        return True
-
-    def bn_sync_gave_up(self):
-        """True when a fused convolution + BatchNorm launch of this plan ever gave up at its grid barrier (its results are then wrong)."""
-        return any(bool(t[1].item()) for t in getattr(self, "_bn_sync", []))
 
     def _next_writer_is_conv(self, a, nd):
         """True when, walking backward from fuse node `nd`, the next writer of a.grad is a stride-1-output convolution /

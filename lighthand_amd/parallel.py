@@ -54,6 +54,7 @@ class LhComm:
             uid = (C.c_char * 128).from_buffer_copy(box[0])
         self.handle = C.c_void_p()
         _lib.check(self.lib.lh_comm_init(C.byref(self.handle), self.rank, self.world_size, uid), "lh_comm_init")
+        self._direct_bufs = {}
 
     def all_reduce_sum_(self, t, stream=None):
         """In-place sum of a contiguous fp32 / bf16 / fp16 device tensor on `stream` (default: the current one)."""
@@ -61,6 +62,33 @@ class LhComm:
         assert t.is_cuda and t.is_contiguous()
         s = (stream or torch.cuda.current_stream()).cuda_stream
         _lib.check(self.lib.lh_comm_allreduce_sum(self.handle, t.data_ptr(), t.numel(), _lib.dtype_code(t.dtype), s), "lh_comm_allreduce_sum")
+        return t
+
+    def direct_sum_(self, t, stream=None):
+        """In-place sum of the contiguous 1-D device tensor t over the ranks as all-to-all + local sum in RANK order (lh_sum_chunks) +
+        all-gather, every launch on `stream` -- capturable, so the direct exchange lives INSIDE the single-graph step.  A length that
+        divides by the rank count is exchanged in place; any other goes through a zero-padded staging buffer (allocated once per
+        bucket: bucket slices of the gradient arena have stable addresses).  Every rank ends with the same bits."""
+        from . import _lib
+        assert t.is_cuda and t.is_contiguous() and t.dim() == 1
+        w, n = self.world_size, t.numel()
+        chunk = (n + w - 1) // w
+        key = (t.data_ptr(), n, t.dtype)
+        bufs = self._direct_bufs.get(key)
+        if bufs is None:
+            bufs = self._direct_bufs[key] = (t if n == w * chunk else torch.zeros(w * chunk, dtype=t.dtype, device=t.device),
+                                             torch.empty(w * chunk, dtype=t.dtype, device=t.device))
+        send, recv = bufs
+        s = (stream or torch.cuda.current_stream()).cuda_stream
+        dt = _lib.dtype_code(t.dtype)
+        if send is not t:
+            send[:n].copy_(t)
+        _lib.check(self.lib.lh_comm_alltoall(self.handle, send.data_ptr(), recv.data_ptr(), chunk, dt, s), "lh_comm_alltoall")
+        mine = send[self.rank * chunk:(self.rank + 1) * chunk]              # this rank's slice of the bucket: summed in place
+        _lib.check(self.lib.lh_sum_chunks(recv.data_ptr(), mine.data_ptr(), w, chunk, dt, s), "lh_sum_chunks")
+        _lib.check(self.lib.lh_comm_allgather(self.handle, mine.data_ptr(), send.data_ptr(), chunk, dt, s), "lh_comm_allgather")
+        if send is not t:
+            t.copy_(send[:n])
         return t
 
     def close(self):
@@ -174,11 +202,10 @@ class GradSync:
         self.comm = comm
         # algo="direct": a bucket is exchanged as all-to-all + local sum in rank order + all-gather -- reduce-scatter and all-gather
         # with ALL peers at once (2 x bytes / N per xGMI link instead of a ring's 2 (N - 1) / N x bytes over one), and
-        # every rank ends with bit-identical sums.  "allreduce" leaves the algorithm to RCCL.  Not with the C-ABI communicator.
+        # every rank ends with bit-identical sums.  "allreduce" leaves the algorithm to RCCL.  With the C-ABI communicator the three steps
+        # are lh_comm_alltoall / lh_sum_chunks / lh_comm_allgather on the side stream (LhComm.direct_sum_): capturable, one graph per step.
         if algo not in ("allreduce", "direct"):
             raise ValueError("algo must be 'allreduce' or 'direct'")
-        if algo == "direct" and comm is not None:
-            raise ValueError("the direct exchange runs on torch.distributed's collectives, not on the lh_comm_* communicator")
         self.algo = algo
         self._direct_bufs = {}
         self.world_size = world_size or (dist.get_world_size(group) if dist.is_initialized() else 1)
@@ -252,7 +279,8 @@ class GradSync:
             ev.record(torch.cuda.current_stream())
             self.stream.wait_event(ev)
             with torch.cuda.stream(self.stream):
-                reduce_ = (lambda t: None) if self.stub else self.comm.all_reduce_sum_ if self.comm is not None else \
+                reduce_ = (lambda t: None) if self.stub else \
+                    (self.comm.direct_sum_ if self.algo == "direct" else self.comm.all_reduce_sum_) if self.comm is not None else \
                     self._direct_sum_ if self.algo == "direct" else (lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group))
                 if self.compress == "bf16":
                     half = self._staging.get(bucket)

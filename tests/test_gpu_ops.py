@@ -164,11 +164,15 @@ CFG_CASES = [(256, 256, 3, 1, 1, 2, 16, 16), (512, 256, 1, 1, 0, 3, 12, 20), (25
 
 @pytest.mark.parametrize("precision", ["bf16", "fp32"])
 @pytest.mark.parametrize("case", CFG_CASES)
-def test_every_conv_kernel_configuration(case, precision, forced_plans):
+def test_every_conv_kernel_configuration(case, precision, forced_plans, monkeypatch):
     """Every compiled-in configuration of the LDS-DMA convolution kernel (tile 64..256, ring depth, 64- / 128-byte
     stages: lh_igemm_candidates) that fits the launch, forced in turn on forward and data gradient: each must match
-    PyTorch, and all must agree BIT FOR BIT with one another (the K-loop order does not depend on the tile)."""
+    PyTorch at the precision's tolerance (fp32 1e-3 relative is the contract; TOL is tighter), and all forms that keep ONE accumulator
+    per output element agree BIT FOR BIT with one another (the K-loop order does not depend on the tile).  The K-split wave-pair forms
+    (ring depth code 30..39, round 6) add two partial sums per element: they are held to PyTorch at TOL and to the other forms at the
+    distance of one extra fp32 rounding of the accumulator (far inside one unit of the 16-bit output grid), not to bit equality."""
     ConvNet, _ = _mods()
+    monkeypatch.setenv("LH_KSPLIT_TILES", "1")              # offer the K-split forms too (off by default: measured equal, other sum order)
     cin, cout, k, s_, p, n, h, w = case
     torch.manual_seed(5)
     x = quant(torch.randn(n, cin, h, w), precision)
@@ -179,7 +183,7 @@ def test_every_conv_kernel_configuration(case, precision, forced_plans):
     ref = ref_m(xr)
     dy = quant(torch.randn_like(ref), precision)
     ref.backward(dy)
-    seen, first = [], None
+    seen, first, ksplit_seen = [], None, False
     idx = 0
     while True:
         chosen = []
@@ -195,8 +199,14 @@ def test_every_conv_kernel_configuration(case, precision, forced_plans):
         assert chosen, "no launch of this plan offered candidates"
         seen.append(tuple(c for c, _ in chosen))
         assert rel_err(out, ref.detach()) < TOL[precision] and rel_err(dx, xr.grad) < TOL[precision], chosen
-        if first is None:
+        ksplit = any(30 <= c[2] < 40 for c, _ in chosen)
+        if first is None and not ksplit:
             first = (out, dx)
+        elif ksplit:
+            ksplit_seen = True
+            if first is not None:       # one more fp32 rounding before the store: at most a last-place flip of a few outputs
+                for a, b in ((out, first[0]), (dx, first[1])):
+                    assert rel_err(a, b) < (1e-6 if precision == "fp32" else 8e-3) and float((a != b).float().mean()) < 0.05, chosen
         else:
             assert torch.equal(out, first[0]) and torch.equal(dx, first[1]), chosen
         idx += 1
@@ -207,6 +217,8 @@ def test_every_conv_kernel_configuration(case, precision, forced_plans):
     assert len(seen) >= 3
     if precision == "bf16" and cout % 256 == 0 and out.shape[0] * out.shape[2] * out.shape[3] > 128:
         assert (256, 256) in tiles
+    if precision == "bf16" and cin * k * k >= 128:
+        assert ksplit_seen, "the K-split wave-pair forms were not offered"
 
 
 @pytest.fixture(scope="module")
@@ -1007,95 +1019,6 @@ def test_short_k_run_does_not_read_past_the_operand(precision, forced_plans):
             assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16)), c.what
             checked += 1
     assert checked >= 2, checked
-
-
-FUSED_BN_CASES = [(256, 2, 16, 16), (96, 3, 12, 20), (64, 1, 9, 9), (512, 2, 8, 8)]
-
-
-@pytest.mark.parametrize("precision", ["bf16", "fp16"])
-@pytest.mark.parametrize("tile", ["big", "small", "tuned"])
-@pytest.mark.parametrize("case", FUSED_BN_CASES)
-def test_conv_bn_relu_as_one_launch_is_bit_identical(case, tile, precision, forced_plans):
-    """lh_igemm_bn_relu (conv + batch-statistics BatchNorm + ReLU in ONE launch: statistics rows, grid barrier, in-launch fold with
-    lh_bn_finalize's arithmetic, second store) against the three launches it replaces (lh_igemm, finalize, lh_fuse_fwd): forward output,
-    running statistics, every gradient bit for bit -- ragged pixel counts, channel counts below the tile, largest / smallest / measured tile."""
-    import copy
-    _, BnNet = _mods()
-    c, n, h, w = case
-    torch.manual_seed(11)
-    proto = BnNet(c, "plain")
-    x = torch.randn(n, c, h, w).to(torch.bfloat16).float()
-    # the tiled forms that have a BatchNorm instantiation (at most four tile rows per thread: the 8-wave forms of the <= 128 x 128 tiles,
-    # the small 4-wave tiles) -- not the persistent pointwise / direct 3x3 kernels, not the 256-wide tiles
-    bn_form = lambda q: (20 <= q[2] < 30 and q[0] <= 128 and q[1] <= 128) or (2 <= q[2] < 10 and (q[0], q[1]) in ((128, 64), (64, 128), (64, 64)))
-    tiled = lambda cands: [q for q in cands if bn_form(q)] or cands
-    if tile != "tuned":
-        forced_plans.force_cfg = (lambda cands: max(tiled(cands), key=lambda q: (q[0] * q[1], q[3]))) if tile == "big" else \
-            (lambda cands: min(tiled(cands), key=lambda q: (q[0] * q[1], q[3])))
-    res = {}
-    try:
-        for mode in ("1", "0"):
-            forced_plans.fuse_bn_train = mode
-            m = copy.deepcopy(proto)
-            torch.manual_seed(12)
-            out, dx, grads = _run_plan(m, x, lambda o: torch.randn_like(o), precision)
-            plan = next(iter(m._lh_plans.values()))
-            nf = getattr(plan, "_n_fused_bn", 0)
-            assert nf == 0 if mode == "0" else (nf == 1 or tile == "tuned"), (mode, [cc.what for cc in plan.fwd if hasattr(cc, "fn")])
-            assert not plan.bn_sync_gave_up()
-            res[mode] = (out, dx, grads, {k: v.cpu().clone() for k, v in m.state_dict().items() if "running" in k or "tracked" in k})
-    finally:
-        forced_plans.fuse_bn_train = "0"
-    a, b = res["1"], res["0"]
-    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
-    for k in b[2]:
-        assert torch.equal(a[2][k], b[2][k]), k
-    for k in b[3]:
-        assert torch.equal(a[3][k], b[3][k]), k
-    assert int(a[3]["bn.num_batches_tracked"]) == 1
-
-
-@pytest.mark.parametrize("case", [(128, 64, 2, 8, 8), (64, 96, 3, 6, 10)])
-def test_deconv_bn_relu_as_one_launch_is_bit_identical(case, forced_plans):
-    """The four sub-pixel phases of a 4x4 / stride-2 transposed convolution + BatchNorm + ReLU as one launch (lh_igemm_phases_bn_relu)
-    against the three launches: bit for bit (pose_resnet.py:219-227)."""
-    import copy
-    from lighthand_amd.module import HipModule
-    cin, cout, n, h, w = case
-
-    class DeconvBn(HipModule):
-        def __init__(self):
-            super().__init__()
-            self.up = nn.ConvTranspose2d(cin, cout, 4, 2, 1, 0, bias=False)
-            self.bn = nn.BatchNorm2d(cout, momentum=0.1)
-            self.out = nn.Conv2d(cout, 8, 1, bias=False)
-
-        def describe(self, gb):
-            x = gb.input_act(cin)
-            gb.output(gb.conv(gb.fuse([(gb.deconv(x, "up", 4), "bn")]), "out", 1, 1, 0))
-
-    torch.manual_seed(21)
-    proto = DeconvBn()
-    x = torch.randn(n, cin, h, w).to(torch.bfloat16).float()
-    res = {}
-    try:
-        for mode in ("1", "0"):
-            forced_plans.fuse_bn_train = mode
-            m = copy.deepcopy(proto)
-            torch.manual_seed(22)
-            out, dx, grads = _run_plan(m, x, lambda o: torch.randn_like(o), "bf16")
-            plan = next(iter(m._lh_plans.values()))
-            assert getattr(plan, "_n_fused_bn", 0) == (1 if mode == "1" else 0), [cc.what for cc in plan.fwd if hasattr(cc, "fn")]
-            assert not plan.bn_sync_gave_up()
-            res[mode] = (out, dx, grads, {k: v.cpu().clone() for k, v in m.state_dict().items() if "running" in k})
-    finally:
-        forced_plans.fuse_bn_train = "0"
-    a, b = res["1"], res["0"]
-    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
-    for k in b[2]:
-        assert torch.equal(a[2][k], b[2][k]), k
-    for k in b[3]:
-        assert torch.equal(a[3][k], b[3][k]), k
 
 
 @pytest.mark.parametrize("shape", [(3, 64, 34, 30), (2, 128, 17, 23), (1, 64, 8, 8), (2, 64, 9, 16)])

@@ -787,6 +787,42 @@ def test_lh_comm_c_abi_single_rank():
         if use_graph:
             assert len(step.graphs) == 1
     assert torch.allclose(got[0], got[1], rtol=1e-5, atol=1e-7), float((got[0] - got[1]).abs().max())
+    # round 6: the pieces of the DIRECT exchange at the C ABI (lh_comm_alltoall / lh_sum_chunks / lh_comm_allgather, and RCCL's own
+    # reduce-scatter): with one rank every one of them is the identity; ragged lengths go through the padded staging buffer; and the
+    # direct exchange lives inside the single captured graph of the data-parallel step (GradSync(algo="direct", comm=...))
+    import ctypes as C
+    from lighthand_amd import _lib
+    lib = _lib.load()
+    rk, nr = C.c_int(-1), C.c_int(-1)
+    assert lib.lh_comm_size(comm.handle, C.byref(rk), C.byref(nr)) == 0 and (rk.value, nr.value) == (0, 1)
+    src = torch.randn(4099, device="cuda")
+    for fn in (lib.lh_comm_reduce_scatter_sum, lib.lh_comm_allgather, lib.lh_comm_alltoall):
+        dst = torch.full_like(src, float("nan"))
+        assert fn(comm.handle, src.data_ptr(), dst.data_ptr(), src.numel(), _lib.LH_F32, torch.cuda.current_stream().cuda_stream) == 0, lib.lh_last_error()
+        torch.cuda.synchronize()
+        assert torch.equal(dst, src)
+    assert lib.lh_comm_alltoall(comm.handle, src.data_ptr(), src.data_ptr(), 16, _lib.LH_F32, None) == -1      # not in place
+    assert lib.lh_comm_allgather(comm.handle, src.data_ptr(), src.data_ptr(), 16, 7, None) == -1               # bad dtype
+    for n in (1 << 16, 4099):
+        for dt in (torch.float32, torch.bfloat16):
+            t = torch.randn(n, device="cuda").to(dt)
+            want = t.clone()
+            comm.direct_sum_(t, stream=side)
+            side.synchronize()
+            assert torch.equal(t, want), (n, dt)
+    got2 = []
+    for use_graph in (True, False):
+        m = _model(18)
+        step = TrainStep(m, 4, 64, 64, lr=1e-3, use_graph=use_graph,
+                         grad_sync=parallel.GradSync(world_size=2, bucket_bytes=2 << 20, comm=comm, algo="direct"))
+        for _ in range(2):
+            step(xb, jb)
+        torch.cuda.synchronize()
+        got2.append(m.arena().flat.clone())
+        if use_graph:
+            assert len(step.graphs) == 1
+    assert torch.allclose(got2[0], got2[1], rtol=1e-5, atol=1e-7)
+    assert torch.equal(got2[1], got[1])                        # one rank: the direct exchange and the all-reduce are both the identity
     comm.close()
 
 
@@ -1062,60 +1098,3 @@ def test_bench_gpus_2_direct_gradient_exchange():
         losses[algo] = out["loss_after"]
     assert losses["direct"] == losses["allreduce"], losses
 
-
-@pytest.mark.parametrize("depth,precision", [(50, "bf16"), (18, "fp16")])
-def test_train_step_with_conv_bn_relu_launches_is_bit_identical(depth, precision):
-    """LH_FUSE_BN_TRAIN=1 (Plan.fuse_bn_train): the convolutions whose whole grid is resident carry their BatchNorm + ReLU
-    (lh_igemm_bn_relu).  Three captured training steps of a whole network with and without them: the same losses, weights and
-    running statistics BIT FOR BIT (same statistics rows, lh_bn_finalize's fold arithmetic, lh_fuse_fwd's elementwise arithmetic)."""
-    from lighthand_amd.engine import Plan
-    from lighthand_amd.runtime import TrainStep
-    x, j = _batch(8, 128, 3)
-    res = []
-    try:
-        for mode in ("1", "0"):
-            Plan.fuse_bn_train = mode
-            m = _model(depth, precision)
-            step = TrainStep(m, 8, 128, 128, lr=1e-3, use_graph=True)
-            losses = [float(step(x, j)) for _ in range(3)]
-            nf = getattr(step.plan, "_n_fused_bn", 0)
-            assert (nf >= 2) if mode == "1" else nf == 0, nf          # (which launches run a tiled form with a BatchNorm instantiation is a measured choice)
-            assert not step.plan.bn_sync_gave_up()
-            res.append((losses, m.arena().flat.clone(), {k: v.clone() for k, v in m.named_buffers()}))
-            step.close()
-    finally:
-        Plan.fuse_bn_train = "0"
-    (la, wa, ba), (lb, wb, bb) = res
-    assert la == lb, (la, lb)
-    assert torch.equal(wa, wb)
-    for k in bb:
-        assert torch.equal(ba[k], bb[k]), k
-
-
-@pytest.mark.parametrize("precision", ["bf16", "fp16"])
-def test_train_step_with_bn_on_the_operand_is_bit_identical(precision):
-    """LH_BN_IN=1 (Plan.bn_in): conv3 of a bottleneck applies bn2 + ReLU to its operand rows itself (lh_igemm_bn_in, persistent pointwise
-    kernel) and stores the activated rows on the way; the node's elementwise launch shrinks to its finalize.  Three captured training
-    steps of R50 with and without: the same losses, weights and running statistics BIT FOR BIT."""
-    from lighthand_amd.engine import Plan
-    from lighthand_amd.runtime import TrainStep
-    x, j = _batch(8, 128, 5)
-    res = []
-    try:
-        for mode in ("1", "0"):
-            Plan.bn_in = mode
-            m = _model(50, precision)
-            step = TrainStep(m, 8, 128, 128, lr=1e-3, use_graph=True)
-            losses = [float(step(x, j)) for _ in range(3)]
-            nb = getattr(step.plan, "_n_bn_in", 0)
-            # (how many conv3 launches run on the pointwise kernel is the autotuner's measured choice at this size: at least one)
-            assert (nb >= 1) if mode == "1" else nb == 0, (nb, [c.what for c in step.plan.fwd if hasattr(c, "fn")])
-            res.append((losses, m.arena().flat.clone(), {k: v.clone() for k, v in m.named_buffers()}))
-            step.close()
-    finally:
-        Plan.bn_in = "0"
-    (la, wa, ba), (lb, wb, bb) = res
-    assert la == lb, (la, lb)
-    assert torch.equal(wa, wb)
-    for k in bb:
-        assert torch.equal(ba[k], bb[k]), k

@@ -94,12 +94,31 @@ def test_gradsync_direct_gloo_world3_pads_ragged_buckets():
     assert all(ok for _, ok, _ in res), res
 
 
-def test_gradsync_rejects_unknown_algorithm_and_direct_on_the_c_abi_communicator():
+def test_gradsync_rejects_unknown_algorithm_and_takes_direct_on_the_c_abi_communicator():
+    """Round 6: the direct exchange also runs on the C-ABI communicator (lh_comm_alltoall / lh_sum_chunks / lh_comm_allgather inside the
+    captured step): GradSync routes a bucket to the communicator's direct_sum_ for algo="direct", to all_reduce_sum_ otherwise."""
     from lighthand_amd import parallel
     with pytest.raises(ValueError):
         parallel.GradSync(1, algo="tree")
-    with pytest.raises(ValueError):
-        parallel.GradSync(1, algo="direct", comm=object())
+
+    class FakeComm:
+        def __init__(self):
+            self.calls = []
+
+        def direct_sum_(self, t):
+            self.calls.append("direct")
+
+        def all_reduce_sum_(self, t):
+            self.calls.append("allreduce")
+
+        def close(self):
+            self.calls.append("close")
+    for algo in ("direct", "allreduce"):
+        comm = FakeComm()
+        sync = parallel.GradSync(2, algo=algo, comm=comm)
+        assert sync.algo == algo and sync.comm is comm
+        sync.close()
+        assert comm.calls == ["close"]
 
 
 def test_init_distributed_single_process_is_noop(monkeypatch):

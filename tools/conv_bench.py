@@ -17,6 +17,10 @@ class Net(HipModule):
     def describe(self, gb):
         gb.output(gb.conv(gb.input_act(cin), "conv", k, s, k // 2))
 
+if os.environ.get("LH_FORCE_CFG"):            # e.g. LH_FORCE_CFG=128,128,33,128: that configuration for every tiled launch that offers it
+    from lighthand_amd.engine import Plan
+    want = tuple(int(v) for v in os.environ["LH_FORCE_CFG"].split(","))
+    Plan.force_cfg = lambda cands: want if want in cands else None
 m = Net().cuda().set_precision(prec)
 plan = m.plan(n, h, w, training=True, backward=True)
 plan.in_act.buf.normal_()
