@@ -142,9 +142,17 @@ extern "C" int lh_comm_alltoall(lh_comm* comm, const void* send, void* recv, siz
     ncclDataType_t t; size_t es;
     if (comm_dtype("lh_comm_alltoall", dtype, &t, &es)) return LH_ERR_ARG;
     const RcclApi& a = rccl();
+    // this rank's own chunk never touches the wire: a device copy on the same stream (a one-rank communicator exchanges nothing)
+    if (hipMemcpyAsync((char*)recv + (size_t)comm->rank * count * es, (const char*)send + (size_t)comm->rank * count * es, count * es,
+                       hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) {
+        lh_set_error("lh_comm_alltoall: device copy of the own chunk failed");
+        return LH_ERR_HIP;
+    }
+    if (comm->nranks == 1) return LH_OK;
     ncclResult_t r = a.group_start();
     if (r != ncclSuccess) return fail("ncclGroupStart", r);
     for (int p = 0; p < comm->nranks && r == ncclSuccess; ++p) {
+        if (p == comm->rank) continue;
         r = a.send((const char*)send + (size_t)p * count * es, count, t, p, comm->comm, (hipStream_t)stream);
         if (r == ncclSuccess) r = a.recv((char*)recv + (size_t)p * count * es, count, t, p, comm->comm, (hipStream_t)stream);
     }

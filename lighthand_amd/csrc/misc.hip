@@ -268,13 +268,13 @@ extern "C" int lh_image_u8_jitter_to_nhwc4(const unsigned char* hwc, void* out, 
 }
 
 template <typename T>
-__global__ void nhwc_to_nchw_kernel(const T* src, float* dst, int n, int hw, int c, int cs) {
+__global__ void nhwc_to_nchw_kernel(const T* src, float* dst, int n, int hw, int c, int cs, int vec) {
     const long total = (long)n * hw;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int b = (int)(i / hw), p = (int)(i % hw);
         const T* s = src + i * cs;
         constexpr int EPC = 16 / sizeof(T);
-        if (cs % EPC == 0) {                     // whole 16-byte chunks per pixel: one vector load per EPC channels (was one 2-byte load per channel)
+        if (vec) {                               // whole, 16-byte ALIGNED chunks per pixel: one vector load per EPC channels (was one 2-byte load per channel)
             for (int c0 = 0; c0 < c; c0 += EPC) {
                 float v[EPC];
                 unpack16<T>(*reinterpret_cast<const uint4*>(s + c0), v);
@@ -288,13 +288,13 @@ __global__ void nhwc_to_nchw_kernel(const T* src, float* dst, int n, int hw, int
     }
 }
 template <typename T>
-__global__ void nchw_to_nhwc_kernel(const float* src, T* dst, int n, int hw, int c, int cs) {
+__global__ void nchw_to_nhwc_kernel(const float* src, T* dst, int n, int hw, int c, int cs, int vec) {
     const long total = (long)n * hw;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int b = (int)(i / hw), p = (int)(i % hw);
         T* d = dst + i * cs;
         constexpr int EPC = 16 / sizeof(T);
-        if (cs % EPC == 0) {                     // whole 16-byte chunks per pixel: gather EPC channels, one vector store
+        if (vec) {                               // whole, 16-byte aligned chunks per pixel: gather EPC channels, one vector store
             for (int c0 = 0; c0 < cs; c0 += EPC) {
                 float v[EPC];
 #pragma unroll
@@ -312,8 +312,11 @@ extern "C" int lh_nhwc_to_nchw_f32(const void* nhwc, float* nchw, int n, int h, 
     LH_REQUIRE(nhwc && nchw && n > 0 && h > 0 && w > 0 && c > 0 && c_stride >= c, "lh_nhwc_to_nchw_f32: bad arguments");
     const long total = (long)n * h * w;
     const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    // the vector path needs 16-byte aligned pixel rows: a channel-sliced base pointer (base + 4 channels, stride 64) takes the scalar loop
+    const int es = lh_dtype_size(dtype);
+    const int vec = es > 0 && c_stride % (16 / es) == 0 && ((uintptr_t)nhwc & 15) == 0;
     LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((nhwc_to_nchw_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                                                   (const T*)nhwc, nchw, n, h * w, c, c_stride));
+                                                   (const T*)nhwc, nchw, n, h * w, c, c_stride, vec));
     LH_LAUNCH_CHECK("nhwc_to_nchw launch");
     return LH_OK;
 }
@@ -322,8 +325,10 @@ extern "C" int lh_nchw_f32_to_nhwc(const float* nchw, void* nhwc, int n, int h, 
     LH_REQUIRE(nhwc && nchw && n > 0 && h > 0 && w > 0 && c > 0 && c_stride >= c, "lh_nchw_f32_to_nhwc: bad arguments");
     const long total = (long)n * h * w;
     const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    const int es = lh_dtype_size(dtype);
+    const int vec = es > 0 && c_stride % (16 / es) == 0 && ((uintptr_t)nhwc & 15) == 0;
     LH_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                                                   nchw, (T*)nhwc, n, h * w, c, c_stride));
+                                                   nchw, (T*)nhwc, n, h * w, c, c_stride, vec));
     LH_LAUNCH_CHECK("nchw_to_nhwc launch");
     return LH_OK;
 }

@@ -874,6 +874,16 @@ class Plan:
         groups = {}
         for u in units:
             groups.setdefault(cls(u), []).append(u)
+        # a layer that is alone in its class joins the group's table of the nearest class (a smaller tile first: it only costs the larger
+        # layer some operand re-reads; a larger tile multiplies padding for the small layer, which streams its operands anyway) -- one
+        # launch + fold less per straggler (R50: the head's 1x1, the projection of stage 2)
+        order = [(256, 256), (128, 128), (64, 64)]
+        for k in order if os.environ.get("LH_WGRAD_TABLE_STRAGGLERS", "1") != "0" else ():
+            if k in groups and len(groups[k]) == 1:
+                i = order.index(k)
+                hosts = [h for h in order[i + 1:] + order[:i][::-1] if h in groups and len(groups[h]) >= 2]
+                if hosts:
+                    groups[hosts[0]] += groups.pop(k)
         out, rest = [], []
         for k, us in groups.items():
             if k is None or len(us) < 2:
@@ -2167,6 +2177,10 @@ class Plan:
         ok = ok and all(a[ig["scale"]] and a[ig["shift"]] and not a[ig["bias"]] and not a[ig["stats"]] and not a[ig["addend_mask"]] for a in (a1_, a2_, a3_))
         ok = ok and not a1_[ig["addend"]] and not a2_[ig["addend"]] and a3_[ig["addend"]] and a1_[ig["src"]] == x.buf.data_ptr()
         ok = ok and a3_[ig["dst"]] not in (a1_[ig["src"]], a3_[ig["addend"]])
+        # lh_bottleneck_infer writes a DENSE 256-channel output and reads a dense residual: a block whose output is a strided or
+        # sliced view (another pixel stride, a placement inside a larger image) keeps its three launches
+        ok = ok and d3.out_pix_stride == 256 and (d3.OH, d3.OW, d3.osh, d3.osw, d3.ooh, d3.oow) == (x.h, x.w, 1, 1, 0, 0)
+        ok = ok and d1.out_pix_stride == 64 and d2.out_pix_stride == 64
         if not ok:
             return False
         bd = _lib.BottleneckDesc(x.n, x.h, x.w, x.c, 64, 256)
