@@ -33,8 +33,8 @@ WORK = {
     ("hrnet32", 256): (20.388, 61.107, 107.2, 321.5),
     ("hrnet48", 256): (41.846, 125.483, 142.9, 428.7),
 }
-PMC_FILE = "r05_pmc_traffic.json"      # per-kernel HBM bytes from the committed rocprofv3 --pmc passes (tools/pmc_traffic.py)
-STATS_FILE = "r05_bench_kernel_stats.csv"   # rocprofv3 --kernel-trace --stats of this same command (profiles/README.md)
+PMC_FILE = "r06_pmc_traffic.json"      # per-kernel HBM bytes from the committed rocprofv3 --pmc passes (tools/pmc_traffic.py)
+STATS_FILE = "r06_bench_kernel_stats.csv"   # rocprofv3 --kernel-trace --stats of this same command (profiles/README.md)
 TRAIN_GFLOP_PER_IMG = 43.128
 FWD_GFLOP_PER_IMG = 14.479
 PEAK_BF16_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA
@@ -571,7 +571,7 @@ def main():
                                     "event_pair_overhead_us": round(agg[name]["gap_ms"] / max(agg[name]["launches"], 1) * 1e3, 2),
                                     "note": "average over every launch of this kernel in the process (train-step and inference-graph launches, "
                                             "weighted by how often each ran), HIP events on the launch stream minus half the measured empty-pair "
-                                            "time: comparable with the AverageNs of rocprofv3 --kernel-trace --stats (profiles/r04_bench_kernel_stats.csv)"})
+                                            "time: comparable with the AverageNs of rocprofv3 --kernel-trace --stats (profiles/" + STATS_FILE + ")"})
             # the largest FAMILY of the step: the BatchNorm / ReLU backward (reduce + coefficient fold + apply kernels per call)
             fam = agg.get("fuse_bwd(all kernels)")
             if fam and fam["ms"] > 0:

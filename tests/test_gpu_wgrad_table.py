@@ -79,7 +79,7 @@ def test_table_launch_matches_torch_and_the_per_layer_launches(precision, monkey
     monkeypatch.setenv("LH_WGRAD_GROUP", "100")                # every layer in one deferred group
     base = _grads(proto, x, dy, precision, {"LH_WGRAD_TABLE": "0"}, monkeypatch)
     assert base[3] == []
-    runs = {"measured": _grads(proto, x, dy, precision, {}, monkeypatch),
+    runs = {"measured": _grads(proto, x, dy, precision, {"LH_WGRAD_TABLE_TUNE_MIN": "0"}, monkeypatch),      # (tables this small are not measured by default)
             "static": _grads(proto, x, dy, precision, {"LH_AUTOTUNE": "0"}, monkeypatch)}
     # forced configurations: split-free / short work items, 8-wave and 4-wave tiles, 32- and 64-row stages
     for tag, force in (("free", "128,128,64,3,100000"), ("short", "128,128,32,4,8"), ("small", "64,64,64,2,6")):

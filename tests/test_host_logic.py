@@ -219,11 +219,13 @@ def test_pmc_traffic_tool_and_profile_guard(tmp_path):
 
     def table(path, counter, rows):
         with open(path, "w") as f:
-            f.write('"Kernel_Name","Counter_Name","Counter_Value"\n')
-            for k, v in rows:
-                f.write(f'"{k}","{counter}",{v}\n')
-    steps = 3
-    kernels = [(conv, 1000.0)] * (2 * steps) + [("adam_kernel", 500.0)] * steps + [("heatmap_argmax_kernel(float const*)", 10.0)] * steps
+            f.write('"Dispatch_Id","Kernel_Name","Counter_Name","Counter_Value"\n')
+            for i, (k, v) in enumerate(rows):
+                f.write(f'{i + 1},"{k}","{counter}",{v}\n')
+    steps = 4
+    one_step = [(conv, 1000.0)] * 2 + [("heatmap_argmax_kernel(float const*)", 10.0), ("adam_kernel", 500.0)]
+    # plan construction (fills) in front of the first step; the first (eager) step; then the steady state
+    kernels = [("FillFunctor<float>", 7000.0)] * 3 + one_step * steps
     table(tmp_path / "f.csv", "FETCH_SIZE", kernels)
     table(tmp_path / "w.csv", "WRITE_SIZE", [(k, v / 2) for k, v in kernels])
     out_txt, out_json = tmp_path / "o.txt", tmp_path / "o.json"
@@ -233,9 +235,12 @@ def test_pmc_traffic_tool_and_profile_guard(tmp_path):
     assert got[k] == {"read_bytes_per_launch": 2 * 1000 * 1024, "write_bytes_per_launch": 500 * 1024, "launches": 2 * steps}
     per_step_read = 2 * 1024 * (2 * 1000 + 500 + 10)
     per_step_write = 1024 * (2 * 500 + 250 + 5)
-    assert got["__train_step__"]["steps"] == steps
+    # the steady state = what was dispatched behind the first Adam launch, over the Adam launches behind it: the construction fills
+    # (and the first step) are not in it; round 5's whole-process figure is kept beside it
+    assert got["__train_step__"]["steps"] == steps - 1
     assert got["__train_step__"]["read_bytes"] == per_step_read and got["__train_step__"]["write_bytes"] == per_step_write
     assert got["__train_step__"]["bytes"] == per_step_read + per_step_write
+    assert got["__train_step__"]["whole_process_bytes_per_step"] == round(per_step_read + per_step_write + 3 * (2 * 7000 + 3500) * 1024 / steps)
     # an inference graph in the process: more arg-max launches than Adam launches -> no per-step figure
     table(tmp_path / "f2.csv", "FETCH_SIZE", kernels + [("heatmap_argmax_kernel(float const*)", 10.0)] * 4)
     subprocess.run([sys.executable, os.path.join(root, "tools", "pmc_traffic.py"), str(tmp_path / "f2.csv"), str(tmp_path / "w.csv"), str(out_txt), str(out_json)], check=True)

@@ -8,9 +8,10 @@ Units and the gfx950 correction follow /opt/skills/guides/MI355X_MICROARCH.md (H
 FETCH_SIZE tallies the 128-byte requests of wide coalesced reads at 64 bytes, so read bytes = 2 * FETCH_SIZE * 1024;
 WRITE_SIZE * 1024 as it is.  The json maps the kernel names bench.py uses to bytes per launch (mean over dispatches).
 When the passes ran `bench.py --train-only` (a process that executes training steps and nothing else; the tuner's trial
-launches are kept out by LH_TUNE_CACHE), the json also carries "__train_step__": the bytes ALL kernels moved, divided by
-the number of steps the process executed (= launches of the once-per-step Adam kernel) -- bench.py's
-roofline.step_traffic."""
+launches are kept out by LH_TUNE_CACHE), the json also carries "__train_step__": the bytes ALL kernels moved BEHIND the first launch of the
+once-per-step Adam kernel (everything in front of it is plan construction -- zero fills of the buffers, pack setup -- and the
+first, eager step), divided by the steps that follow it (= Adam launches - 1) -- bench.py's roofline.step_traffic.  (Round 5
+divided the whole process by all steps: ~2 % of construction fills counted as step traffic.)"""
 import collections
 import csv
 import json
@@ -29,18 +30,26 @@ def demangle(name):
 
 
 def load(path, counter):
+    """{kernel: [sum, dispatches]} and the steady-state share: (sum over the dispatches behind the first Adam launch, Adam launches behind it)."""
     acc = collections.defaultdict(lambda: [0.0, 0])
+    rows = []
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
         a = acc[r["Kernel_Name"]]
         a[0] += float(r["Counter_Value"])
         a[1] += 1
-    return acc
+        rows.append((int(r["Dispatch_Id"]), r["Kernel_Name"], float(r["Counter_Value"])))
+    rows.sort()
+    adam = [d for d, k, _ in rows if "adam_kernel" in k]
+    steady = (0.0, 0)
+    if len(adam) >= 2:
+        steady = (sum(v for d, _, v in rows if adam[0] < d <= adam[-1]), len(adam) - 1)
+    return acc, steady
 
 
 def main():
-    fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+    (fetch, fsteady), (write, wsteady) = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
     rows = []
     for k, (v, n) in fetch.items():
         w, wn = write.get(k, (0.0, 0))
@@ -59,16 +68,19 @@ def main():
     steps = sum(n for k, n, *_ in rows if "adam_kernel" in k)
     # a training step decodes its heat-maps once; a process that also replays the inference graph launches the arg-max more often
     train_only = steps > 0 and sum(n for k, n, *_ in rows if "heatmap_argmax" in k) == steps
-    if train_only:
-        rd_all = sum(rd * n for _, n, rd, _, _ in rows)
-        wr_all = sum(wr * write.get(k, (0.0, 0))[1] for k, _, _, wr, _ in rows)
-        out["__train_step__"] = {"bytes": round((rd_all + wr_all) / steps), "read_bytes": round(rd_all / steps),
-                                 "write_bytes": round(wr_all / steps), "steps": steps,
-                                 "note": "all kernels of the process / launches of the once-per-step Adam kernel; valid for a "
-                                         "`bench.py --train-only` process only (an inference graph in the process would be counted in)"}
+    if train_only and fsteady[1] >= 1 and fsteady[1] == wsteady[1]:
+        n_st = fsteady[1]
+        rd_all, wr_all = 2 * fsteady[0] * 1024, wsteady[0] * 1024
+        whole = (sum(rd * n for _, n, rd, _, _ in rows) + sum(wr * write.get(k, (0.0, 0))[1] for k, _, _, wr, _ in rows)) / steps
+        out["__train_step__"] = {"bytes": round((rd_all + wr_all) / n_st), "read_bytes": round(rd_all / n_st),
+                                 "write_bytes": round(wr_all / n_st), "steps": n_st,
+                                 "whole_process_bytes_per_step": round(whole),
+                                 "note": "all kernels dispatched behind the first Adam launch / the Adam launches behind it (plan construction and the "
+                                         "first eager step excluded); valid for a `bench.py --train-only` process only (an inference graph in the "
+                                         "process would be counted in).  whole_process_bytes_per_step = round 5's figure (everything / all steps)"}
         with open(sys.argv[3], "a") as f:
-            f.write(f"\nWhole process: {rd_all / 1e9:.2f} GB read + {wr_all / 1e9:.2f} GB written over {steps} training steps = "
-                    f"{(rd_all + wr_all) / steps / 1e9:.2f} GB per step (bench.py --train-only).\n")
+            f.write(f"\nSteady state (behind the first Adam launch): {rd_all / 1e9:.2f} GB read + {wr_all / 1e9:.2f} GB written over {n_st} training steps = "
+                    f"{(rd_all + wr_all) / n_st / 1e9:.2f} GB per step (bench.py --train-only); the whole process over all {steps} steps: {whole / 1e9:.2f} GB per step.\n")
     json.dump(out, open(sys.argv[4], "w"), indent=1)
 
 

@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/refresh
 rm -rf $O && mkdir -p $O
 export LH_TUNE_CACHE=$PWD/$O/tune_cache.txt
-R=${LH_ROUND:-r05}
+R=${LH_ROUND:-r06}
 timeout -k 10 900 python bench.py > $O/bench.json 2> $O/bench.err
 tail -c 600 $O/bench.json
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o $R -- python3 bench.py --no-cpu-baseline --no-extra > $O/stats.log 2>&1

@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")/.."
 O=gpurun_out/refresh
-R=${LH_ROUND:-r05}
+R=${LH_ROUND:-r06}
 cp $O/bench.json profiles/${R}_bench.json
 cp "$(find $O/stats -name "${R}_kernel_stats.csv" | head -1)" profiles/${R}_bench_kernel_stats.csv
 cp $O/layers.txt profiles/${R}_layers.txt
@@ -22,7 +22,7 @@ ls -la profiles/
 # the bench line was printed before the PMC passes of the same session existed: fill its roofline.traffic from them
 python - <<'PY'
 import json, os
-R = os.environ.get("LH_ROUND", "r05")
+R = os.environ.get("LH_ROUND", "r06")
 b = json.load(open(f"profiles/{R}_bench.json"))
 pmc = json.load(open(f"profiles/{R}_pmc_traffic.json"))
 k = b.get("roofline", {}).get("kernel")
