@@ -765,10 +765,54 @@ extern "C" int lh_wgrad_table_build(const lh_wgrad_call* calls, int n, int dtype
         }
         order[i] = i;
     }
-    // longest items first: workgroups are dispatched in grid order and the launch ends with its last one
+    // Work-item order.  Workgroup ids are dealt round-robin over the 8 XCDs (block b runs on XCD b % 8, each with a private L2), and the
+    // items that share operand rows are the taps x tiles of ONE pixel split of ONE layer (every tap of a 3x3 walks the same x / dy rows,
+    // the channel tiles of a 1x1 share one of the two operands): such a GROUP is laid out on ONE XCD -- consecutive positions of that
+    // XCD's sub-sequence b = 8 k + x -- so that its members run side by side and read their rows from that L2 once instead of once per
+    // item from the fabric (PMC, R50's 32-layer table: 3.2 GB of L2 misses per launch for ~1 GB of operands with the per-layer order).
+    // Groups (at most 16 items) are taken longest item first and handed to the XCD with the least work so far, so every XCD's queue
+    // runs from long to short items and the queues are equal in cost; queues that hold fewer items end in empty items, which exit at once.
+    // LH_WGRAD_TABLE_XCD=0: the plain longest-first order with the per-layer XCD remap.
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return args[x].steps_per_split > args[y].steps_per_split; });
-    long n_items = 0, n_fold_items = 0;
-    for (int i = 0; i < n; ++i) n_items += (long)args[i].tiles * args[i].ntaps * args[i].nsplit;
+    const char* xsw = getenv("LH_WGRAD_TABLE_XCD");
+    const bool by_xcd = !(xsw && atoi(xsw) == 0);
+    struct Group { int prob, first, count; };                         // `count` consecutive block indices of problem `prob` from `first`
+    std::vector<Group> groups;
+    std::vector<int2> item_list;
+    if (by_xcd) {
+        // groups of at most 16 items (half an XCD's CUs for the 8-wave tile): the taps x tiles of one split, cut where there are more
+        for (int k = 0; k < n; ++k) {
+            const int i = order[k], per = args[i].tiles * args[i].ntaps;
+            args[i].xcd = 0;                                          // the table places the items; the body must not remap them
+            const int parts = (per + 15) / 16, sz = (per + parts - 1) / parts;
+            for (int sp = 0; sp < args[i].nsplit; ++sp)
+                for (int o = 0; o < per; o += sz) groups.push_back({i, sp * per + o, std::min(sz, per - o)});
+        }
+        std::stable_sort(groups.begin(), groups.end(), [&](const Group& a, const Group& b) {
+            return args[a.prob].steps_per_split > args[b.prob].steps_per_split;
+        });
+        // longest items first, each group to the XCD with the least work so far: every XCD's queue runs long -> short, equal in cost
+        std::vector<int2> queue[8];
+        long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (const Group& g : groups) {
+            int x = 0;
+            for (int y = 1; y < 8; ++y)
+                if (load[y] < load[x]) x = y;
+            for (int b = 0; b < g.count; ++b) queue[x].push_back(int2{g.prob, g.first + b});
+            load[x] += (long)g.count * args[g.prob].steps_per_split;
+        }
+        size_t len = 0;
+        for (int x = 0; x < 8; ++x) len = std::max(len, queue[x].size());
+        for (size_t pos = 0; pos < len; ++pos)
+            for (int x = 0; x < 8; ++x) item_list.push_back(pos < queue[x].size() ? queue[x][pos] : int2{-1, 0});
+        while (!item_list.empty() && item_list.back().x < 0) item_list.pop_back();
+    } else {
+        for (int k = 0; k < n; ++k) {
+            const int i = order[k], cnt = args[i].tiles * args[i].ntaps * args[i].nsplit;
+            for (int b = 0; b < cnt; ++b) item_list.push_back(int2{i, b});
+        }
+    }
+    long n_items = (long)item_list.size(), n_fold_items = 0;
     for (const WreduceArgs& r : folds)
         n_fold_items += r.contig ? ceil_div((long)r.n_out * r.n_in, 256) : ceil_div(wgrad_reduce_threads(r.n_out, r.n_in, r.ntaps), 256);
     LH_REQUIRE(n_items < (1L << 30) && n_fold_items < (1L << 30), "lh_wgrad_table_build: too many work items");
@@ -790,11 +834,7 @@ extern "C" int lh_wgrad_table_build(const lh_wgrad_call* calls, int n, int dtype
     char* blob = (char*)host_blob;
     memset(blob, 0, t.table_bytes);
     memcpy(blob, args.data(), sizeof(WgradArgs) * n);
-    int2* it = (int2*)(blob + t.off_items);
-    for (int k = 0; k < n; ++k) {
-        const int i = order[k], cnt = args[i].tiles * args[i].ntaps * args[i].nsplit;
-        for (int b = 0; b < cnt; ++b) *it++ = int2{i, b};
-    }
+    memcpy(blob + t.off_items, item_list.data(), sizeof(int2) * item_list.size());
     if (!folds.empty()) memcpy(blob + t.off_fold_args, folds.data(), sizeof(WreduceArgs) * folds.size());
     int2* fi = (int2*)(blob + t.off_fold_items);
     for (int k = 0; k < (int)folds.size(); ++k) {

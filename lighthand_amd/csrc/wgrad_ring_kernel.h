@@ -333,6 +333,7 @@ __global__ __launch_bounds__(64 * WO * WI, 2) void wgrad_ring_table_kernel(const
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int2 it = items[blockIdx.x];
     const int prob = __builtin_amdgcn_readfirstlane(it.x), bid = __builtin_amdgcn_readfirstlane(it.y);
+    if (prob < 0) return;                 // padding of a round of the XCD-aware item order (lh_wgrad_table_build)
     const WgradArgs* g = tab + prob;
     WgradArgs p;
     p.x = g->x; p.dy = g->dy; p.zero = g->zero; p.slab = g->slab;

@@ -144,13 +144,14 @@ def test_explicit_wgrad_configuration_must_fit():
     assert b"does not fit" in lib.lh_last_error()
 
 
-def test_wgrad_table_planner_runs_without_a_device():
+def test_wgrad_table_planner_runs_without_a_device(monkeypatch):
     """lh_wgrad_table_build's size query is host arithmetic: the weight gradients of R50's stage 4 at batch 64 (three bottlenecks +
     the projection, pose_resnet.py:61-99, 177-192: M = 64 x 8 x 8 pixels) in one table.  Automatic item length: the tiles alone fill the
     machine twice -> split-free, the 1x1 members written by the kernel itself (only the 3x3 ones need the fold launch); a short item
     length splits every member; an unknown tile is refused."""
     from lighthand_amd import _lib
     lib = _lib.load()
+    monkeypatch.setenv("LH_WGRAD_TABLE_XCD", "0")                  # the plain longest-first item order: exact item counts
     shapes = [(512, 2048, 1), (512, 512, 3), (2048, 512, 1)] * 2 + [(512, 1024, 1), (512, 512, 3), (2048, 512, 1), (2048, 1024, 1)]
     descs, rs, calls = [], [], (_lib.WgradCall * len(shapes))()
     for i, (cout, cin, k) in enumerate(shapes):
@@ -174,6 +175,12 @@ def test_wgrad_table_planner_runs_without_a_device():
     big = (C.c_int * 4)(256, 256, 32, 3)
     assert lib.lh_wgrad_table_build(calls, len(shapes), _lib.LH_BF16, big, 0, None, None, 0, C.byref(info)) == 0
     assert 3 * 256 < info.n_items < 6 * 256 and info.nsplit_max >= 2   # 236 tiles do not fill 256 CUs twice: about four rounds of items
+    # the default item order lays the taps x tiles of one pixel split of one layer on ONE XCD, eight groups per round, rounds padded
+    # with empty items: never fewer items than the plain order, and the padding stays below one round's worth per round
+    monkeypatch.delenv("LH_WGRAD_TABLE_XCD")
+    plain = info.n_items
+    assert lib.lh_wgrad_table_build(calls, len(shapes), _lib.LH_BF16, big, 0, None, None, 0, C.byref(info)) == 0
+    assert plain <= info.n_items <= 2 * plain
     bad = (C.c_int * 4)(96, 96, 64, 3)
     assert lib.lh_wgrad_table_build(calls, len(shapes), _lib.LH_BF16, bad, 0, None, None, 0, C.byref(info)) == -3
     assert b"not compiled in" in lib.lh_last_error()

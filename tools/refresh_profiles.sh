@@ -11,7 +11,7 @@ O=gpurun_out/refresh
 rm -rf $O && mkdir -p $O
 export LH_TUNE_CACHE=$PWD/$O/tune_cache.txt
 R=${LH_ROUND:-r06}
-timeout -k 10 900 python bench.py > $O/bench.json 2> $O/bench.err
+LH_TUNE_ITERS=20 timeout -k 10 900 python bench.py > $O/bench.json 2> $O/bench.err
 tail -c 600 $O/bench.json
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o $R -- python3 bench.py --no-cpu-baseline --no-extra > $O/stats.log 2>&1
 timeout -k 10 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --train-only > $O/pmc_fetch.log 2>&1
