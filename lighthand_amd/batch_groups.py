@@ -33,29 +33,25 @@ class BatchGroups:
                 items += [[t] for t in range(i, j + 1)]
                 i = j + 1
                 continue
-            # LH_BATCH=2: two half-groups (branches 0-1 | the rest) on two stream lanes, each merged pairwise -- the deep-K,
-            # few-workgroup convolutions of the low-resolution branches then overlap the wide shallow ones of the others
+            # (two half-groups on two stream lanes -- LH_BATCH=2, round 2 -- were measured slower, 17.0 vs 16.0 ms, and removed in round 6)
             order = sorted(lanes)
-            halves = [order[:2], order[2:]] if self.batch_split and len(order) >= 3 else [order]
-            if len(halves) == 1:
-                self.nodes[i] = self.nodes[j] = ("nop", {})
+            self.nodes[i] = self.nodes[j] = ("nop", {})
             items.append([i])
-            for hi, half in enumerate(halves):
-                for L in half:
-                    for t in lanes[L]:
-                        self.node_lanes[t] = hi
-                queues = [list(lanes[L]) for L in half]
-                while any(queues):
-                    heads = {}
-                    for q in queues:
-                        if q:
-                            heads.setdefault(self.nodes[q[0]][0], []).append(q)
-                    kind = max(heads, key=lambda k: (len(heads[k]), k == "conv"))
-                    qs = heads[kind]
-                    if len(qs) >= 2 and kind in ("conv", "fuse"):
-                        items.append([q.pop(0) for q in qs])
-                    else:
-                        items.append([qs[0].pop(0)])
+            for L in order:
+                for t in lanes[L]:
+                    self.node_lanes[t] = 0
+            queues = [list(lanes[L]) for L in order]
+            while any(queues):
+                heads = {}
+                for q in queues:
+                    if q:
+                        heads.setdefault(self.nodes[q[0]][0], []).append(q)
+                kind = max(heads, key=lambda k: (len(heads[k]), k == "conv"))
+                qs = heads[kind]
+                if len(qs) >= 2 and kind in ("conv", "fuse"):
+                    items.append([q.pop(0) for q in qs])
+                else:
+                    items.append([qs[0].pop(0)])
             items.append([j])
             i = j + 1
         return items
@@ -102,10 +98,9 @@ class BatchGroups:
                 ring = {c for c in cfgs if c[2] != 100}
                 if len(ring) > 1 or any(not 2 <= c[2] < 10 or (c[0], c[1]) not in self._MULTI_TILES for c in ring):
                     return None
-                if len(ring) != len(cfgs) and (os.environ.get("LH_MIXED", "0") not in ("1", "32") or any((c[0], c[1]) != (64, 128) for c in ring)):
-                    # direct 3x3 members share a launch with the 64 x 128 tile only (igemm_mixed_kernel.h), and only when the
-                    # mixed launch was asked for: members tuned one by one may pick the direct kernel in a default build, where
-                    # the mixed kernel (measured slower) must not run -- they are launched one by one instead
+                if len(ring) != len(cfgs):
+                    # members tuned one by one may pick the direct 3x3 kernel: direct and tiled members do not share a launch (the mixed
+                    # grid of round 4 was measured slower and removed) -- they are launched one by one instead
                     return None
                 arr = (_lib.IgemmCall * n)()
                 for i, c in enumerate(calls):

@@ -307,11 +307,6 @@ __device__ __forceinline__ long walk_round(long r, long rounds, bool rev) { retu
 
 struct FuseArgs {
     int exp;                     // bn_exp_flags() >> 2 (forward bits)
-    // slice kernel only (fuse_fwd_slice_body): the BatchNorm finalize of terms 0 / 1 runs inside the launch (has_fin bit t)
-    FinalizeArgs fin[2];
-    int has_fin;
-    int slice_ppg;               // pixels per workgroup of a channel slice
-    int slice_w;                 // channels per slice (64 | 32)
     const unsigned char* x[4];
     const float* scale[4];
     const float* shift[4];
@@ -473,162 +468,13 @@ __global__ __launch_bounds__(256) void fuse_fwd_flat_multi_kernel(const LhMulti<
     fuse_fwd_flat_body<T, NT>(m.a[i], bid, nblk);
 }
 
-// Channel-slice form for SMALL tensors: BatchNorm finalize + apply as ONE launch.  A workgroup owns 64 channels of a range
-// of pixels; it first folds the statistics slab of ITS 64 channels ([rows][2][c] partial sums the convolution epilogues
-// wrote: rows x 512 bytes, four row lanes per channel, fp64, fixed order), derives mean / invstd / scale / shift like
-// bn_finalize_fused_body (the workgroups of pixel group 0 also store them for the backward pass and update the running
-// statistics), then streams its pixels: 128 contiguous bytes per pixel and term.  One launch instead of two on the
-// dependency chain of every BatchNorm of stages 3-4 and of HRNet's branches, whose tensors are a few MB: the separate
-// finalize launch was 5-6 us of pure launch + fold latency in front of an 8 us elementwise pass.
-template <typename T, int NT>
-__device__ __forceinline__ void fuse_fwd_slice_body(const FuseArgs& p, const int bid, const int nblk) {
-    constexpr int EPC = 16 / sizeof(T);
-    const int SW = p.slice_w;                         // channels per slice: 64, or 32 for 32-channel tensors (HRNet's widest-resolution branch)
-    const int CPS = SW / EPC;                         // 16-byte chunks per slice
-    const int PL = 256 / CPS;                         // pixel lanes
-    const int NP = 256 / SW;                          // row lanes of the fold
-    __shared__ double red[2][16][64];
-    __shared__ float scsh[NT][2][64];
-    const int nslices = p.c / SW;
-    const int slice = bid % nslices, grp = bid / nslices;
-    const int cbase = slice * SW;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        if (!((p.has_fin >> t) & 1)) {
-            if (threadIdx.x < SW) {
-                scsh[t][0][threadIdx.x] = p.scale[t] ? p.scale[t][cbase + threadIdx.x] : 1.f;
-                scsh[t][1][threadIdx.x] = p.scale[t] ? p.shift[t][cbase + threadIdx.x] : 0.f;
-            }
-            continue;
-        }
-        const FinalizeArgs& f = p.fin[t];
-        const float* slab = (const float*)f.slab;
-        // The fold is arithmetically THE SAME as bn_finalize_fused_body's (slab_totals_then: 16 row lanes per channel with its
-        // grouping of eight / four rows, lanes summed in ascending order), so a node gets bit-identical statistics whether its
-        // finalize runs in this launch or as a launch of its own (a merged multi-problem call may decide differently from
-        // the same call on its own).  A thread takes the row lanes part, part + NP, ... of its channel.
-        const int ch = threadIdx.x % SW, part = threadIdx.x / SW;
-        const long cc = f.c;
-        const float* col = slab + cbase + ch;
-        if (t) __syncthreads();                       // the previous term's partial sums have been consumed
-        // <= 128 rows (the planner's rule): a row lane holds at most eight rows.  ALL rows of the thread's row lanes are
-        // requested before the first sum (one memory round trip instead of one per lane), then summed in that order.
-        constexpr int MAXL = 8;                       // row lanes per thread at most (SW = 32: 256 / 32 = 8 parts -> 2 lanes; SW = 64: 4)
-        float av[MAXL / 2][8], bv[MAXL / 2][8];
-#pragma unroll
-        for (int k = 0; k < MAXL / 2; ++k) {
-            const int rl = part + k * NP;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int r = rl + 16 * u;
-                // every lane issues every load (rows past the slab re-read row 0; they are never summed): a load under a
-                // runtime condition would be branched around and waited for one at a time
-                const long rr = (rl < 16 && r < f.rows) ? r : 0;
-                av[k][u] = col[(rr * 2) * cc];
-                bv[k][u] = col[(rr * 2 + 1) * cc];
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < MAXL / 2; ++k) {
-            const int rl = part + k * NP;
-            if (rl >= 16) continue;
-            double a = 0.0, b = 0.0;
-            int u0 = 0;
-            if (rl + 112 < f.rows) {
-                a += (((double)av[k][0] + (double)av[k][1]) + ((double)av[k][2] + (double)av[k][3])) + (((double)av[k][4] + (double)av[k][5]) + ((double)av[k][6] + (double)av[k][7]));
-                b += (((double)bv[k][0] + (double)bv[k][1]) + ((double)bv[k][2] + (double)bv[k][3])) + (((double)bv[k][4] + (double)bv[k][5]) + ((double)bv[k][6] + (double)bv[k][7]));
-                u0 = 8;
-            } else if (rl + 48 < f.rows) {
-                a += ((double)av[k][0] + (double)av[k][1]) + ((double)av[k][2] + (double)av[k][3]);
-                b += ((double)bv[k][0] + (double)bv[k][1]) + ((double)bv[k][2] + (double)bv[k][3]);
-                u0 = 4;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (u >= u0 && rl + 16 * u < f.rows) { a += (double)av[k][u]; b += (double)bv[k][u]; }
-            red[0][rl][ch] = a;
-            red[1][rl][ch] = b;
-        }
-        __syncthreads();
-        if (threadIdx.x < SW) {
-            double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { s0 += red[0][i][ch]; s1 += red[1][i][ch]; }
-            const int gc = cbase + ch, count = f.count;
-            const double mean = s0 / count;
-            double var = s1 / count - mean * mean;
-            if (var < 0.0) var = 0.0;
-            const float invstd = (float)(1.0 / sqrt(var + (double)f.eps));
-            const float g = f.gamma ? f.gamma[gc] : 1.f, be = f.beta ? f.beta[gc] : 0.f;
-            const float sc = g * invstd, sh = be - (float)mean * sc;
-            scsh[t][0][ch] = sc;
-            scsh[t][1][ch] = sh;
-            if (grp == 0) {                           // one workgroup per slice publishes (same values in every group)
-                f.scale[gc] = sc;
-                f.shift[gc] = sh;
-                if (f.smean) f.smean[gc] = (float)mean;
-                if (f.sinv) f.sinv[gc] = invstd;
-                if (f.rmean) f.rmean[gc] = (1.f - f.momentum) * f.rmean[gc] + f.momentum * (float)mean;
-                if (f.rvar) {
-                    const double unb = count > 1 ? var * ((double)count / (count - 1)) : var;
-                    f.rvar[gc] = (1.f - f.momentum) * f.rvar[gc] + f.momentum * (float)unb;
-                }
-            }
-        }
-        if (bid == 0 && threadIdx.x == 0 && f.nbt) *f.nbt += 1;
-    }
-    __syncthreads();
-    const int chunk = threadIdx.x % CPS, plane = threadIdx.x / CPS;
-    float sc[NT][EPC], sh[NT][EPC];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) { sc[t][e] = scsh[t][0][chunk * EPC + e]; sh[t][e] = scsh[t][1][chunk * EPC + e]; }
-    const long P = p.total / (p.c / EPC);             // pixels
-    const long p0 = (long)grp * p.slice_ppg;
-    long p1 = p0 + p.slice_ppg;
-    if (p1 > P) p1 = P;
-    const int nchunk = p.c / EPC;
-    auto body = [&](auto NTc) __attribute__((always_inline)) {
-        constexpr bool LNT = decltype(NTc)::value;
-        for (long px = p0 + plane; px < p1; px += PL) {
-            const long idx = px * nchunk + slice * CPS + chunk;
-            float acc[EPC];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                float v[EPC];
-                unpack16<T>(ld16<LNT>(p.x[t] + idx * 16), v);
-                if (p.scale[t]) {
-#pragma unroll
-                    for (int e = 0; e < EPC; ++e) v[e] = v[e] * sc[t][e] + sh[t][e];
-                }
-#pragma unroll
-                for (int e = 0; e < EPC; ++e) acc[e] = t == 0 ? v[e] : acc[e] + v[e];
-            }
-            if (p.relu) {
-#pragma unroll
-                for (int e = 0; e < EPC; ++e) acc[e] = fmaxf(acc[e], 0.f);
-            }
-            const uint4 u = pack16<T>(acc);
-            *reinterpret_cast<uint4*>(p.out + idx * 16) = u;
-            if (p.mask) p.mask[idx] = positive_bits<T>(u);
-        }
-    };
-    if (p.exp & 1) body(std::true_type{}); else body(std::false_type{});
-}
-template <typename T, int NT>
-__global__ __launch_bounds__(256) void fuse_fwd_slice_kernel(const FuseArgs p) { fuse_fwd_slice_body<T, NT>(p, blockIdx.x, gridDim.x); }
-template <typename T, int NT>
-__global__ __launch_bounds__(256) void fuse_fwd_slice_multi_kernel(const LhMulti<FuseArgs> m) {
-    int bid, nblk;
-    const int i = lh_multi_pick(m, bid, nblk);
-    fuse_fwd_slice_body<T, NT>(m.a[i], bid, nblk);
-}
+// (Round 4's channel-slice form -- BatchNorm finalize + apply as ONE launch for small tensors -- was measured slower than the two launches
+//  (the fold every workgroup repeats costs more than the 5.4 us finalize launch it removes) and removed in round 6.)
 
 // ---- launch records: a C-ABI call is first PLANNED into the kernel launches it consists of (kind, grid, argument block),
 // then run -- one record as a plain launch, the records of several independent calls that agree in kind as one
 // multi-problem launch (multi.h).
-enum BnKind { K_FF_GEN, K_FF_FLAT1, K_FF_FLAT2, K_FF_SLICE1, K_FF_SLICE2, K_FB_REDUCE_GEN, K_FB_REDUCE_FLAT, K_FB_REDUCE_FLAT_X, K_FB_COEF, K_FB_APPLY_GEN,
+enum BnKind { K_FF_GEN, K_FF_FLAT1, K_FF_FLAT2, K_FB_REDUCE_GEN, K_FB_REDUCE_FLAT, K_FB_REDUCE_FLAT_X, K_FB_COEF, K_FB_APPLY_GEN,
               K_FB_APPLY_FLAT, K_FB_APPLY_FLAT_X, K_FB_APPLY2 };
 struct FuseBwdArgs;
 struct FuseBwd2Args;
@@ -644,9 +490,9 @@ static int flat_grid(long total) {
 }
 
 // pre_fin (out): bit t set when term t carries a BatchNorm finalize (lh_fuse_desc.fin) that the planned kernel does NOT run
-// itself -- the caller launches it first.  allow_slice = false plans the streaming kernels only.
+// itself -- the caller launches it first.
 static int plan_fuse_fwd(const lh_fuse_desc* d, void* out, int n, int h, int w, int c, int dtype, FuseArgs* ap, int* kind, int* grid_out,
-                         int* pre_fin = nullptr, bool allow_slice = true) {
+                         int* pre_fin = nullptr) {
     LH_REQUIRE(d && out && d->nterms >= 1 && d->nterms <= 4, "lh_fuse_fwd: bad descriptor");
     const int es = lh_dtype_size(dtype);
     LH_REQUIRE(es > 0 && c % (16 / es) == 0, "lh_fuse_fwd: c %d not a multiple of the 16-byte chunk", c);
@@ -674,8 +520,7 @@ static int plan_fuse_fwd(const lh_fuse_desc* d, void* out, int n, int h, int w, 
     const int nchunk = c / (16 / es);
     bool flat = d->nterms <= 2 && (nchunk & (nchunk - 1)) == 0 && nchunk <= 256;
     for (int t = 0; t < d->nterms; ++t) flat = flat && a.log2up[t] == 0;
-    a.has_fin = 0; a.slice_ppg = 0; a.slice_w = 0;
-    int fin_mask = 0, rows_max = 0;
+    int fin_mask = 0;
     for (int t = 0; t < d->nterms; ++t) {
         const lh_bn_finalize_call* f = d->fin[t];
         if (!f) continue;
@@ -683,31 +528,6 @@ static int plan_fuse_fwd(const lh_fuse_desc* d, void* out, int n, int h, int w, 
         LH_REQUIRE(f->stats && f->rows > 0 && f->count > 0 && f->c == c && f->scale == d->scale[t] && f->shift == d->shift[t] && f->scale && f->shift,
                    "lh_fuse_fwd: term %d: the pending finalize must produce this term's scale / shift (c %d vs %d)", t, f->c, c);
         fin_mask |= 1 << t;
-        rows_max = f->rows > rows_max ? f->rows : rows_max;
-    }
-    // small tensors: finalize + apply as ONE launch (fuse_fwd_slice_body) -- <= 128 slab rows (the 16-lane fold of the finalize
-    // kernel, whose arithmetic the slice kernel reproduces with all its rows in flight at once; a workgroup folds rows x 2 x 64 floats), <= 48 MB per tensor, channel
-    // slices of 64 (or the whole 32-channel row)
-    // MEASURED SLOWER (round 4: R50 step 9.67-9.69 ms with it vs 9.59 without, HRNet unchanged): the fold every workgroup
-    // repeats (rows x 512 bytes + two barriers) costs more than the 5.4 us finalize launch it removes.  Off unless LH_BN_SLICE=1.
-    static const bool slice_on = getenv("LH_BN_SLICE") && atoi(getenv("LH_BN_SLICE")) != 0;
-    const int sw = c % 64 == 0 ? 64 : (c == 32 ? 32 : 0);
-    if (flat && fin_mask && allow_slice && slice_on && sw && rows_max <= 128 && total * 16 <= (48L << 20)) {
-        const long P = (long)n * h * w;
-        const int pl = 256 / (sw / (16 / es));
-        long ppg = 4L * rows_max > 128 ? 4L * rows_max : 128;       // payload of a workgroup >= 2 x the statistics it folds
-        ppg = (ppg + pl - 1) / pl * pl;
-        const long G = (P + ppg - 1) / ppg;
-        a.has_fin = fin_mask; a.slice_ppg = (int)ppg; a.slice_w = sw;
-        for (int t = 0; t < d->nterms && t < 2; ++t) {
-            const lh_bn_finalize_call* f = d->fin[t];
-            if (f) a.fin[t] = finalize_args(f->stats, f->rows, f->count, f->c, f->gamma, f->beta, f->running_mean, f->running_var,
-                                            f->num_batches_tracked, f->momentum, f->eps, f->scale, f->shift, f->save_mean, f->save_invstd);
-        }
-        *grid_out = (int)(G * (c / sw));
-        *kind = d->nterms == 1 ? K_FF_SLICE1 : K_FF_SLICE2;
-        if (pre_fin) *pre_fin = 0;
-        return LH_OK;
     }
     if (pre_fin) *pre_fin = fin_mask;
     if (flat) {
@@ -1287,8 +1107,6 @@ static int bn_run(const BnLaunch* const* L, int n, int dtype, hipStream_t s) {
         case K_FF_GEN: LH_DISPATCH_DTYPE(dtype, T, BN_RUN((fuse_fwd_kernel<T>), (fuse_fwd_multi_kernel<T>), ff, FuseArgs)); break;
         case K_FF_FLAT1: LH_DISPATCH_DTYPE(dtype, T, BN_RUN((fuse_fwd_flat_kernel<T, 1>), (fuse_fwd_flat_multi_kernel<T, 1>), ff, FuseArgs)); break;
         case K_FF_FLAT2: LH_DISPATCH_DTYPE(dtype, T, BN_RUN((fuse_fwd_flat_kernel<T, 2>), (fuse_fwd_flat_multi_kernel<T, 2>), ff, FuseArgs)); break;
-        case K_FF_SLICE1: LH_DISPATCH_DTYPE(dtype, T, BN_RUN((fuse_fwd_slice_kernel<T, 1>), (fuse_fwd_slice_multi_kernel<T, 1>), ff, FuseArgs)); break;
-        case K_FF_SLICE2: LH_DISPATCH_DTYPE(dtype, T, BN_RUN((fuse_fwd_slice_kernel<T, 2>), (fuse_fwd_slice_multi_kernel<T, 2>), ff, FuseArgs)); break;
         case K_FB_REDUCE_GEN: LH_DISPATCH_DTYPE(dtype, T, BN_RUN((fuse_bwd_reduce_kernel<T>), (fuse_bwd_reduce_multi_kernel<T>), fb, FuseBwdArgs)); break;
         case K_FB_REDUCE_FLAT: LH_DISPATCH_DTYPE(dtype, T, BN_RUN((fuse_bwd_reduce_flat_kernel<T, false>), (fuse_bwd_reduce_flat_multi_kernel<T, false>), fb, FuseBwdArgs)); break;
         case K_FB_REDUCE_FLAT_X: LH_DISPATCH_DTYPE(dtype, T, BN_RUN((fuse_bwd_reduce_flat_kernel<T, true>), (fuse_bwd_reduce_flat_multi_kernel<T, true>), fb, FuseBwdArgs)); break;
@@ -1463,7 +1281,7 @@ extern "C" int lh_fuse_fwd_multi(const lh_fuse_fwd_call* calls, int n, int dtype
             BnLaunch& r = plans[i][0];
             int pre = 0;
             const int rc = plan_fuse_fwd(calls[i].d, calls[i].out, calls[i].n, calls[i].h, calls[i].w, calls[i].c, dtype, &r.ff, &r.kind, &r.grid,
-                                         &pre, pass == 0);
+                                         &pre);
             if (rc) return rc;
             for (int t = 0; t < calls[i].d->nterms; ++t)
                 if ((pre >> t) & 1) fins.push_back(*calls[i].d->fin[t]);

@@ -32,31 +32,20 @@ extern "C" int lh_bottleneck_infer(const lh_bottleneck_desc* d, const void* x, c
     a.x = (const unsigned char*)x; a.w1 = (const unsigned char*)w1; a.w2 = (const unsigned char*)w2; a.w3 = (const unsigned char*)w3;
     a.s1 = s1; a.b1 = b1; a.s2 = s2; a.b2 = b2; a.s3 = s3; a.b3 = b3;
     a.n = d->n; a.h = d->h; a.w = d->w; a.cin = d->cin; a.kpad1 = (d->cin + 63) / 64 * 64;
-    // Two forms (bottleneck_infer_kernel.h): 16 x 16 tiles, one 8-wave workgroup per CU (default) -- or 8 x 16 tiles, 4 waves, 75 KB of
-    // LDS, two workgroups per CU (LH_BNK_FORM=8; measured equal to 3 % slower: 1 148 / 747 vs 1 133 / 695 us on the C5 stage-1 shapes --
-    // the launch moves 4.4 GB through the fabric either way: x with its halo, x AGAIN as the residual, the output).
-    static const int form = getenv("LH_BNK_FORM") ? atoi(getenv("LH_BNK_FORM")) : 16;
-    const bool small = form != 16;
-    const long ntile = small ? (long)d->n * ceil_div(d->h, 8) * ceil_div(d->w, 16) : nt;
-    a.grid = (int)(small ? (ntile < 512 ? ntile : 512) : (ntile < 256 ? ntile : 256));
-    const int lds = small ? lh_bottleneck_lds_bytes(8, 3) : lh_bottleneck_lds_bytes(16, 4);
+    // 16 x 16 tiles, one 8-wave workgroup per CU.  (An 8 x 16 / 4-wave form with two workgroups per CU was equal to 3 % slower -- the launch moves
+    // 4.4 GB through the fabric either way: x with its halo, x AGAIN as the residual, the output -- and was removed in round 6.)
+    a.grid = (int)(nt < 256 ? nt : 256);
+    const int lds = lh_bottleneck_lds_bytes(16, 4);
     hipStream_t s = (hipStream_t)stream;
-    const void* fn = small ? (dtype == LH_BF16 ? reinterpret_cast<const void*>(&bottleneck_infer_kernel<bf16, 8, 4, 3>)
-                                               : reinterpret_cast<const void*>(&bottleneck_infer_kernel<f16, 8, 4, 3>))
-                           : (dtype == LH_BF16 ? reinterpret_cast<const void*>(&bottleneck_infer_kernel<bf16, 16, 8, 4>)
-                                               : reinterpret_cast<const void*>(&bottleneck_infer_kernel<f16, 16, 8, 4>));
+    const void* fn = dtype == LH_BF16 ? reinterpret_cast<const void*>(&bottleneck_infer_kernel<bf16, 16, 8, 4>)
+                                      : reinterpret_cast<const void*>(&bottleneck_infer_kernel<f16, 16, 8, 4>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) {
         lh_set_error("lh_bottleneck_infer: cannot raise dynamic LDS to %d bytes: %s", lds, hipGetErrorString(e));
         return LH_ERR_HIP;
     }
-    if (small) {
-        if (dtype == LH_BF16) hipLaunchKernelGGL((bottleneck_infer_kernel<bf16, 8, 4, 3>), dim3(a.grid), dim3(256), lds, s, a);
-        else hipLaunchKernelGGL((bottleneck_infer_kernel<f16, 8, 4, 3>), dim3(a.grid), dim3(256), lds, s, a);
-    } else {
-        if (dtype == LH_BF16) hipLaunchKernelGGL((bottleneck_infer_kernel<bf16, 16, 8, 4>), dim3(a.grid), dim3(512), lds, s, a);
-        else hipLaunchKernelGGL((bottleneck_infer_kernel<f16, 16, 8, 4>), dim3(a.grid), dim3(512), lds, s, a);
-    }
+    if (dtype == LH_BF16) hipLaunchKernelGGL((bottleneck_infer_kernel<bf16, 16, 8, 4>), dim3(a.grid), dim3(512), lds, s, a);
+    else hipLaunchKernelGGL((bottleneck_infer_kernel<f16, 16, 8, 4>), dim3(a.grid), dim3(512), lds, s, a);
     LH_LAUNCH_CHECK("bottleneck_infer launch");
     return LH_OK;
 }

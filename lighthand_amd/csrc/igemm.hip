@@ -422,7 +422,7 @@ static int igemm_impl(const lh_igemm_desc* d, const void* in, const void* wpack,
     if (prep_args) {            // lh_igemm_multi: hand the argument block back instead of launching
         LH_REQUIRE(ring && ((rc_.depth >= 2 && rc_.depth < LH_WIDE_DEPTH) || rc_.depth == 100),
                    "lh_igemm_multi: problem does not run on the LDS-DMA ring kernel or the direct 3x3 kernel (its cfg must name a tiled or the direct configuration)");
-        if (rc_.depth == 100) {                     // direct 3x3 member of a mixed launch (igemm_mixed_kernel.h): its persistent grid
+        if (rc_.depth == 100) {                     // a lone direct 3x3 problem handed to lh_igemm_multi: its persistent grid
             a.pw_cb = (d->cout + 63) / 64;
             a.pw_g = lh_d3_rows(d);
         } else {
@@ -522,26 +522,9 @@ extern "C" int lh_igemm_multi(const lh_igemm_call* calls, int n, int dtype, void
             if (rc) return rc;
             continue;
         }
-        // mixed launch (igemm_mixed_kernel.h): direct 3x3 bodies beside the 64 x 128 ring tile
-        if (cfg0.bm == 0) cfg0 = RingCfg{64, 128, 2, 64};
-        LH_REQUIRE(cfg0.bm == 64 && cfg0.bp == 128, "lh_igemm_multi: direct 3x3 problems share a launch with the 64 x 128 tile only (got %dx%d)", cfg0.bm, cfg0.bp);
-        int kinds[LH_MULTI_MAX] = {0, 0, 0, 0};
-        bool stats = false, stats_all = true;
-        for (int i = 0; i < cnt; ++i) {
-            const int j = order[i];
-            m.a[i] = tmp[j];
-            if (cfgs[j].depth == 100) {
-                kinds[i] = cfgs[j].kb;
-                m.first[i + 1] = m.first[i] + m.a[i].pw_g * m.a[i].pw_cb;
-                stats = stats || m.a[i].stats != nullptr;
-                stats_all = stats_all && m.a[i].stats != nullptr;
-            } else {
-                m.first[i + 1] = m.first[i] + ceil_div(m.a[i].M, cfg0.bp) * ceil_div(m.a[i].cout, cfg0.bm);
-            }
-        }
-        LH_REQUIRE(!stats || stats_all, "lh_igemm_multi: the direct 3x3 problems of one call must all (or none) write BatchNorm statistics");
-        const int rc = lh_igemm_mixed_multi_launch(m, kinds, cfg0, dtype, stats, (hipStream_t)stream);
-        if (rc) return rc;
+        // (round 4's mixed launch -- direct 3x3 bodies beside ring tiles in one grid -- was measured slower and removed in round 6)
+        lh_set_error("lh_igemm_multi: direct 3x3 problems do not share a launch with tiled ones (launch them one by one)");
+        return LH_ERR_UNSUPPORTED;
     }
     return LH_OK;
 }

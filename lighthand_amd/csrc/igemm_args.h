@@ -79,7 +79,6 @@ int lh_ring_candidates(const lh_igemm_desc* d, int dtype, int* out, int max);
 int lh_igemm_ring_launch(const IgemmArgs& a, const RingCfg& c, int dtype, hipStream_t s);
 template <typename A> struct LhMulti;
 int lh_igemm_ring_multi_launch(LhMulti<IgemmArgs>& m, const RingCfg& c, int dtype, hipStream_t s);
-int lh_igemm_mixed_multi_launch(LhMulti<IgemmArgs>& m, const int* kinds, const RingCfg& c, int dtype, bool stats, hipStream_t s);
 bool lh_pw_supported(const lh_igemm_desc* d, int dtype);
 bool lh_d3_supported(const lh_igemm_desc* d, int dtype);
 int lh_d3_rows(const lh_igemm_desc* d);

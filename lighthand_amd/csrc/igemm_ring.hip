@@ -16,8 +16,6 @@ int lh_ring_launch_bf16_small(const IgemmArgs& a, const RingCfg& c, hipStream_t 
 int lh_ring_launch_f16_big(const IgemmArgs& a, const RingCfg& c, hipStream_t s);
 int lh_ring_launch_f16_mid(const IgemmArgs& a, const RingCfg& c, hipStream_t s);
 int lh_ring_launch_f16_small(const IgemmArgs& a, const RingCfg& c, hipStream_t s);
-int lh_ring_launch_bf16_wide(const IgemmArgs& a, const RingCfg& c, hipStream_t s);
-int lh_ring_launch_f16_wide(const IgemmArgs& a, const RingCfg& c, hipStream_t s);
 int lh_ring_launch_bf16_dense(const IgemmArgs& a, const RingCfg& c, hipStream_t s);
 int lh_ring_launch_f16_dense(const IgemmArgs& a, const RingCfg& c, hipStream_t s);
 int lh_ring_launch_bf16_ksplit(const IgemmArgs& a, const RingCfg& c, hipStream_t s);
@@ -25,9 +23,6 @@ int lh_ring_launch_f16_ksplit(const IgemmArgs& a, const RingCfg& c, hipStream_t 
 int lh_ring_launch_f32(const IgemmArgs& a, const RingCfg& c, hipStream_t s);
 int lh_ring_multi_launch_bf16(const LhMulti<IgemmArgs>& m, const RingCfg& c, hipStream_t s);
 int lh_ring_multi_launch_f16(const LhMulti<IgemmArgs>& m, const RingCfg& c, hipStream_t s);
-struct MixedKinds { int k[LH_MULTI_MAX]; };
-int lh_mixed_multi_launch_bf16(const LhMulti<IgemmArgs>& m, const MixedKinds& kt, const RingCfg& c, bool stats, hipStream_t s);
-int lh_mixed_multi_launch_f16(const LhMulti<IgemmArgs>& m, const MixedKinds& kt, const RingCfg& c, bool stats, hipStream_t s);
 int lh_pw_launch_bf16(const IgemmArgs& a, const RingCfg& c, hipStream_t s);
 int lh_pw_launch_f16(const IgemmArgs& a, const RingCfg& c, hipStream_t s);
 int lh_d3_launch_bf16(const IgemmArgs& a, const RingCfg& c, hipStream_t s);
@@ -38,9 +33,6 @@ int lh_pw_occ_f16(const RingCfg& c, bool stats);
 static const RingCfg kCfg16[] = {
 #define X(BM, BP, WC, WP, D, KB) {BM, BP, D, KB},
     LH_RING_CFGS_16BIT(X)
-#undef X
-#define X(BM, BP, WC, WP, D, KB) {BM, BP, D + LH_WIDE_DEPTH, KB},
-    LH_RING_CFGS_WIDE(X)
 #undef X
 #define X(BM, BP, WC, WP, D, KB) {BM, BP, D + LH_DENSE_DEPTH, KB},
     LH_RING_CFGS_DENSE(X)
@@ -67,9 +59,8 @@ static void cfg_table(int dtype, const RingCfg** t, int* n) {
     else { *t = kCfg16; *n = (int)(sizeof(kCfg16) / sizeof(RingCfg)); }
 }
 
-// ring depth of a tiled configuration (the wide-wave form carries it as depth + LH_WIDE_DEPTH, the dense-wave forms as depth + LH_DENSE_DEPTH)
+// ring depth of a tiled configuration (the dense-wave forms carry it as depth + LH_DENSE_DEPTH, the K-split forms as depth + LH_KSPLIT_DEPTH)
 static inline int ring_depth(const RingCfg& c) { return c.depth >= 100 ? c.depth : c.depth % 10 == 0 ? 10 : c.depth % 10; }
-static inline bool ring_wide(const RingCfg& c) { return c.depth >= LH_WIDE_DEPTH && c.depth < LH_DENSE_DEPTH; }
 static inline bool ring_dense(const RingCfg& c) { return c.depth >= LH_DENSE_DEPTH && c.depth < LH_DENSE_DEPTH + 10; }
 static inline bool ring_ksplit(const RingCfg& c) { return c.depth >= LH_KSPLIT_DEPTH && c.depth < LH_KSPLIT_DEPTH + 10; }
 
@@ -127,9 +118,6 @@ static bool cfg_fits(const lh_igemm_desc* d, int dtype, const RingCfg& c) {
     if (c.bm > 64 && d->cout <= c.bm / 2) return false;               // (these three only multiply zeros / repeat a shallower ring)
     if (c.bp > 64 && M <= c.bp / 2) return false;
     if (ring_depth(c) > 2 && ring_depth(c) - 1 > stages) return false;
-    // the wide-wave tile pays for 256 x 256 of prologue / epilogue with one wave per SIMD: large launches only.  Measured 20-25 %
-    // SLOWER than the 8-wave form on every launch of C5 / C2 (profiles/r04_c5_deconv_what_holds_the_pipe.txt), so the tuner is
-    // not offered it unless LH_WIDE_TILES=1 (tests, experiments); an explicit cfg still runs it.
     // dense-wave forms (LH_DENSE_TILES=0: not offered).  Built for launches that leave a CU one workgroup; measured 2-9 % ahead
     // on larger launches as well (two co-resident workgroups = four waves per SIMD), so every launch is offered them
     if (ring_dense(c)) {
@@ -143,11 +131,6 @@ static bool cfg_fits(const lh_igemm_desc* d, int dtype, const RingCfg& c) {
     if (ring_ksplit(c)) {
         const char* sw = getenv("LH_KSPLIT_TILES");
         if (!(sw && atoi(sw) != 0) || stages < 2) return false;
-    }
-    if (ring_wide(c)) {
-        const char* sw = getenv("LH_WIDE_TILES");                 // read per query (host side, planning time only)
-        const bool offer = sw && atoi(sw) != 0;
-        if (!offer || ((M + 255) / 256) * ((d->cout + 255) / 256) < 128 || stages < 4) return false;
     }
     return true;
 }
@@ -397,7 +380,6 @@ int lh_igemm_ring_launch(const IgemmArgs& a0, const RingCfg& c, int dtype, hipSt
             rc = lh_ring_launch_bf16_big(a, c, s);
             if (rc == 1) rc = lh_ring_launch_bf16_mid(a, c, s);
             if (rc == 1) rc = lh_ring_launch_bf16_small(a, c, s);
-            if (rc == 1) rc = lh_ring_launch_bf16_wide(a, c, s);
             if (rc == 1) rc = lh_ring_launch_bf16_dense(a, c, s);
             if (rc == 1) rc = lh_ring_launch_bf16_ksplit(a, c, s);
             break;
@@ -405,7 +387,6 @@ int lh_igemm_ring_launch(const IgemmArgs& a0, const RingCfg& c, int dtype, hipSt
             rc = lh_ring_launch_f16_big(a, c, s);
             if (rc == 1) rc = lh_ring_launch_f16_mid(a, c, s);
             if (rc == 1) rc = lh_ring_launch_f16_small(a, c, s);
-            if (rc == 1) rc = lh_ring_launch_f16_wide(a, c, s);
             if (rc == 1) rc = lh_ring_launch_f16_dense(a, c, s);
             if (rc == 1) rc = lh_ring_launch_f16_ksplit(a, c, s);
             break;
@@ -438,30 +419,6 @@ int lh_igemm_ring_multi_launch(LhMulti<IgemmArgs>& m, const RingCfg& c, int dtyp
     if (rc == 1) {
         lh_set_error("igemm_ring_multi: no multi-problem kernel for tile %dx%d depth %d kb %d dtype %d (4-wave tiles, 16-bit types)",
                      c.bm, c.bp, c.depth, c.kb, dtype);
-        return LH_ERR_UNSUPPORTED;
-    }
-    return rc;
-}
-
-// direct 3x3 bodies and ring-tile bodies in one grid (igemm_mixed_kernel.h); kinds[i] = channels per tap of a direct member, 0 = ring
-int lh_igemm_mixed_multi_launch(LhMulti<IgemmArgs>& m, const int* kinds, const RingCfg& c, int dtype, bool stats, hipStream_t s) {
-    const unsigned char* z = zero_page();
-    unsigned char* dp = dump_page();
-    if (!z || !dp) {
-        lh_set_error("igemm_mixed_multi: cannot resolve the zero page on this device");
-        return LH_ERR_HIP;
-    }
-    MixedKinds kt;
-    for (int i = 0; i < LH_MULTI_MAX; ++i) kt.k[i] = i < m.n ? kinds[i] : 0;
-    for (int i = 0; i < m.n; ++i) { m.a[i].zero = z; m.a[i].dump = dp; }
-    for (int i = 0; i < m.n; ++i)
-        if (kinds[i] == 0)
-            if (int e = lh_ring_offsets_fit(m.a[i], c.bm, c.bp, 2)) return e;
-    int rc = 1;
-    if (dtype == LH_BF16) rc = lh_mixed_multi_launch_bf16(m, kt, c, stats, s);
-    else if (dtype == LH_F16) rc = lh_mixed_multi_launch_f16(m, kt, c, stats, s);
-    if (rc == 1) {
-        lh_set_error("igemm_mixed_multi: no mixed kernel for ring depth %d kb %d dtype %d (64 x 128 tile, 16-bit types)", c.depth, c.kb, dtype);
         return LH_ERR_UNSUPPORTED;
     }
     return rc;

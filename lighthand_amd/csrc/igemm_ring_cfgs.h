@@ -15,12 +15,9 @@
     X(64,64,2,2,2,64) X(64,64,2,2,4,64) X(64,64,2,2,2,128) X(64,64,2,2,3,128) \
     X(64,64,2,2,4,128)
 #define LH_RING_CFGS_16BIT(X) LH_RING_CFGS_BIG(X) LH_RING_CFGS_MID(X) LH_RING_CFGS_SMALL(X)
-// The "wide-wave" form of the 256 x 256 tile: FOUR waves (one per SIMD), 128 x 128 per wave, up to 512 registers per
-// lane (256 of them accumulators): half the LDS fragment reads per MFMA of the 8-wave form.  Same K order, same
-// epilogue: bit-identical results.  In RingCfg / lh_igemm_desc.cfg its ring depth is written depth + LH_WIDE_DEPTH.
+// (Ring depth codes 10..19 belonged to the "wide-wave" form of the 256 x 256 tile -- four waves of 128 x 128 -- which was 20-25 % slower than the
+//  8-wave tile on every launch, profiles/r04_c5_deconv_what_holds_the_pipe.txt, and was removed in round 6.)
 #define LH_WIDE_DEPTH 10
-#define LH_RING_CFGS_WIDE(X) \
-    X(256,256,2,2,3,64) X(256,256,2,2,4,64) X(256,256,2,2,2,128)
 // The "dense-wave" forms: EIGHT waves (two per SIMD) on the tiles the 4-wave forms run with one wave per SIMD.  A launch
 // of <= 256 workgroups (stages 3-4 of the ResNets at batch 64) leaves every CU with ONE workgroup, and with one wave per
 // SIMD the wave's own LDS-DMA issue (address arithmetic included), fragment reads and MFMAs run one after the other

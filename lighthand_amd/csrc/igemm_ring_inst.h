@@ -5,7 +5,7 @@
 #include "igemm_ring_kernel.h"
 
 #ifndef LH_DCODE
-#define LH_DCODE 0          // offset of the ring depth in RingCfg.depth (LH_WIDE_DEPTH for the wide-wave configurations)
+#define LH_DCODE 0          // offset of the ring depth in RingCfg.depth (LH_DENSE_DEPTH / LH_KSPLIT_DEPTH for the dense-wave / K-split configurations)
 #endif
 
 #ifndef LH_LAUNCH

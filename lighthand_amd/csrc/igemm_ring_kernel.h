@@ -73,11 +73,6 @@ template <> struct MmaR<float> {
 #define LH_ABL 0
 #endif
 
-// Debug-only: -DLH_WIDE_PLAIN=1 runs the wide-wave tile through the plain stage loop (A/B of its software pipeline).
-#ifndef LH_WIDE_PLAIN
-#define LH_WIDE_PLAIN 0
-#endif
-
 typedef __attribute__((address_space(3))) void* lds_void_p;
 typedef const __attribute__((address_space(1))) void* gbl_void_p;
 
@@ -296,52 +291,12 @@ __device__ __forceinline__ void igemm_ring_body(const IgemmArgs& p, unsigned cha
     // K slice kk of the stage at byte offset `so`
     auto step = [&](auto KKc, unsigned so) { step_at(offA[decltype(KKc)::value] + so, offB[decltype(KKc)::value] + so); };
 
-    // The wide-wave form (one wave per SIMD, 128 x 128 per wave): no partner wave covers this wave's stalls, so the stage is
-    // software-pipelined instead -- the fragment reads of the first K slice are issued BEFORE the ring refill (they land
-    // while the refill's LDS-DMA instructions issue), and the reads of the second slice are issued under the last two
-    // MFMA groups of the first (a second fragment register set; the counted waits allow for the younger reads).
-    constexpr bool WIDE = NWAVE == 4 && CT * PT >= 64;
     auto mfma_group = [&](auto Ic, uint4 (&F)[NR]) {
         constexpr int i = decltype(Ic)::value;
 #pragma unroll
         for (int j = 0; j < PT; ++j)
             if (!(LH_ABL & 1)) MmaR<T>::run(F[PT + i], F[j], acc[i][j]);
     };
-    auto wide_stage = [&](unsigned so) {
-        uint4 F0[NR];
-        static_for<0, NR>([&](auto r) { rd(r, F0[decltype(r)::value], offA[0] + so, offB[0] + so); });
-        __builtin_amdgcn_sched_barrier(0);
-        if (issued < S) issue();
-        if constexpr (KSUB == 1) {
-            static_for<0, CT>([&](auto Ic) {
-                __builtin_amdgcn_sched_barrier(0);
-                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(CT - 1 - decltype(Ic)::value) : "memory");
-                __builtin_amdgcn_sched_barrier(0);
-                mfma_group(Ic, F0);
-            });
-        } else {
-            uint4 F1[NR];
-            const unsigned ca = offA[KSUB - 1] + so, cb = offB[KSUB - 1] + so;
-            static_for<0, CT>([&](auto Ic) {
-                constexpr int i = decltype(Ic)::value;
-                __builtin_amdgcn_sched_barrier(0);
-                // group CT - 1 waits for its weight fragment with the PT pixel fragments of the next slice behind it
-                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(i == CT - 1 ? PT : CT - 1 - i) : "memory");
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (i == CT - 2) static_for<0, PT>([&](auto r) { rd(r, F1[decltype(r)::value], ca, cb); });
-                if constexpr (i == CT - 1) static_for<PT, NR>([&](auto r) { rd(r, F1[decltype(r)::value], ca, cb); });
-                __builtin_amdgcn_sched_barrier(0);
-                mfma_group(Ic, F0);
-            });
-            static_for<0, CT>([&](auto Ic) {
-                __builtin_amdgcn_sched_barrier(0);
-                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(CT - 1 - decltype(Ic)::value) : "memory");
-                __builtin_amdgcn_sched_barrier(0);
-                mfma_group(Ic, F1);
-            });
-        }
-    };
-
     // waves 4-7 of the 8-wave tile share their SIMDs with waves 0-3: they refill the ring half a stage later
     const bool late = NWAVE == 8 && KSUB == 2 && wave >= NWAVE / 2;
     int cslot = 0;                                   // ring slot of the stage being consumed
@@ -351,10 +306,6 @@ __device__ __forceinline__ void igemm_ring_body(const IgemmArgs& p, unsigned cha
         __builtin_amdgcn_s_barrier();
         const unsigned so = cslot * STAGE;
         if (++cslot == D) cslot = 0;
-        if constexpr (WIDE && !LH_WIDE_PLAIN) {
-            wide_stage(so);
-            continue;
-        }
         // the refill goes into the slot of stage s - 1, whose reads every wave retired before the barrier
         if (!late && issued < S) issue();
         if constexpr (KZ == 2) {                     // this wave's K slice of the stage only (its pair partner takes the other)
@@ -399,9 +350,8 @@ __device__ __forceinline__ void igemm_ring_body(const IgemmArgs& p, unsigned cha
 #endif
 }
 
-// waves per SIMD the register budget is sized for: 2, except the wide-wave form of the 256 x 256 tile (four waves holding
-// 128 x 128 each: 256 accumulator registers per lane, one wave per SIMD)
-template <int BM, int BP, int WC, int WP> constexpr int ring_waves_per_simd() { return (BM / WC) * (BP / WP) >= 128 * 128 ? 1 : 2; }
+// waves per SIMD the register budget is sized for
+template <int BM, int BP, int WC, int WP> constexpr int ring_waves_per_simd() { return 2; }
 
 template <typename T, int BM, int BP, int WC, int WP, int D, int KB>
 __global__ __launch_bounds__(64 * WC * WP, (ring_waves_per_simd<BM, BP, WC, WP>())) void igemm_ring_kernel(const IgemmArgs p) {

@@ -59,7 +59,6 @@ class Plan(Tuner, WgradSchedule, BatchGroups, InferRewrites):
         # branches) are compiled as a GROUP whose launches merge into lh_*_multi calls (one grid for 2-4 problems) on the
         # main stream, instead of one launch per branch on stream lanes.  16-bit types; LH_BATCH=0 keeps the lanes.
         self.batch = os.environ.get("LH_BATCH", "1") != "0" and self.es == 2 and self.n_lanes > 1
-        self.batch_split = os.environ.get("LH_BATCH", "1") == "2"
         self.wgrad_batch = os.environ.get("LH_WGRAD_BATCH", "1") != "0" and self.es == 2
         # Table launches (round 6): ALL weight gradients of a deferred group that share a tile class run as ONE grid with a split count
         # per layer + at most one fold grid (lh_wgrad_table_run; _table_wgrads).  LH_WGRAD_TABLE=0: one launch (+ fold) per layer.
@@ -300,8 +299,6 @@ class Plan(Tuner, WgradSchedule, BatchGroups, InferRewrites):
             if 20 <= depth < 30:                # the dense-wave forms (eight waves on the 4-wave tiles, igemm_ring_cfgs.h)
                 wc, wp = {(128, 128): (2, 4), (128, 64): (4, 2), (64, 128): (2, 4), (64, 64): (2, 4), (128, 256): (2, 4), (256, 128): (4, 2)}[(bm, bp)]
                 depth -= 20
-            elif 10 <= depth < 20:              # the wide-wave form of the 256 x 256 tile (four waves)
-                wc, wp, depth = 2, 2, depth - 10
             if depth:
                 return f"igemm_ring_kernel<{t}, {bm}, {bp}, {wc}, {wp}, {depth}, {kb}>"
             return f"igemm_kernel<{t}, {bm}, {bp}, {wc}, {wp}>"

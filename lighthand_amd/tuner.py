@@ -398,28 +398,9 @@ class Tuner:
                 c = {tuple(buf[5 * i:5 * i + 4]) for i in range(n)}
                 common = c if common is None else common & c
             cands = sorted(c + (0,) for c in (common or ()) if 2 <= c[2] < 10 and (c[0], c[1]) in self._MULTI_TILES)      # 4-wave tiled forms (the multi-problem kernels)
-            # MIXED launches (igemm_mixed_kernel.h; experiment, LH_MIXED=1): the members the direct 3x3 kernel takes (C = 32 / 64
-            # per tap: HRNet's two high-resolution branches) run its body inside the merged grid, the others the 64 x 128 ring
-            # tile -- whose stage size the 64-byte K run of the 32-channel member no longer dictates.  Candidate = (tile
-            # configuration of the ring members, 1).  MEASURED (round 4, HRNet-W32 bs 32 fp16, tuned from scratch): the tuner
-            # prefers the mixed form in 3 of 26 groups, step 13.30-13.35 vs 13.27 ms -- the direct body's 156 KB of LDS leave
-            # one workgroup per CU for the whole grid (832 workgroups = 3.25 rounds); off by default.
-            direct = []
-            for d in ds:
-                buf, n = self._igemm_candidates(d)
-                direct.append(next((tuple(buf[5 * i:5 * i + 4]) for i in range(n) if buf[5 * i + 2] == 100), None))
-            mixed = os.environ.get("LH_MIXED", "0")        # "1": every member the direct kernel takes; "32": only the 32-channel ones (79 KB of LDS: two workgroups per CU)
-            if mixed == "32":
-                direct = [dc if dc is not None and dc[3] == 32 else None for dc in direct]
-            if mixed in ("1", "32") and any(direct) and len(ds) >= 2:
-                rest = None
-                for d, dc in zip(ds, direct):
-                    if dc is None:
-                        buf, n = self._igemm_candidates(d)
-                        c = {tuple(buf[5 * i:5 * i + 4]) for i in range(n)}
-                        rest = c if rest is None else rest & c
-                ring = sorted(c for c in rest if (c[0], c[1]) == (64, 128) and 2 <= c[2] < 10) if rest is not None else [(64, 128, 2, 64)]
-                cands += [c + (1,) for c in ring]
+            # (a 5th element of a candidate marked round 4's MIXED launch -- direct 3x3 bodies inside the merged grid; measured slower, removed in
+            #  round 6: it is always 0 now and stays in the tuple so that the shipped database's entries keep their form)
+            direct = [None] * len(ds)
             hit = type(self)._TUNE_CACHE.get(key)
             if hit is not None and len(hit) == 4:
                 hit = tuple(hit) + (0,)               # entries of earlier rounds: one tiled configuration for all members

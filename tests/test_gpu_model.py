@@ -699,22 +699,3 @@ for kind, nd in plan.nodes:                            # every BatchNorm's folde
     pass
 print("SHA", h.hexdigest())
 """
-
-
-def test_bn_slice_kernel_is_bit_identical_to_finalize_then_apply():
-    """Round-4 advisor: the one-launch form of BatchNorm finalize + apply (fuse_fwd_slice_kernel, LH_BN_SLICE=1, off by default
-    because it measured slower) had no test.  Train-mode R18 forwards (batch statistics, running-statistic updates,
-    num_batches_tracked) in two processes, LH_BN_SLICE=0 and =1, static kernel choice: heat-maps and every running statistic must
-    agree bit for bit -- the slice kernel folds the statistics slab with the finalize kernel's own arithmetic and lets exactly
-    one workgroup per channel slice update the running statistics."""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = _SLICE_SNIPPET.format(root=root)
-    shas = []
-    for sl in ("0", "1"):
-        env = dict(os.environ, LH_AUTOTUNE="0", LH_BN_SLICE=sl, LH_TUNE_CACHE="0")
-        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        shas.append([l for l in r.stdout.splitlines() if l.startswith("SHA ")][-1])
-    assert shas[0] == shas[1], shas

@@ -221,71 +221,6 @@ def test_every_conv_kernel_configuration(case, precision, forced_plans, monkeypa
         assert ksplit_seen, "the K-split wave-pair forms were not offered"
 
 
-@pytest.fixture(scope="module")
-def wide_tiles_offered():
-    """The wide-wave configurations are compiled in but only offered to the tuner with LH_WIDE_TILES=1 (they lose to the 8-wave
-    tile everywhere: profiles/r04_c5_deconv_what_holds_the_pipe.txt).  The library reads the switch once per process, so the
-    library reads the switch at every candidate query."""
-    import os
-    old = os.environ.get("LH_WIDE_TILES")
-    os.environ["LH_WIDE_TILES"] = "1"
-    yield
-    if old is None:
-        os.environ.pop("LH_WIDE_TILES", None)
-    else:
-        os.environ["LH_WIDE_TILES"] = old
-
-
-WIDE_CASES = [  # cin, cout, k, s, p, n, h, w, transposed -- at least 128 tiles of 256 x 256, which is where the form is offered
-    (256, 256, 3, 1, 1, 9, 61, 61, False),       # ragged pixel count: the last pixel tile is partial
-    (512, 256, 1, 1, 0, 8, 64, 64, False),
-    (128, 512, 3, 2, 1, 8, 96, 96, False),
-    (256, 256, 4, 2, 1, 8, 64, 64, True),        # the four sub-pixel phases of a transposed convolution as one launch
-]
-
-
-@pytest.mark.parametrize("precision", ["bf16", "fp16"])
-@pytest.mark.parametrize("case", WIDE_CASES)
-def test_wide_wave_configurations(case, precision, forced_plans, wide_tiles_offered):
-    """The wide-wave form of the 256 x 256 tile (four waves, 128 x 128 per wave, ring depth written depth + 10:
-    igemm_ring_cfgs.h) on launches large enough to be offered it: forward and data gradient match PyTorch and agree BIT
-    FOR BIT with the 8-wave form of the same tile and with a 128 x 128 configuration."""
-    ConvNet, _ = _mods()
-    cin, cout, k, s_, p, n, h, w, tr = case
-    torch.manual_seed(11)
-    x = quant(torch.randn(n, cin, h, w), precision)
-    ref_m = nn.ConvTranspose2d(cin, cout, k, 2, 1, 0, bias=False) if tr else nn.Conv2d(cin, cout, k, s_, p, bias=False)
-    with torch.no_grad():
-        ref_m.weight.copy_(quant(ref_m.weight, precision))
-    xr = x.clone().requires_grad_(True)
-    ref = ref_m(xr)
-    dy = quant(torch.randn_like(ref), precision)
-    ref.backward(dy)
-    offered, results = set(), []
-    picks = [lambda c: 10 <= c[2] < 100 and c[3] == 128, lambda c: 10 <= c[2] < 100 and c[3] == 64 and c[2] == 13,
-             lambda c: 10 <= c[2] < 100 and c[2] == 14, lambda c: c[:2] == (256, 256) and c[2] < 10, lambda c: c[:2] == (128, 128)]
-    for sel in picks:
-        chosen = []
-
-        def pick(cands, sel=sel, chosen=chosen):
-            offered.update(c for c in cands if 10 <= c[2] < 100)
-            m_ = [c for c in cands if sel(c)]
-            c = m_[0] if m_ else cands[0]
-            chosen.append(c)
-            return c
-        forced_plans.force_cfg = pick
-        m = ConvNet(cin, cout, k, s_, p, bias=False, transposed=tr)
-        m.conv.load_state_dict(ref_m.state_dict())
-        out, dx, _ = _run_plan(m, x, lambda o: dy, precision)
-        assert rel_err(out, ref.detach()) < TOL[precision] and rel_err(dx, xr.grad) < TOL[precision], chosen
-        results.append((chosen, out, dx))
-    print(case, precision, "wide configurations offered:", sorted(offered), "| chosen:", [r[0] for r in results])
-    assert {c[2] for c in offered} >= {12, 13, 14} or cin * k * k < 256, offered
-    assert any(10 <= c[2] < 100 for c in results[0][0]), results[0][0]
-    for chosen, out, dx in results[1:]:
-        assert torch.equal(out, results[0][1]) and torch.equal(dx, results[0][2]), chosen
-
-
 def test_conv_tile_bn_statistics(forced_plans):
     """conv -> BN -> ReLU (+ residual) with the largest and the smallest tile forced: the tile's epilogue writes the BN
     partial sums (one slab row per pixel tile), so running statistics, BN parameter gradients and the data gradient must
