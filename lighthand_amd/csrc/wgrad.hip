@@ -812,6 +812,20 @@ extern "C" int lh_wgrad_table_build(const lh_wgrad_call* calls, int n, int dtype
             for (int b = 0; b < cnt; ++b) item_list.push_back(int2{i, b});
         }
     }
+    {   // every (problem, block) exactly once, whatever the order: a block left out would leave its slab slice unwritten
+        std::vector<long> first_of(n + 1, 0);
+        for (int i = 0; i < n; ++i) first_of[i + 1] = first_of[i] + (long)args[i].tiles * args[i].ntaps * args[i].nsplit;
+        std::vector<unsigned char> seen((size_t)first_of[n], 0);
+        long placed = 0;
+        for (const int2& it : item_list) {
+            if (it.x < 0) continue;
+            const long cnt = first_of[it.x + 1] - first_of[it.x];
+            LH_REQUIRE(it.x < n && it.y >= 0 && it.y < cnt && !seen[(size_t)(first_of[it.x] + it.y)], "lh_wgrad_table_build: internal error in the work-item order");
+            seen[(size_t)(first_of[it.x] + it.y)] = 1;
+            ++placed;
+        }
+        LH_REQUIRE(placed == first_of[n], "lh_wgrad_table_build: internal error: %ld of %ld work items placed", placed, first_of[n]);
+    }
     long n_items = (long)item_list.size(), n_fold_items = 0;
     for (const WreduceArgs& r : folds)
         n_fold_items += r.contig ? ceil_div((long)r.n_out * r.n_in, 256) : ceil_div(wgrad_reduce_threads(r.n_out, r.n_in, r.ntaps), 256);

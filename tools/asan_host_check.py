@@ -116,6 +116,33 @@ def run():
         for dt in (_lib.LH_F32, _lib.LH_BF16, _lib.LH_F16):
             lib.lh_igemm_phases_rows(arr, 4, dt)
             calls += 1
+    # table launches of the weight gradient (lh_wgrad_table_build, size query: host arithmetic only -- the per-problem split counts, the
+    # XCD-aware work-item order with its coverage check, blob offsets): the layers of every batch / size of the table as ONE table each,
+    # every compiled-in tile class, automatic and forced item lengths, both item orders
+    by_shape = {}
+    for (n, h, w, cin, cout, k, st) in layer_table():
+        if cin % 8 == 0 and cout % 8 == 0:
+            by_shape.setdefault((n, h * w > 0), []).append((n, h, w, cin, cout, k, st))
+    for layers in by_shape.values():
+        keep, arr = [], (_lib.WgradCall * len(layers))()
+        for i, (n, h, w, cin, cout, k, st) in enumerate(layers):
+            fwd, _ = conv_fwd(n, h, w, cin, cout, k, st)
+            taps = (C.c_int * (2 * k * k))(*[v for r in range(k) for q in range(k) for v in (r, q)])
+            keep += [fwd, taps]
+            arr[i].d, arr[i].rows, arr[i].x, arr[i].dy, arr[i].dy_pix_stride = C.pointer(fwd), 0, 4096, 8192, cout
+            arr[i].n_out, arr[i].n_in, arr[i].grad = cout, cin, 1 << 20
+            arr[i].so, arr[i].si, arr[i].sr, arr[i].ss = cin * k * k, k * k, k, 1
+            arr[i].taps_rs, arr[i].accumulate = C.cast(taps, C.POINTER(C.c_int)), 0
+        info = _lib.WgradTableInfo()
+        for xcd in ("1", "0"):
+            os.environ["LH_WGRAD_TABLE_XCD"] = xcd
+            for cfg in ((256, 256, 64, 2), (128, 128, 64, 3), (64, 64, 32, 4)):
+                for target in (0, 1, 7, 64, 100000):
+                    rc = lib.lh_wgrad_table_build(arr, len(layers), _lib.LH_BF16, (C.c_int * 4)(*cfg), target, None, None, 0, C.byref(info))
+                    assert rc == 0 and info.n_items > 0 and info.table_bytes >= info.off_fold_items >= info.off_fold_args > info.off_items > 0, (rc, lib.lh_last_error())
+                    calls += 1
+        os.environ.pop("LH_WGRAD_TABLE_XCD", None)
+    assert lib.lh_wgrad_table_build(None, 1, _lib.LH_BF16, (C.c_int * 4)(128, 128, 64, 3), 0, None, None, 0, C.byref(_lib.WgradTableInfo())) != 0
     for args in ((64, 128, 128), (8, 128, 128), (3, 37, 41)):
         lib.lh_stem_conv_rows(*args)
         lib.lh_maxpool3x3s2_bwd_gated_rows(args[0], args[1], args[2], 64, _lib.LH_BF16)
