@@ -180,6 +180,25 @@ def test_train_cli_end_to_end(tmp_path, capsys):
     assert best <= first
 
 
+def test_train_cli_trains_and_validates_on_the_short_last_batch(tmp_path, capsys):
+    """src/tools/train.py:27-38 builds both loaders with the default drop_last=False: 20 training samples at batch 8 are THREE iterations per
+    epoch (8, 8, 4) and 12 validation samples two batches (8, 4).  The short batch runs on a step of its own shape that shares the optimizer:
+    after two epochs Adam has taken 6 steps (the checkpoint's optimizer state says so), and --drop_last gives the 4-step run."""
+    from lighthand_amd.tools import train as T
+    steps = {}
+    for tag, extra in (("ref", []), ("drop", ["--drop_last"])):
+        args = T.parse_args(["--root_path", str(tmp_path / tag), "--synthetic", "20", "--val_synthetic", "12", "--batch_size", "8", "--epoch", "2",
+                             "--depth", "18", "--size", "64", "--precision", "bf16", "--reset", "--count", "5"] + extra)
+        best = T.main(args)
+        out = capsys.readouterr().out
+        assert np.isfinite(best) and out.count("valid loss") == 2
+        assert ("iter 0/3" in out) == (tag == "ref") and ("iter 0/2" in out) == (tag == "drop"), out
+        sd = torch.load(os.path.join(args.output_dir, "checkpoint-good", "state_dict.bin"), map_location="cpu")
+        st = sd["optimizer_state_dict"]["state"]
+        steps[tag] = (int(float(st[0]["step"])), sd["epoch"])
+    assert steps["ref"][0] == 3 * (steps["ref"][1] + 1) and steps["drop"][0] == 2 * (steps["drop"][1] + 1), steps
+
+
 def test_train_entry_point_takes_datasets(tmp_path, capsys, monkeypatch):
     """main(args, train_set=, val_set=) (reference: src/tools/train.py:24-38 builds the datasets): any Dataset of
     (image, joint_2d, ...) samples.  (a) the reference's sample layout -- normalised float [3, S, S], joints [21, 3],
