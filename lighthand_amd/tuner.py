@@ -12,6 +12,15 @@ from ._lib import FuseBwdDesc, FuseDesc, IgemmDesc, check
 from .graph import Act, _Call, _Marker, _desc, _ptr, _taps_array
 
 
+def _record_time(key, choice, ms):
+    """LH_TUNE_TIMES=<file>: every timed candidate as a line (key, choice, milliseconds for the timed launches) -- tools/ensemble_tune.py adds the
+    times of several sessions (boxes of the pool differ in what they favour among near-ties) and picks the candidate that is fastest in the sum."""
+    path = os.environ.get("LH_TUNE_TIMES")
+    if path:
+        with open(path, "a") as f:
+            f.write(repr((key, tuple(choice), float(ms))) + "\n")
+
+
 class Tuner:
     # ------------------------------------------------------------------ kernel autotuning
     _TUNE_CACHE = {}        # launch signature -> (bm, bp, depth, kb): shared by every plan of the process
@@ -251,6 +260,7 @@ class Tuner:
                         b.record(stream)
                         b.synchronize()
                         t = a.elapsed_time(b)
+                    _record_time(key, cfg, t)
                     if os.environ.get("LH_TUNE_LOG"):
                         print(f"[tune {role or ''} {lead.k_run}x{lead.ntaps}->{lead.cout} M={lead.n * lead.ho * lead.wo} addend={addend}] cfg {cfg}: "
                               f"{t / type(self).tune_iters() * 1e3:7.1f} us", flush=True)
@@ -307,6 +317,7 @@ class Tuner:
                         b.record(stream)
                         b.synchronize()
                         t = a.elapsed_time(b)
+                    _record_time(key, (bo, bi, enc), t)
                     if best is None or t < best[0]:
                         best = (t, (bo, bi, enc))
                 hit = best[1]
@@ -360,6 +371,7 @@ class Tuner:
                     run = lambda: check(self.lib.lh_wgrad_table_run(blob.data_ptr(), C.byref(info), self.dt, sp), "autotune lh_wgrad_table_run")
                     run()
                     t = self._timed_cold(run, [], type(self).tune_iters())
+                    _record_time(key, tuple(cfg) + (info.target_stages if target else 0,), t)
                     if os.environ.get("LH_WGRAD_TABLE_LOG"):
                         print(f"[table {n} x wgrad] cfg {cfg} target {target:5d} items {info.n_items:5d} fold {info.n_fold_items:5d} "
                               f"slab {info.workspace_bytes >> 20:4d} MiB nsplit<= {info.nsplit_max:3d}: {t / type(self).tune_iters() * 1e3:8.1f} us", flush=True)
@@ -432,6 +444,7 @@ class Tuner:
                         d.cfg[0], d.cfg[1], d.cfg[2], d.cfg[3] = mc
                     run()
                     t = self._timed_cold(run, warm, type(self).tune_iters())
+                    _record_time(key, cfg, t)
                     if os.environ.get("LH_TUNE_LOG"):
                         print(f"[tune {role or ''} {lead.k_run}x{lead.ntaps}->{lead.cout} M={lead.n * lead.ho * lead.wo} addend={addend}] cfg {cfg}: "
                               f"{t / type(self).tune_iters() * 1e3:7.1f} us", flush=True)
