@@ -7,7 +7,9 @@ The arithmetic of ``ColorJitter`` lives in torchvision (a dependency of the refe
 this image: reference pins torchvision 0.12, requirements.yaml), so this file restates torchvision's PUBLISHED tensor
 algorithm (torchvision/transforms/functional_tensor.py: ``_blend``, ``rgb_to_grayscale``, ``adjust_brightness /
 contrast / saturation / hue``, ``_rgb2hsv``, ``_hsv2rgb``) -- parity UNPINNED by torchvision itself; pinned by the
-closed-form known answers of tests/test_oracle_golden.py (identity factors, grey world, pure-colour hue rotations).
+closed-form known answers of tests/test_oracle_golden.py (identity factors, grey world, pure-colour hue rotations) and, since round 6,
+cross-checked against Pillow's ImageEnhance / 8-bit HSV shift -- what torchvision's OTHER (PIL) backend calls for the same four ops --
+to 8-bit quantisation (test_color_jitter_ops_agree_with_pillow_image_enhance): an independent implementation, still not torchvision.
 The random draw (``ColorJitter.get_params``: factor ~ U[max(0, 1 - v), 1 + v], hue ~ U[-h, h], op order = randperm(4))
 stays on the host: the device kernel takes per-image factors and an op order.
 """

@@ -163,3 +163,38 @@ def test_color_jitter_oracle_known_answers():
     want = (np.transpose(u8, (2, 0, 1)).astype(np.float32) / 255.0 - np.array([0.485, 0.456, 0.406], np.float32)[:, None, None]) \
         / np.array([0.229, 0.224, 0.225], np.float32)[:, None, None]
     assert np.allclose(oc.input_pipeline(u8, 4, 4), want, atol=1e-6)
+
+
+def test_color_jitter_ops_agree_with_pillow_image_enhance():
+    """oracle/color.py restates torchvision's TENSOR ColorJitter ops; torchvision is absent from this image, so it cannot be pinned by
+    torchvision itself.  An independent implementation IS here: Pillow's ImageEnhance, which is what torchvision's PIL backend calls
+    (functional_pil.adjust_brightness / contrast / saturation = ImageEnhance.Brightness / Contrast / Color(img).enhance(f); adjust_hue =
+    shift the H channel of img.convert("HSV") by uint8(f * 255) with wrap-around).  The two backends of torchvision implement the same
+    published definition on float and on uint8 data: the oracle must agree with Pillow to 8-bit quantisation -- brightness / saturation
+    within 1.5 levels, contrast 2 (Pillow rounds the grey mean to an integer), hue within the quantisation of Pillow's 8-bit HSV round trip (one hue step of 1/255 turn moves a saturated
+    colour by 6 levels, and uint8(f * 255) truncates the shift by up to another step: measured mean 0.6-1.6 levels, 99th percentile 4-11; a
+    wrong sextant, sign of the shift or grey weight is tens of levels)."""
+    from PIL import Image, ImageEnhance
+    from oracle import color as oc
+    rng = np.random.RandomState(3)
+    for trial in range(4):
+        u8 = rng.randint(0, 256, size=(24, 31, 3)).astype(np.uint8)
+        if trial == 3:
+            u8[:, :16] = u8[:, :16] // 4 + 96                     # a low-saturation half
+        img = Image.fromarray(u8, "RGB")
+        x = (u8.astype(np.float32) / 255.0).transpose(2, 0, 1)   # ToTensor
+        for f in (0.5, 0.8, 1.0, 1.3, 1.5):
+            for name, enh, fn, tol in (("brightness", ImageEnhance.Brightness, oc.adjust_brightness, 1.5), ("contrast", ImageEnhance.Contrast, oc.adjust_contrast, 2.0),
+                                       ("saturation", ImageEnhance.Color, oc.adjust_saturation, 1.5)):
+                want = np.asarray(enh(img).enhance(f), dtype=np.float32).transpose(2, 0, 1)
+                got = fn(x, f) * 255.0
+                assert np.abs(got - want).max() <= tol, (name, f, float(np.abs(got - want).max()))
+        for f in (-0.5, -0.2, 0.0, 0.1, 0.5):
+            h, s, v = img.convert("HSV").split()
+            nh = np.array(h, dtype=np.uint8)
+            with np.errstate(over="ignore"):
+                nh = (nh.astype(np.int32) + int(np.uint8(np.int32(f * 255)))).astype(np.uint8)      # uint8 wrap-around, as functional_pil does
+            want = np.asarray(Image.merge("HSV", (Image.fromarray(nh, "L"), s, v)).convert("RGB"), dtype=np.float32).transpose(2, 0, 1)
+            got = oc.adjust_hue(x, f) * 255.0
+            d = np.abs(got - want)
+            assert d.mean() < 2.0 and np.quantile(d, 0.99) <= 12.0, (f, float(d.mean()), float(np.quantile(d, 0.99)), float(d.max()))
