@@ -165,8 +165,12 @@ int lh_igemm(const lh_igemm_desc* d, const void* in, const void* wpack, void* ou
  * -- instead of dout, and writes the per-block partial sums { sum g, sum g * (x - mean) * invstd } per channel into `partial`
  * (fp32 [rows][2][cout], rows = lh_igemm_stats_rows: the layout of the forward statistics).  lh_fuse_bwd then takes them
  * (lh_fuse_bwd_desc.pre_partial / pre_rows) and skips its own reduce pass over dout and x: one read of dout, one launch
- * less per BatchNorm.  x has the layout of this launch's output (same pixel stride).  Tiled LDS-DMA configurations only
- * (lh_igemm_config: ring depth 2..9); LH_ERR_UNSUPPORTED otherwise. */
+ * less per BatchNorm.  x has the layout of this launch's output (same pixel stride).
+ * mask (optional; dense outputs): the activation is a residual tail a = relu(BN(x) + r) (`out += residual; relu`,
+ * pose_resnet.py:96-97) -- its sign does not follow from x alone, it is read from the relu_mask bits lh_fuse_fwd stored for the tail
+ * (scale / shift are then unused and may be NULL).  `partial` has lh_igemm_gated_rows rows.
+ * Tiled LDS-DMA configurations (lh_igemm_config: ring depth 2..9 and the dense-wave forms) and the persistent pointwise kernel
+ * (ring depth 1); LH_ERR_UNSUPPORTED otherwise. */
 typedef struct {
     const void* x;
     const float* mean;
@@ -174,7 +178,9 @@ typedef struct {
     const float* scale;
     const float* shift;
     float* partial;
+    const void* mask;
 } lh_bn_bwd_gate;
+int lh_igemm_gated_rows(const lh_igemm_desc* d, int dtype);
 int lh_igemm_gated(const lh_igemm_desc* d, const void* in, const void* wpack, void* out, const void* addend, const void* addend_mask,
                    const lh_bn_bwd_gate* gate, int dtype, void* stream);
 /* Phase batching: 2..4 lh_igemm launches that share input, output tensor, sizes and epilogue and differ only in weight
@@ -368,8 +374,9 @@ typedef struct {
     const void* relu_mask;      /* mask bits written by lh_fuse_fwd; when set, `out` is not read and may be NULL */
     int strips_cap;             /* 0 = default (512): upper bound on the strips of the streaming reduce pass = rows of the
                                  * partial-sum slab; 256 is the measured choice for nodes that share lh_fuse_bwd_multi launches */
-    const float* pre_partial;   /* single BN term under a ReLU whose dout was written by lh_igemm_gated: dout is already the gated
-                                 * gradient and these are its partial sums [pre_rows][2][c] -- no reduce pass, no mask */
+    const float* pre_partial;   /* ONE BN term under a ReLU -- alone, or beside one identity term (a residual tail) -- whose dout was written
+                                 * by lh_igemm_gated: dout is already the gated gradient and these are its partial sums
+                                 * [pre_rows][2][c] -- no reduce pass, no mask */
     int pre_rows;
     const void* l2_touch;       /* optional (round 5), as lh_fuse_desc.l2_touch: the last apply pass of the call warms these bytes in L2 */
     size_t l2_touch_bytes;

@@ -47,7 +47,7 @@ class FuseBwdDesc(C.Structure):
 
 class BnBwdGate(C.Structure):          # lh_igemm_gated
     _fields_ = [("x", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p),
-                ("partial", C.c_void_p)]
+                ("partial", C.c_void_p), ("mask", C.c_void_p)]
 
 
 class IgemmCall(C.Structure):          # one entry of lh_igemm_multi = the arguments of lh_igemm
@@ -128,6 +128,7 @@ SIGNATURES = {
     "lh_wgrad_tile": (_I, [C.POINTER(IgemmDesc), _I, _I, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "lh_wgrad_candidates": (_I, [C.POINTER(IgemmDesc), _I, _I, _I, C.POINTER(_I), _I]),
     "lh_igemm_stats_rows": (_I, [C.POINTER(IgemmDesc), _I]),
+    "lh_igemm_gated_rows": (_I, [C.POINTER(IgemmDesc), _I]),
     "lh_igemm_gated": (_I, [C.POINTER(IgemmDesc), _P, _P, _P, _P, _P, C.POINTER(BnBwdGate), _I, _P]),
     "lh_wgrad_slab_bytes": (_SZ, [C.POINTER(IgemmDesc), _I, _I, _I]),
     "lh_wgrad": (_I, [C.POINTER(IgemmDesc), _P, _P, _I, _I, _I, _P, _I, _P]),

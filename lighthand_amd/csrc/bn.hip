@@ -1314,6 +1314,7 @@ static int plan_fuse_bwd(const lh_fuse_bwd_desc* d, int n, int h, int w, int c, 
             m2.accumulate[k] = d->accumulate[k];
         }
     }
+    if (merge2 && d->pre_partial) { m2.relu = 0; m2.out = nullptr; m2.mask = nullptr; }      // dout is the gated gradient already
     if (merge2) {
         m2.count = (long)n * h * w;
         for (int k = 0; k < 2; ++k) { m2.fold_slab[k] = nullptr; m2.fold_rows[k] = 0; m2.dgamma[k] = nullptr; m2.dbeta[k] = nullptr; }
@@ -1335,9 +1336,12 @@ static int plan_fuse_bwd(const lh_fuse_bwd_desc* d, int n, int h, int w, int c, 
         const int nchunk = c / (16 / es);
         const bool flat = a.l == 0 && (nchunk & (nchunk - 1)) == 0 && nchunk <= 256;
         // dout written by lh_igemm_gated: already the gated gradient, its partial sums come with it
-        const bool pre = d->pre_partial != nullptr;
-        if (pre) {
-            LH_REQUIRE(d->nterms == 1 && d->relu && a.x && d->pre_rows >= 1 && a.l == 0, "lh_fuse_bwd: pre_partial takes ONE BatchNorm term under a ReLU");
+        const bool pre = d->pre_partial != nullptr && a.x;
+        if (d->pre_partial) {
+            // one BatchNorm term under the ReLU, alone or with an identity term beside it (a residual tail, merged apply pass)
+            const bool tail = merge2 && !(d->x[0] && d->x[1]);
+            LH_REQUIRE((d->nterms == 1 || tail) && d->relu && d->pre_rows >= 1 && a.l == 0 && (a.x || tail),
+                       "lh_fuse_bwd: pre_partial takes ONE BatchNorm term under a ReLU (alone, or beside one identity term)");
             a.relu = 0;
             a.out = nullptr; a.mask = nullptr;
         }

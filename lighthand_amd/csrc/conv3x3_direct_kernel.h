@@ -39,7 +39,8 @@ __device__ __forceinline__ void d3_lds_dma16(const unsigned char* src, unsigned 
 
 // The kernel proper for workgroup `b` of its launch (plain launch: the block index; the mixed multi-problem launch of
 // igemm_mixed_kernel.h: the index inside the problem the workgroup belongs to).  512 threads.
-template <typename T, int C, bool STATS>
+// GATE (with STATS; lh_igemm_gated): see igemm_wave_epilogue.h -- the constants area holds mean, invstd, scale, shift of the gated BatchNorm.
+template <typename T, int C, bool STATS, bool GATE = false>
 __device__ __forceinline__ void conv3x3_direct_body(const IgemmArgs& p, unsigned char* smem, const int b) {
     constexpr int ES = sizeof(T);
     static_assert(ES == 2 && (C == 32 || C == 64), "16-bit element types, 32 or 64 input channels per tap");
@@ -89,13 +90,21 @@ __device__ __forceinline__ void conv3x3_direct_body(const IgemmArgs& p, unsigned
         float* cst = reinterpret_cast<float*>(smem + OFF_CST);
         for (int c = tid; c < BM; c += 64 * NWAVE) {
             const int gc = cblk * BM + c;
-            float sv = 1.f, bv = 0.f;
-            if (gc < p.cout) {
-                if (p.bias) bv = p.bias[gc];
-                if (p.scale) { sv = p.scale[gc]; bv = bv * sv + p.shift[gc]; }
+            if constexpr (GATE) {
+                const int gk = gc < p.cout ? gc : p.cout - 1;
+                cst[c] = p.gmean[gk];
+                cst[BM + c] = p.ginv[gk];
+                cst[2 * BM + c] = p.gmask ? 0.f : p.gscale[gk];
+                cst[3 * BM + c] = p.gmask ? 0.f : p.gshift[gk];
+            } else {
+                float sv = 1.f, bv = 0.f;
+                if (gc < p.cout) {
+                    if (p.bias) bv = p.bias[gc];
+                    if (p.scale) { sv = p.scale[gc]; bv = bv * sv + p.shift[gc]; }
+                }
+                cst[c] = sv;
+                cst[BM + c] = bv;
             }
-            cst[c] = sv;
-            cst[BM + c] = bv;
         }
     }
 
@@ -218,7 +227,7 @@ __device__ __forceinline__ void conv3x3_direct_body(const IgemmArgs& p, unsigned
         unsigned char* stg = (ALIAS ? smem + OFF_PATCH + buf * PATCH : smem + OFF_STG) + wave * STG;
         const int n = t / (ty_n * tx_n), rem = t - n * (ty_n * tx_n);
         const int oy0 = (rem / tx_n) * TH + PT * wave, ox0 = (rem % tx_n) * TW;
-        wave_epilogue<T, BM, PT, STATS>(p, acc, stg, cst, cblk, lane, [&](int row) {
+        wave_epilogue<T, BM, PT, STATS, GATE>(p, acc, stg, cst, cblk, lane, [&](int row) {
             const int y = oy0 + (row >> 4), x = ox0 + (row & 15);
             return (y < H && x < W) ? ((long)n * H + y) * W + x : -1L;
         }, s1, s2);
@@ -233,10 +242,10 @@ __device__ __forceinline__ void conv3x3_direct_body(const IgemmArgs& p, unsigned
     }
 }
 
-template <typename T, int C, bool STATS>
+template <typename T, int C, bool STATS, bool GATE = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_direct_kernel(const IgemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    conv3x3_direct_body<T, C, STATS>(p, smem, blockIdx.x);
+    conv3x3_direct_body<T, C, STATS, GATE>(p, smem, blockIdx.x);
 }
 
 static inline int lh_d3_lds_bytes(int c) {
@@ -261,8 +270,10 @@ template <typename T, int C>
 static int launch_d3(const IgemmArgs& a0, hipStream_t s) {
     IgemmArgs a = a0;
     lh_d3_grid(C, a.n, a.ho, a.wo, a.cout, &a.pw_g, &a.pw_cb);
-    const int lds = lh_d3_lds_bytes(C);
-    const void* fn = a.stats ? reinterpret_cast<const void*>(&conv3x3_direct_kernel<T, C, true>)
+    const bool gate = a.gx != nullptr;
+    const int lds = lh_d3_lds_bytes(C) + (gate ? 2 * 64 * 4 : 0);            // the gate's two extra constant vectors
+    const void* fn = gate ? reinterpret_cast<const void*>(&conv3x3_direct_kernel<T, C, true, true>)
+                   : a.stats ? reinterpret_cast<const void*>(&conv3x3_direct_kernel<T, C, true>)
                              : reinterpret_cast<const void*>(&conv3x3_direct_kernel<T, C, false>);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -272,7 +283,8 @@ static int launch_d3(const IgemmArgs& a0, hipStream_t s) {
         }
     }
     dim3 grid(a.pw_g * a.pw_cb);
-    if (a.stats) hipLaunchKernelGGL((conv3x3_direct_kernel<T, C, true>), grid, dim3(512), lds, s, a);
+    if (gate) hipLaunchKernelGGL((conv3x3_direct_kernel<T, C, true, true>), grid, dim3(512), lds, s, a);
+    else if (a.stats) hipLaunchKernelGGL((conv3x3_direct_kernel<T, C, true>), grid, dim3(512), lds, s, a);
     else hipLaunchKernelGGL((conv3x3_direct_kernel<T, C, false>), grid, dim3(512), lds, s, a);
     LH_LAUNCH_CHECK("conv3x3_direct launch");
     return LH_OK;

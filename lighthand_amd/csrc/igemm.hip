@@ -337,6 +337,16 @@ extern "C" int lh_igemm_stats_rows(const lh_igemm_desc* d, int dtype) {
     return (int)((M + bp - 1) / bp);
 }
 
+// rows of the partial-sum slab a gated launch (lh_igemm_gated) writes: those of the statistics slab, except on the pointwise kernel, whose
+// gate instantiation may hold a different number of workgroups per CU
+extern "C" int lh_igemm_gated_rows(const lh_igemm_desc* d, int dtype) {
+    if (d && d->cfg[2] == 1 && lh_ring_supported(d, dtype)) {
+        RingCfg c;
+        if (lh_ring_resolve(d, dtype, &c) == LH_OK && c.depth == 1) return lh_pw_rows(d, c, dtype, true);
+    }
+    return lh_igemm_stats_rows(d, dtype);
+}
+
 struct PhaseSet {                 // lh_igemm_phases: the other descriptors / packs of the batch (lead = descs[lead])
     const lh_igemm_desc* const* descs;
     const void* const* wpacks;
@@ -367,11 +377,14 @@ static int igemm_impl(const lh_igemm_desc* d, const void* in, const void* wpack,
     a.scale = scale; a.shift = shift;
     LH_REQUIRE((scale == nullptr) == (shift == nullptr), "lh_igemm: scale and shift must come together");
     a.head_w = nullptr; a.head_bias = nullptr; a.head_out = nullptr; a.head_j = 0; a.head_wstride = 0;
-    a.gx = nullptr; a.gmean = a.ginv = a.gscale = a.gshift = nullptr;
+    a.gx = nullptr; a.gmean = a.ginv = a.gscale = a.gshift = nullptr; a.gmask = nullptr;
     if (gate) {
-        LH_REQUIRE(gate->x && gate->mean && gate->invstd && gate->scale && gate->shift && gate->partial, "lh_igemm_gated: null pointer in the gate");
+        LH_REQUIRE(gate->x && gate->mean && gate->invstd && gate->partial && (gate->mask || (gate->scale && gate->shift)),
+                   "lh_igemm_gated: null pointer in the gate (the sign of the activation comes from scale + shift or from mask)");
         LH_REQUIRE(!bias && !scale && !d->relu && !phases && !head, "lh_igemm_gated: a data gradient carries no bias / affine / ReLU / phases");
+        LH_REQUIRE(!gate->mask || d->out_pix_stride == d->cout, "lh_igemm_gated: gate.mask needs a dense output (mask bits index 16-byte chunks)");
         a.gx = (const unsigned char*)gate->x; a.gmean = gate->mean; a.ginv = gate->invstd; a.gscale = gate->scale; a.gshift = gate->shift;
+        a.gmask = (const unsigned char*)gate->mask;
         a.stats = gate->partial;
     }
     a.n = d->n; a.hi = d->hi; a.wi = d->wi; a.in_pix_stride = d->in_pix_stride; a.k_run = d->k_run;
@@ -433,8 +446,8 @@ static int igemm_impl(const lh_igemm_desc* d, const void* in, const void* wpack,
         *prep_cfg = rc_;
         return LH_OK;
     }
-    if (gate && !(ring && ((rc_.depth >= 2 && rc_.depth < 10) || (rc_.depth >= LH_DENSE_DEPTH && rc_.depth < LH_KSPLIT_DEPTH + 10)) && es == 2)) {
-        lh_set_error("lh_igemm_gated: the launch does not run on a tiled LDS-DMA configuration (ring depth %d)", ring ? rc_.depth : 0);
+    if (gate && !(ring && (rc_.depth == 1 || rc_.depth == 100 || (rc_.depth >= 2 && rc_.depth < 10) || (rc_.depth >= LH_DENSE_DEPTH && rc_.depth < LH_KSPLIT_DEPTH + 10)) && es == 2)) {
+        lh_set_error("lh_igemm_gated: the launch runs neither on a tiled LDS-DMA configuration nor on a persistent kernel (ring depth %d)", ring ? rc_.depth : 0);
         return LH_ERR_UNSUPPORTED;
     }
     if (ring) {

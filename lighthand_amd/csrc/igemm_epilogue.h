@@ -146,13 +146,15 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, unsigned char
     uint4 ad[NR];
     uint4 xd[NR];                                     // BatchNorm-backward gate (lh_igemm_gated): the BN input at the output position
     unsigned mbits[NR];
+    unsigned gbits[NR];
     // gate constants of this thread's EPC channels (every thread loads, index clamped)
     float gmean[EPC], ginv[EPC], gsc[EPC], gsh[EPC];
     if (p.gx) {
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
             const int gk = col0 + e < p.cout ? col0 + e : p.cout - 1;
-            gmean[e] = p.gmean[gk]; ginv[e] = p.ginv[gk]; gsc[e] = p.gscale[gk]; gsh[e] = p.gshift[gk];
+            gmean[e] = p.gmean[gk]; ginv[e] = p.ginv[gk];
+            gsc[e] = p.gmask ? 0.f : p.gscale[gk]; gsh[e] = p.gmask ? 0.f : p.gshift[gk];
         }
     }
 #pragma unroll
@@ -174,10 +176,12 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, unsigned char
             if (p.addend_mask) mbits[k] = *(ok ? p.addend_mask + eoff / EPC : p.zero);    // addend = upstream gradient, gated by the activation's ReLU mask
         }
         xd[k] = uint4{0u, 0u, 0u, 0u};
+        gbits[k] = 0xffu;
         if (p.gx) {
             const bool ok = opx[k] >= 0;
             const long eoff = (long)((unsigned long)(unsigned)(ok ? opx[k] : 0) * (unsigned)p.out_pix_stride) + col0;
             xd[k] = *reinterpret_cast<const uint4*>(ok ? p.gx + eoff * ES : p.zero);
+            if (p.gmask) gbits[k] = *(ok ? p.gmask + eoff / EPC : p.zero);      // a residual tail: its sign was stored as mask bits
         }
     }
 #pragma unroll
@@ -216,7 +220,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, unsigned char
             unpack16<T>(xd[k], xv);
 #pragma unroll
             for (int e = 0; e < EPC; ++e) {
-                g[e] = (xv[e] * gsc[e] + gsh[e]) > 0.f ? g[e] : 0.f;
+                g[e] = (p.gmask ? ((gbits[k] >> e) & 1u) != 0u : (xv[e] * gsc[e] + gsh[e]) > 0.f) ? g[e] : 0.f;
                 s1[e] += g[e];
                 s2[e] += g[e] * (xv[e] - gmean[e]) * ginv[e];
             }

@@ -11,9 +11,10 @@ int LH_FN(const IgemmArgs& a, const RingCfg& c, hipStream_t s) {
     return 1;
 }
 
-int LH_OCC_FN(const RingCfg& c, bool stats) {
+int LH_OCC_FN(const RingCfg& c, int mode) {
 #define X(BM, KC, PT) \
-    if (c.bm == BM && c.kb == KC && c.bp == 16 * PT) return stats ? pw_occupancy<LH_T, BM, KC, PT, true>() : pw_occupancy<LH_T, BM, KC, PT, false>();
+    if (c.bm == BM && c.kb == KC && c.bp == 16 * PT)  \
+        return mode == 2 ? pw_occupancy<LH_T, BM, KC, PT, true, true>() : mode == 1 ? pw_occupancy<LH_T, BM, KC, PT, true>() : pw_occupancy<LH_T, BM, KC, PT, false>();
     LH_PW_CFGS(X)
 #undef X
     return 2;

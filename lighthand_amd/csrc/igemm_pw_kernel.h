@@ -26,8 +26,11 @@
 #define LH_PW_NT 0          // debug builds only (-DLH_PW_NT=1): A/B of the cache policy of the operand-row loads
 #endif
 
-template <typename T, int BM, int KC, int PT, bool STATS>
+// GATE (with STATS; lh_igemm_gated): the output is the gradient of an activation relu(BN(gx)) or of a residual tail relu(BN(gx) + r): the
+// epilogue stores the ReLU-gated gradient and the statistics row holds { sum g, sum g * xhat } (igemm_wave_epilogue.h).
+template <typename T, int BM, int KC, int PT, bool STATS, bool GATE = false>
 __global__ __launch_bounds__(256, 2) void igemm_pw_kernel(const IgemmArgs p) {
+    static_assert(!GATE || STATS, "the gate leaves its sums in the statistics row");
     // two operand register sets (the rows of tile n + 1 are requested before tile n is multiplied) where the register
     // file holds them beside the accumulators and the statistics
     constexpr bool DB = KC <= 256 && !(BM == 256 && KC >= 128) && (2 * PT * (KC / 32) * 4 + (BM / 16) * PT * 4 + (STATS ? (BM / 64) * 16 : 0)) <= 176;
@@ -44,7 +47,7 @@ __global__ __launch_bounds__(256, 2) void igemm_pw_kernel(const IgemmArgs p) {
     constexpr int NSB = BM / SUBW;
     constexpr int RS = SUBW * ES + 8;                 // staging row pitch: 34 dwords -> the ds_write_b64 of 16 pixels hit 32 banks once
     constexpr int STG = PT * 16 * RS;                 // staging bytes per wave
-    constexpr int CST = PANEL + 4 * STG;              // per-channel constants: float sv[BM], bv[BM]
+    constexpr int CST = PANEL + 4 * STG;              // per-channel constants: float sv[BM], bv[BM] (GATE: mean, invstd, scale, shift of the gated BatchNorm)
     constexpr int NI = PANEL / 1024;                  // LDS-DMA instructions that fill the panel
     static_assert(NI % 4 == 0 && NI / 4 <= 60, "panel fill: instructions per wave");
 
@@ -74,13 +77,21 @@ __global__ __launch_bounds__(256, 2) void igemm_pw_kernel(const IgemmArgs p) {
         float* cst = reinterpret_cast<float*>(smem + CST);
         for (int c = tid; c < BM; c += 256) {
             const int gc = cblk * BM + c;
-            float sv = 1.f, bv = 0.f;
-            if (gc < p.cout) {
-                if (p.bias) bv = p.bias[gc];
-                if (p.scale) { sv = p.scale[gc]; bv = bv * sv + p.shift[gc]; }
+            if constexpr (GATE) {                         // a data gradient carries no bias / affine: the slots hold the gate's constants
+                const int gk = gc < p.cout ? gc : p.cout - 1;
+                cst[c] = p.gmean[gk];
+                cst[BM + c] = p.ginv[gk];
+                cst[2 * BM + c] = p.gmask ? 0.f : p.gscale[gk];
+                cst[3 * BM + c] = p.gmask ? 0.f : p.gshift[gk];
+            } else {
+                float sv = 1.f, bv = 0.f;
+                if (gc < p.cout) {
+                    if (p.bias) bv = p.bias[gc];
+                    if (p.scale) { sv = p.scale[gc]; bv = bv * sv + p.shift[gc]; }
+                }
+                cst[c] = sv;
+                cst[BM + c] = bv;
             }
-            cst[c] = sv;
-            cst[BM + c] = bv;
         }
     }
 
@@ -183,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void igemm_pw_kernel(const IgemmArgs p) {
             return;
         }
         const int m0 = t * PT * 16;
-        wave_epilogue<T, BM, PT, STATS>(p, acc, stg, cst, cblk, lane, [&](int row) { const int m = m0 + row; return m < M ? (long)m : -1L; }, s1, s2);
+        wave_epilogue<T, BM, PT, STATS, GATE>(p, acc, stg, cst, cblk, lane, [&](int row) { const int m = m0 + row; return m < M ? (long)m : -1L; }, s1, s2);
     };
     if constexpr (DB) {
         while (t < ntile) {
@@ -207,14 +218,14 @@ __global__ __launch_bounds__(256, 2) void igemm_pw_kernel(const IgemmArgs p) {
 }
 
 // Workgroups of this instantiation a CU holds at once (registers, LDS), 1..4; 2 when no device can be asked.
-template <typename T, int BM, int KC, int PT, bool STATS>
+template <typename T, int BM, int KC, int PT, bool STATS, bool GATE = false>
 static int pw_occupancy() {
     static int cached[64] = {0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 2;
     if (cached[dev]) return cached[dev];
-    const int lds = lh_pw_lds_bytes(BM, KC, PT);
-    const void* fn = reinterpret_cast<const void*>(&igemm_pw_kernel<T, BM, KC, PT, STATS>);
+    const int lds = lh_pw_lds_bytes(BM, KC, PT, GATE);
+    const void* fn = reinterpret_cast<const void*>(&igemm_pw_kernel<T, BM, KC, PT, STATS, GATE>);
     if (lds > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return 1;
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 256, lds) != hipSuccess || n < 1) return 2;
@@ -226,11 +237,13 @@ static int pw_occupancy() {
 template <typename T, int BM, int KC, int PT>
 static int launch_pw(const IgemmArgs& a0, hipStream_t s) {
     IgemmArgs a = a0;
-    const int occ = a.stats ? pw_occupancy<T, BM, KC, PT, true>() : pw_occupancy<T, BM, KC, PT, false>();
+    const bool gate = a.gx != nullptr;
+    const int occ = gate ? pw_occupancy<T, BM, KC, PT, true, true>() : a.stats ? pw_occupancy<T, BM, KC, PT, true>() : pw_occupancy<T, BM, KC, PT, false>();
     lh_pw_grid(BM, KC, PT, a.M, a.cout, occ, &a.pw_g, &a.pw_cb);
-    const int lds = lh_pw_lds_bytes(BM, KC, PT);
+    const int lds = lh_pw_lds_bytes(BM, KC, PT, gate);
     dim3 grid(a.pw_g * a.pw_cb);
-    if (a.stats) hipLaunchKernelGGL((igemm_pw_kernel<T, BM, KC, PT, true>), grid, dim3(256), lds, s, a);
+    if (gate) hipLaunchKernelGGL((igemm_pw_kernel<T, BM, KC, PT, true, true>), grid, dim3(256), lds, s, a);
+    else if (a.stats) hipLaunchKernelGGL((igemm_pw_kernel<T, BM, KC, PT, true>), grid, dim3(256), lds, s, a);
     else hipLaunchKernelGGL((igemm_pw_kernel<T, BM, KC, PT, false>), grid, dim3(256), lds, s, a);
     LH_LAUNCH_CHECK("igemm_pw launch");
     return LH_OK;

@@ -27,8 +27,8 @@ int lh_pw_launch_bf16(const IgemmArgs& a, const RingCfg& c, hipStream_t s);
 int lh_pw_launch_f16(const IgemmArgs& a, const RingCfg& c, hipStream_t s);
 int lh_d3_launch_bf16(const IgemmArgs& a, const RingCfg& c, hipStream_t s);
 int lh_d3_launch_f16(const IgemmArgs& a, const RingCfg& c, hipStream_t s);
-int lh_pw_occ_bf16(const RingCfg& c, bool stats);
-int lh_pw_occ_f16(const RingCfg& c, bool stats);
+int lh_pw_occ_bf16(const RingCfg& c, int mode);
+int lh_pw_occ_f16(const RingCfg& c, int mode);
 
 static const RingCfg kCfg16[] = {
 #define X(BM, BP, WC, WP, D, KB) {BM, BP, D, KB},
@@ -154,14 +154,14 @@ static bool pw_fits(const lh_igemm_desc* d, int dtype, const RingCfg& c) {
     return false;
 }
 
-int lh_pw_occupancy(const RingCfg& c, int dtype, bool stats) {
-    return dtype == LH_BF16 ? lh_pw_occ_bf16(c, stats) : lh_pw_occ_f16(c, stats);
+int lh_pw_occupancy(const RingCfg& c, int dtype, int mode) {
+    return dtype == LH_BF16 ? lh_pw_occ_bf16(c, mode) : lh_pw_occ_f16(c, mode);
 }
 
 // rows of the statistics slab a pointwise launch writes: one per workgroup of a channel block
-int lh_pw_rows(const lh_igemm_desc* d, const RingCfg& c, int dtype) {
+int lh_pw_rows(const lh_igemm_desc* d, const RingCfg& c, int dtype, bool gate) {
     int g, cb;
-    lh_pw_grid(c.bm, c.kb, c.bp / 16, (long)d->n * d->ho * d->wo, d->cout, lh_pw_occupancy(c, dtype, true), &g, &cb);
+    lh_pw_grid(c.bm, c.kb, c.bp / 16, (long)d->n * d->ho * d->wo, d->cout, lh_pw_occupancy(c, dtype, gate ? 2 : 1), &g, &cb);
     return g;
 }
 

@@ -15,7 +15,11 @@
 
 // pix(row) -> output pixel index of staging row `row` (0 .. 16 * PT - 1), or -1 when the row lies outside the problem.
 // s1 / s2: running per-lane sums of the stored values / their squares, [BM / 64][8] (STATS).
-template <typename T, int BM, int PT, bool STATS, typename PixFn, int NS>
+// GATE (lh_igemm_gated, a data gradient whose output is the gradient of a = relu(BN(gx)) or of a residual tail a = relu(BN(gx) + r)):
+// the value stored is g = v * (a > 0) -- the sign recomputed from gx * scale + shift, or read from the mask bits lh_fuse_fwd stored for a
+// tail (p.gmask) -- and s1 / s2 take { g, g * (gx - mean) * invstd }: the first half of that BatchNorm's backward pass (bn.hip
+// fuse_bwd_reduce_flat_body) on the tile the wave holds.  cst = mean[BM], invstd[BM], scale[BM], shift[BM]; no affine on the accumulator.
+template <typename T, int BM, int PT, bool STATS, bool GATE = false, typename PixFn, int NS>
 __device__ __forceinline__ void wave_epilogue(const IgemmArgs& p, f32x4 (&acc)[BM / 16][PT], unsigned char* stg, const float* cst,
                                               const int cblk, const int lane, PixFn&& pix, float (&s1)[NS][8], float (&s2)[NS][8]) {
     constexpr int ES = sizeof(T), EPC = 8, SUBW = 64, NSB = BM / SUBW, RS = SUBW * ES + 8;
@@ -29,8 +33,8 @@ __device__ __forceinline__ void wave_epilogue(const IgemmArgs& p, f32x4 (&acc)[B
         for (int it = 0; it < 4; ++it) {
             const int i = sb * 4 + it;
             const int col = i * 16 + q * 4;
-            const float4 sv = *reinterpret_cast<const float4*>(cst + col);
-            const float4 bv = *reinterpret_cast<const float4*>(cst + BM + col);
+            const float4 sv = GATE ? float4{1.f, 1.f, 1.f, 1.f} : *reinterpret_cast<const float4*>(cst + col);
+            const float4 bv = GATE ? float4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const float4*>(cst + BM + col);
 #pragma unroll
             for (int j = 0; j < PT; ++j) {
                 union { uint2 u; T e[4]; } pk;
@@ -48,6 +52,21 @@ __device__ __forceinline__ void wave_epilogue(const IgemmArgs& p, f32x4 (&acc)[B
         uint4 ad[NP];
         unsigned mb[NP];
         long opix[NP];
+        uint4 xd[GATE ? NP : 1];                            // GATE: the BatchNorm input at the output position, the tail's mask byte
+        unsigned gm[GATE ? NP : 1];
+        float gmean[EPC], ginv[EPC], gsc[EPC], gsh[EPC];
+        if constexpr (GATE) {
+            const int cc = sb * SUBW + rch * EPC;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float4 a = *reinterpret_cast<const float4*>(cst + cc + 4 * h), b = *reinterpret_cast<const float4*>(cst + BM + cc + 4 * h);
+                const float4 c = *reinterpret_cast<const float4*>(cst + 2 * BM + cc + 4 * h), d = *reinterpret_cast<const float4*>(cst + 3 * BM + cc + 4 * h);
+                gmean[4 * h] = a.x; gmean[4 * h + 1] = a.y; gmean[4 * h + 2] = a.z; gmean[4 * h + 3] = a.w;
+                ginv[4 * h] = b.x; ginv[4 * h + 1] = b.y; ginv[4 * h + 2] = b.z; ginv[4 * h + 3] = b.w;
+                gsc[4 * h] = c.x; gsc[4 * h + 1] = c.y; gsc[4 * h + 2] = c.z; gsc[4 * h + 3] = c.w;
+                gsh[4 * h] = d.x; gsh[4 * h + 1] = d.y; gsh[4 * h + 2] = d.z; gsh[4 * h + 3] = d.w;
+            }
+        }
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
             opix[k] = col_ok ? pix(k * 8 + rrow) : -1L;
@@ -57,6 +76,12 @@ __device__ __forceinline__ void wave_epilogue(const IgemmArgs& p, f32x4 (&acc)[B
                 const long eoff = opix[k] * p.out_pix_stride + col0;
                 ad[k] = *reinterpret_cast<const uint4*>(opix[k] >= 0 ? p.addend + eoff * ES : p.zero);
                 if (p.addend_mask) mb[k] = *(opix[k] >= 0 ? p.addend_mask + eoff / EPC : p.zero);     // every lane loads
+            }
+            if constexpr (GATE) {
+                const long eoff = opix[k] * p.out_pix_stride + col0;
+                xd[k] = *reinterpret_cast<const uint4*>(opix[k] >= 0 ? p.gx + eoff * ES : p.zero);
+                gm[k] = 0xffu;
+                if (p.gmask) gm[k] = *(opix[k] >= 0 ? p.gmask + eoff / EPC : p.zero);
             }
         }
 #pragma unroll
@@ -85,7 +110,23 @@ __device__ __forceinline__ void wave_epilogue(const IgemmArgs& p, f32x4 (&acc)[B
                 }
                 u = pack16<T>(v);
             }
-            if constexpr (STATS) {
+            if constexpr (GATE) {
+                float g[EPC], xv[EPC];
+                unpack16<T>(u, g);
+                unpack16<T>(xd[k], xv);
+                if (p.gmask) {
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) g[e] = ((gm[k] >> e) & 1u) ? g[e] : 0.f;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) g[e] = (xv[e] * gsc[e] + gsh[e]) > 0.f ? g[e] : 0.f;
+                }
+                if (opix[k] >= 0) {
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) { s1[sb][e] += g[e]; s2[sb][e] += g[e] * (xv[e] - gmean[e]) * ginv[e]; }
+                }
+                u = pack16<T>(g);
+            } else if constexpr (STATS) {
                 if (opix[k] >= 0) {
                     float fv[EPC];
                     unpack16<T>(u, fv);

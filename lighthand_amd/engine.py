@@ -209,20 +209,21 @@ class Plan(Tuner, WgradSchedule, BatchGroups, InferRewrites):
             yield max(descs, key=lambda d: d.ntaps), sum(d.ntaps for d in descs)
             return
         for dd, pk in zip(descs, packs):
-            self._tune([dd], addend=kind, role="dgrad")
             # (networks with parallel branches: not gated -- their batch groups would not be, and a plan must compute the
             #  same sums whether its branches run as groups or on stream lanes)
             gi = self._gate_info.get(id(x)) if (self.bn_gate and first and len(descs) == 1 and self.n_lanes == 1 and self.es == 2) else None
+            gkind, gbytes = self._gate_kind(gi, x, amask is not None), x.pixels * x.c * self.es
+            self._tune([dd], addend=kind, role="dgrad", gate=(gkind, gbytes) if gkind else None)
             cfg = (C.c_int * 5)()
-            if gi is not None and len(self._uses.get(id(x), [])) == 1 and x.c == x.c_valid and x.pixels * x.c * self.es <= self.bn_gate_bytes and \
-                    self.lib.lh_igemm_config(C.byref(dd), self.dt, cfg) == 0 and (2 <= cfg[2] < 10 or 20 <= cfg[2] < 40):
-                # x = relu(BN(raw)) with this convolution as its only consumer: the launch stores the ReLU-gated gradient
-                # and the BatchNorm-backward partial sums of its tile (the node's backward skips its reduce pass)
-                rows = self.lib.lh_igemm_stats_rows(C.byref(dd), self.dt)
+            if gkind and self.lib.lh_igemm_config(C.byref(dd), self.dt, cfg) == 0 and self._cfg_gateable(cfg, gkind, gbytes):
+                # x = relu(BN(raw)) with this convolution as its only consumer -- or a residual tail relu(BN(raw) + r) whose other
+                # consumer, the next tail's identity term, rides in as this launch's masked addend: the launch stores the ReLU-gated
+                # gradient and the BatchNorm-backward partial sums of its tile (the node's backward skips its reduce pass)
+                rows = self.lib.lh_igemm_gated_rows(C.byref(dd), self.dt)
                 partial = self._alloc(rows * 2 * x.c, dtype=torch.float32)
                 st = gi["st"]
                 gate = _lib.BnBwdGate(gi["raw"].buf.data_ptr(), st["mean"].data_ptr(), st["invstd"].data_ptr(), st["scale"].data_ptr(),
-                                      st["shift"].data_ptr(), partial.data_ptr())
+                                      st["shift"].data_ptr(), partial.data_ptr(), _ptr(gi.get("mask")))
                 self.keep += [dd, gate]
                 c = _Call(self.lib.lh_igemm_gated, (C.byref(dd), _ptr(dy), _ptr(pk), _ptr(dx), _ptr(addend), _ptr(amask), C.byref(gate), self.dt),
                           what + " + BN-backward gate")
@@ -233,6 +234,30 @@ class Plan(Tuner, WgradSchedule, BatchGroups, InferRewrites):
             else:
                 self._igemm(self.bwd, dd, dy, pk, dx, addend, None, None, what, addend_mask=amask)
             yield dd, dd.ntaps
+
+    def _gate_kind(self, gi, x, masked_addend):
+        """May the first writer of x.grad, a data gradient, take the BatchNorm-backward gate of x's node (lh_igemm_gated)?  None | 'x' | 'mask'.
+        'x': a single-term node a = relu(BN(raw)) whose only consumer is this convolution.  'mask' (round 6): a residual tail
+        relu(BN(raw) + r) -- this convolution is its only consumer, or the other one is the next tail, whose identity gradient has been
+        folded into this launch as its masked addend."""
+        if gi is None or x.c != x.c_valid:
+            return None
+        uses = len(self._uses.get(id(x), []))
+        if gi.get("mask") is not None:
+            return "mask" if self.bn_gate_tail and (uses == 1 or (uses == 2 and masked_addend)) else None
+        return "x" if uses == 1 else None
+
+    def _cfg_gateable(self, cfg, kind, nbytes):
+        """Does kernel configuration cfg take the gate for a tensor of nbytes?  The tiled kernels up to LH_BN_GATE_MAX_MB (measured,
+        rounds 4-6: beyond it the epilogue's read of raw costs a tile-per-workgroup launch more than the reduce pass it replaces), the
+        persistent kernels (pointwise, direct 3x3: streams of independent waves, the extra read rides with the others) up to
+        LH_BN_GATE_PW_MAX_MB; tails up to LH_BN_GATE_TAIL_MAX_MB on either."""
+        pw, tiled = cfg[2] in (1, 100), (2 <= cfg[2] < 10 or 20 <= cfg[2] < 40)
+        if not (tiled or (pw and self.bn_gate_pw)):
+            return False
+        if kind == "mask":
+            return nbytes <= (self.bn_gate_tail_bytes if pw else min(self.bn_gate_tail_bytes, self.bn_gate_tiled_tail_bytes))
+        return nbytes <= (self.bn_gate_pw_bytes if pw else self.bn_gate_bytes)
 
     def _patch(self, call, relu=None, **ptrs):
         a = list(call.args)
@@ -346,6 +371,11 @@ class Plan(Tuner, WgradSchedule, BatchGroups, InferRewrites):
         self._bnrelu_info = {}             # id(a = relu(BN(x))) -> its lh_fuse_fwd call and BN state (training plans; _c_maxpool)
         self.bn_gate = os.environ.get("LH_BN_GATE", "1") != "0"
         self.bn_gate_bytes = float(os.environ.get("LH_BN_GATE_MAX_MB", "9")) * (1 << 20)
+        self.bn_gate_pw = os.environ.get("LH_BN_GATE_PW", "1") != "0"               # round 6: the pointwise kernel's epilogue takes the gate too
+        self.bn_gate_pw_bytes = float(os.environ.get("LH_BN_GATE_PW_MAX_MB", "1024")) * (1 << 20)
+        self.bn_gate_tail = os.environ.get("LH_BN_GATE_TAIL", "1") != "0"           # round 6: residual tails (sign from the stored mask bits)
+        self.bn_gate_tail_bytes = float(os.environ.get("LH_BN_GATE_TAIL_MAX_MB", "1024")) * (1 << 20)
+        self.bn_gate_tiled_tail_bytes = float(os.environ.get("LH_BN_GATE_TILED_TAIL_MAX_MB", "1024")) * (1 << 20)
         # consumers of every activation in forward order: (kind, node) -- backward visits them in reverse
         self._uses = {}
         for kind, nd in self.nodes:
@@ -935,6 +965,11 @@ class Plan(Tuner, WgradSchedule, BatchGroups, InferRewrites):
             fd.relu_mask = relu_bits.data_ptr()
         if self.training and self.with_bwd and relu and len(terms) == 1 and terms[0][1] is not None and terms[0][2] == 0:
             self._gate_info[id(out)] = dict(raw=terms[0][0], st=bn_state[0])
+        bn_terms = [i for i, (_, bn, _) in enumerate(terms) if bn is not None]
+        if (self.training and self.with_bwd and relu_bits is not None and len(terms) == 2 and len(bn_terms) == 1
+                and all(l == 0 for _, _, l in terms) and all(a.c == out.c for a, _, _ in terms)):
+            # a residual tail relu(BN(raw) + identity): its sign is in the mask bits
+            self._gate_info[id(out)] = dict(raw=terms[bn_terms[0]][0], st=bn_state[bn_terms[0]], mask=relu_bits)
         self.fwd.append(_Call(self.lib.lh_fuse_fwd, (C.byref(fd), obuf.data_ptr(), out.n, out.h, out.w, c, self.dt), "fuse fwd"))
         if self.training and relu and len(terms) == 1 and terms[0][1] is not None and terms[0][2] == 0 and relu_bits is None:
             # what a max-pool that follows needs to take this node's elementwise pass over (_c_maxpool)
@@ -974,7 +1009,7 @@ class Plan(Tuner, WgradSchedule, BatchGroups, InferRewrites):
                     bd.dbeta[i] = self.grads[bn + ".bias"].data_ptr()
             self.keep.append(bd)
             args = [C.byref(bd), out.n, out.h, out.w, c, 0, self.dt]
-            call = _Call(self.lib.lh_fuse_bwd, None, "fuse bwd")
+            call = _Call(self.lib.lh_fuse_bwd, None, "fuse bwd" + (" (reduce pass done by the gated data gradient)" if pre is not None else ""))
 
             def set_ws(ptr):
                 args[5] = ptr
@@ -1036,7 +1071,7 @@ class Plan(Tuner, WgradSchedule, BatchGroups, InferRewrites):
             assert self._first_write(x), "maxpool input gradient must be produced by the pool alone"
             gi = self._gate_info.get(id(x)) if (self.bn_gate and self.n_lanes == 1 and self.es == 2 and os.environ.get("LH_POOL_GATE", "1") != "0") else None
             nch = x.c * self.es // 16
-            if gi is not None and len(self._uses.get(id(x), [])) == 1 and x.c == x.c_valid and nch & (nch - 1) == 0 and nch <= 256:
+            if gi is not None and gi.get("mask") is None and len(self._uses.get(id(x), [])) == 1 and x.c == x.c_valid and nch & (nch - 1) == 0 and nch <= 256:
                 # x = relu(BN(raw)) with the pool as its only reader: the pool's backward stores the ReLU-gated gradient and the
                 # BatchNorm-backward partial sums (the node's backward skips its reduce pass), as lh_igemm_gated does for convolutions
                 rows = self.lib.lh_maxpool3x3s2_bwd_gated_rows(x.n, x.h, x.w, x.c, self.dt)

@@ -183,7 +183,7 @@ class Tuner:
             raise _lib.LightHandError(f"lh_igemm_candidates returned {n} entries for a buffer of {type(self)._MAX_CANDS}")
         return buf, n
 
-    def _tune(self, descs, with_stats=False, addend=None, role=None):
+    def _tune(self, descs, with_stats=False, addend=None, role=None, gate=None):
         """Measured kernel choice (cdna guide: measure, don't guess): time every compiled-in configuration that fits
         this launch (lh_igemm_candidates) on scratch operands of the real size and write the fastest into the
         descriptors' cfg.  One descriptor = lh_igemm; several = the phases of lh_igemm_phases (one shared choice).
@@ -203,7 +203,7 @@ class Tuner:
             return
         # addend: None | 'plain' | 'masked' -- the epilogue of an accumulating / masked-addend data gradient moves up to three
         # times the bytes of a plain one, which shifts the best tile
-        key = (self.dt, with_stats) + tuple(self._desc_key(d) for d in descs) + ((addend,) if addend else ())
+        key = (self.dt, with_stats) + tuple(self._desc_key(d) for d in descs) + ((addend,) if addend else ()) + (("gate-" + gate[0],) if gate else ())
         hit = type(self)._TUNE_CACHE.get(key) if type(self).force_cfg is None else None
         buf, n = self._igemm_candidates(lead)
         cands = [tuple(buf[5 * i:5 * i + 4]) for i in range(n)]
@@ -244,11 +244,29 @@ class Tuner:
                     def run():
                         check(self.lib.lh_igemm(C.byref(lead), src.data_ptr(), packs[0].data_ptr(), dst.data_ptr(), _ptr(add), _ptr(amask), None, None, None,
                                                 _ptr(stats), self.dt, sp), "autotune lh_igemm")
+                run_plain, run_gated, penalty = run, None, 0.0
+                if gate is not None and len(descs) == 1:
+                    nout = lead.n * lead.OH * lead.OW * lead.out_pix_stride
+                    gx = self._scratch("gate_x", nout * es + 256)
+                    gvec = self._scratch("gate_vec", 4 * lead.cout * 4 + 256).view(torch.float32)
+                    gvec[:4 * lead.cout] = 1.0
+                    gpart = self._scratch("stats", rows * 2 * lead.cout * 4 + 256)
+                    gbits = self._scratch("gate_bits", nout * es // 16 + 256) if gate[0] == "mask" else None
+                    c_ = lead.cout
+                    gt = _lib.BnBwdGate(gx.data_ptr(), gvec.data_ptr(), gvec.data_ptr() + 4 * c_, gvec.data_ptr() + 8 * c_, gvec.data_ptr() + 12 * c_,
+                                        gpart.data_ptr(), _ptr(gbits))
+
+                    def run_gated():
+                        check(self.lib.lh_igemm_gated(C.byref(lead), src.data_ptr(), packs[0].data_ptr(), dst.data_ptr(), _ptr(add), _ptr(amask),
+                                                      C.byref(gt), self.dt, sp), "autotune lh_igemm_gated")
+                    penalty = 2.0 * gate[1] / 4.5e12 * 1e3 + 2e-3           # ms per launch: the reduce pass lh_fuse_bwd keeps
                 best = None
                 cold = os.environ.get("LH_TUNE_COLD", "1") != "0"
                 for cfg in cands:
                     for d in descs:
                         d.cfg[0], d.cfg[1], d.cfg[2], d.cfg[3] = cfg
+                    gated = run_gated is not None and self._cfg_gateable(cfg, gate[0], gate[1])
+                    run = run_gated if gated else run_plain
                     run()
                     if cold:                  # input = the previous kernel's output (warm), everything else cold
                         t = self._timed_cold(run, [src[:lead.n * lead.hi * lead.wi * lead.in_pix_stride * es]], type(self).tune_iters())
@@ -260,9 +278,11 @@ class Tuner:
                         b.record(stream)
                         b.synchronize()
                         t = a.elapsed_time(b)
+                    if run_gated is not None and not gated:
+                        t += penalty * type(self).tune_iters()
                     _record_time(key, cfg, t)
                     if os.environ.get("LH_TUNE_LOG"):
-                        print(f"[tune {role or ''} {lead.k_run}x{lead.ntaps}->{lead.cout} M={lead.n * lead.ho * lead.wo} addend={addend}] cfg {cfg}: "
+                        print(f"[tune {role or ''} {lead.k_run}x{lead.ntaps}->{lead.cout} M={lead.n * lead.ho * lead.wo} addend={addend} gate={gate and gate[0]}{'' if gate is None else ('+' if gated else '-')}] cfg {cfg}: "
                               f"{t / type(self).tune_iters() * 1e3:7.1f} us", flush=True)
                     if best is None or t < best[0]:
                         best = (t, cfg)

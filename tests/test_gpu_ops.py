@@ -992,3 +992,84 @@ def test_gated_pool_backward_equals_plain_backward_then_gate(shape, dtype):
     got = partial.double().sum(0)
     assert torch.allclose(got[0], g64.sum((0, 1, 2)), rtol=2e-3, atol=2e-2)
     assert torch.allclose(got[1], (g64 * xhat).sum((0, 1, 2)), rtol=2e-3, atol=2e-2)
+
+
+@pytest.mark.parametrize("kernel", ["pw", "tiled"])
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_bn_backward_gate_on_the_pointwise_kernel_and_on_residual_tails(kernel, precision, forced_plans, monkeypatch):
+    """Round 6 (verdict item 2): lh_igemm_gated on the persistent pointwise kernel, and for residual tails a = relu(BN(x) + r)
+    (`out += residual; relu`, pose_resnet.py:96-97), whose sign comes from the mask bits lh_fuse_fwd stored (lh_bn_bwd_gate.mask).  Two
+    identity blocks of 1x1 convolutions: the tail of the first has two consumers -- the second block's first convolution, whose data gradient
+    is the FIRST writer of its gradient and takes the second tail's identity gradient as a masked addend, and that tail itself.  With the gate
+    that data gradient stores g = dz * mask and the partial sums of BN-backward; the tail's backward runs without its reduce pass.  Gate on /
+    off: the gated launches appear (the tail's AND the single-term nodes' in front of a 1x1 data gradient), every gradient agrees to the
+    rounding of the 16-bit activation gradients, and with PyTorch within the precision's tolerance."""
+    import copy
+    from lighthand_amd import _lib
+    from lighthand_amd.module import HipModule
+    C4, Cq, n, h, w = 128, 64, 3, 12, 20
+
+    class Net(HipModule):
+        def __init__(self):
+            super().__init__()
+            self.c0 = nn.Conv2d(16, C4, 1, bias=False); self.b0 = nn.BatchNorm2d(C4)
+            for k in (1, 2):
+                setattr(self, f"a{k}", nn.Conv2d(C4, Cq, 1, bias=False)); setattr(self, f"an{k}", nn.BatchNorm2d(Cq))
+                setattr(self, f"b{k}", nn.Conv2d(Cq, C4, 1, bias=False)); setattr(self, f"bn{k}", nn.BatchNorm2d(C4))
+            self.out = nn.Conv2d(C4, 8, 1, bias=False)
+
+        def describe(self, gb):
+            z = gb.fuse([(gb.conv(gb.input_act(16), "c0", 1, 1, 0), "b0")])
+            for k in (1, 2):
+                a = gb.fuse([(gb.conv(z, f"a{k}", 1, 1, 0), f"an{k}")])
+                z = gb.fuse([(gb.conv(a, f"b{k}", 1, 1, 0), f"bn{k}"), z])
+            gb.output(gb.conv(z, "out", 1, 1, 0))
+
+        def torch_forward(self, x):
+            z = F.relu(self.b0(self.c0(x)))
+            for k in (1, 2):
+                a = F.relu(getattr(self, f"an{k}")(getattr(self, f"a{k}")(z)))
+                z = F.relu(getattr(self, f"bn{k}")(getattr(self, f"b{k}")(a)) + z)
+            return self.out(z)
+
+    lib = _lib.load()
+    torch.manual_seed(31)
+    proto = Net()
+    td = {"bf16": torch.bfloat16, "fp16": torch.float16}[precision]
+    with torch.no_grad():
+        for p_ in proto.parameters():
+            p_.copy_(p_.to(td).float())
+    x = torch.randn(n, 16, h, w).to(td).float()
+    if kernel == "pw":
+        forced_plans.force_cfg = lambda cands: max([c for c in cands if c[2] == 1] or cands[:1], key=lambda c: (c[2] == 1, c[0], c[1]))
+    else:
+        forced_plans.force_cfg = lambda cands: next(c for c in cands if c[2] not in (1, 100))
+    res, gated = {}, {}
+    dy = torch.randn(n, 8, h, w)
+    for gate in ("0", "1"):
+        monkeypatch.setenv("LH_BN_GATE", gate)
+        m = copy.deepcopy(proto)
+        out, dx, grads = _run_plan(m, x, lambda o: dy, precision)
+        plan = next(iter(m._lh_plans.values()))
+        calls = [c for c in plan.bwd if getattr(c, "fn", None) is lib.lh_igemm_gated]
+        gated[gate] = (len(calls), sum(1 for k in plan.keep if isinstance(k, _lib.BnBwdGate) and k.mask))
+        res[gate] = (out, dx, grads)
+    assert gated["0"] == (0, 0), gated
+    # gated: both tails (mask bits; the second has the output convolution as its only consumer), and the single-term nodes an1 / an2
+    # (their only consumer is a 1x1 data gradient)
+    assert gated["1"] == (4, 2), gated
+    a, b = res["0"], res["1"]
+    assert torch.equal(a[0], b[0])
+    assert rel_err(a[1], b[1]) < 2e-2, rel_err(a[1], b[1])
+    for k in a[2]:
+        assert rel_err(a[2][k], b[2][k]) < 3e-2, (k, rel_err(a[2][k], b[2][k]))
+    ref = copy.deepcopy(proto).train()
+    xr = x.clone().requires_grad_(True)
+    o = ref.torch_forward(xr)
+    o.backward(dy)
+    assert rel_err(b[0], o.detach()) < TOL[precision]
+    # a stack of four train-mode BatchNorms on random weights amplifies the 16-bit rounding of ANY path (the ungated one included) to tens
+    # of percent in dx: the gated path must not be further from PyTorch than the ungated one
+    e_off, e_on = rel_err(a[1], xr.grad), rel_err(b[1], xr.grad)
+    print(f"{kernel} {precision}: gated launches {gated['1']}, dx vs PyTorch: gate off {e_off:.3e}, on {e_on:.3e}; on vs off {rel_err(a[1], b[1]):.3e}")
+    assert e_on < 1.25 * e_off + 1e-2, (e_off, e_on)
