@@ -168,7 +168,9 @@ int lh_igemm(const lh_igemm_desc* d, const void* in, const void* wpack, void* ou
  * less per BatchNorm.  x has the layout of this launch's output (same pixel stride).
  * mask (optional; dense outputs): the activation is a residual tail a = relu(BN(x) + r) (`out += residual; relu`,
  * pose_resnet.py:96-97) -- its sign does not follow from x alone, it is read from the relu_mask bits lh_fuse_fwd stored for the tail
- * (scale / shift are then unused and may be NULL).  `partial` has lh_igemm_gated_rows rows.
+ * (scale / shift are then unused and may be NULL).  x2 (optional, with mask; pointwise kernel only): r is a projection shortcut
+ * BN2(x2) (`residual = self.downsample(x)`, pose_resnet.py:93-94) -- partial2 takes { sum g, sum g * (x2 - mean2) * invstd2 }.
+ * `partial` / `partial2` have lh_igemm_gated_rows(d, dtype, nterms = 1 | 2) rows.
  * Tiled LDS-DMA configurations (lh_igemm_config: ring depth 2..9 and the dense-wave forms) and the persistent pointwise kernel
  * (ring depth 1); LH_ERR_UNSUPPORTED otherwise. */
 typedef struct {
@@ -179,8 +181,12 @@ typedef struct {
     const float* shift;
     float* partial;
     const void* mask;
+    const void* x2;
+    const float* mean2;
+    const float* invstd2;
+    float* partial2;
 } lh_bn_bwd_gate;
-int lh_igemm_gated_rows(const lh_igemm_desc* d, int dtype);
+int lh_igemm_gated_rows(const lh_igemm_desc* d, int dtype, int nterms);
 int lh_igemm_gated(const lh_igemm_desc* d, const void* in, const void* wpack, void* out, const void* addend, const void* addend_mask,
                    const lh_bn_bwd_gate* gate, int dtype, void* stream);
 /* Phase batching: 2..4 lh_igemm launches that share input, output tensor, sizes and epilogue and differ only in weight
@@ -374,12 +380,14 @@ typedef struct {
     const void* relu_mask;      /* mask bits written by lh_fuse_fwd; when set, `out` is not read and may be NULL */
     int strips_cap;             /* 0 = default (512): upper bound on the strips of the streaming reduce pass = rows of the
                                  * partial-sum slab; 256 is the measured choice for nodes that share lh_fuse_bwd_multi launches */
-    const float* pre_partial;   /* ONE BN term under a ReLU -- alone, or beside one identity term (a residual tail) -- whose dout was written
+    const float* pre_partial;   /* a ReLU node with ONE BN term -- alone, or beside one identity term (a residual tail) -- or with TWO BN
+                                 * terms (a tail with a projection shortcut; pre_partial2 then holds term 1's sums) whose dout was written
                                  * by lh_igemm_gated: dout is already the gated gradient and these are its partial sums
                                  * [pre_rows][2][c] -- no reduce pass, no mask */
     int pre_rows;
     const void* l2_touch;       /* optional (round 5), as lh_fuse_desc.l2_touch: the last apply pass of the call warms these bytes in L2 */
     size_t l2_touch_bytes;
+    const float* pre_partial2;  /* with pre_partial and two BN terms: the partial sums of term 1 (pre_partial: term 0), same rows */
 } lh_fuse_bwd_desc;
 size_t lh_fuse_bwd_workspace_bytes(int n, int h, int w, int c);
 int lh_fuse_bwd(const lh_fuse_bwd_desc* d, int n, int h, int w, int c, void* workspace,

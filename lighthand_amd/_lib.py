@@ -42,12 +42,12 @@ class FuseBwdDesc(C.Structure):
                 ("dgamma", C.c_void_p * 4), ("dbeta", C.c_void_p * 4), ("log2up", C.c_int * 4),
                 ("accumulate", C.c_int * 4), ("nterms", C.c_int), ("relu", C.c_int),
                 ("relu_mask", C.c_void_p), ("strips_cap", C.c_int), ("pre_partial", C.c_void_p), ("pre_rows", C.c_int),
-                ("l2_touch", C.c_void_p), ("l2_touch_bytes", C.c_size_t)]
+                ("l2_touch", C.c_void_p), ("l2_touch_bytes", C.c_size_t), ("pre_partial2", C.c_void_p)]
 
 
 class BnBwdGate(C.Structure):          # lh_igemm_gated
     _fields_ = [("x", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p),
-                ("partial", C.c_void_p), ("mask", C.c_void_p)]
+                ("partial", C.c_void_p), ("mask", C.c_void_p), ("x2", C.c_void_p), ("mean2", C.c_void_p), ("invstd2", C.c_void_p), ("partial2", C.c_void_p)]
 
 
 class IgemmCall(C.Structure):          # one entry of lh_igemm_multi = the arguments of lh_igemm
@@ -128,7 +128,7 @@ SIGNATURES = {
     "lh_wgrad_tile": (_I, [C.POINTER(IgemmDesc), _I, _I, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "lh_wgrad_candidates": (_I, [C.POINTER(IgemmDesc), _I, _I, _I, C.POINTER(_I), _I]),
     "lh_igemm_stats_rows": (_I, [C.POINTER(IgemmDesc), _I]),
-    "lh_igemm_gated_rows": (_I, [C.POINTER(IgemmDesc), _I]),
+    "lh_igemm_gated_rows": (_I, [C.POINTER(IgemmDesc), _I, _I]),
     "lh_igemm_gated": (_I, [C.POINTER(IgemmDesc), _P, _P, _P, _P, _P, C.POINTER(BnBwdGate), _I, _P]),
     "lh_wgrad_slab_bytes": (_SZ, [C.POINTER(IgemmDesc), _I, _I, _I]),
     "lh_wgrad": (_I, [C.POINTER(IgemmDesc), _P, _P, _I, _I, _I, _P, _I, _P]),

@@ -1336,12 +1336,14 @@ static int plan_fuse_bwd(const lh_fuse_bwd_desc* d, int n, int h, int w, int c, 
         const int nchunk = c / (16 / es);
         const bool flat = a.l == 0 && (nchunk & (nchunk - 1)) == 0 && nchunk <= 256;
         // dout written by lh_igemm_gated: already the gated gradient, its partial sums come with it
-        const bool pre = d->pre_partial != nullptr && a.x;
+        const bool two_bn = d->nterms == 2 && d->x[0] && d->x[1];
+        const float* pre_slab = !(d->pre_partial && a.x) ? nullptr : (two_bn && t == 1) ? d->pre_partial2 : d->pre_partial;
+        const bool pre = pre_slab != nullptr;
         if (d->pre_partial) {
-            // one BatchNorm term under the ReLU, alone or with an identity term beside it (a residual tail, merged apply pass)
-            const bool tail = merge2 && !(d->x[0] && d->x[1]);
-            LH_REQUIRE((d->nterms == 1 || tail) && d->relu && d->pre_rows >= 1 && a.l == 0 && (a.x || tail),
-                       "lh_fuse_bwd: pre_partial takes ONE BatchNorm term under a ReLU (alone, or beside one identity term)");
+            // one BatchNorm term under the ReLU, alone or with an identity term beside it (a residual tail, merged apply pass); or a tail
+            // with a projection shortcut: two BatchNorm terms, each with its slab
+            LH_REQUIRE((d->nterms == 1 || merge2) && d->relu && d->pre_rows >= 1 && a.l == 0 && (a.x || merge2) && (!two_bn || d->pre_partial2),
+                       "lh_fuse_bwd: pre_partial takes a ReLU node with one BatchNorm term (alone, or beside one identity term) or a two-term tail with pre_partial2");
             a.relu = 0;
             a.out = nullptr; a.mask = nullptr;
         }
@@ -1372,7 +1374,7 @@ static int plan_fuse_bwd(const lh_fuse_bwd_desc* d, int n, int h, int w, int c, 
             a.partial = (float*)((unsigned char*)workspace + (size_t)t * term_bytes);
             const long slab_floats = pre ? 0 : strips * 2 * c;      // pre: the slab is the caller's, the workspace holds the scratch only
             double* scratch = (double*)(a.partial + ((slab_floats + 3) & ~3L));
-            if (pre) a.partial = const_cast<float*>(d->pre_partial);
+            if (pre) a.partial = const_cast<float*>(pre_slab);
             double* totals = scratch + (long)ceil_div(strips, 256) * 2 * c;
             a.totals = totals;
             a.coef = (float*)(totals + 2 * c) + (size_t)(merge2 ? t : 0) * 2 * c;   // merging keeps one coefficient block per term

@@ -149,7 +149,7 @@ __device__ __forceinline__ void conv3x3_direct_body(const IgemmArgs& p, unsigned
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) aoff[kk] = pl * ROWB + ((((SL == 8 ? 4 * kk : 0) + q) ^ fswz(pl)) << 4);
 
-    float s1[STATS ? 1 : 1][8], s2[STATS ? 1 : 1][8];
+    float s1[STATS ? 1 : 1][8], s2[STATS ? 1 : 1][8], s3[1][8];          // s3: the two-term gate of the pointwise kernel, unused here
 #pragma unroll
     for (int e = 0; e < 8; ++e) s1[0][e] = s2[0][e] = 0.f;
     const float* cst = reinterpret_cast<const float*>(smem + OFF_CST);
@@ -227,10 +227,10 @@ __device__ __forceinline__ void conv3x3_direct_body(const IgemmArgs& p, unsigned
         unsigned char* stg = (ALIAS ? smem + OFF_PATCH + buf * PATCH : smem + OFF_STG) + wave * STG;
         const int n = t / (ty_n * tx_n), rem = t - n * (ty_n * tx_n);
         const int oy0 = (rem / tx_n) * TH + PT * wave, ox0 = (rem % tx_n) * TW;
-        wave_epilogue<T, BM, PT, STATS, GATE>(p, acc, stg, cst, cblk, lane, [&](int row) {
+        wave_epilogue<T, BM, PT, STATS, (GATE ? 1 : 0)>(p, acc, stg, cst, cblk, lane, [&](int row) {
             const int y = oy0 + (row >> 4), x = ox0 + (row & 15);
             return (y < H && x < W) ? ((long)n * H + y) * W + x : -1L;
-        }, s1, s2);
+        }, s1, s2, s3);
         // the next patch (requested between this tile's MFMAs) must have landed; this tile's 2 * PT stores -- the youngest
         // vector-memory operations of the wave, their count fixed by the dump-page rule of wave_epilogue -- stay in flight
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PT) : "memory");

@@ -339,10 +339,10 @@ extern "C" int lh_igemm_stats_rows(const lh_igemm_desc* d, int dtype) {
 
 // rows of the partial-sum slab a gated launch (lh_igemm_gated) writes: those of the statistics slab, except on the pointwise kernel, whose
 // gate instantiation may hold a different number of workgroups per CU
-extern "C" int lh_igemm_gated_rows(const lh_igemm_desc* d, int dtype) {
+extern "C" int lh_igemm_gated_rows(const lh_igemm_desc* d, int dtype, int nterms) {
     if (d && d->cfg[2] == 1 && lh_ring_supported(d, dtype)) {
         RingCfg c;
-        if (lh_ring_resolve(d, dtype, &c) == LH_OK && c.depth == 1) return lh_pw_rows(d, c, dtype, true);
+        if (lh_ring_resolve(d, dtype, &c) == LH_OK && c.depth == 1) return lh_pw_rows(d, c, dtype, nterms >= 2 ? 2 : 1);
     }
     return lh_igemm_stats_rows(d, dtype);
 }
@@ -378,6 +378,7 @@ static int igemm_impl(const lh_igemm_desc* d, const void* in, const void* wpack,
     LH_REQUIRE((scale == nullptr) == (shift == nullptr), "lh_igemm: scale and shift must come together");
     a.head_w = nullptr; a.head_bias = nullptr; a.head_out = nullptr; a.head_j = 0; a.head_wstride = 0;
     a.gx = nullptr; a.gmean = a.ginv = a.gscale = a.gshift = nullptr; a.gmask = nullptr;
+    a.gx2 = nullptr; a.gmean2 = a.ginv2 = nullptr; a.stats2 = nullptr;
     if (gate) {
         LH_REQUIRE(gate->x && gate->mean && gate->invstd && gate->partial && (gate->mask || (gate->scale && gate->shift)),
                    "lh_igemm_gated: null pointer in the gate (the sign of the activation comes from scale + shift or from mask)");
@@ -386,6 +387,10 @@ static int igemm_impl(const lh_igemm_desc* d, const void* in, const void* wpack,
         a.gx = (const unsigned char*)gate->x; a.gmean = gate->mean; a.ginv = gate->invstd; a.gscale = gate->scale; a.gshift = gate->shift;
         a.gmask = (const unsigned char*)gate->mask;
         a.stats = gate->partial;
+        if (gate->x2) {
+            LH_REQUIRE(gate->mask && gate->mean2 && gate->invstd2 && gate->partial2, "lh_igemm_gated: a second BatchNorm term (x2) needs mask, mean2, invstd2, partial2");
+            a.gx2 = (const unsigned char*)gate->x2; a.gmean2 = gate->mean2; a.ginv2 = gate->invstd2; a.stats2 = gate->partial2;
+        }
     }
     a.n = d->n; a.hi = d->hi; a.wi = d->wi; a.in_pix_stride = d->in_pix_stride; a.k_run = d->k_run;
     a.kspt = (d->k_run * es + 63) / 64;
@@ -448,6 +453,10 @@ static int igemm_impl(const lh_igemm_desc* d, const void* in, const void* wpack,
     }
     if (gate && !(ring && (rc_.depth == 1 || rc_.depth == 100 || (rc_.depth >= 2 && rc_.depth < 10) || (rc_.depth >= LH_DENSE_DEPTH && rc_.depth < LH_KSPLIT_DEPTH + 10)) && es == 2)) {
         lh_set_error("lh_igemm_gated: the launch runs neither on a tiled LDS-DMA configuration nor on a persistent kernel (ring depth %d)", ring ? rc_.depth : 0);
+        return LH_ERR_UNSUPPORTED;
+    }
+    if (gate && gate->x2 && !(ring && rc_.depth == 1)) {
+        lh_set_error("lh_igemm_gated: two BatchNorm terms are gated by the pointwise kernel only (ring depth %d)", ring ? rc_.depth : 0);
         return LH_ERR_UNSUPPORTED;
     }
     if (ring) {

@@ -22,6 +22,10 @@ struct IgemmArgs {
     const float* gscale;
     const float* gshift;
     const unsigned char* gmask;      // optional: the activation is a residual tail relu(BN(gx) + r) -- its sign comes from the stored mask bits
+    const unsigned char* gx2;        // optional (with gmask, pointwise kernel): r = BN2(gx2), a projection shortcut -- `stats2` takes { sum g, sum g * xhat2 }
+    const float* gmean2;
+    const float* ginv2;
+    float* stats2;
     // Fused 1x1 head (lh_igemm_phases_head, 256 x 256 tile only): the tile -- after affine + ReLU -- is multiplied by
     // head_w [>= 32 rows][cout] (K-major pack rows of the 1x1 convolution, rows >= head_j zero) inside the epilogue and
     // only head_out[n][j][OH][OW] (fp32) is written; `out` is not touched
@@ -55,8 +59,8 @@ struct RingCfg {
 
 // workgroups per channel block of a pointwise launch: every CU holds `occ` workgroups for the whole launch (occ = what the
 // occupancy query reports for the instantiation, 1..4: lh_pw_occupancy)
-static inline int lh_pw_lds_bytes(int bm, int kc, int pt, bool gate = false) {      // panel, staging, per-channel constants (2 vectors; 4 with the gate)
-    return bm * kc * 2 + 4 * pt * 16 * (64 * 2 + 8) + (gate ? 4 : 2) * bm * 4;
+static inline int lh_pw_lds_bytes(int bm, int kc, int pt, int gate = 0) {      // panel, staging, per-channel constants (2 vectors; 4 / 6 with the gate of one / two BatchNorm terms)
+    return bm * kc * 2 + 4 * pt * 16 * (64 * 2 + 8) + (2 + 2 * gate) * bm * 4;
 }
 
 static inline void lh_pw_grid(int bm, int kc, int pt, long M, int cout, int occ, int* G, int* CB) {
@@ -83,5 +87,5 @@ int lh_igemm_ring_multi_launch(LhMulti<IgemmArgs>& m, const RingCfg& c, int dtyp
 bool lh_pw_supported(const lh_igemm_desc* d, int dtype);
 bool lh_d3_supported(const lh_igemm_desc* d, int dtype);
 int lh_d3_rows(const lh_igemm_desc* d);
-int lh_pw_rows(const lh_igemm_desc* d, const RingCfg& c, int dtype, bool gate = false);
-int lh_pw_occupancy(const RingCfg& c, int dtype, int mode);      // mode: 0 plain, 1 statistics, 2 BatchNorm-backward gate
+int lh_pw_rows(const lh_igemm_desc* d, const RingCfg& c, int dtype, int gate = 0);
+int lh_pw_occupancy(const RingCfg& c, int dtype, int mode);      // mode: 0 plain, 1 statistics, 2 / 3 BatchNorm-backward gate of one / two terms

@@ -14,7 +14,8 @@ int LH_FN(const IgemmArgs& a, const RingCfg& c, hipStream_t s) {
 int LH_OCC_FN(const RingCfg& c, int mode) {
 #define X(BM, KC, PT) \
     if (c.bm == BM && c.kb == KC && c.bp == 16 * PT)  \
-        return mode == 2 ? pw_occupancy<LH_T, BM, KC, PT, true, true>() : mode == 1 ? pw_occupancy<LH_T, BM, KC, PT, true>() : pw_occupancy<LH_T, BM, KC, PT, false>();
+        return mode == 3 ? pw_occupancy<LH_T, BM, KC, PT, true, 2>() : mode == 2 ? pw_occupancy<LH_T, BM, KC, PT, true, 1>()  \
+             : mode == 1 ? pw_occupancy<LH_T, BM, KC, PT, true>() : pw_occupancy<LH_T, BM, KC, PT, false>();
     LH_PW_CFGS(X)
 #undef X
     return 2;

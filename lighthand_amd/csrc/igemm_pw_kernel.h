@@ -27,8 +27,9 @@
 #endif
 
 // GATE (with STATS; lh_igemm_gated): the output is the gradient of an activation relu(BN(gx)) or of a residual tail relu(BN(gx) + r): the
-// epilogue stores the ReLU-gated gradient and the statistics row holds { sum g, sum g * xhat } (igemm_wave_epilogue.h).
-template <typename T, int BM, int KC, int PT, bool STATS, bool GATE = false>
+// epilogue stores the ReLU-gated gradient and the statistics row holds { sum g, sum g * xhat } (igemm_wave_epilogue.h).  GATE = 2: r is a
+// projection shortcut BN2(gx2), a second statistics row takes { sum g, sum g * xhat2 }.
+template <typename T, int BM, int KC, int PT, bool STATS, int GATE = 0>
 __global__ __launch_bounds__(256, 2) void igemm_pw_kernel(const IgemmArgs p) {
     static_assert(!GATE || STATS, "the gate leaves its sums in the statistics row");
     // two operand register sets (the rows of tile n + 1 are requested before tile n is multiplied) where the register
@@ -83,6 +84,7 @@ __global__ __launch_bounds__(256, 2) void igemm_pw_kernel(const IgemmArgs p) {
                 cst[BM + c] = p.ginv[gk];
                 cst[2 * BM + c] = p.gmask ? 0.f : p.gscale[gk];
                 cst[3 * BM + c] = p.gmask ? 0.f : p.gshift[gk];
+                if constexpr (GATE == 2) { cst[4 * BM + c] = p.gmean2[gk]; cst[5 * BM + c] = p.ginv2[gk]; }
             } else {
                 float sv = 1.f, bv = 0.f;
                 if (gc < p.cout) {
@@ -142,11 +144,15 @@ __global__ __launch_bounds__(256, 2) void igemm_pw_kernel(const IgemmArgs p) {
     unsigned char* stg = smem + PANEL + wave * STG;
     const float* cst = reinterpret_cast<const float*>(smem + CST);
 
-    float s1[STATS ? NSB : 1][EPC], s2[STATS ? NSB : 1][EPC];
+    float s1[STATS ? NSB : 1][EPC], s2[STATS ? NSB : 1][EPC], s3[GATE == 2 ? NSB : 1][EPC];
 #pragma unroll
     for (int i = 0; i < (STATS ? NSB : 1); ++i)
 #pragma unroll
         for (int e = 0; e < EPC; ++e) s1[i][e] = s2[i][e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < (GATE == 2 ? NSB : 1); ++i)
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) s3[i][e] = 0.f;
 
     auto tilework = [&](const int t, uint4 (&Bf)[PT][KS], auto&& prefetch) {
         f32x4 acc[CT][PT];
@@ -194,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void igemm_pw_kernel(const IgemmArgs p) {
             return;
         }
         const int m0 = t * PT * 16;
-        wave_epilogue<T, BM, PT, STATS, GATE>(p, acc, stg, cst, cblk, lane, [&](int row) { const int m = m0 + row; return m < M ? (long)m : -1L; }, s1, s2);
+        wave_epilogue<T, BM, PT, STATS, GATE>(p, acc, stg, cst, cblk, lane, [&](int row) { const int m = m0 + row; return m < M ? (long)m : -1L; }, s1, s2, s3);
     };
     if constexpr (DB) {
         while (t < ntile) {
@@ -214,11 +220,15 @@ __global__ __launch_bounds__(256, 2) void igemm_pw_kernel(const IgemmArgs p) {
         // one slab row per workgroup (rows = workgroups per channel block)
         __syncthreads();                                 // every wave is done with the panel
         wave_stats_row<BM, 4>(s1, s2, reinterpret_cast<float*>(smem), p.stats ? p.stats + (long)g * 2 * p.cout : nullptr, cblk, p.cout, tid);
+        if constexpr (GATE == 2) {
+            __syncthreads();                             // the first row has been read out of the scratch
+            wave_stats_row<BM, 4>(s1, s3, reinterpret_cast<float*>(smem), p.stats2 + (long)g * 2 * p.cout, cblk, p.cout, tid);
+        }
     }
 }
 
 // Workgroups of this instantiation a CU holds at once (registers, LDS), 1..4; 2 when no device can be asked.
-template <typename T, int BM, int KC, int PT, bool STATS, bool GATE = false>
+template <typename T, int BM, int KC, int PT, bool STATS, int GATE = 0>
 static int pw_occupancy() {
     static int cached[64] = {0};
     int dev = 0;
@@ -237,12 +247,14 @@ static int pw_occupancy() {
 template <typename T, int BM, int KC, int PT>
 static int launch_pw(const IgemmArgs& a0, hipStream_t s) {
     IgemmArgs a = a0;
-    const bool gate = a.gx != nullptr;
-    const int occ = gate ? pw_occupancy<T, BM, KC, PT, true, true>() : a.stats ? pw_occupancy<T, BM, KC, PT, true>() : pw_occupancy<T, BM, KC, PT, false>();
+    const int gate = a.gx2 ? 2 : a.gx ? 1 : 0;
+    const int occ = gate == 2 ? pw_occupancy<T, BM, KC, PT, true, 2>() : gate ? pw_occupancy<T, BM, KC, PT, true, 1>()
+                  : a.stats ? pw_occupancy<T, BM, KC, PT, true>() : pw_occupancy<T, BM, KC, PT, false>();
     lh_pw_grid(BM, KC, PT, a.M, a.cout, occ, &a.pw_g, &a.pw_cb);
     const int lds = lh_pw_lds_bytes(BM, KC, PT, gate);
     dim3 grid(a.pw_g * a.pw_cb);
-    if (gate) hipLaunchKernelGGL((igemm_pw_kernel<T, BM, KC, PT, true, true>), grid, dim3(256), lds, s, a);
+    if (gate == 2) hipLaunchKernelGGL((igemm_pw_kernel<T, BM, KC, PT, true, 2>), grid, dim3(256), lds, s, a);
+    else if (gate) hipLaunchKernelGGL((igemm_pw_kernel<T, BM, KC, PT, true, 1>), grid, dim3(256), lds, s, a);
     else if (a.stats) hipLaunchKernelGGL((igemm_pw_kernel<T, BM, KC, PT, true>), grid, dim3(256), lds, s, a);
     else hipLaunchKernelGGL((igemm_pw_kernel<T, BM, KC, PT, false>), grid, dim3(256), lds, s, a);
     LH_LAUNCH_CHECK("igemm_pw launch");

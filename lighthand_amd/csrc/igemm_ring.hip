@@ -159,9 +159,9 @@ int lh_pw_occupancy(const RingCfg& c, int dtype, int mode) {
 }
 
 // rows of the statistics slab a pointwise launch writes: one per workgroup of a channel block
-int lh_pw_rows(const lh_igemm_desc* d, const RingCfg& c, int dtype, bool gate) {
+int lh_pw_rows(const lh_igemm_desc* d, const RingCfg& c, int dtype, int gate) {
     int g, cb;
-    lh_pw_grid(c.bm, c.kb, c.bp / 16, (long)d->n * d->ho * d->wo, d->cout, lh_pw_occupancy(c, dtype, gate ? 2 : 1), &g, &cb);
+    lh_pw_grid(c.bm, c.kb, c.bp / 16, (long)d->n * d->ho * d->wo, d->cout, lh_pw_occupancy(c, dtype, 1 + gate), &g, &cb);
     return g;
 }
 

@@ -19,9 +19,12 @@
 // the value stored is g = v * (a > 0) -- the sign recomputed from gx * scale + shift, or read from the mask bits lh_fuse_fwd stored for a
 // tail (p.gmask) -- and s1 / s2 take { g, g * (gx - mean) * invstd }: the first half of that BatchNorm's backward pass (bn.hip
 // fuse_bwd_reduce_flat_body) on the tile the wave holds.  cst = mean[BM], invstd[BM], scale[BM], shift[BM]; no affine on the accumulator.
-template <typename T, int BM, int PT, bool STATS, bool GATE = false, typename PixFn, int NS>
+// GATE = 2: the tail's other term is a projection shortcut r = BN2(gx2): s3 takes g * (gx2 - mean2) * invstd2 (cst continues with mean2[BM],
+// invstd2[BM]); the sign comes from the mask bits.
+template <typename T, int BM, int PT, bool STATS, int GATE = 0, typename PixFn, int NS, int NS3>
 __device__ __forceinline__ void wave_epilogue(const IgemmArgs& p, f32x4 (&acc)[BM / 16][PT], unsigned char* stg, const float* cst,
-                                              const int cblk, const int lane, PixFn&& pix, float (&s1)[NS][8], float (&s2)[NS][8]) {
+                                              const int cblk, const int lane, PixFn&& pix, float (&s1)[NS][8], float (&s2)[NS][8],
+                                              float (&s3)[NS3][8]) {
     constexpr int ES = sizeof(T), EPC = 8, SUBW = 64, NSB = BM / SUBW, RS = SUBW * ES + 8;
     const int q = lane >> 4, pl = lane & 15;
     const int rrow = lane >> 3, rch = lane & 7;         // read-back: 8 lanes x 16 bytes = one 128-byte line of a pixel row
@@ -53,8 +56,9 @@ __device__ __forceinline__ void wave_epilogue(const IgemmArgs& p, f32x4 (&acc)[B
         unsigned mb[NP];
         long opix[NP];
         uint4 xd[GATE ? NP : 1];                            // GATE: the BatchNorm input at the output position, the tail's mask byte
+        uint4 xd2[GATE == 2 ? NP : 1];
         unsigned gm[GATE ? NP : 1];
-        float gmean[EPC], ginv[EPC], gsc[EPC], gsh[EPC];
+        float gmean[EPC], ginv[EPC], gsc[EPC], gsh[EPC], gmean2[EPC], ginv2[EPC];
         if constexpr (GATE) {
             const int cc = sb * SUBW + rch * EPC;
 #pragma unroll
@@ -65,6 +69,11 @@ __device__ __forceinline__ void wave_epilogue(const IgemmArgs& p, f32x4 (&acc)[B
                 ginv[4 * h] = b.x; ginv[4 * h + 1] = b.y; ginv[4 * h + 2] = b.z; ginv[4 * h + 3] = b.w;
                 gsc[4 * h] = c.x; gsc[4 * h + 1] = c.y; gsc[4 * h + 2] = c.z; gsc[4 * h + 3] = c.w;
                 gsh[4 * h] = d.x; gsh[4 * h + 1] = d.y; gsh[4 * h + 2] = d.z; gsh[4 * h + 3] = d.w;
+                if constexpr (GATE == 2) {
+                    const float4 a2 = *reinterpret_cast<const float4*>(cst + 4 * BM + cc + 4 * h), b2 = *reinterpret_cast<const float4*>(cst + 5 * BM + cc + 4 * h);
+                    gmean2[4 * h] = a2.x; gmean2[4 * h + 1] = a2.y; gmean2[4 * h + 2] = a2.z; gmean2[4 * h + 3] = a2.w;
+                    ginv2[4 * h] = b2.x; ginv2[4 * h + 1] = b2.y; ginv2[4 * h + 2] = b2.z; ginv2[4 * h + 3] = b2.w;
+                }
             }
         }
 #pragma unroll
@@ -82,6 +91,7 @@ __device__ __forceinline__ void wave_epilogue(const IgemmArgs& p, f32x4 (&acc)[B
                 xd[k] = *reinterpret_cast<const uint4*>(opix[k] >= 0 ? p.gx + eoff * ES : p.zero);
                 gm[k] = 0xffu;
                 if (p.gmask) gm[k] = *(opix[k] >= 0 ? p.gmask + eoff / EPC : p.zero);
+                if constexpr (GATE == 2) xd2[k] = *reinterpret_cast<const uint4*>(opix[k] >= 0 ? p.gx2 + eoff * ES : p.zero);
             }
         }
 #pragma unroll
@@ -124,6 +134,12 @@ __device__ __forceinline__ void wave_epilogue(const IgemmArgs& p, f32x4 (&acc)[B
                 if (opix[k] >= 0) {
 #pragma unroll
                     for (int e = 0; e < EPC; ++e) { s1[sb][e] += g[e]; s2[sb][e] += g[e] * (xv[e] - gmean[e]) * ginv[e]; }
+                    if constexpr (GATE == 2) {
+                        float x2[EPC];
+                        unpack16<T>(xd2[k], x2);
+#pragma unroll
+                        for (int e = 0; e < EPC; ++e) s3[sb][e] += g[e] * (x2[e] - gmean2[e]) * ginv2[e];
+                    }
                 }
                 u = pack16<T>(g);
             } else if constexpr (STATS) {

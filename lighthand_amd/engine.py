@@ -219,18 +219,23 @@ class Plan(Tuner, WgradSchedule, BatchGroups, InferRewrites):
                 # x = relu(BN(raw)) with this convolution as its only consumer -- or a residual tail relu(BN(raw) + r) whose other
                 # consumer, the next tail's identity term, rides in as this launch's masked addend: the launch stores the ReLU-gated
                 # gradient and the BatchNorm-backward partial sums of its tile (the node's backward skips its reduce pass)
-                rows = self.lib.lh_igemm_gated_rows(C.byref(dd), self.dt)
+                two = gkind == "mask2"
+                rows = self.lib.lh_igemm_gated_rows(C.byref(dd), self.dt, 2 if two else 1)
                 partial = self._alloc(rows * 2 * x.c, dtype=torch.float32)
+                partial2 = self._alloc(rows * 2 * x.c, dtype=torch.float32) if two else None
                 st = gi["st"]
                 gate = _lib.BnBwdGate(gi["raw"].buf.data_ptr(), st["mean"].data_ptr(), st["invstd"].data_ptr(), st["scale"].data_ptr(),
                                       st["shift"].data_ptr(), partial.data_ptr(), _ptr(gi.get("mask")))
+                if two:
+                    st2 = gi["st2"]
+                    gate.x2, gate.mean2, gate.invstd2, gate.partial2 = gi["raw2"].buf.data_ptr(), st2["mean"].data_ptr(), st2["invstd"].data_ptr(), partial2.data_ptr()
                 self.keep += [dd, gate]
                 c = _Call(self.lib.lh_igemm_gated, (C.byref(dd), _ptr(dy), _ptr(pk), _ptr(dx), _ptr(addend), _ptr(amask), C.byref(gate), self.dt),
                           what + " + BN-backward gate")
                 c.keep = dd
                 c.ig = dict(src=1, dst=3, addend=4, addend_mask=5)
                 self.bwd.append(c)
-                self._gated[id(x)] = (partial, rows)
+                self._gated[id(x)] = (partial, rows, partial2)
             else:
                 self._igemm(self.bwd, dd, dy, pk, dx, addend, None, None, what, addend_mask=amask)
             yield dd, dd.ntaps
@@ -244,7 +249,8 @@ class Plan(Tuner, WgradSchedule, BatchGroups, InferRewrites):
             return None
         uses = len(self._uses.get(id(x), []))
         if gi.get("mask") is not None:
-            return "mask" if self.bn_gate_tail and (uses == 1 or (uses == 2 and masked_addend)) else None
+            ok = self.bn_gate_tail and (uses == 1 or (uses == 2 and masked_addend))
+            return None if not ok else "mask2" if gi.get("raw2") is not None else "mask"
         return "x" if uses == 1 else None
 
     def _cfg_gateable(self, cfg, kind, nbytes):
@@ -255,6 +261,8 @@ class Plan(Tuner, WgradSchedule, BatchGroups, InferRewrites):
         pw, tiled = cfg[2] in (1, 100), (2 <= cfg[2] < 10 or 20 <= cfg[2] < 40)
         if not (tiled or (pw and self.bn_gate_pw)):
             return False
+        if kind == "mask2":                # two BatchNorm terms (a projection shortcut): the pointwise kernel only
+            return cfg[2] == 1 and self.bn_gate_tail2 and nbytes <= self.bn_gate_tail_bytes
         if kind == "mask":
             return nbytes <= (self.bn_gate_tail_bytes if pw else min(self.bn_gate_tail_bytes, self.bn_gate_tiled_tail_bytes))
         return nbytes <= (self.bn_gate_pw_bytes if pw else self.bn_gate_bytes)
@@ -376,6 +384,7 @@ class Plan(Tuner, WgradSchedule, BatchGroups, InferRewrites):
         self.bn_gate_tail = os.environ.get("LH_BN_GATE_TAIL", "1") != "0"           # round 6: residual tails (sign from the stored mask bits)
         self.bn_gate_tail_bytes = float(os.environ.get("LH_BN_GATE_TAIL_MAX_MB", "1024")) * (1 << 20)
         self.bn_gate_tiled_tail_bytes = float(os.environ.get("LH_BN_GATE_TILED_TAIL_MAX_MB", "1024")) * (1 << 20)
+        self.bn_gate_tail2 = os.environ.get("LH_BN_GATE_TAIL2", "1") != "0"         # ... tails with a projection shortcut (two BatchNorm terms)
         # consumers of every activation in forward order: (kind, node) -- backward visits them in reverse
         self._uses = {}
         for kind, nd in self.nodes:
@@ -970,6 +979,10 @@ class Plan(Tuner, WgradSchedule, BatchGroups, InferRewrites):
                 and all(l == 0 for _, _, l in terms) and all(a.c == out.c for a, _, _ in terms)):
             # a residual tail relu(BN(raw) + identity): its sign is in the mask bits
             self._gate_info[id(out)] = dict(raw=terms[bn_terms[0]][0], st=bn_state[bn_terms[0]], mask=relu_bits)
+        if (self.training and self.with_bwd and relu_bits is not None and len(terms) == 2 and len(bn_terms) == 2
+                and all(l == 0 for _, _, l in terms) and all(a.c == out.c for a, _, _ in terms)):
+            # ... with a projection shortcut: relu(BN(raw) + BN2(raw2))
+            self._gate_info[id(out)] = dict(raw=terms[0][0], st=bn_state[0], mask=relu_bits, raw2=terms[1][0], st2=bn_state[1])
         self.fwd.append(_Call(self.lib.lh_fuse_fwd, (C.byref(fd), obuf.data_ptr(), out.n, out.h, out.w, c, self.dt), "fuse fwd"))
         if self.training and relu and len(terms) == 1 and terms[0][1] is not None and terms[0][2] == 0 and relu_bits is None:
             # what a max-pool that follows needs to take this node's elementwise pass over (_c_maxpool)
@@ -988,6 +1001,8 @@ class Plan(Tuner, WgradSchedule, BatchGroups, InferRewrites):
             pre = self._gated.get(id(out))
             if pre is not None:                                     # dout was written by lh_igemm_gated: gated, with its partial sums
                 bd.pre_partial, bd.pre_rows = pre[0].data_ptr(), pre[1]
+                if len(pre) > 2 and pre[2] is not None:
+                    bd.pre_partial2 = pre[2].data_ptr()
             for i, (a, bn, l) in enumerate(terms):
                 bd.log2up[i] = l
                 if not a.needs_grad:

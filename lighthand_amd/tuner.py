@@ -251,15 +251,19 @@ class Tuner:
                     gvec = self._scratch("gate_vec", 4 * lead.cout * 4 + 256).view(torch.float32)
                     gvec[:4 * lead.cout] = 1.0
                     gpart = self._scratch("stats", rows * 2 * lead.cout * 4 + 256)
-                    gbits = self._scratch("gate_bits", nout * es // 16 + 256) if gate[0] == "mask" else None
+                    gbits = self._scratch("gate_bits", nout * es // 16 + 256) if gate[0] != "x" else None
                     c_ = lead.cout
                     gt = _lib.BnBwdGate(gx.data_ptr(), gvec.data_ptr(), gvec.data_ptr() + 4 * c_, gvec.data_ptr() + 8 * c_, gvec.data_ptr() + 12 * c_,
                                         gpart.data_ptr(), _ptr(gbits))
+                    if gate[0] == "mask2":
+                        gt.x2, gt.mean2, gt.invstd2 = self._scratch("gate_x2", nout * es + 256).data_ptr(), gvec.data_ptr(), gvec.data_ptr() + 4 * c_
+                        gt.partial2 = self._scratch("gate_part2", rows * 2 * lead.cout * 4 + 256).data_ptr()
 
                     def run_gated():
                         check(self.lib.lh_igemm_gated(C.byref(lead), src.data_ptr(), packs[0].data_ptr(), dst.data_ptr(), _ptr(add), _ptr(amask),
                                                       C.byref(gt), self.dt, sp), "autotune lh_igemm_gated")
-                    penalty = 2.0 * gate[1] / 4.5e12 * 1e3 + 2e-3           # ms per launch: the reduce pass lh_fuse_bwd keeps
+                    # ms per launch: the reduce pass lh_fuse_bwd keeps (per BatchNorm term: dout and that term's x)
+                    penalty = (4.0 if gate[0] == "mask2" else 2.0) * gate[1] / 4.5e12 * 1e3 + 2e-3
                 best = None
                 cold = os.environ.get("LH_TUNE_COLD", "1") != "0"
                 for cfg in cands:

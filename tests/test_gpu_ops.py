@@ -998,8 +998,9 @@ def test_gated_pool_backward_equals_plain_backward_then_gate(shape, dtype):
 @pytest.mark.parametrize("precision", ["bf16", "fp16"])
 def test_bn_backward_gate_on_the_pointwise_kernel_and_on_residual_tails(kernel, precision, forced_plans, monkeypatch):
     """Round 6 (verdict item 2): lh_igemm_gated on the persistent pointwise kernel, and for residual tails a = relu(BN(x) + r)
-    (`out += residual; relu`, pose_resnet.py:96-97), whose sign comes from the mask bits lh_fuse_fwd stored (lh_bn_bwd_gate.mask).  Two
-    identity blocks of 1x1 convolutions: the tail of the first has two consumers -- the second block's first convolution, whose data gradient
+    (`out += residual; relu`, pose_resnet.py:96-97), whose sign comes from the mask bits lh_fuse_fwd stored (lh_bn_bwd_gate.mask).  Three
+    blocks of 1x1 convolutions, the first with a projection shortcut (two BatchNorm terms under the ReLU: lh_bn_bwd_gate.x2), two
+    identity blocks: the tail of the second has two consumers -- the second block's first convolution, whose data gradient
     is the FIRST writer of its gradient and takes the second tail's identity gradient as a masked addend, and that tail itself.  With the gate
     that data gradient stores g = dz * mask and the partial sums of BN-backward; the tail's backward runs without its reduce pass.  Gate on /
     off: the gated launches appear (the tail's AND the single-term nodes' in front of a 1x1 data gradient), every gradient agrees to the
@@ -1012,24 +1013,27 @@ def test_bn_backward_gate_on_the_pointwise_kernel_and_on_residual_tails(kernel, 
     class Net(HipModule):
         def __init__(self):
             super().__init__()
-            self.c0 = nn.Conv2d(16, C4, 1, bias=False); self.b0 = nn.BatchNorm2d(C4)
-            for k in (1, 2):
+            self.c0 = nn.Conv2d(16, C4, 1, bias=False); self.n0 = nn.BatchNorm2d(C4)
+            for k in (0, 1, 2):
                 setattr(self, f"a{k}", nn.Conv2d(C4, Cq, 1, bias=False)); setattr(self, f"an{k}", nn.BatchNorm2d(Cq))
                 setattr(self, f"b{k}", nn.Conv2d(Cq, C4, 1, bias=False)); setattr(self, f"bn{k}", nn.BatchNorm2d(C4))
+            self.p = nn.Conv2d(C4, C4, 1, bias=False); self.pn = nn.BatchNorm2d(C4)       # block 0: projection shortcut (pose_resnet.py:93-94)
             self.out = nn.Conv2d(C4, 8, 1, bias=False)
 
         def describe(self, gb):
-            z = gb.fuse([(gb.conv(gb.input_act(16), "c0", 1, 1, 0), "b0")])
-            for k in (1, 2):
+            z = gb.fuse([(gb.conv(gb.input_act(16), "c0", 1, 1, 0), "n0")])
+            for k in (0, 1, 2):
+                r = (gb.conv(z, "p", 1, 1, 0), "pn") if k == 0 else z
                 a = gb.fuse([(gb.conv(z, f"a{k}", 1, 1, 0), f"an{k}")])
-                z = gb.fuse([(gb.conv(a, f"b{k}", 1, 1, 0), f"bn{k}"), z])
+                z = gb.fuse([(gb.conv(a, f"b{k}", 1, 1, 0), f"bn{k}"), r])
             gb.output(gb.conv(z, "out", 1, 1, 0))
 
         def torch_forward(self, x):
-            z = F.relu(self.b0(self.c0(x)))
-            for k in (1, 2):
+            z = F.relu(self.n0(self.c0(x)))
+            for k in (0, 1, 2):
+                r = self.pn(self.p(z)) if k == 0 else z
                 a = F.relu(getattr(self, f"an{k}")(getattr(self, f"a{k}")(z)))
-                z = F.relu(getattr(self, f"bn{k}")(getattr(self, f"b{k}")(a)) + z)
+                z = F.relu(getattr(self, f"bn{k}")(getattr(self, f"b{k}")(a)) + r)
             return self.out(z)
 
     lib = _lib.load()
@@ -1055,9 +1059,10 @@ def test_bn_backward_gate_on_the_pointwise_kernel_and_on_residual_tails(kernel, 
         gated[gate] = (len(calls), sum(1 for k in plan.keep if isinstance(k, _lib.BnBwdGate) and k.mask))
         res[gate] = (out, dx, grads)
     assert gated["0"] == (0, 0), gated
-    # gated: both tails (mask bits; the second has the output convolution as its only consumer), and the single-term nodes an1 / an2
+    # gated: the tails (mask bits) -- block 0's has a projection shortcut (two BatchNorm terms: the pointwise kernel only), block 1's the
+    # next tail as its second consumer, block 2's the output convolution as its only one -- and the single-term nodes an0 / an1 / an2
     # (their only consumer is a 1x1 data gradient)
-    assert gated["1"] == (4, 2), gated
+    assert gated["1"] == ((6, 3) if kernel == "pw" else (5, 2)), gated
     a, b = res["0"], res["1"]
     assert torch.equal(a[0], b[0])
     assert rel_err(a[1], b[1]) < 2e-2, rel_err(a[1], b[1])

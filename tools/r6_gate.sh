@@ -6,7 +6,7 @@ timeout -k 10 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_model.py
 [ $rc = 0 ] || exit 1
 O=gpurun_out/r6_gate_ab.txt; : > $O
 one() { python bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-roofline --no-extra 2>gpurun_out/r6_gate_err_$TAG.txt | python -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print(d['ms_per_step'], d['ms_per_step_median'], d['c_abi_calls_per_step'], d['loss_after'])"; }
-V=("A:LH_BN_GATE_PW=0 LH_BN_GATE_TAIL=0" "B:LH_X=1" "G:LH_BN_GATE_MAX_MB=20" "H:LH_BN_GATE_MAX_MB=40" "I:LH_BN_GATE_TILED_TAIL_MAX_MB=9")
+V=("A:LH_BN_GATE_PW=0 LH_BN_GATE_TAIL=0" "B:LH_X=1" "J:LH_BN_GATE_TAIL2=0")
 for rep in 0 1 2; do
   for v in "${V[@]}"; do
     tag=${v%%:*}; envs=${v#*:}
