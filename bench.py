@@ -579,7 +579,7 @@ def main():
                 fr.update({"family": "fuse_bwd (fuse_bwd_reduce* + fuse_bwd_coef_fused + fuse_bwd_apply*)", "calls_per_train_step": fam["launches"],
                            "ms_per_train_step": round(fam["ms"], 3), "algorithmic_bytes_per_step": int(fam["bytes"]),
                            "share_of_profiled_ms": round(fam["ms"] / sum(v["ms"] for v in agg.values()), 3)})
-                # `frac` above is against the family's OWN pass count (five tensor passes per BatchNorm node), NOT a roofline fraction
+                # `frac` above is against the family's OWN pass count (five tensor passes per BatchNorm node, three behind a gated data gradient), NOT a roofline fraction
                 # in SURVEY 8(d)'s sense: 8(d) charges the BatchNorm backward one re-read of y per BatchNorm term, everything
                 # else these kernels move is traffic a perfect fusion would not have
                 b8 = getattr(step.plan, "bn_bwd_8d_bytes", 0.0)
@@ -587,7 +587,8 @@ def main():
                     fr["section_8d_bytes_per_step"] = int(b8)
                     fr["over_section_8d"] = round(fam["bytes"] / b8, 2)
                     fr["frac_of_section_8d_roof"] = round(b8 / (PEAK_HBM_GBS * 1e9) * 1e3 / fam["ms"], 4)
-                    fr["note"] = ("frac = the family's own algorithmic bytes (5 passes per BatchNorm node) over the HBM peak; "
+                    fr["note"] = ("frac = the family's own algorithmic bytes (5 tensor passes per BatchNorm node; 3 where a gated data gradient, "
+                                  "lh_igemm_gated, did the reduce pass in its epilogue -- its read of x is charged to that launch) over the HBM peak; "
                                   "frac_of_section_8d_roof = the bytes SURVEY 8(d) charges to it (one re-read of y) over the HBM peak")
                 out["roofline_family"] = fr
             # per kernel: [ms per step, launches, TFLOP/s of its algorithmic FLOPs, GB/s of its algorithmic bytes, governing roof of the

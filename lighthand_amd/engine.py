@@ -231,7 +231,7 @@ class Plan(Tuner, WgradSchedule, BatchGroups, InferRewrites):
                     gate.x2, gate.mean2, gate.invstd2, gate.partial2 = gi["raw2"].buf.data_ptr(), st2["mean"].data_ptr(), st2["invstd"].data_ptr(), partial2.data_ptr()
                 self.keep += [dd, gate]
                 c = _Call(self.lib.lh_igemm_gated, (C.byref(dd), _ptr(dy), _ptr(pk), _ptr(dx), _ptr(addend), _ptr(amask), C.byref(gate), self.dt),
-                          what + " + BN-backward gate")
+                          what + " + BN-backward gate" + (" (mask bits)" if gi.get("mask") is not None else ""))
                 c.keep = dd
                 c.ig = dict(src=1, dst=3, addend=4, addend_mask=5)
                 self.bwd.append(c)
@@ -239,6 +239,22 @@ class Plan(Tuner, WgradSchedule, BatchGroups, InferRewrites):
             else:
                 self._igemm(self.bwd, dd, dy, pk, dx, addend, None, None, what, addend_mask=amask)
             yield dd, dd.ntaps
+
+    def _gate_meta(self, dd, x):
+        """(kernel name, extra algorithmic bytes) of the data gradient just emitted when it is a gated launch (lh_igemm_gated): the persistent
+        kernels have gate instantiations of their own (igemm_pw_kernel<.., true, terms>, conv3x3_direct_kernel<.., true, true>), and the
+        epilogue reads the BatchNorm input of every gated term (what the reduce pass of lh_fuse_bwd no longer reads) plus the mask bits."""
+        c = self.bwd[-1]
+        if getattr(c, "fn", None) is not self.lib.lh_igemm_gated:
+            return None, 0.0
+        g = self._gated[id(x)]
+        terms = 2 if len(g) > 2 and g[2] is not None else 1
+        name = self._kname(dd, stats=True)
+        if name.startswith("igemm_pw_kernel"):
+            name = name[:-1] + f", {terms}>"
+        elif name.startswith("conv3x3_direct_kernel"):
+            name = name[:-1] + ", true>"
+        return name, float(terms) * x.pixels * x.c * self.es + (x.pixels * x.c / 8 if "mask" in c.what else 0.0)
 
     def _gate_kind(self, gi, x, masked_addend):
         """May the first writer of x.grad, a data gradient, take the BatchNorm-backward gate of x's node (lh_igemm_gated)?  None | 'x' | 'mask'.
@@ -752,9 +768,10 @@ class Plan(Tuner, WgradSchedule, BatchGroups, InferRewrites):
             if x.needs_grad:
                 for dd, ntaps in self._dgrad(ddescs, dy, dpacks, x, nd["w"] + " dgrad"):
                     batched = ntaps != dd.ntaps or (len(ddescs) > 1 and self.bwd[-1].ig is not None)
-                    self.profile_meta.append(("bwd", self.bwd[-1], self._kname(dd), 2.0 * dd.n * dd.ho * dd.wo * cin * cout * ntaps,
-                                              (x.pixels * x.c + y.pixels * y.c) * self.es if batched else
-                                              (dd.n * dd.ho * dd.wo * x.c + y.pixels * y.c / (s * s)) * self.es))
+                    gname, gbytes = self._gate_meta(dd, x)
+                    self.profile_meta.append(("bwd", self.bwd[-1], gname or self._kname(dd), 2.0 * dd.n * dd.ho * dd.wo * cin * cout * ntaps,
+                                              gbytes + ((x.pixels * x.c + y.pixels * y.c) * self.es if batched else
+                                                        (dd.n * dd.ho * dd.wo * x.c + y.pixels * y.c / (s * s)) * self.es)))
         blk.append(emit)
 
     def _c_stem(self, nd, blk, bias):
@@ -926,7 +943,8 @@ class Plan(Tuner, WgradSchedule, BatchGroups, InferRewrites):
                 wl.append(self._bias_grad(dy, y, cout, gb_))
             if x.needs_grad:
                 for _dd, _nt in self._dgrad([dg], dy, [gpack], x, nd["w"] + " deconv dgrad"):
-                    self.profile_meta.append(("bwd", self.bwd[-1], self._kname(dg), flops, (x.pixels * x.c + y.pixels * y.c) * self.es))
+                    gname, gbytes = self._gate_meta(dg, x)
+                    self.profile_meta.append(("bwd", self.bwd[-1], gname or self._kname(dg), flops, gbytes + (x.pixels * x.c + y.pixels * y.c) * self.es))
         blk.append(emit)
 
     # ---- BatchNorm + sum + ReLU ------------------------------------------------------------------
@@ -1035,7 +1053,8 @@ class Plan(Tuner, WgradSchedule, BatchGroups, InferRewrites):
             # apply pass reads them again and writes one gradient per term that takes one (5 tensor passes per BN)
             n_bn = sum(1 for _, bn, _ in terms if bn is not None)
             n_dx = sum(1 for i in range(len(terms)) if bd.dx[i])
-            passes = (2 * (1 + n_bn) if n_bn else 1) + n_dx
+            # (a node whose dout came from a gated data gradient has no reduce pass: that launch's epilogue read x -- charged to it, _gate_meta)
+            passes = ((1 if pre is not None else 2) * (1 + n_bn) if n_bn else 1) + n_dx
             self.profile_meta.append(("bwd", self.bwd[-1], "fuse_bwd(all kernels)", 0.0, float(passes) * out.pixels * c * self.es))
             # what SURVEY 8(d)'s traffic model itself charges to the BatchNorm backward: ONE re-read of y per BatchNorm term
             self.bn_bwd_8d_bytes = getattr(self, "bn_bwd_8d_bytes", 0.0) + float(n_bn) * out.pixels * c * self.es

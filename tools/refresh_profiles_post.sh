@@ -26,18 +26,19 @@ R = os.environ.get("LH_ROUND", "r06")
 b = json.load(open(f"profiles/{R}_bench.json"))
 pmc = json.load(open(f"profiles/{R}_pmc_traffic.json"))
 k = b.get("roofline", {}).get("kernel")
-if k in pmc and b["roofline"].get("traffic") is None:
+if k in pmc:                     # always from the PMC passes of THIS session (the bench line itself carries the previous committed profile's)
     b["roofline"]["traffic"] = pmc[k]["read_bytes_per_launch"] + pmc[k]["write_bytes_per_launch"]
     b["roofline"]["traffic_note"] = ("bytes per launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of the same session (separate passes, corrected per the "
                                      f"MI355X guide), profiles/{R}_pmc_hbm_traffic.txt")
     b["roofline"]["traffic_source"] = f"PMC passes of the same session (profiles/{R}_pmc_traffic.json)"
     print("roofline.traffic <-", b["roofline"]["traffic"])
 st = pmc.get("__train_step__")
-if st and (b.get("roofline", {}).get("step_traffic") or {}).get("bytes") is None:
+if st:
     alg = b["roofline"]["step_traffic"]["algorithmic_bytes"] if b["roofline"].get("step_traffic") else 12064000000
     b["roofline"]["step_traffic"] = {"bytes": st["bytes"], "read_bytes": st["read_bytes"], "write_bytes": st["write_bytes"], "algorithmic_bytes": alg,
                                      "over_algorithmic": round(st["bytes"] / alg, 3),
-                                     "source": f"PMC passes of the same session (profiles/{R}_pmc_traffic.json: `bench.py --train-only`, {st['steps']} training steps)"}
+                                     "whole_process_bytes_per_step": st.get("whole_process_bytes_per_step"),
+                                     "source": f"PMC passes of the same session (profiles/{R}_pmc_traffic.json: `bench.py --train-only`, {st['steps']} training steps behind the first Adam launch)"}
     print("roofline.step_traffic <-", b["roofline"]["step_traffic"]["bytes"], b["roofline"]["step_traffic"]["over_algorithmic"])
 json.dump(b, open(f"profiles/{R}_bench.json", "w"))
 PY
