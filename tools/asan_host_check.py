@@ -89,8 +89,11 @@ def run():
                 for i in range(min(nc, 320)):                                 # every candidate resolves to a valid configuration
                     d.cfg[0], d.cfg[1], d.cfg[2], d.cfg[3] = ibuf[5 * i], ibuf[5 * i + 1], ibuf[5 * i + 2], ibuf[5 * i + 3]
                     lib.lh_igemm_config(C.byref(d), dt, cfg)
-                    lib.lh_igemm_stats_rows(C.byref(d), dt)
-                    calls += 2
+                    rows = lib.lh_igemm_stats_rows(C.byref(d), dt)
+                    for nterms in (1, 2):                                     # the gated launch's slab (round 6): as many rows, except on the pointwise kernel
+                        gr = lib.lh_igemm_gated_rows(C.byref(d), dt, nterms)
+                        assert gr >= 1 and (cfg[2] == 1 or gr == rows), (gr, rows, tuple(cfg))
+                    calls += 4
                 for j in range(8):
                     d.cfg[j] = 0
                 calls += 5
