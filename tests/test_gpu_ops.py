@@ -1058,6 +1058,39 @@ def test_bn_backward_gate_on_the_pointwise_kernel_and_on_residual_tails(kernel, 
         calls = [c for c in plan.bwd if getattr(c, "fn", None) is lib.lh_igemm_gated]
         gated[gate] = (len(calls), sum(1 for k in plan.keep if isinstance(k, _lib.BnBwdGate) and k.mask))
         res[gate] = (out, dx, grads)
+        # every gated launch against its OWN stored output: zero where the activation was not positive, and the slab rows add up to
+        # sum g and sum g * xhat of what was stored (fp64 on the host), for one and for two BatchNorm terms
+        gates = [k for k in plan.keep if isinstance(k, _lib.BnBwdGate)]
+        assert len(gates) == len(calls)
+        hip = C.CDLL("libamdhip64.so")
+
+        def dev(ptr, numel, dtype):
+            t = torch.empty(numel, dtype=dtype, device="cuda")
+            assert hip.hipMemcpy(C.c_void_p(t.data_ptr()), C.c_void_p(ptr), C.c_size_t(numel * t.element_size()), 3) == 0
+            return t
+        for c, g in zip(calls, gates):
+            d = c.keep
+            M, Cc = d.n * d.OH * d.OW, d.cout
+            assert d.out_pix_stride == Cc
+            stored = dev(c.args[3], M * Cc, plan.tdtype).view(M, Cc).double()
+            xin = dev(g.x, M * Cc, plan.tdtype).view(M, Cc).double()
+            mean, inv = dev(g.mean, Cc, torch.float32).double(), dev(g.invstd, Cc, torch.float32).double()
+            if g.mask:
+                bits = dev(g.mask, M * Cc // 8, torch.uint8).view(M, Cc // 8, 1)
+                on = ((bits >> torch.arange(8, device="cuda", dtype=torch.uint8).view(1, 1, 8)) & 1).bool().view(M, Cc)
+            else:
+                on = (xin.float() * dev(g.scale, Cc, torch.float32) + dev(g.shift, Cc, torch.float32)) > 0
+            assert float(stored[~on].abs().max() if (~on).any() else 0.0) == 0.0, c.what
+            rows = lib.lh_igemm_gated_rows(C.byref(d), plan.dt, 2 if g.x2 else 1)
+            slabs = [(g.partial, xin, mean, inv)]
+            if g.x2:
+                slabs.append((g.partial2, dev(g.x2, M * Cc, plan.tdtype).view(M, Cc).double(), dev(g.mean2, Cc, torch.float32).double(),
+                              dev(g.invstd2, Cc, torch.float32).double()))
+            for ptr, xv, mn, iv in slabs:
+                got = dev(ptr, rows * 2 * Cc, torch.float32).view(rows, 2, Cc).double().sum(0)
+                want0, want1 = stored.sum(0), (stored * (xv - mn) * iv).sum(0)
+                assert torch.allclose(got[0], want0, rtol=2e-3, atol=2e-3 * float(stored.abs().sum(0).max())), c.what
+                assert torch.allclose(got[1], want1, rtol=2e-3, atol=2e-3 * float((stored * (xv - mn) * iv).abs().sum(0).max())), c.what
     assert gated["0"] == (0, 0), gated
     # gated: the tails (mask bits) -- block 0's has a projection shortcut (two BatchNorm terms: the pointwise kernel only), block 1's the
     # next tail as its second consumer, block 2's the output convolution as its only one -- and the single-term nodes an0 / an1 / an2
