@@ -53,6 +53,10 @@ class Plan(Tuner, WgradSchedule, BatchGroups, InferRewrites):
         model.describe(gb)
         self.nodes = gb.nodes
         self.node_lanes = gb.node_lanes
+        self.node_branch, inside = [], False                   # node sits inside a fork .. join region (branch 0 runs on lane 0, and
+        for kind, _ in gb.nodes:                                # _batch_order moves grouped regions to lane 0: the lanes do not say it)
+            inside = (inside or kind == "fork") and kind != "join"
+            self.node_branch.append(inside)
         self.n_lanes = max(gb.node_lanes) + 1 if gb.node_lanes else 1
         self.use_lanes = self.n_lanes > 1
         # Multi-problem launches: the nodes at the same position of the parallel chains of a fork .. join region (HRNet's
@@ -209,9 +213,12 @@ class Plan(Tuner, WgradSchedule, BatchGroups, InferRewrites):
             yield max(descs, key=lambda d: d.ntaps), sum(d.ntaps for d in descs)
             return
         for dd, pk in zip(descs, packs):
-            # (networks with parallel branches: not gated -- their batch groups would not be, and a plan must compute the
-            #  same sums whether its branches run as groups or on stream lanes)
-            gi = self._gate_info.get(id(x)) if (self.bn_gate and first and len(descs) == 1 and self.n_lanes == 1 and self.es == 2) else None
+            # (networks with parallel branches: gated OUTSIDE their branch regions only -- HRNet's stem, layer1, transitions: 12.93 -> 12.84 ms.
+            #  Inside them the members of a batch group run merged tiled launches whose reduce passes are merged too: carrying the gates into
+            #  lh_igemm_multi was measured +0.26 ms SLOWER, round 6; a plan computes the same sums whether its branches run as groups or lanes)
+            in_branch = self._emit_group > 1 or self._cur_lane != 0 or getattr(self, "_in_branch", False)
+            gi = self._gate_info.get(id(x)) if (self.bn_gate and first and len(descs) == 1 and self.es == 2 and
+                                                (self.n_lanes == 1 or (self.bn_gate_branches and not in_branch))) else None
             gkind, gbytes = self._gate_kind(gi, x, amask is not None), x.pixels * x.c * self.es
             self._tune([dd], addend=kind, role="dgrad", gate=(gkind, gbytes) if gkind else None)
             cfg = (C.c_int * 5)()
@@ -401,6 +408,7 @@ class Plan(Tuner, WgradSchedule, BatchGroups, InferRewrites):
         self.bn_gate_tail_bytes = float(os.environ.get("LH_BN_GATE_TAIL_MAX_MB", "1024")) * (1 << 20)
         self.bn_gate_tiled_tail_bytes = float(os.environ.get("LH_BN_GATE_TILED_TAIL_MAX_MB", "1024")) * (1 << 20)
         self.bn_gate_tail2 = os.environ.get("LH_BN_GATE_TAIL2", "1") != "0"         # ... tails with a projection shortcut (two BatchNorm terms)
+        self.bn_gate_branches = os.environ.get("LH_BN_GATE_BRANCHES", "1") != "0"   # ... in networks with parallel branches (HRNet), outside the branch regions
         # consumers of every activation in forward order: (kind, node) -- backward visits them in reverse
         self._uses = {}
         for kind, nd in self.nodes:
@@ -498,7 +506,7 @@ class Plan(Tuner, WgradSchedule, BatchGroups, InferRewrites):
                 self._forced = group_forced.get(item[0])          # the data gradients are tuned while the blocks are emitted
                 for j, i in enumerate(item):
                     (kind, nd), blk, lane = self.nodes[i], bwd_blocks[i], self.node_lanes[i]
-                    self._cur_lane = lane
+                    self._cur_lane, self._in_branch = lane, self.node_branch[i]
                     if self._forced is not None:
                         self._forced["member"] = j
                     if kind == "fork" and self.wgrad_group > 0:      # end of a branch region in backward order: every lane hands
